@@ -1,0 +1,131 @@
+"""ctypes binding of libddpm_ood_hip.so (C ABI: include/ddpm_ood_hip.h).
+
+The product path has no CPU / PyTorch fallback: if the HIP library is missing this module
+raises at first use, and every op refuses non-ROCm tensors.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_LIB = None
+LIB_NAME = "libddpm_ood_hip.so"
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("in1", C.c_void_p), ("in2", C.c_void_p), ("C1", C.c_int), ("C2", C.c_int),
+        ("w_packed", C.c_void_p), ("w_raw", C.c_void_p), ("bias", C.c_void_p),
+        ("gscale", C.c_void_p), ("gshift", C.c_void_p),
+        ("chan_add", C.c_void_p), ("chan_add_stride", C.c_int),
+        ("residual", C.c_void_p), ("out", C.c_void_p),
+        ("B", C.c_int), ("Cout", C.c_int),
+        ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+        ("ksize", C.c_int), ("mode", C.c_int), ("act", C.c_int), ("force_direct", C.c_int),
+    ]
+
+
+MAX_LEVELS = 8
+
+
+class UNetConfig(C.Structure):
+    _fields_ = [
+        ("spatial_dims", C.c_int), ("in_channels", C.c_int), ("out_channels", C.c_int),
+        ("num_levels", C.c_int),
+        ("num_channels", C.c_int * MAX_LEVELS), ("attention_levels", C.c_int * MAX_LEVELS),
+        ("num_res_blocks", C.c_int * MAX_LEVELS), ("num_head_channels", C.c_int * MAX_LEVELS),
+        ("norm_num_groups", C.c_int), ("norm_eps", C.c_float), ("use_proj_attn", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+SIGNATURES = {
+    "ddpm_abi_version": (C.c_int, []),
+    "ddpm_last_error": (C.c_char_p, []),
+    "ddpm_conv_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "ddpm_packed_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ddpm_pack_conv_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p]),
+    "ddpm_gn_scale_shift_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "ddpm_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_float, C.c_void_p]),
+    "ddpm_timestep_embedding_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_add_noise_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
+                                     C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "ddpm_plms_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int64,
+                                     C.c_void_p]),
+    "ddpm_clamp_mse_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "ddpm_unet_create": (C.c_void_p, [C.POINTER(UNetConfig)]),
+    "ddpm_unet_destroy": (None, [C.c_void_p]),
+    "ddpm_unet_param_blob_floats": (C.c_size_t, [C.c_void_p]),
+    "ddpm_unet_bind_param_blob": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddpm_unet_num_params": (C.c_int, [C.c_void_p]),
+    "ddpm_unet_param_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "ddpm_unet_param_numel": (C.c_int64, [C.c_void_p, C.c_int]),
+    "ddpm_unet_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ddpm_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "ddpm_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+
+def lib_path() -> Path:
+    env = os.environ.get("DDPM_OOD_HIP_LIB")
+    return Path(env) if env else Path(__file__).resolve().parent / LIB_NAME
+
+
+def load():
+    """Load the shared library (once).  Raises HipLibraryMissing -- never falls back."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not p.exists():
+        raise HipLibraryMissing(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or ddpm_ood_amd/csrc/build.sh.  There is no CPU fallback for the reconstruction path.")
+    lib = C.CDLL(str(p))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ddpm_abi_version() != 1:
+        raise HipLibraryMissing(f"{p}: ABI version {lib.ddpm_abi_version()} != 1")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ddpm_last_error().decode() or f"error code {rc}"
+        if rc == -2:
+            raise KeyError(f"{what}: {msg}")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what}: {msg}")
+
+
+def require_device_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a ROCm device tensor: the HIP reconstruction path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ptr(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,79 @@
+// Shared host/device helpers for libddpm_ood_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/ddpm_ood_hip.h"
+
+namespace ddpm {
+
+void set_error(const char *fmt, ...);
+
+inline hipStream_t as_stream(ddpm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define DDPM_CHECK_ARG(cond, ...)                \
+  do {                                           \
+    if (!(cond)) {                               \
+      ::ddpm::set_error(__VA_ARGS__);            \
+      return DDPM_EINVAL;                        \
+    }                                            \
+  } while (0)
+
+#define DDPM_CHECK_LAUNCH()                                                    \
+  do {                                                                         \
+    hipError_t e_ = hipGetLastError();                                         \
+    if (e_ != hipSuccess) {                                                    \
+      ::ddpm::set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return (int)e_;                                                          \
+    }                                                                          \
+  } while (0)
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 floats of LDS.
+// Deterministic: fixed butterfly inside the wave, fixed order across waves.
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- internal launchers shared between api.hip and the UNet engine ---------------------
+int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s);
+bool conv_mfma_supported(const ddpm_conv_desc &d);
+int launch_conv_mfma(const ddpm_conv_desc &d, hipStream_t s);
+int launch_conv_direct(const ddpm_conv_desc &d, hipStream_t s);
+size_t packed_conv_weight_floats(int Cout, int Cin, int ksize);
+int launch_pack_conv_weight(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize, int cout_offset,
+                            int Cout_total, hipStream_t s);
+int launch_gn_scale_shift(const float *in1, const float *in2, int C1, int C2, const float *gamma, const float *beta,
+                          float *scale, float *shift, int B, int HW, int groups, float eps, hipStream_t s);
+int launch_attention(const float *qkv, const float *residual, float *out, int B, int C, int N, int heads, float scale,
+                     hipStream_t s);
+int launch_timestep_embedding(const int64_t *t, const float *freqs, float *out, int B, int dim, hipStream_t s);
+int launch_copy_f32(const float *src, float *dst, int64_t n, hipStream_t s);
+
+// MFMA conv tiling constants (shared by the packer and the kernel)
+constexpr int kConvCc = 8;     // input channels staged per chunk
+constexpr int kConvNT = 128;   // output channels per workgroup
+constexpr int kConvMT = 128;   // output pixels per workgroup
+
+}  // namespace ddpm

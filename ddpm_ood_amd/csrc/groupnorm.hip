@@ -1,0 +1,88 @@
+// groupnorm.hip -- GroupNorm statistics -> per-(image, channel) scale / shift.
+//
+// Replaces the statistics half of F.group_norm inside ResnetBlock / AttentionBlock / out
+// (SURVEY.md 2.3 row "group_norm(32 groups, eps=1e-6) + silu"; reference call site
+// /root/reference/src/trainers/reconstruct.py:151-153).  The normalise + SiLU half is fused
+// into the consuming convolution's staging (conv_mfma.hip), so this kernel is the only extra
+// pass over the activation: one workgroup per (image, group), two-pass mean / variance in
+// fp32 (second pass re-reads the <= 64 KB group from L2), wave64 shuffle reductions.
+// HBM-bound: algorithmic bytes = 4 * C * HW per image.  Handles a virtual torch.cat of two
+// sources, including groups that straddle the seam (384 = 256 + 128 channels, 12 per group).
+#include "common.h"
+
+namespace ddpm {
+
+__global__ __launch_bounds__(256) void gn_scale_shift_kernel(const float *__restrict__ in1,
+                                                             const float *__restrict__ in2, int C1, int C2,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, float *__restrict__ scale,
+                                                             float *__restrict__ shift, int HW, int G, float eps) {
+  __shared__ float red[4];
+  const int C = C1 + C2;
+  const int cpg = C / G;
+  const int n = blockIdx.y, g = blockIdx.x;
+  const int c0 = g * cpg;
+  const int tid = threadIdx.x;
+  const int count = cpg * HW;
+
+  auto plane = [&](int c) -> const float * {
+    return (c < C1) ? in1 + ((size_t)n * C1 + c) * HW : in2 + ((size_t)n * C2 + (c - C1)) * HW;
+  };
+
+  float s = 0.f;
+  if ((HW & 3) == 0) {
+    const int hw4 = HW >> 2;
+    for (int e = tid; e < cpg * hw4; e += 256) {
+      const int c = e / hw4, p4 = e - c * hw4;
+      const float4 v = reinterpret_cast<const float4 *>(plane(c0 + c))[p4];
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (int e = tid; e < count; e += 256) {
+      const int c = e / HW, p = e - c * HW;
+      s += plane(c0 + c)[p];
+    }
+  }
+  const float mean = block_sum_256(s, red) / (float)count;
+
+  float q = 0.f;
+  if ((HW & 3) == 0) {
+    const int hw4 = HW >> 2;
+    for (int e = tid; e < cpg * hw4; e += 256) {
+      const int c = e / hw4, p4 = e - c * hw4;
+      const float4 v = reinterpret_cast<const float4 *>(plane(c0 + c))[p4];
+      const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  } else {
+    for (int e = tid; e < count; e += 256) {
+      const int c = e / HW, p = e - c * HW;
+      const float a = plane(c0 + c)[p] - mean;
+      q += a * a;
+    }
+  }
+  const float var = block_sum_256(q, red) / (float)count;  // biased, as torch
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (tid < cpg) {
+    const int c = c0 + tid;
+    const float sc = rstd * gamma[c];
+    scale[(size_t)n * C + c] = sc;
+    shift[(size_t)n * C + c] = -sc * mean + beta[c];
+  }
+}
+
+int launch_gn_scale_shift(const float *in1, const float *in2, int C1, int C2, const float *gamma, const float *beta,
+                          float *scale, float *shift, int B, int HW, int groups, float eps, hipStream_t s) {
+  const int C = C1 + C2;
+  DDPM_CHECK_ARG(in1 && gamma && beta && scale && shift, "gn: null pointer");
+  DDPM_CHECK_ARG(C2 == 0 || in2, "gn: C2 > 0 but in2 is NULL");
+  DDPM_CHECK_ARG(groups > 0 && C % groups == 0, "gn: C %% groups != 0");
+  DDPM_CHECK_ARG(C / groups <= 256, "gn: more than 256 channels per group");
+  DDPM_CHECK_ARG(B > 0 && B <= 65535 && HW > 0, "gn: bad B / HW");
+  hipLaunchKernelGGL(gn_scale_shift_kernel, dim3(groups, B), dim3(256), 0, s, in1, in2, C1, C2, gamma, beta, scale,
+                     shift, HW, groups, eps);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace ddpm

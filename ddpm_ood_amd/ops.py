@@ -1,0 +1,173 @@
+"""Thin Python wrappers over the stand-alone C-ABI operators (include/ddpm_ood_hip.h).
+
+Used by the scheduler / trainer mirrors and by the per-kernel parity tests.  Every function
+takes ROCm device tensors and launches on torch's current HIP stream; none falls back to
+PyTorch ops.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, ptr, require_device_f32, stream_ptr
+
+CONV_NORMAL, CONV_STRIDE2, CONV_UPSAMPLE2 = 0, 1, 2
+ACT_NONE, ACT_SILU = 0, 1
+
+
+def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor | None:
+    """torch [Cout, Cin, k, k] (or [out, in]) -> MFMA-packed weight, or None if unpackable."""
+    lib = _lib.load()
+    w = require_device_f32(weight, "weight")
+    cout, cin = w.shape[0], w.shape[1]
+    k = w.shape[2] if w.ndim == 4 else 1
+    n = lib.ddpm_packed_conv_weight_floats(cout, cin, k)
+    if n == 0:
+        return None
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib.ddpm_pack_conv_weight_f32(ptr(w), ptr(out), cout, cin, k, 0, cout, stream_ptr()), "pack_conv_weight")
+    return out
+
+
+def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NONE, mode=CONV_NORMAL,
+         chan_add=None, chan_add_offset=0, residual=None, packed=None, force_direct=False):
+    """Fused conv / linear.  x: [B, C1, H, W]; x2: optional second source of a virtual concat."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    w = require_device_f32(weight, "weight")
+    if x.ndim == 2:  # Linear: [B, C] == [B, C, 1, 1]
+        x = x[:, :, None, None]
+        was_linear = True
+    else:
+        was_linear = False
+    B, C1, Hi, Wi = x.shape
+    cout = w.shape[0]
+    k = w.shape[2] if w.ndim == 4 else 1
+    if mode == CONV_STRIDE2:
+        Ho, Wo = (Hi + 1) // 2, (Wi + 1) // 2
+    elif mode == CONV_UPSAMPLE2:
+        Ho, Wo = 2 * Hi, 2 * Wi
+    else:
+        Ho, Wo = Hi, Wi
+    if packed is None and not force_direct:
+        packed = pack_conv_weight(w)
+    out = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    keep = [x, w, out, packed]
+    d = ConvDesc()
+    d.in1 = ptr(x)
+    d.C1 = C1
+    if x2 is not None:
+        x2 = require_device_f32(x2, "x2")
+        d.in2, d.C2 = ptr(x2), x2.shape[1]
+        keep.append(x2)
+    d.w_packed = ptr(packed)
+    d.w_raw = ptr(w)
+    if bias is not None:
+        bias = require_device_f32(bias, "bias")
+        d.bias = ptr(bias)
+    if gscale is not None:
+        gscale = require_device_f32(gscale, "gscale")
+        gshift = require_device_f32(gshift, "gshift")
+        d.gscale, d.gshift = ptr(gscale), ptr(gshift)
+    if chan_add is not None:
+        chan_add = require_device_f32(chan_add, "chan_add")
+        d.chan_add = chan_add.data_ptr() + 4 * chan_add_offset
+        d.chan_add_stride = chan_add.shape[1]
+    if residual is not None:
+        residual = require_device_f32(residual, "residual")
+        d.residual = ptr(residual)
+    d.out = ptr(out)
+    d.B, d.Cout, d.Hi, d.Wi, d.Ho, d.Wo = B, cout, Hi, Wi, Ho, Wo
+    d.ksize, d.mode, d.act, d.force_direct = k, mode, act, int(force_direct)
+    check(lib.ddpm_conv_f32(C.byref(d), stream_ptr()), "conv")
+    return out[:, :, 0, 0] if was_linear else out
+
+
+def gn_scale_shift(x, gamma, beta, groups: int, eps: float, x2=None):
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    B, C1 = x.shape[:2]
+    hw = x[0, 0].numel()
+    C2 = 0
+    if x2 is not None:
+        x2 = require_device_f32(x2, "x2")
+        C2 = x2.shape[1]
+    gamma = require_device_f32(gamma, "gamma")
+    beta = require_device_f32(beta, "beta")
+    scale = torch.empty((B, C1 + C2), dtype=torch.float32, device=x.device)
+    shift = torch.empty_like(scale)
+    check(lib.ddpm_gn_scale_shift_f32(ptr(x), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(scale), ptr(shift), B, hw,
+                                      groups, eps, stream_ptr()), "gn_scale_shift")
+    return scale, shift
+
+
+def attention(qkv, residual, num_heads: int, scale: float):
+    """qkv: [B, 3C, N] -> [B, C, N] = softmax(scale q^T k) v (+ residual)."""
+    lib = _lib.load()
+    qkv = require_device_f32(qkv, "qkv")
+    B, C3, N = qkv.shape
+    Cc = C3 // 3
+    if residual is not None:
+        residual = require_device_f32(residual, "residual")
+    out = torch.empty((B, Cc, N), dtype=torch.float32, device=qkv.device)
+    check(lib.ddpm_attention_f32(ptr(qkv), ptr(residual), ptr(out), B, Cc, N, num_heads, scale, stream_ptr()),
+          "attention")
+    return out
+
+
+def timestep_embedding(timesteps, freqs, dim: int):
+    lib = _lib.load()
+    if not timesteps.is_cuda or timesteps.dtype != torch.int64:
+        raise RuntimeError("timesteps must be an int64 ROCm device tensor")
+    freqs = require_device_f32(freqs, "freqs")
+    out = torch.empty((timesteps.shape[0], dim), dtype=torch.float32, device=timesteps.device)
+    check(lib.ddpm_timestep_embedding_f32(ptr(timesteps.contiguous()), ptr(freqs), ptr(out), timesteps.shape[0], dim,
+                                          stream_ptr()), "timestep_embedding")
+    return out
+
+
+def add_noise(x0, noise, sqrt_ac: np.ndarray, sqrt_1m_ac: np.ndarray, b_scale: float = 1.0):
+    lib = _lib.load()
+    x0 = require_device_f32(x0, "original_samples")
+    noise = require_device_f32(noise, "noise")
+    B = x0.shape[0]
+    a = np.ascontiguousarray(sqrt_ac, dtype=np.float32)
+    b = np.ascontiguousarray(sqrt_1m_ac, dtype=np.float32)
+    assert a.shape == (B,) and b.shape == (B,)
+    out = torch.empty_like(x0)
+    check(lib.ddpm_add_noise_f32(ptr(x0), ptr(noise), a.ctypes.data_as(C.POINTER(C.c_float)),
+                                 b.ctypes.data_as(C.POINTER(C.c_float)), float(b_scale), ptr(out), B,
+                                 x0[0].numel(), stream_ptr()), "add_noise")
+    return out
+
+
+def plms_step(sample, ets, kind: int, sample_coeff: float, coef_eps: float, denom: float, *, v_prediction=False,
+              v_a: float = 0.0, v_b: float = 0.0, out=None):
+    """ets: newest-first list of eps tensors (1..4 of them)."""
+    lib = _lib.load()
+    sample = require_device_f32(sample, "sample")
+    es = [require_device_f32(e, "model_output") for e in ets] + [None] * (4 - len(ets))
+    if out is None:
+        out = torch.empty_like(sample)
+    check(lib.ddpm_plms_step_f32(ptr(sample), ptr(es[0]), ptr(es[1]), ptr(es[2]), ptr(es[3]), kind,
+                                 int(v_prediction), v_a, v_b, sample_coeff, coef_eps, denom, ptr(out),
+                                 sample.numel(), stream_ptr()), "plms_step")
+    return out
+
+
+def clamp_mse_(orig, recon, b_scale: float = 1.0):
+    """In place: recon <- clamp(recon / b_scale, 0, 1); returns per-image MSE [B]."""
+    lib = _lib.load()
+    orig = require_device_f32(orig, "images_original")
+    if not recon.is_contiguous():
+        raise ValueError("recon must be contiguous (it is updated in place)")
+    recon = require_device_f32(recon, "reconstructions")
+    B = orig.shape[0]
+    mse = torch.empty(B, dtype=torch.float32, device=orig.device)
+    check(lib.ddpm_clamp_mse_f32(ptr(orig), ptr(recon), float(b_scale), ptr(mse), B, orig[0].numel(), stream_ptr()),
+          "clamp_mse")
+    return mse

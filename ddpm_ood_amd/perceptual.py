@@ -1,0 +1,143 @@
+"""``PerceptualLoss`` (LPIPS-AlexNet) with the reference's call surface.
+
+Mirror of /root/reference/src/losses/perceptual_loss.py:47-186 over an in-tree restatement of
+``lpips.LPIPS(net='alex', version='0.1', lpips=True, spatial=False)`` (the
+``lpips`` wheel is not installed here).  Per BASELINE.json's north_star and SURVEY.md 8(a)
+row a9 this similarity score stays on PyTorch-ROCm device ops (MIOpen) for now; fused HIP
+kernels for it are the "next" row f-2.  24 MFLOP per image pair at 32x32 -- 6e-5 of a
+reconstruction's cost.
+
+state_dict keys follow lpips (``net.slice1.0.weight`` ... ``lins.0.model.1.weight``,
+``scaling_layer.shift/scale``) so real LPIPS weights can be loaded with ``--lpips_weights``;
+without them seeded synthetic weights are used (the trained ones need the network).
+"""
+
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+import torch.nn as nn
+
+
+class _ScalingLayer(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("shift", torch.tensor([-0.030, -0.088, -0.188])[None, :, None, None])
+        self.register_buffer("scale", torch.tensor([0.458, 0.448, 0.450])[None, :, None, None])
+
+    def forward(self, x):
+        return (x - self.shift) / self.scale  # broadcasts 1-channel input to 3 channels
+
+
+class _Alex(nn.Module):
+    def __init__(self):
+        super().__init__()
+        spec = {
+            "slice1": [("0", nn.Conv2d(3, 64, 11, 4, 2)), ("1", nn.ReLU())],
+            "slice2": [("2", nn.MaxPool2d(3, 2)), ("3", nn.Conv2d(64, 192, 5, 1, 2)), ("4", nn.ReLU())],
+            "slice3": [("5", nn.MaxPool2d(3, 2)), ("6", nn.Conv2d(192, 384, 3, 1, 1)), ("7", nn.ReLU())],
+            "slice4": [("8", nn.Conv2d(384, 256, 3, 1, 1)), ("9", nn.ReLU())],
+            "slice5": [("10", nn.Conv2d(256, 256, 3, 1, 1)), ("11", nn.ReLU())],
+        }
+        for name, mods in spec.items():
+            seq = nn.Sequential()
+            for k, m in mods:
+                seq.add_module(k, m)
+            setattr(self, name, seq)
+
+    def forward(self, x):
+        outs = []
+        for name in ("slice1", "slice2", "slice3", "slice4", "slice5"):
+            x = getattr(self, name)(x)
+            outs.append(x)
+        return outs
+
+
+class _NetLinLayer(nn.Module):
+    def __init__(self, chn_in):
+        super().__init__()
+        self.model = nn.Sequential(nn.Dropout(), nn.Conv2d(chn_in, 1, 1, 1, 0, bias=False))
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class LPIPS(nn.Module):
+    CHNS = (64, 192, 384, 256, 256)
+
+    def __init__(self, seed: int = 1234, **_ignored):
+        super().__init__()
+        self.scaling_layer = _ScalingLayer()
+        self.net = _Alex()
+        self.lins = nn.ModuleList([_NetLinLayer(c) for c in self.CHNS])
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for p in self.net.parameters():
+                bound = 1.0 / (p[0].numel() ** 0.5) if p.ndim > 1 else 0.05
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * bound)
+            for lin in self.lins:
+                w = lin.model[1].weight
+                w.copy_(torch.rand(w.shape, generator=g) / w.shape[1])
+        self.eval()
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def forward(self, in0, in1, normalize: bool = False):
+        if normalize:
+            in0 = 2 * in0 - 1
+            in1 = 2 * in1 - 1
+        f0 = self.net(self.scaling_layer(in0))
+        f1 = self.net(self.scaling_layer(in1))
+        val = 0
+        for k in range(5):
+            n0 = f0[k] / (torch.sqrt(torch.sum(f0[k] ** 2, dim=1, keepdim=True)) + 1e-10)
+            n1 = f1[k] / (torch.sqrt(torch.sum(f1[k] ** 2, dim=1, keepdim=True)) + 1e-10)
+            val = val + self.lins[k]((n0 - n1) ** 2).mean([2, 3], keepdim=True)
+        return val
+
+
+class PerceptualLoss(nn.Module):
+    def __init__(self, dimensions: int, include_pixel_loss: bool = True, is_fake_3d: bool = True,
+                 drop_ratio: float = 0.0, fake_3d_axis: Tuple[int, ...] = (2, 3, 4), lpips_kwargs: Dict = None,
+                 lpips_normalize: bool = True, spatial: bool = False):
+        super().__init__()
+        if dimensions not in (2, 3):
+            raise NotImplementedError("Perceptual loss is implemented only in 2D and 3D.")
+        if dimensions == 3 and is_fake_3d is False:
+            raise NotImplementedError("True 3D perceptual loss is not implemented yet.")
+        self.dimensions = dimensions
+        self.include_pixel_loss = include_pixel_loss
+        self.fake_3D_views = (
+            ([((0, 2, 1, 3, 4), (1, 3, 4))] if 2 in fake_3d_axis else [])
+            + ([((0, 3, 1, 2, 4), (1, 2, 4))] if 3 in fake_3d_axis else [])
+            + ([((0, 4, 1, 2, 3), (1, 2, 3))] if 4 in fake_3d_axis else [])
+        ) if is_fake_3d else None
+        self.keep_ratio = 1 - drop_ratio
+        self.lpips_normalize = lpips_normalize
+        self.perceptual_function = LPIPS(**(lpips_kwargs or {}))
+        self.perceptual_factor = 1
+
+    @torch.no_grad()
+    def forward(self, y: torch.Tensor, y_pred: torch.Tensor) -> torch.Tensor:
+        y = y.float()
+        y_pred = y_pred.float()
+        if self.dimensions == 3 and self.fake_3D_views:
+            loss = torch.zeros(())
+            for permute_dims, view_dims in self.fake_3D_views:  # reference quirk Q7: the last view wins
+                loss = self._calculate_fake_3d_loss(y, y_pred, permute_dims, view_dims) * self.perceptual_factor
+            return loss
+        return self.perceptual_function.forward(y, y_pred, normalize=self.lpips_normalize) * self.perceptual_factor
+
+    def _calculate_fake_3d_loss(self, y, y_pred, permute_dims, view_dims):
+        ys = y.permute(*permute_dims).contiguous().view(-1, *(y.shape[d] for d in view_dims))
+        ps = y_pred.permute(*permute_dims).contiguous().view(-1, *(y_pred.shape[d] for d in view_dims))
+        n = int(ps.shape[0] * self.keep_ratio)  # keep_ratio == 1 on the path; identity order (Q7)
+        return torch.mean(self.perceptual_function.forward(ys[:n], ps[:n], normalize=self.lpips_normalize))
+
+    def get_perceptual_factor(self) -> float:
+        return self.perceptual_factor
+
+    def set_perceptual_factor(self, perceptual_factor: float) -> float:
+        self.perceptual_factor = perceptual_factor
+        return self.get_perceptual_factor()

@@ -1,0 +1,379 @@
+"""``Reconstruct``: the multi-t reconstruction trainer with the reference's surface.
+
+Mirrors /root/reference/src/trainers/base.py:19-164 (setup half: device / process group,
+stage-1 model, ``small`` / ``big`` UNet constructor arguments, schedule parameters, checkpoint
+load with the reference's exceptions) and /root/reference/src/trainers/reconstruct.py:29-330
+(``get_scores`` hot loops, CSV files, ``_vflip`` / ``_hflip`` out-set variants).
+
+What is MI355X-native here (and differs in mechanism, not in results, from the reference):
+  * the UNet forward is one native call (ddpm_unet_forward), the PLMS update / add_noise /
+    clamp+MSE are single fused HIP kernels; there is no autocast (fp32 throughout, Q5);
+  * timesteps live on the device (one cached int64 tensor per step value, Q18) and scores
+    come back with ONE device->host copy per batch instead of 2*B ``.item()`` syncs per t;
+  * noise is an explicit, host-generated, per-image seeded input (``--seed`` finally has an
+    effect, Q2), so results do not depend on batch composition or rank count;
+  * images are sharded round-robin over ranks and scores return through a single RCCL
+    all_gather of a dense [n, n_t, 2] fp32 tensor (+ int32 ids) instead of
+    all_gather_object of pickled dict rows; only rank 0 writes the CSV (Q6).
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import pandas as pd
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import _lib, ops
+from .data import get_data_loader
+from .perceptual import PerceptualLoss
+from .scheduler import DDPMScheduler, PNDMScheduler
+from .unet import DiffusionModelUNet
+from .vqvae import VQVAE, PassthroughVQVAE
+
+MODEL_CONFIGS = {  # /root/reference/src/trainers/base.py:65-86
+    "small": dict(num_channels=(128, 256, 256), attention_levels=(False, False, True), num_res_blocks=1,
+                  num_head_channels=256),
+    "big": dict(num_channels=(256, 512, 768), attention_levels=(True, True, True), num_res_blocks=2,
+                num_head_channels=256),
+}
+
+
+def image_noise(seed: int, index: int, t_start: int, shape) -> torch.Tensor:
+    """The noise input of one (image, t_start) reconstruction: host fp32 N(0, 1), a pure
+    function of (seed, global image index, t_start)."""
+    g = torch.Generator().manual_seed((int(seed) * 1_000_003 + int(index)) * 1_009 + int(t_start))
+    return torch.randn(tuple(shape), generator=g, dtype=torch.float32)
+
+
+def batch_noise(seed: int, indices, t_start: int, shape) -> torch.Tensor:
+    return torch.stack([image_noise(seed, i, t_start, shape[1:]) for i in indices])
+
+
+def snr_shift_tables(scheduler, snr_shift: float) -> None:
+    """/root/reference/src/trainers/reconstruct.py:106-117 (same code at base.py:104-116)."""
+    snr = scheduler.alphas_cumprod / (1 - scheduler.alphas_cumprod)
+    target_snr = snr * snr_shift
+    new_alphas_cumprod = 1 / (torch.pow(target_snr, -1) + 1)
+    new_alphas = torch.zeros_like(new_alphas_cumprod)
+    new_alphas[0] = new_alphas_cumprod[0]
+    for i in range(1, len(new_alphas)):
+        new_alphas[i] = new_alphas_cumprod[i] / new_alphas_cumprod[i - 1]
+    scheduler.betas = 1 - new_alphas
+    scheduler.alphas = new_alphas
+    scheduler.alphas_cumprod = new_alphas_cumprod
+
+
+def gather_scores(ids: torch.Tensor, scores: torch.Tensor):
+    """Single all_gather of dense per-image scores.
+
+    ids: int32 [n_local] global image indices; scores: fp32 [n_local, n_t, 2].
+    Returns (ids, scores) concatenated rank-major on every rank (the reference's
+    all_gather_object semantics, reconstruct.py:238-242, in 2 MB instead of 30 MB of pickles).
+    Short shards are padded with id = -1 and dropped after the gather."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return ids, scores
+    world = dist.get_world_size()
+    n = torch.tensor([ids.shape[0]], dtype=torch.int64, device=ids.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    n_max = int(max(int(c) for c in counts))
+    n_t = scores.shape[1]
+    # ids travel inside the same fp32 payload (exact for ids < 2^24): one collective, not two
+    payload = torch.full((n_max, n_t * 2 + 1), -1.0, dtype=torch.float32, device=scores.device)
+    payload[: ids.shape[0], 0] = ids.to(torch.float32)
+    payload[: ids.shape[0], 1:] = scores.reshape(ids.shape[0], -1)
+    out = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(out, payload)
+    allp = torch.cat(out, dim=0)
+    keep = allp[:, 0] >= 0
+    allp = allp[keep]
+    return allp[:, 0].to(torch.int32), allp[:, 1:].reshape(-1, n_t, 2)
+
+
+class BaseTrainer:
+    def __init__(self, args):
+        # initialise the process group if launched with torchrun (base.py:22-33)
+        if "LOCAL_RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            print("Setting up DDP.")
+            self.ddp = True
+            local_rank = int(os.environ["LOCAL_RANK"])
+            if local_rank != 0:
+                sys.stdout = sys.stderr = open(os.devnull, "w")
+            if not dist.is_initialized():
+                # backend "nccl" IS RCCL on ROCm: one process per GPU, xGMI underneath
+                dist.init_process_group(backend="nccl", init_method="env://")
+            self.device = torch.device(f"cuda:{local_rank}")
+        else:
+            self.ddp = False
+            self.device = torch.device("cuda:0")
+        if not torch.cuda.is_available():
+            raise RuntimeError("No ROCm device visible: the HIP reconstruction path has no CPU fallback "
+                               "(the CPU oracle under oracle/ is test infrastructure only)")
+        _lib.load()  # fail before any work if the native library is missing
+        torch.cuda.set_device(self.device)
+        self.rank = dist.get_rank() if self.ddp else 0
+        self.world = dist.get_world_size() if self.ddp else 1
+
+        print(f"Arguments: {str(args)}")
+        for k, v in vars(args).items():
+            print(f"  {k}: {v}")
+
+        # stage-1 model (base.py:44-64)
+        if args.vqvae_checkpoint:
+            vqvae_checkpoint_path = Path(args.vqvae_checkpoint)
+            vqvae_config_path = vqvae_checkpoint_path.parent / "vqvae_config.json"
+            if not vqvae_checkpoint_path.exists():
+                raise FileNotFoundError(f"Cannot find VQ-VAE checkpoint {vqvae_checkpoint_path}")
+            if not vqvae_config_path.exists():
+                raise FileNotFoundError(f"Cannot find VQ-VAE config {vqvae_config_path}")
+            with open(vqvae_config_path, "r") as f:
+                self.vqvae_config = json.load(f)
+            self.vqvae_model = VQVAE(**self.vqvae_config)
+            ddpm_channels = self.vqvae_config["embedding_dim"]
+        else:
+            self.vqvae_model = PassthroughVQVAE()
+            ddpm_channels = 1 if args.is_grayscale else 3
+        if args.model_type not in MODEL_CONFIGS:
+            raise ValueError(f"Do not recognise model type {args.model_type}")
+        self.model = DiffusionModelUNet(spatial_dims=args.spatial_dimension, in_channels=ddpm_channels,
+                                        out_channels=ddpm_channels, with_conditioning=False,
+                                        use_proj_attn=bool(getattr(args, "use_proj_attn", 0)),
+                                        **MODEL_CONFIGS[args.model_type]).to(self.device)
+        print(f"{sum(p.numel() for p in self.model.parameters()):,} model parameters")
+
+        self.prediction_type = args.prediction_type
+        self.beta_schedule = args.beta_schedule
+        self.beta_start = args.beta_start
+        self.beta_end = args.beta_end
+        self.b_scale = args.b_scale
+        self.snr_shift = args.snr_shift
+        self.scheduler = DDPMScheduler(num_train_timesteps=1000, prediction_type=self.prediction_type,
+                                       schedule=self.beta_schedule, beta_start=self.beta_start,
+                                       beta_end=self.beta_end)
+        if self.snr_shift != 1:
+            print("Changing scheduler parameters to shift SNR")
+            snr_shift_tables(self.scheduler, self.snr_shift)
+        self.simplex_noise = bool(args.simplex_noise)
+        if self.simplex_noise:
+            raise NotImplementedError("--simplex_noise is off the path (default 0, in no BASELINE config)")
+        self.spatial_dimension = args.spatial_dimension
+        self.image_size = int(args.image_size) if args.image_size else args.image_size
+        if args.latent_pad:
+            self.do_latent_pad = True
+            self.latent_pad = args.latent_pad
+            self.inverse_latent_pad = [-x for x in self.latent_pad]
+        else:
+            self.do_latent_pad = False
+
+        # checkpoint (base.py:133-158; map_location added so a CPU-saved file loads, Q4)
+        self.run_dir = Path(args.output_dir) / args.model_name
+        if args.ddpm_checkpoint_epoch:
+            checkpoint_path = self.run_dir / f"checkpoint_{int(args.ddpm_checkpoint_epoch)}.pth"
+        else:
+            checkpoint_path = self.run_dir / "checkpoint.pth"
+        if checkpoint_path.exists():
+            checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+            self.found_checkpoint = True
+            self.start_epoch = checkpoint["epoch"] + 1
+            self.global_step = checkpoint["global_step"]
+            self.model.load_state_dict(checkpoint["model_state_dict"])
+            self.best_loss = checkpoint["best_loss"]
+            print(f"Resuming training using checkpoint {checkpoint_path} at epoch {self.start_epoch}")
+        else:
+            self.start_epoch = 0
+            self.best_loss = 1000
+            self.global_step = 0
+            self.found_checkpoint = False
+        # no optimizer, no GradScaler, no DDP wrap: inference only, every rank reads the same
+        # checkpoint file instead of the reference's DDP parameter broadcast (Q15)
+
+
+class Reconstruct(BaseTrainer):
+    def __init__(self, args):
+        super().__init__(args)
+        if not self.found_checkpoint:
+            raise FileNotFoundError("Failed to find a saved model checkpoint.")
+        self.out_dir = self.run_dir / "ood"
+        if self.rank == 0:
+            self.out_dir.mkdir(exist_ok=True)
+        self.seed = int(args.seed)
+        self.num_inference_steps = int(getattr(args, "honour_num_inference_steps", 0)
+                                       and args.num_inference_steps) or 100  # Q1: 100 is hard-coded
+        self.reset_scheduler_per_t = bool(getattr(args, "reset_scheduler_per_t", 0))
+        self.timestep_list = getattr(args, "timestep_list", "monai")
+        self.lpips_weights = getattr(args, "lpips_weights", None)
+        self._loader_args = dict(batch_size=args.batch_size, is_grayscale=bool(args.is_grayscale),
+                                 image_size=self.image_size, drop_last=bool(args.drop_last),
+                                 spatial_dimension=args.spatial_dimension, image_roi=args.image_roi,
+                                 rank=self.rank, world=self.world)
+        self.val_loader = get_data_loader(args.validation_ids,
+                                          first_n=int(args.first_n_val) if args.first_n_val else args.first_n_val,
+                                          **self._loader_args)
+        self.in_loader = get_data_loader(args.in_ids, first_n=int(args.first_n) if args.first_n else args.first_n,
+                                         **self._loader_args)
+        self._ts_cache = {}
+        self._pl = None
+        self.last_stats = {}
+
+    # ---- helpers -------------------------------------------------------------------------------------
+    def _timesteps_tensor(self, step: int, batch: int) -> torch.Tensor:
+        key = (int(step), batch)
+        t = self._ts_cache.get(key)
+        if t is None:
+            t = torch.full((batch,), int(step), dtype=torch.int64, device=self.device)
+            self._ts_cache[key] = t
+        return t
+
+    def _perceptual(self) -> PerceptualLoss:
+        if self._pl is None:
+            pl = PerceptualLoss(dimensions=self.spatial_dimension, include_pixel_loss=False,
+                                is_fake_3d=True if self.spatial_dimension == 3 else False, lpips_normalize=True,
+                                spatial=False)
+            if self.lpips_weights:
+                pl.perceptual_function.load_state_dict(torch.load(self.lpips_weights, map_location="cpu"))
+            self._pl = pl.to(self.device)
+        return self._pl
+
+    def make_scheduler(self) -> PNDMScheduler:
+        s = PNDMScheduler(num_train_timesteps=1000, skip_prk_steps=True, prediction_type=self.prediction_type,
+                          schedule=self.beta_schedule, beta_start=self.beta_start, beta_end=self.beta_end,
+                          timestep_list=self.timestep_list)
+        if self.snr_shift != 1:
+            snr_shift_tables(s, self.snr_shift)
+        s.set_timesteps(self.num_inference_steps)
+        return s
+
+    # ---- the hot loops (reconstruct.py:72-250) ---------------------------------------------------
+    @torch.no_grad()
+    def get_scores(self, loader, dataset_name, inference_skip_factor):
+        if self.ddp:
+            sys.stdout, sys.stderr = sys.__stdout__, sys.__stderr__
+            print(f"{self.rank}: {dataset_name}")
+        else:
+            print(f"{dataset_name}")
+        pl = self._perceptual()
+        self.model.eval()
+        ids_all, names_all, scores_all, t_values = [], [], [], None
+        n_recon = n_fwd = 0
+        for batch in loader:
+            sched = self.make_scheduler()  # one per batch: PLMS history leaks across t-starts (Q3)
+            timesteps = sched.timesteps
+            start_points = reversed(timesteps)[1::inference_skip_factor]
+            t_values = [int(t) for t in start_points]
+
+            t1 = time.time()
+            images_original = batch["image"].to(self.device, non_blocking=True).float().contiguous()
+            images = self.vqvae_model.encode_stage_2_inputs(images_original)
+            if self.do_latent_pad:
+                images = F.pad(input=images, pad=self.latent_pad, mode="constant", value=0)
+            B = images.shape[0]
+            idx = batch["index"]
+            per_t = []
+            for t_start in start_points:
+                if self.reset_scheduler_per_t:
+                    sched.set_timesteps(self.num_inference_steps)
+                start_timesteps = torch.Tensor([t_start] * B).long()
+                noise = batch_noise(self.seed, idx, int(t_start), images.shape).to(self.device, non_blocking=True)
+                x = sched.add_noise(original_samples=images, noise=noise, timesteps=start_timesteps,
+                                    b_scale=self.b_scale)
+                for step in timesteps[timesteps <= t_start]:
+                    eps = self.model(x, timesteps=self._timesteps_tensor(int(step), B))
+                    x, _ = sched.step(eps, step, x)
+                    n_fwd += B
+                if self.do_latent_pad:
+                    x = F.pad(input=x, pad=self.inverse_latent_pad, mode="constant", value=0).contiguous()
+                x = self.vqvae_model.decode_stage_2_outputs(x)
+                mse = ops.clamp_mse_(images_original, x, self.b_scale)  # x / b_scale, clamp_(0, 1), MSE
+                if self.spatial_dimension == 2:
+                    if images_original.shape[3] == 28:
+                        pd_ = pl(F.pad(images_original, (2, 2, 2, 2)), F.pad(x, (2, 2, 2, 2)))
+                    else:
+                        pd_ = pl(images_original, x)
+                    pd_ = pd_.reshape(B)
+                else:
+                    pd_ = torch.stack([pl(images_original[b, None, ...], x[b, None, ...]).reshape(())
+                                       for b in range(B)])
+                per_t.append(torch.stack([pd_, mse], dim=1))
+                n_recon += B
+            scores = torch.stack(per_t, dim=1)  # [B, n_t, 2] on the device
+            scores_all.append(scores)
+            ids_all.append(torch.tensor(idx, dtype=torch.int32))
+            names_all.extend(batch["image_meta_dict"]["filename_or_obj"])
+            torch.cuda.current_stream().synchronize()
+            t2 = time.time()
+            if self.ddp:
+                print(f"{self.rank}: Took {t2-t1}s for a batch size of {B}")
+            else:
+                print(f"Took {t2-t1}s for a batch size of {B}")
+        self.last_stats = {"reconstructions": n_recon, "unet_forwards": n_fwd}
+
+        if not scores_all:
+            return []
+        scores = torch.cat(scores_all, dim=0)
+        ids = torch.cat(ids_all).to(self.device)
+        name_of = dict(zip((int(i) for i in torch.cat(ids_all)), names_all))
+        if self.ddp:
+            ids, scores = gather_scores(ids, scores)
+            # every rank can name every image: the id list is the same file on every rank
+            name_of = {i: n for i, n in enumerate(loader.all_names)} if hasattr(loader, "all_names") else name_of
+            if int(os.environ["LOCAL_RANK"]) != 0:
+                sys.stdout = sys.stderr = open(os.devnull, "w")
+        ids = ids.cpu().tolist()
+        scores = scores.cpu()  # the one device->host copy
+        results = []
+        # row order of the reference: per batch, per t_start, per image
+        bs = loader.batch_size
+        for s in range(0, len(ids), bs):
+            for j, t in enumerate(t_values):
+                for b in range(s, min(len(ids), s + bs)):
+                    filename = name_of.get(ids[b], str(ids[b]))
+                    stem = Path(filename).stem.replace(".nii", "").replace(".gz", "")
+                    results.append({"filename": stem, "type": dataset_name, "t": t,
+                                    "perceptual_difference": scores[b, j, 0].item(), "mse": scores[b, j, 1].item()})
+        return results
+
+    def _write(self, results_list, name):
+        if self.rank == 0:
+            pd.DataFrame(results_list).to_csv(self.out_dir / f"results_{name}.csv")
+
+    def reconstruct(self, args):
+        if bool(args.run_val):
+            self._write(self.get_scores(self.val_loader, "val", args.inference_skip_factor), "val")
+        if bool(args.run_in):
+            self._write(self.get_scores(self.in_loader, "in", args.inference_skip_factor), "in")
+        if bool(args.run_out):
+            for out in args.out_ids.split(","):
+                print(out)
+                flips = {}
+                if "vflip" in out:
+                    out = out.replace("_vflip", "")
+                    flips, suffix = {"add_vflip": True}, "_vflip"
+                elif "hflip" in out:
+                    out = out.replace("_hflip", "")
+                    flips, suffix = {"add_hflip": True}, "_hflip"
+                else:
+                    suffix = ""
+                out_loader = get_data_loader(out, first_n=int(args.first_n) if args.first_n else args.first_n,
+                                             **flips, **self._loader_args)
+                dataset_name = dataset_stem(out) + suffix
+                self._write(self.get_scores(out_loader, "out", args.inference_skip_factor), dataset_name)
+
+
+def dataset_stem(ids: str) -> str:
+    """Path(out).stem.split("_")[0] of the reference (reconstruct.py:287,308,327); synthetic
+    specs are named by their kind."""
+    if str(ids).startswith("synthetic:"):
+        parts = str(ids).split(":")
+        name = parts[1]
+        for p in parts[2:]:
+            if p.startswith("name="):
+                name = p[5:]
+        return name
+    return Path(ids).stem.split("_")[0]

@@ -1,0 +1,169 @@
+/*
+ * ddpm_ood_hip.h -- C ABI of libddpm_ood_hip.so (gfx950 / CDNA4).
+ *
+ * Drop-in boundary for the multi-t DDPM reconstruction hot path of marksgraham/ddpm-ood.
+ * The reference has no FFI of its own: its boundary is the duck-typed Python call surface
+ * between src/trainers/reconstruct.py and the third-party `generative` package
+ * (SURVEY.md 8b).  Each entry point below names the reference call site it replaces.
+ * The Python mirror classes in ddpm_ood_amd/ bind these symbols with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated;
+ *   - tensors are contiguous fp32 NC(D)HW, timesteps are int64 (torch.long);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - nothing here allocates, frees or synchronises: workspaces and packed-parameter blobs
+ *     are caller-owned (PyTorch-ROCm caching allocator in the Python host);
+ *   - return value 0 = success, otherwise a negative DDPM_E* code or a positive
+ *     hipError_t; ddpm_last_error() returns a thread-local message.
+ */
+#ifndef DDPM_OOD_HIP_H
+#define DDPM_OOD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDPM_ABI_VERSION 1
+
+#define DDPM_EINVAL (-1)      /* bad argument / unsupported shape      */
+#define DDPM_ENOPARAM (-2)    /* unknown or missing parameter name     */
+#define DDPM_EWORKSPACE (-3)  /* caller workspace too small            */
+
+typedef void *ddpm_stream_t;
+
+int ddpm_abi_version(void);
+const char *ddpm_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Stand-alone operators (each replaces one ATen dispatch chain on the path).
+ * ---------------------------------------------------------------------------------- */
+
+/* conv modes / activation flags for ddpm_conv_f32 */
+#define DDPM_CONV_NORMAL 0
+#define DDPM_CONV_STRIDE2 1   /* kernel 3, stride 2, pad 1  (Downsample.op)               */
+#define DDPM_CONV_UPSAMPLE2 2 /* nearest x2 folded into the input indexing (Upsample)     */
+#define DDPM_ACT_NONE 0
+#define DDPM_ACT_SILU 1
+
+/* Fused convolution / linear descriptor.  out = conv(act(affine(cat(in1,in2)))) + bias
+ *                                               + chan_add[n, co] + residual
+ * Replaces, inside DiffusionModelUNet.forward (reference call
+ * src/trainers/reconstruct.py:151-153): F.group_norm+F.silu (via gscale/gshift),
+ * torch.cat (in1/in2), F.interpolate(nearest) (mode), F.conv2d / F.linear (HW == 1),
+ * the "+ temb[:, :, None, None]" broadcast (chan_add) and the residual add.            */
+typedef struct ddpm_conv_desc {
+  const float *in1;      /* [B, C1, Hi, Wi]                                              */
+  const float *in2;      /* [B, C2, Hi, Wi] or NULL -- virtual channel concat            */
+  int C1, C2;
+  const float *w_packed; /* MFMA layout (ddpm_pack_conv_weight_f32) or NULL              */
+  const float *w_raw;    /* torch layout [Cout, Cin, k, k]; used when w_packed == NULL or
+                            the shape has no MFMA tiling                                 */
+  const float *bias;     /* [Cout] or NULL                                               */
+  const float *gscale;   /* [B, Cin] per-(image, channel) GroupNorm scale or NULL        */
+  const float *gshift;   /* [B, Cin]                                                     */
+  const float *chan_add; /* [B, chan_add_stride], entry [n, co] added, or NULL           */
+  int chan_add_stride;
+  const float *residual; /* [B, Cout, Ho, Wo] or NULL                                    */
+  float *out;            /* [B, Cout, Ho, Wo]                                            */
+  int B, Cout;
+  int Hi, Wi;            /* stored input extent                                          */
+  int Ho, Wo;            /* output extent                                                */
+  int ksize;             /* 1 or 3                                                       */
+  int mode;              /* DDPM_CONV_*                                                  */
+  int act;               /* DDPM_ACT_* applied after the affine                          */
+  int force_direct;      /* 1: take the generic direct kernel even if MFMA tiling exists */
+} ddpm_conv_desc;
+
+int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream);
+
+/* Number of floats of the packed form of a [Cout, Cin, k, k] weight (0 if unpackable). */
+size_t ddpm_packed_conv_weight_floats(int Cout, int Cin, int ksize);
+/* Pack torch-layout weights into rows [cout_offset, cout_offset + Cout) of a packed
+ * weight with `Cout_total` rows (lets q/k/v or all time_emb_proj share one GEMM).       */
+int ddpm_pack_conv_weight_f32(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize,
+                              int cout_offset, int Cout_total, ddpm_stream_t stream);
+
+/* GroupNorm statistics -> per-(image, channel) scale/shift so that
+ * y = x * scale + shift == F.group_norm(x, G, gamma, beta, eps).  cat(in1, in2) virtual. */
+int ddpm_gn_scale_shift_f32(const float *in1, const float *in2, int C1, int C2, const float *gamma,
+                            const float *beta, float *scale, float *shift, int B, int HW, int groups,
+                            float eps, ddpm_stream_t stream);
+
+/* Self-attention core of AttentionBlock (A.3): qkv is [B, 3C, N] (q rows, then k, then v,
+ * channel-major exactly as a 1x1 conv over NCHW produces them); out = softmax(scale q^T k) v
+ * + residual, written as [B, C, N].  Replaces torch.baddbmm / softmax / torch.bmm.       */
+int ddpm_attention_f32(const float *qkv, const float *residual, float *out, int B, int C, int N,
+                       int num_heads, float scale, ddpm_stream_t stream);
+
+/* get_timestep_embedding: out[b, :half] = cos(t_b * freqs), out[b, half:] = sin(...).   */
+int ddpm_timestep_embedding_f32(const int64_t *timesteps, const float *freqs, float *out, int B, int dim,
+                                ddpm_stream_t stream);
+
+/* scheduler.add_noise (src/trainers/reconstruct.py:143-147):
+ * out = sqrt_ac[b] * (x0 * b_scale) + sqrt_1m_ac[b] * noise ; coefficients are HOST arrays. */
+int ddpm_add_noise_f32(const float *x0, const float *noise, const float *h_sqrt_ac, const float *h_sqrt_1m_ac,
+                       float b_scale, float *out, int B, int64_t chw, ddpm_stream_t stream);
+
+/* PNDMScheduler.step_plms + _get_prev_sample (src/trainers/reconstruct.py:155-157).
+ * eps' = combination `kind` of up to four eps tensors (newest first):
+ *   0: e0            1: (e0 + e1) / 2          2: (3 e0 - e1) / 2
+ *   3: (23 e0 - 16 e1 + 5 e2) / 12             4: (1/24)(55 e0 - 59 e1 + 37 e2 - 9 e3)
+ * v-prediction (v_a != 0 or v_b != 0... flag): eps' = v_a * eps' + v_b * sample
+ * prev = sample_coeff * sample - (coef_eps * eps') / denom                                  */
+int ddpm_plms_step_f32(const float *sample, const float *e0, const float *e1, const float *e2, const float *e3,
+                       int kind, int v_prediction, float v_a, float v_b, float sample_coeff, float coef_eps,
+                       float denom, float *prev, int64_t numel, ddpm_stream_t stream);
+
+/* recon = clamp(recon * inv_b_scale... (recon / b_scale), 0, 1) in place and
+ * mse[b] = mean((orig - recon)^2) (src/trainers/reconstruct.py:167-168,188-191).          */
+int ddpm_clamp_mse_f32(const float *orig, float *recon, float b_scale, float *mse, int B, int64_t chw,
+                       ddpm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * UNet engine: DiffusionModelUNet(x, timesteps) as one native call
+ * (ctor kwargs: src/trainers/base.py:66-86; call: src/trainers/reconstruct.py:151-153).
+ * ---------------------------------------------------------------------------------- */
+#define DDPM_MAX_LEVELS 8
+
+typedef struct ddpm_unet_config {
+  int spatial_dims;                    /* 2 (3 is reserved for the LDM row)               */
+  int in_channels, out_channels;
+  int num_levels;
+  int num_channels[DDPM_MAX_LEVELS];
+  int attention_levels[DDPM_MAX_LEVELS];
+  int num_res_blocks[DDPM_MAX_LEVELS];
+  int num_head_channels[DDPM_MAX_LEVELS];
+  int norm_num_groups;
+  float norm_eps;
+  int use_proj_attn;                   /* SURVEY A.3 open point; default 0                */
+} ddpm_unet_config;
+
+typedef struct ddpm_unet ddpm_unet;
+
+ddpm_unet *ddpm_unet_create(const ddpm_unet_config *cfg);
+void ddpm_unet_destroy(ddpm_unet *h);
+
+/* Parameter storage: the caller allocates `ddpm_unet_param_blob_floats` floats on the device,
+ * binds them, then pushes every state_dict tensor by its MONAI-Generative key name
+ * (SURVEY A.5); conv / linear weights are re-laid-out for the MFMA kernels on the device.  */
+size_t ddpm_unet_param_blob_floats(const ddpm_unet *h);
+int ddpm_unet_bind_param_blob(ddpm_unet *h, float *blob);
+int ddpm_unet_num_params(const ddpm_unet *h);
+const char *ddpm_unet_param_name(const ddpm_unet *h, int i);
+int64_t ddpm_unet_param_numel(const ddpm_unet *h, int i);
+int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *src, int64_t numel, ddpm_stream_t stream);
+/* "freqs" (timestep-embedding frequency table, [num_channels[0] / 2]) is pushed through
+ * ddpm_unet_set_param too; it is computed by the host exactly as the reference does.      */
+
+size_t ddpm_unet_workspace_bytes(const ddpm_unet *h, int B, int H, int W);
+int ddpm_unet_forward(ddpm_unet *h, const float *x, const int64_t *timesteps, float *out, int B, int H, int W,
+                      void *workspace, size_t workspace_bytes, ddpm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDPM_OOD_HIP_H */

@@ -1,0 +1,227 @@
+"""-m gpu: per-kernel parity of the HIP operators (through the C ABI) against plain PyTorch
+CPU fp32 ops -- the per-op ground truth named in SURVEY.md 8(c).
+
+Tolerances (fp32): conv / GEMM outputs are compared with
+    |hip - ref| <= 2e-5 * (1 + max|ref|)     [k-ordered fp32 FMA chain vs oneDNN blocking; the
+    f32 MFMA is exact fp32, so the only difference is summation order, ~1e-7 * sum|a b|]
+elementwise kernels with 1e-6 absolute.
+"""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, ref, tol=2e-5):
+    a = a.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    err = (a - ref).abs().max().item()
+    bound = tol * (1.0 + ref.abs().max().item())
+    assert math.isfinite(err) and err <= bound, f"max err {err:.3e} > {bound:.3e}"
+
+
+def _ref_conv(x, x2, w, b, gn, act, mode, chan_add, residual):
+    xin = x if x2 is None else torch.cat([x, x2], 1)
+    if gn is not None:
+        gamma, beta, G, eps = gn
+        xin = F.group_norm(xin, G, gamma, beta, eps)
+    if act:
+        xin = F.silu(xin)
+    if mode == 2:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    k = w.shape[-1] if w.ndim == 4 else 1
+    y = F.conv2d(xin, w if w.ndim == 4 else w[:, :, None, None], b, stride=2 if mode == 1 else 1,
+                 padding=1 if k == 3 else 0)
+    if chan_add is not None:
+        y = y + chan_add[:, :, None, None]
+    if residual is not None:
+        y = y + residual
+    return y
+
+
+CONV_CASES = [
+    # B, C1, C2, Cout, H, k, mode, gn, act, chan_add, residual
+    (2, 128, 0, 128, 32, 3, 0, True, True, True, False),    # down0 conv1
+    (2, 128, 0, 128, 32, 3, 0, True, True, False, True),    # down0 conv2 + identity skip
+    (2, 128, 0, 128, 32, 3, 1, False, False, False, False),  # downsampler 32 -> 16
+    (2, 128, 0, 256, 16, 3, 0, True, True, True, False),    # down1 conv1
+    (3, 256, 0, 256, 16, 3, 1, False, False, False, False),  # downsampler 16 -> 8
+    (3, 256, 256, 256, 8, 3, 0, True, True, True, False),   # up0 conv1 on a virtual concat
+    (2, 256, 128, 256, 16, 3, 0, True, True, True, False),  # 384 ch: GroupNorm group straddles the seam
+    (2, 256, 0, 256, 8, 3, 2, False, False, False, False),   # upsampler 8 -> 16
+    (2, 256, 0, 256, 16, 3, 2, False, False, False, False),  # upsampler 16 -> 32
+    (2, 256, 128, 128, 32, 1, 0, False, False, False, True),  # 1x1 skip + residual
+    (1, 256, 0, 768, 8, 1, 0, True, False, False, False),    # fused QKV (affine, no SiLU), partial tile
+    (5, 256, 256, 256, 8, 3, 0, True, True, True, False),   # odd batch: ragged last tile
+    (1, 256, 0, 512, 64, 3, 0, True, True, False, False),   # W = 64 (two staging positions)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("force_direct", [False, True])
+def test_conv(device, case, force_direct):
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, Cout, H, k, mode, gn, act, chan, res = case
+    if force_direct and H == 64:
+        pytest.skip("direct kernel at 64x64x512 is only slow, not different")
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    Cin = C1 + C2
+    x = torch.randn(B, C1, H, H, generator=g)
+    x2 = torch.randn(B, C2, H, H, generator=g) * 1.5 + 0.3 if C2 else None
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    Ho = H // 2 if mode == 1 else (2 * H if mode == 2 else H)
+    gamma = torch.randn(Cin, generator=g) * 0.2 + 1
+    beta = torch.randn(Cin, generator=g) * 0.2
+    chan_add = torch.randn(B, Cout + 64, generator=g) if chan else None
+    residual = torch.randn(B, Cout, Ho, Ho, generator=g) if res else None
+    ref = _ref_conv(x, x2, w, b, (gamma, beta, 32, 1e-6) if gn else None, act, mode,
+                    chan_add[:, 32:32 + Cout] if chan else None, residual)
+
+    d = lambda t: None if t is None else t.to(device)
+    gs = gh = None
+    if gn:
+        gs, gh = ops.gn_scale_shift(d(x), d(gamma), d(beta), 32, 1e-6, x2=d(x2))
+    y = ops.conv(d(x), d(w), d(b), x2=d(x2), gscale=gs, gshift=gh, act=int(act), mode=mode, chan_add=d(chan_add),
+                 chan_add_offset=32, residual=d(residual), force_direct=force_direct)
+    torch.cuda.synchronize()
+    _close(y, ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 128, 32), (2, 3, 128, 32), (2, 128, 1, 32), (2, 128, 3, 32),
+                                   (2, 1, 128, 28), (1, 32, 64, 14), (2, 64, 64, 7)])
+def test_conv_direct_shapes(device, shape):
+    """conv_in / conv_out and extents with no MFMA tiling (28, 14, 7) take the direct kernel."""
+    from ddpm_ood_amd import ops
+
+    B, Cin, Cout, H = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    y = ops.conv(x.to(device), w.to(device), b.to(device))
+    _close(y, F.conv2d(x, w, b, padding=1))
+    if H % 2 == 0:
+        y = ops.conv(x.to(device), w.to(device), b.to(device), mode=1)
+        _close(y, F.conv2d(x, w, b, padding=1, stride=2))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,act", [(16, 128, 512, 0), (256, 512, 512, 1), (3, 512, 2432, 1),
+                                            (130, 512, 256, 0), (4, 32, 96, 1)])
+def test_linear(device, B, Cin, Cout, act):
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, Cin, generator=g)
+    w = torch.randn(Cout, Cin, generator=g) / math.sqrt(Cin)
+    b = torch.randn(Cout, generator=g)
+    y = ops.conv(x.to(device), w.to(device), b.to(device), act=act)
+    _close(y, F.linear(F.silu(x) if act else x, w, b))
+
+
+@pytest.mark.parametrize("B,C1,C2,HW", [(2, 128, 0, 1024), (3, 256, 128, 256), (2, 256, 256, 64), (1, 64, 0, 49),
+                                        (2, 768, 0, 4096)])
+def test_gn_scale_shift(device, B, C1, C2, HW):
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, C1, HW, generator=g) * 2 + 0.7
+    x2 = torch.randn(B, C2, HW, generator=g) - 1 if C2 else None
+    C = C1 + C2
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    sc, sh = ops.gn_scale_shift(x.to(device), gamma.to(device), beta.to(device), 32, 1e-6,
+                                x2=None if x2 is None else x2.to(device))
+    xin = x if x2 is None else torch.cat([x, x2], 1)
+    ref = F.group_norm(xin, 32, gamma, beta, 1e-6)
+    got = xin * sc.cpu()[:, :, None] + sh.cpu()[:, :, None]
+    _close(got, ref, tol=5e-6)
+
+
+@pytest.mark.parametrize("B,heads,N", [(3, 1, 64), (2, 2, 256), (1, 3, 100), (2, 1, 8), (1, 1, 1024)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_attention(device, B, heads, N, with_res):
+    from ddpm_ood_amd import ops
+
+    C = 256 * heads
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B, 3 * C, N, generator=g)
+    qkv[:, :C] *= 1.5  # make the softmax peaky enough to exercise the running max
+    res = torch.randn(B, C, N, generator=g) if with_res else None
+    scale = 1 / math.sqrt(C / heads)
+    out = ops.attention(qkv.to(device), None if res is None else res.to(device), heads, scale)
+    q, k, v = (t.reshape(B, heads, 256, N) for t in qkv.split(C, dim=1))
+    s = torch.einsum("bhdi,bhdj->bhij", q, k) * scale
+    o = torch.einsum("bhij,bhdj->bhdi", s.softmax(-1), v).reshape(B, C, N)
+    _close(out, o + res if with_res else o, tol=1e-5)
+
+
+def test_attention_online_softmax_rescale(device):
+    """Force the running-max rescale: the largest logit of every query sits in the LAST key block."""
+    from ddpm_ood_amd import ops
+
+    B, C, N = 1, 256, 256
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B, 3 * C, N, generator=g) * 0.3
+    qkv[:, C:2 * C, 200] = qkv[:, :C, :].mean(-1) * 0 + 3.0 * torch.sign(qkv[:, :C, 5])  # spike key 200
+    out = ops.attention(qkv.to(device), None, 1, 1 / 16.0)
+    q, k, v = qkv.split(C, dim=1)
+    s = torch.einsum("bdi,bdj->bij", q, k) / 16.0
+    _close(out, torch.einsum("bij,bdj->bdi", s.softmax(-1), v), tol=1e-5)
+
+
+def test_timestep_embedding_and_known_answer(device):
+    from ddpm_ood_amd import ops
+    from oracle.unet import get_timestep_embedding
+
+    t = torch.tensor([0, 10, 650, 990], dtype=torch.int64)
+    half = 64
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+    out = ops.timestep_embedding(t.to(device), freqs.to(device), 128).cpu()
+    assert torch.equal(out[0], torch.cat([torch.ones(64), torch.zeros(64)]))  # t = 0 -> [1..1, 0..0]
+    assert (out - get_timestep_embedding(t, 128)).abs().max() < 2e-6
+
+
+def test_add_noise_plms_clamp_mse(device):
+    from ddpm_ood_amd import ops
+    from ddpm_ood_amd.scheduler import PNDMScheduler
+    import oracle
+
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.rand(6, 1, 32, 32, generator=g)
+    noise = torch.randn(6, 1, 32, 32, generator=g)
+    kw = dict(num_train_timesteps=1000, skip_prk_steps=True, schedule="scaled_linear_beta", beta_start=0.0015,
+              beta_end=0.0195)
+    hs, osch = PNDMScheduler(**kw), oracle.PNDMScheduler(**kw)
+    hs.set_timesteps(100)
+    osch.set_timesteps(100)
+    assert torch.equal(hs.timesteps, osch.timesteps) and torch.equal(hs.alphas_cumprod, osch.alphas_cumprod)
+    t = torch.tensor([650] * 6)
+    xh = hs.add_noise(x0.to(device), noise.to(device), t, b_scale=1.7)
+    xo = osch.add_noise(x0 * 1.7, noise, t)
+    assert (xh.cpu() - xo).abs().max() < 1e-6
+    # walk 7 PLMS steps with synthetic eps: exercises every multistep formula incl. the Heun-style start
+    xh, xo_ = xh, xo
+    for i, step in enumerate(hs.timesteps[hs.timesteps <= 650][:7]):
+        eps = torch.randn(6, 1, 32, 32, generator=g)
+        xh, _ = hs.step(eps.to(device), step, xh)
+        xo_, _ = osch.step(eps, step, xo_)
+        assert (xh.cpu() - xo_).abs().max() < 2e-6, f"step {i}"
+    rec = (xh * 0.4 + 0.3).contiguous()
+    mse = ops.clamp_mse_(x0.to(device), rec, 1.7)
+    ref = ((xo_ * 0.4 + 0.3) / 1.7).clamp(0, 1)
+    assert (rec.cpu() - ref).abs().max() < 1e-6
+    assert (mse.cpu() - torch.square(x0 - ref).mean(dim=(1, 2, 3))).abs().max() < 1e-7
+
+
+def test_no_cpu_fallback():
+    from ddpm_ood_amd import ops
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.conv(torch.zeros(1, 8, 8, 8), torch.zeros(8, 8, 3, 3))

@@ -1,0 +1,129 @@
+"""-m gpu: whole-network and whole-trajectory parity of the HIP path against the CPU oracle.
+
+Tolerance (stated by BASELINE.json's north_star): per-image MSE / LPIPS Z-scores within 1e-4
+fp32 on identical inputs / seeds.  A single UNet forward is held to 1e-4 * (1 + max|ref|).
+"""
+
+import math
+
+import pandas as pd
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(num_channels=(128, 256, 256), attention_levels=(False, False, True), num_res_blocks=1,
+             num_head_channels=256)
+
+
+def _pair(device, channels=1, cfg=SMALL, seed=1, **extra):
+    import oracle
+    from ddpm_ood_amd import DiffusionModelUNet
+    from ddpm_ood_amd.synthetic import random_state_dict
+
+    sd = random_state_dict(channels=channels, seed=seed, config=cfg)
+    ref = oracle.DiffusionModelUNet(2, channels, channels, **cfg, **extra).eval()
+    ref.load_state_dict(sd)
+    hip = DiffusionModelUNet(2, channels, channels, **cfg, **extra)
+    hip.load_state_dict(sd)
+    return ref, hip.to(device).eval()
+
+
+@pytest.mark.parametrize("channels,B,H", [(1, 2, 32), (3, 3, 32), (1, 5, 16), (1, 1, 64)])
+def test_unet_forward_small(device, channels, B, H):
+    ref, hip = _pair(device, channels)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, channels, H, H, generator=g)
+    t = torch.tensor([10, 650, 990, 0, 330][:B])
+    with torch.no_grad():
+        yr = ref(x, timesteps=t)
+    yh = hip(x.to(device), timesteps=t.to(device)).cpu()
+    err = (yh - yr).abs().max().item()
+    assert math.isfinite(err) and err <= 1e-4 * (1 + yr.abs().max().item()), err
+    assert yr.abs().max() > 0.05  # not vacuous (finding 12)
+
+
+def test_unet_forward_generic_config_and_proj_attn(device):
+    """Channel counts without an MFMA tiling (64/96) run entirely on the direct kernels; also covers
+    use_proj_attn=True, 2 res blocks and attention at an upper level with n = 256 tokens."""
+    cfg = dict(num_channels=(64, 256), attention_levels=(False, True), num_res_blocks=2, num_head_channels=256)
+    ref, hip = _pair(device, 1, cfg, use_proj_attn=True)
+    x = torch.randn(2, 1, 32, 32, generator=torch.Generator().manual_seed(8))
+    t = torch.tensor([500, 20])
+    with torch.no_grad():
+        yr = ref(x, timesteps=t)
+    yh = hip(x.to(device), timesteps=t.to(device)).cpu()
+    assert (yh - yr).abs().max().item() <= 1e-4 * (1 + yr.abs().max().item())
+
+
+def test_unet_missing_key_and_bad_shape(device):
+    from ddpm_ood_amd import DiffusionModelUNet
+
+    m = DiffusionModelUNet(2, 1, 1, **SMALL).to(device)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 1, 30, 30, device=device), timesteps=torch.zeros(1, dtype=torch.long, device=device))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 32, 32), timesteps=torch.zeros(1, dtype=torch.long))
+
+
+def _args(tmp_path, **kw):
+    import argparse
+
+    d = dict(seed=2, output_dir=str(tmp_path), model_name="fashionmnist_synth", validation_ids="synthetic:blobs:n=4:seed=10",
+             in_ids="synthetic:blobs:n=4:seed=11", out_ids="synthetic:noise:n=4:seed=12:name=MNIST",
+             spatial_dimension=2, image_size=None, image_roi=None, latent_pad=None, vqvae_checkpoint=None,
+             ddpm_checkpoint_epoch=None, prediction_type="epsilon", model_type="small",
+             beta_schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195, b_scale=1.0, snr_shift=1,
+             simplex_noise=0, batch_size=4, augmentation=0, cache_data=1, num_workers=0, first_n_val=None,
+             first_n=None, eval_checkpoint=None, drop_last=False, is_grayscale=1, run_val=1, run_in=1, run_out=1,
+             num_inference_steps=100, inference_skip_factor=64)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def test_trajectory_scores_match_oracle(device, tmp_path):
+    """cfg1-shaped: k = 64 -> t in {10, 650}, 68 UNet forwards per image, stale PLMS history
+    carried from the t=10 trajectory into the t=650 one (Q3).  HIP path vs CPU oracle on the same
+    images, weights and per-image noise: MSE / LPIPS per (image, t) and the Z-scores built from them."""
+    import oracle
+    from ddpm_ood_amd import synthetic
+    from ddpm_ood_amd.data import get_data_loader
+    from ddpm_ood_amd.trainer import Reconstruct, batch_noise
+
+    args = _args(tmp_path)
+    sd = synthetic.write_checkpoint(tmp_path / args.model_name, "small", 1, seed=1)
+    rec = Reconstruct(args)
+    rows_h = {}
+    for name, ids in (("val", args.validation_ids), ("in", args.in_ids), ("out", args.out_ids)):
+        loader = get_data_loader(ids, batch_size=4, is_grayscale=True)
+        rows_h[name] = pd.DataFrame(rec.get_scores(loader, name, 64))
+    assert rec.last_stats["unet_forwards"] == 4 * 68
+
+    ref = oracle.DiffusionModelUNet(2, 1, 1, **SMALL).eval()
+    ref.load_state_dict(sd)
+    pl = oracle.PerceptualLoss(dimensions=2, include_pixel_loss=False, is_fake_3d=False, lpips_normalize=True)
+    pl.perceptual_function.load_state_dict(rec._perceptual().perceptual_function.state_dict())
+
+    class NoiseFromTrainer:  # the oracle draws noise through the same pure function of (seed, image, t)
+        def __init__(self):
+            self.calls = []
+
+    rows_o = {}
+    for name, ids in (("val", args.validation_ids), ("in", args.in_ids), ("out", args.out_ids)):
+        loader = get_data_loader(ids, batch_size=4, is_grayscale=True)
+        rows_o[name] = pd.DataFrame(oracle.get_scores(
+            loader, name, 64, model=ref, vqvae=oracle.PassthroughVQVAE(), perceptual=pl,
+            noise_fn=lambda batch, t, shape: batch_noise(2, batch["index"], t, shape),
+            beta_schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195))
+    for name in rows_h:
+        h, o = rows_h[name], rows_o[name]
+        assert list(h["filename"]) == list(o["filename"]) and list(h["t"]) == list(o["t"])
+        assert sorted(set(h["t"])) == [10, 650]
+        for col in ("mse", "perceptual_difference"):
+            rel = ((h[col] - o[col]).abs() / (o[col].abs() + 1e-6)).max()
+            assert rel < 2e-4, (name, col, rel)
+    dh, _, auc_h = oracle.z_scores_and_auroc(rows_h["val"], rows_h["in"], rows_h["out"])
+    do, _, auc_o = oracle.z_scores_and_auroc(rows_o["val"], rows_o["in"], rows_o["out"])
+    for col in ("z_score_mse", "z_score_perceptual_difference"):
+        assert (dh[col] - do[col]).abs().max() < 1e-4 * max(1.0, do[col].abs().max()), col
+    assert abs(auc_h - auc_o) <= 1e-3
