@@ -65,6 +65,8 @@ SIGNATURES = {
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int64,
                                      C.c_void_p]),
     "ddpm_clamp_mse_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "ddpm_prof_enable": (C.c_int, [C.c_int]),
+    "ddpm_prof_report": (C.c_int, [C.c_char_p, C.c_size_t]),
     "ddpm_unet_create": (C.c_void_p, [C.POINTER(UNetConfig)]),
     "ddpm_unet_destroy": (None, [C.c_void_p]),
     "ddpm_unet_param_blob_floats": (C.c_size_t, [C.c_void_p]),

@@ -1,5 +1,10 @@
 // api.hip -- error plumbing and the extern "C" wrappers of the stand-alone operators.
 #include <stdarg.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -14,9 +19,65 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+// ---- in-situ profiler ---------------------------------------------------------------------------
+struct ProfRec {
+  hipEvent_t a, b;
+  const char *kernel;
+  double flops, bytes;
+};
+bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+
+void prof_begin(hipStream_t s, const char *kernel, double flops, double bytes) {
+  ProfRec r{nullptr, nullptr, kernel, flops, bytes};
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  (void)hipEventRecord(r.a, s);
+  g_recs.push_back(r);
+}
+
+void prof_end(hipStream_t s) {
+  if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, s);
+}
+
 }  // namespace ddpm
 
 using namespace ddpm;
+
+extern "C" int ddpm_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+
+extern "C" int ddpm_prof_report(char *buf, size_t cap) {
+  struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
+  std::map<std::string, Agg> agg;
+  for (auto &r : g_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      Agg &a = agg[r.kernel];
+      a.n += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_recs.clear();
+  std::string out = "{";
+  bool first = true;
+  for (auto &kv : agg) {
+    char line[512];
+    snprintf(line, sizeof(line), "%s\"%s\": {\"launches\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+             first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes);
+    out += line;
+    first = false;
+  }
+  out += "}";
+  if (!buf || out.size() + 1 > cap) {
+    set_error("prof_report: buffer too small (%zu needed)", out.size() + 1);
+    return DDPM_EINVAL;
+  }
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return (int)out.size();
+}
 
 extern "C" int ddpm_abi_version(void) { return DDPM_ABI_VERSION; }
 extern "C" const char *ddpm_last_error(void) { return g_err; }

@@ -182,6 +182,7 @@ int launch_attention(const float *qkv, const float *residual, float *out, int B,
     attr_done = true;
   }
   dim3 grid((N + kQB - 1) / kQB, heads, B);
+  ProfScope prof(s, "attention", 4.0 * B * (double)N * N * C, 4.0 * B * C * (double)N * (residual ? 5 : 4));
   hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, residual, out, C, N, heads, scale);
   DDPM_CHECK_LAUNCH();
   return 0;

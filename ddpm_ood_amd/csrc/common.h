@@ -32,6 +32,21 @@ inline hipStream_t as_stream(ddpm_stream_t s) { return reinterpret_cast<hipStrea
 
 constexpr int kWave = 64;
 
+// ---- in-situ profiler (api.hip) ----------------------------------------------------------------
+extern bool g_prof_on;
+void prof_begin(hipStream_t s, const char *kernel, double flops, double bytes);
+void prof_end(hipStream_t s);
+struct ProfScope {
+  hipStream_t s;
+  bool on;
+  ProfScope(hipStream_t st, const char *kernel, double flops, double bytes) : s(st), on(g_prof_on) {
+    if (on) prof_begin(s, kernel, flops, bytes);
+  }
+  ~ProfScope() {
+    if (on) prof_end(s);
+  }
+};
+
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

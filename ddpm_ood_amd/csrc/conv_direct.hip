@@ -74,6 +74,10 @@ int launch_conv_direct(const ddpm_conv_desc &d, hipStream_t s) {
   DDPM_CHECK_ARG(d.ksize == 1 || d.ksize == 3, "conv_direct: ksize must be 1 or 3");
   DDPM_CHECK_ARG(d.B <= 65535, "conv_direct: batch > 65535");
   const int HWo = d.Ho * d.Wo;
+  const double cin = d.C1 + d.C2, taps = d.ksize * d.ksize;
+  ProfScope prof(s, "conv_direct", 2.0 * d.B * HWo * d.Cout * cin * taps,
+                 4.0 * ((double)d.B * cin * d.Hi * d.Wi + (double)d.B * HWo * d.Cout * (d.residual ? 2 : 1) +
+                        d.Cout * cin * taps));
   if (d.Cout <= 4) {
     dim3 grid((HWo + 255) / 256, d.Cout, d.B);
     hipLaunchKernelGGL(conv_direct_kernel<1>, grid, dim3(256), 0, s, d);

@@ -283,6 +283,13 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_
     attr_done = true;
   }
   dim3 grid((g.M + kConvMT - 1) / kConvMT, d.Cout / kConvNT);
+  // algorithmic work of this launch: 2*M*Cout*Cin*taps FLOP; input + output (+ residual)
+  // + weights bytes, each counted once
+  const double flops = 2.0 * g.M * d.Cout * (double)g.Cin * NTAPS;
+  const double bytes = 4.0 * ((double)d.B * g.Cin * g.HWi + (double)g.M * d.Cout * (d.residual ? 2 : 1) +
+                              (double)d.Cout * g.Cin * NTAPS);
+  ProfScope prof(s, NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu" : "conv3x3_mfma") : (AFFINE ? "conv1x1_mfma_gn" : "conv1x1_mfma"),
+                 flops, bytes);
   hipLaunchKernelGGL((conv_mfma_kernel<NTAPS, NPOS, AFFINE>), grid, dim3(256), lds, s, d, g);
   DDPM_CHECK_LAUNCH();
   return 0;

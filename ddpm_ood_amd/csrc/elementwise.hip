@@ -125,6 +125,8 @@ int launch_plms_step(const PlmsArgs &a, int kind, hipStream_t s) {
   int64_t b = (a.numel + 255) / 256;
   if (b > 4096) b = 4096;
   const dim3 grid((int)b), blk(256);
+  const int neps = kind == 0 ? 1 : (kind <= 2 ? 2 : kind);
+  ProfScope prof(s, "plms_step", 8.0 * a.numel, 4.0 * a.numel * (2 + neps));
   switch (kind) {
     case 0: hipLaunchKernelGGL(plms_step_kernel<0>, grid, blk, 0, s, a); break;
     case 1: hipLaunchKernelGGL(plms_step_kernel<1>, grid, blk, 0, s, a); break;
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(256) void clamp_mse_kernel(const float *__restrict_
 
 int launch_clamp_mse(const float *orig, float *recon, float b_scale, float *mse, int B, int64_t chw, hipStream_t s) {
   DDPM_CHECK_ARG(orig && recon && mse && B > 0 && chw > 0 && b_scale != 0.f, "clamp_mse: bad argument");
+  ProfScope prof(s, "clamp_mse", 5.0 * B * chw, 12.0 * B * chw);
   hipLaunchKernelGGL(clamp_mse_kernel, dim3(B), dim3(256), 0, s, orig, recon, b_scale, mse, chw);
   DDPM_CHECK_LAUNCH();
   return 0;

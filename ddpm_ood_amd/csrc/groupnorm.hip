@@ -79,6 +79,7 @@ int launch_gn_scale_shift(const float *in1, const float *in2, int C1, int C2, co
   DDPM_CHECK_ARG(groups > 0 && C % groups == 0, "gn: C %% groups != 0");
   DDPM_CHECK_ARG(C / groups <= 256, "gn: more than 256 channels per group");
   DDPM_CHECK_ARG(B > 0 && B <= 65535 && HW > 0, "gn: bad B / HW");
+  ProfScope prof(s, "gn_scale_shift", 5.0 * B * C * HW, 4.0 * B * C * (double)HW);
   hipLaunchKernelGGL(gn_scale_shift_kernel, dim3(groups, B), dim3(256), 0, s, in1, in2, C1, C2, gamma, beta, scale,
                      shift, HW, groups, eps);
   DDPM_CHECK_LAUNCH();

@@ -88,7 +88,7 @@ def gather_scores(ids: torch.Tensor, scores: torch.Tensor):
     # ids travel inside the same fp32 payload (exact for ids < 2^24): one collective, not two
     payload = torch.full((n_max, n_t * 2 + 1), -1.0, dtype=torch.float32, device=scores.device)
     payload[: ids.shape[0], 0] = ids.to(torch.float32)
-    payload[: ids.shape[0], 1:] = scores.reshape(ids.shape[0], -1)
+    payload[: ids.shape[0], 1:] = scores.reshape(ids.shape[0], n_t * 2)  # (an empty shard has 0 rows)
     out = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(out, payload)
     allp = torch.cat(out, dim=0)
@@ -221,6 +221,7 @@ class Reconstruct(BaseTrainer):
         self._ts_cache = {}
         self._pl = None
         self.last_stats = {}
+        self.profile_first_steps = False  # bench.py: hipEvent-bracket the first UNet step of each t-start
 
     # ---- helpers -------------------------------------------------------------------------------------
     def _timesteps_tensor(self, step: int, batch: int) -> torch.Tensor:
@@ -253,14 +254,16 @@ class Reconstruct(BaseTrainer):
     # ---- the hot loops (reconstruct.py:72-250) ---------------------------------------------------
     @torch.no_grad()
     def get_scores(self, loader, dataset_name, inference_skip_factor):
-        if self.ddp:
+        quiet = getattr(self, "quiet", False)
+        if self.ddp and not quiet:
             sys.stdout, sys.stderr = sys.__stdout__, sys.__stderr__
             print(f"{self.rank}: {dataset_name}")
-        else:
+        elif not quiet:
             print(f"{dataset_name}")
         pl = self._perceptual()
         self.model.eval()
-        ids_all, names_all, scores_all, t_values = [], [], [], None
+        ids_all, names_all, scores_all = [], [], []
+        t_values = [int(t) for t in reversed(self.make_scheduler().timesteps)[1::inference_skip_factor]]
         n_recon = n_fwd = 0
         for batch in loader:
             sched = self.make_scheduler()  # one per batch: PLMS history leaks across t-starts (Q3)
@@ -283,9 +286,15 @@ class Reconstruct(BaseTrainer):
                 noise = batch_noise(self.seed, idx, int(t_start), images.shape).to(self.device, non_blocking=True)
                 x = sched.add_noise(original_samples=images, noise=noise, timesteps=start_timesteps,
                                     b_scale=self.b_scale)
+                first = self.profile_first_steps
                 for step in timesteps[timesteps <= t_start]:
+                    if first:
+                        _lib.load().ddpm_prof_enable(1)
                     eps = self.model(x, timesteps=self._timesteps_tensor(int(step), B))
                     x, _ = sched.step(eps, step, x)
+                    if first:
+                        _lib.load().ddpm_prof_enable(0)
+                        first = False
                     n_fwd += B
                 if self.do_latent_pad:
                     x = F.pad(input=x, pad=self.inverse_latent_pad, mode="constant", value=0).contiguous()
@@ -308,22 +317,28 @@ class Reconstruct(BaseTrainer):
             names_all.extend(batch["image_meta_dict"]["filename_or_obj"])
             torch.cuda.current_stream().synchronize()
             t2 = time.time()
-            if self.ddp:
+            if quiet:
+                pass
+            elif self.ddp:
                 print(f"{self.rank}: Took {t2-t1}s for a batch size of {B}")
             else:
                 print(f"Took {t2-t1}s for a batch size of {B}")
         self.last_stats = {"reconstructions": n_recon, "unet_forwards": n_fwd}
 
-        if not scores_all:
+        if not scores_all and not self.ddp:
             return []
-        scores = torch.cat(scores_all, dim=0)
-        ids = torch.cat(ids_all).to(self.device)
-        name_of = dict(zip((int(i) for i in torch.cat(ids_all)), names_all))
+        if scores_all:
+            scores = torch.cat(scores_all, dim=0)
+            ids = torch.cat(ids_all).to(self.device)
+        else:  # a rank whose shard is empty still takes part in the collective
+            scores = torch.zeros((0, len(t_values), 2), dtype=torch.float32, device=self.device)
+            ids = torch.zeros((0,), dtype=torch.int32, device=self.device)
+        name_of = dict(zip((int(i) for i in ids.cpu()), names_all))
         if self.ddp:
             ids, scores = gather_scores(ids, scores)
             # every rank can name every image: the id list is the same file on every rank
             name_of = {i: n for i, n in enumerate(loader.all_names)} if hasattr(loader, "all_names") else name_of
-            if int(os.environ["LOCAL_RANK"]) != 0:
+            if int(os.environ["LOCAL_RANK"]) != 0 and not quiet:
                 sys.stdout = sys.stderr = open(os.devnull, "w")
         ids = ids.cpu().tolist()
         scores = scores.cpu()  # the one device->host copy

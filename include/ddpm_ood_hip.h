@@ -163,6 +163,15 @@ size_t ddpm_unet_workspace_bytes(const ddpm_unet *h, int B, int H, int W);
 int ddpm_unet_forward(ddpm_unet *h, const float *x, const int64_t *timesteps, float *out, int B, int H, int W,
                       void *workspace, size_t workspace_bytes, ddpm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * In-situ kernel timing (bench.py's roofline leg).  While enabled, every kernel launch of
+ * this library is bracketed by hipEvents on the launch stream; the report synchronises those
+ * events and writes one JSON object {"kernel": {"launches", "ms", "flops", "bytes"}, ...}
+ * (algorithmic FLOPs / bytes per DESIGN.md) into buf.  Returns bytes written or < 0.
+ * ---------------------------------------------------------------------------------- */
+int ddpm_prof_enable(int on);
+int ddpm_prof_report(char *buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

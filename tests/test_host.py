@@ -1,0 +1,166 @@
+"""CPU: host-side logic of the product package (no GPU, no HIP compute calls)."""
+
+import json
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+import oracle
+
+G = Path(__file__).resolve().parent / "golden"
+SCHED = dict(schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195)
+
+
+def test_cli_flags_match_reference():
+    import reconstruct as cli
+
+    ref = json.load(open(G / "cli_flags.json"))
+    assert len(ref) == 34
+    args = cli.parse_args([])
+    for name, spec in ref.items():
+        assert hasattr(args, name), f"--{name} missing"
+        assert getattr(args, name) == spec["default"], name
+    a = cli.parse_args(["--image_roi", "(-1, 20)", "--latent_pad", "(1,1,1,1)", "--first_n", "16",
+                        "--inference_skip_factor", "64", "--is_grayscale", "1"])
+    assert a.image_roi == (-1, 20) and a.latent_pad == (1, 1, 1, 1) and a.first_n == "16"
+    import ood_detection as ocli
+
+    o = ocli.parse_args(["--model_name", "fashionmnist", "--output_dir", "x"])
+    assert (o.max_t, o.min_t, o.t_skip, o.seed) == (1000, 0, 1, 2)
+
+
+def test_product_scheduler_host_logic_equals_oracle():
+    from ddpm_ood_amd.scheduler import PNDMScheduler, noise_schedule
+
+    for name in ("linear", "linear_beta", "scaled_linear", "scaled_linear_beta", "sigmoid_beta", "cosine"):
+        assert torch.equal(noise_schedule(name, 1000, 1e-4, 2e-2), oracle.make_betas(name, 1000, 1e-4, 2e-2))
+    with pytest.raises(ValueError):
+        noise_schedule("quadratic", 10)
+    h = PNDMScheduler(num_train_timesteps=1000, skip_prk_steps=True, **SCHED)
+    o = oracle.PNDMScheduler(num_train_timesteps=1000, skip_prk_steps=True, **SCHED)
+    h.set_timesteps(100)
+    o.set_timesteps(100)
+    assert torch.equal(h.timesteps, o.timesteps) and torch.equal(h.alphas_cumprod, o.alphas_cumprod)
+    z = np.load(G / "schedule.npz")
+    got = np.asarray([h.plms_coefficients(t, t - 10)[:3] for t in range(0, 1000, 10)], dtype=np.float32)
+    assert np.array_equal(got, z["scaled_plms_coef"])
+    # the scheduler surface the reference exercises: reversed(), mask indexing, iteration of 0-d tensors
+    starts = reversed(h.timesteps)[1::64]
+    assert [int(t) for t in starts] == [10, 650]
+    assert [int(s) for s in h.timesteps[h.timesteps <= starts[0]]] == [10, 0]
+    h.betas = h.betas * 1.0  # assignable tables (SNR shift, reconstruct.py:106-117)
+
+
+def test_snr_shift_matches_oracle():
+    from ddpm_ood_amd.scheduler import PNDMScheduler
+    from ddpm_ood_amd.trainer import snr_shift_tables
+    from oracle.reconstruct import snr_shift_tables as o_shift
+
+    h = PNDMScheduler(num_train_timesteps=1000, skip_prk_steps=True, **SCHED)
+    o = oracle.PNDMScheduler(num_train_timesteps=1000, skip_prk_steps=True, **SCHED)
+    snr_shift_tables(h, 0.25)
+    o_shift(o, 0.25)
+    assert torch.equal(h.alphas_cumprod, o.alphas_cumprod) and torch.equal(h.betas, o.betas)
+
+
+def test_data_ingest_and_partition(tmp_path):
+    from ddpm_ood_amd.data import get_data_loader, partition, scale_intensity
+
+    paths = []
+    rng = np.random.default_rng(0)
+    for i in range(5):
+        p = tmp_path / f"img_{i}.npy"
+        np.save(p, rng.integers(0, 255, (28, 28), dtype=np.uint8))
+        paths.append(str(p))
+    (tmp_path / "FashionMNIST_test.csv").write_text(",".join(paths) + "\n")
+    ld = get_data_loader(str(tmp_path / "FashionMNIST_test.csv"), batch_size=2, is_grayscale=True, image_size=32,
+                         first_n=4)
+    batches = list(ld)
+    assert [b["image"].shape for b in batches] == [(2, 1, 32, 32), (2, 1, 32, 32)]
+    assert batches[0]["image_meta_dict"]["filename_or_obj"][1] == paths[1]
+    x = torch.cat([b["image"] for b in batches])
+    assert float(x.min()) == 0.0 and float(x.max()) == 1.0  # per-image min-max (Q13)
+    flip = get_data_loader(str(tmp_path / "FashionMNIST_test.csv"), 4, is_grayscale=True, image_size=32, first_n=4,
+                           add_vflip=True)
+    assert torch.equal(next(iter(flip))["image"], torch.flip(x, dims=(2,)))
+    assert scale_intensity(torch.ones(1, 1, 2, 2)).abs().max() == 0  # constant image -> 0
+    assert partition(10, 1, 4) == [1, 5, 9] and sorted(sum((partition(10, r, 4) for r in range(4)), [])) == list(range(10))
+    with pytest.raises(FileNotFoundError):
+        get_data_loader(str(tmp_path / "absent.csv"), 2)
+
+
+def test_noise_is_a_pure_function_of_seed_image_t():
+    from ddpm_ood_amd.trainer import batch_noise
+
+    a = batch_noise(2, [3, 7], 650, (2, 1, 8, 8))
+    b = batch_noise(2, [7], 650, (1, 1, 8, 8))
+    assert torch.equal(a[1], b[0]) and not torch.equal(a[0], a[1])
+    assert not torch.equal(batch_noise(3, [7], 650, (1, 1, 8, 8)), b)
+
+
+def test_ood_scoring_matches_oracle_and_handles_duplicates(tmp_path):
+    from ddpm_ood_amd import ood
+
+    df = pd.read_csv(G / "trajectory_rows.csv", index_col=0)
+    val, inn, out = (df[df["type"] == t] for t in ("val", "in", "out"))
+    dup = pd.concat([inn, inn.iloc[:3].assign(mse=99.0)])  # DDP padding duplicates: keep-first (Q21)
+    d1, m1, a1 = ood.score(val, dup, out)
+    d2, m2, a2 = oracle.z_scores_and_auroc(val, inn, out)
+    assert a1 == a2 and np.allclose(d1["z_score_mse"], d2["z_score_mse"])
+    gold = json.load(open(G / "ood_scores.json"))
+    assert np.allclose(d1["z_score_mse"], gold["z_score_mse"], atol=1e-9)
+    # strict t window (ood_detection.py:59-61)
+    d3, _, _ = ood.score(val, inn, out, max_t=650, min_t=0)
+    assert set(d3["t"]) == {10}
+    # end-to-end through the CLI-shaped main()
+    run = tmp_path / "fashionmnist_x" / "ood"
+    run.mkdir(parents=True)
+    val.to_csv(run / "results_val.csv")
+    inn.to_csv(run / "results_in.csv")
+    for name in ood.out_datasets_for("fashionmnist_x"):
+        out.to_csv(run / f"results_{name}.csv")
+    import argparse
+    res = ood.main(argparse.Namespace(output_dir=str(tmp_path), model_name="fashionmnist_x", max_t=1000, min_t=0))
+    assert set(res) == {"MNIST", "FashionMNIST_vflip", "FashionMNIST_hflip"} and all(v == a2 for v in res.values())
+    assert ood.count_model_evaluations([10, 650]) == 68
+    with pytest.raises(ValueError):
+        ood.out_datasets_for("imagenet")
+
+
+def test_reference_exceptions_are_kept(tmp_path):
+    """FileNotFoundError / ValueError of the reference's setup (base.py:47-50,87-88; reconstruct.py:31-32)
+    -- checked up to the point where a GPU becomes necessary."""
+    from ddpm_ood_amd.trainer import dataset_stem
+    from ddpm_ood_amd.vqvae import VQVAE, PassthroughVQVAE
+
+    assert dataset_stem("/data/FashionMNIST_test.csv") == "FashionMNIST"
+    assert dataset_stem("synthetic:noise:n=4:name=MNIST") == "MNIST"
+    x = torch.ones(1, 1, 2, 2)
+    p = PassthroughVQVAE()
+    assert p.encode_stage_2_inputs(x) is x and p.decode_stage_2_outputs(x) is x
+    with pytest.raises(NotImplementedError):
+        VQVAE(embedding_dim=128)
+    if not torch.cuda.is_available():
+        import reconstruct as cli
+        from ddpm_ood_amd.trainer import Reconstruct
+
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            Reconstruct(cli.parse_args(["--output_dir", str(tmp_path), "--model_name", "m"]))
+
+
+def test_unet_holder_rejects_bad_configs():
+    from ddpm_ood_amd import DiffusionModelUNet
+
+    with pytest.raises(ValueError):
+        DiffusionModelUNet(2, 1, 1, num_channels=(100, 128), attention_levels=(False, False), num_res_blocks=1)
+    with pytest.raises(ValueError):
+        DiffusionModelUNet(2, 1, 1, num_channels=(128, 128), attention_levels=(False,), num_res_blocks=1)
+    with pytest.raises(NotImplementedError):
+        DiffusionModelUNet(2, 1, 1, num_channels=(128,), attention_levels=(False,), with_conditioning=True)
+    m = DiffusionModelUNet(2, 1, 1, num_channels=(128, 128), attention_levels=(False, True), num_res_blocks=1,
+                           num_head_channels=128)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 8, 8), timesteps=torch.zeros(1, dtype=torch.long))
