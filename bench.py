@@ -53,33 +53,59 @@ def make_args(run_root, n_images, batch):
         num_inference_steps=100, inference_skip_factor=SKIP, **SCHED)
 
 
-def cpu_baseline(state_dict):
-    """Oracle (kind "port": the reference's dependencies cannot be installed) on the host
-    cores: 8 images x t in {10, 490, 970} (inference_skip_factor=48) = 24 reconstructions, 150 UNet
-    forwards per image -- the same mean of 50 forwards per reconstruction as the timed workload."""
+def cpu_baseline_worker():
+    """Runs in a fresh subprocess (own OpenMP pool): the oracle on the host cores.
+    Sample: 8 images x t in {10, 490, 970} (inference_skip_factor=48) = 24 reconstructions,
+    150 UNet forwards per image -- the same mean of 50 forwards per reconstruction as the timed
+    workload.  kind "port": the reference's own dependencies cannot be installed."""
     import oracle
     from ddpm_ood_amd.data import get_data_loader
+    from ddpm_ood_amd.synthetic import random_state_dict
     from ddpm_ood_amd.trainer import MODEL_CONFIGS, batch_noise
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     model = oracle.DiffusionModelUNet(2, 1, 1, **MODEL_CONFIGS["small"]).eval()
-    model.load_state_dict(state_dict)
+    model.load_state_dict(random_state_dict("small", 1, seed=1))
     pl = oracle.PerceptualLoss(dimensions=2, include_pixel_loss=False, is_fake_3d=False, lpips_normalize=True)
     loader = get_data_loader("synthetic:blobs:n=8:seed=0", batch_size=8, is_grayscale=True)
     kw = dict(model=model, vqvae=oracle.PassthroughVQVAE(), perceptual=pl,
               noise_fn=lambda batch, t, shape: batch_noise(2, batch["index"], t, shape),
               beta_schedule=SCHED["beta_schedule"], beta_start=SCHED["beta_start"], beta_end=SCHED["beta_end"])
-    with torch.no_grad():  # short warm-up (oneDNN primitive creation): t = 10 only
-        oracle.get_scores(loader, "val", 1000, **kw)
+    oracle.get_scores(loader, "val", 1000, **kw)  # warm-up (oneDNN primitive creation): t = 10 only
     t0 = time.perf_counter()
     rows = oracle.get_scores(loader, "val", 48, **kw)
     dt = time.perf_counter() - t0
     assert sorted({r["t"] for r in rows}) == [10, 490, 970]
-    return {"value": round(len(rows) / dt, 4), "unit": "reconstructions/s", "cores": torch.get_num_threads(),
-            "kind": "port", "seconds": round(dt, 2),
-            "sample": "8 images x t_start in {10, 490, 970}: 24 reconstructions, 1200 UNet image-forwards "
-                      "(mean 50 per reconstruction as in the timed workload), CPU fp32 oracle incl. LPIPS + MSE"}
+    print(json.dumps({"value": round(len(rows) / dt, 4), "unit": "reconstructions/s",
+                      "cores": torch.get_num_threads(), "kind": "port", "seconds": round(dt, 2),
+                      "sample": "8 images x t_start in {10, 490, 970}: 24 reconstructions, 1200 UNet "
+                                "image-forwards (mean 50 per reconstruction as in the timed workload), CPU fp32 "
+                                "oracle incl. LPIPS + MSE"}))
+
+
+def cpu_baseline(_state_dict=None):
+    """Oracle timing in a subprocess with a bounded thread count and a hard timeout: on the GPU
+    box an OpenMP pool as wide as its 256 logical CPUs made these small convolutions crawl
+    (> 8 min); min(cpu_count, 32) threads is what is used and reported as `cores`."""
+    import subprocess
+
+    threads = min(os.cpu_count() or 1, 32)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    try:
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-worker"], env=env,
+                             capture_output=True, text=True, timeout=240)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:  # timeout / parse error: report it, never fake a number
+        return {"value": None, "unit": "reconstructions/s", "cores": threads, "kind": "port",
+                "sample": f"failed: {type(e).__name__}: {e}"[:300]}
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries exactly one JSON line)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -89,7 +115,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step (256 = the reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.cpu_baseline_worker:
+        return cpu_baseline_worker()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -127,8 +156,10 @@ def main():
             rec.profile_first_steps = False
             return rows
 
-        for _ in range(a.warmup):
+        log(f"setup done (model on device, {a.batch} images resident)")
+        for i in range(a.warmup):
             step()
+            log(f"warmup step {i} done")
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -139,6 +170,7 @@ def main():
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        log(f"timed region done: {a.steps} step(s) in {dt:.2f} s")
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device=rec.device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -186,6 +218,7 @@ def main():
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sd)
+        log(f"cpu baseline done: {line['cpu_baseline']}")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -22,14 +22,14 @@ void set_error(const char *fmt, ...) {
 // ---- in-situ profiler ---------------------------------------------------------------------------
 struct ProfRec {
   hipEvent_t a, b;
-  const char *kernel;
+  std::string kernel;
   double flops, bytes;
 };
 bool g_prof_on = false;
 static std::vector<ProfRec> g_recs;
 
 void prof_begin(hipStream_t s, const char *kernel, double flops, double bytes) {
-  ProfRec r{nullptr, nullptr, kernel, flops, bytes};
+  ProfRec r{nullptr, nullptr, std::string(kernel), flops, bytes};
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
   (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
@@ -64,7 +64,7 @@ extern "C" int ddpm_prof_report(char *buf, size_t cap) {
   std::string out = "{";
   bool first = true;
   for (auto &kv : agg) {
-    char line[512];
+    char line[768];
     snprintf(line, sizeof(line), "%s\"%s\": {\"launches\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
              first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes);
     out += line;

@@ -26,6 +26,8 @@
 //   * GroupNorm arrives as per-(image, channel) scale/shift and is applied, with SiLU, while
 //     staging; zero padding is applied AFTER the activation, as F.conv2d(pad=1) of the
 //     activated tensor does.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ddpm {
@@ -288,8 +290,14 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_
   const double flops = 2.0 * g.M * d.Cout * (double)g.Cin * NTAPS;
   const double bytes = 4.0 * ((double)d.B * g.Cin * g.HWi + (double)g.M * d.Cout * (d.residual ? 2 : 1) +
                               (double)d.Cout * g.Cin * NTAPS);
-  ProfScope prof(s, NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu" : "conv3x3_mfma") : (AFFINE ? "conv1x1_mfma_gn" : "conv1x1_mfma"),
-                 flops, bytes);
+  const char *kname = NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu" : "conv3x3_mfma")
+                                  : (AFFINE ? "conv1x1_mfma_gn" : "conv1x1_mfma");
+  char kshape[160];
+  if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {  // development: one profile row per layer shape
+    snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d m%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo, d.mode);
+    kname = kshape;
+  }
+  ProfScope prof(s, kname, flops, bytes);
   hipLaunchKernelGGL((conv_mfma_kernel<NTAPS, NPOS, AFFINE>), grid, dim3(256), lds, s, d, g);
   DDPM_CHECK_LAUNCH();
   return 0;
