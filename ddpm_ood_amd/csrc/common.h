@@ -48,6 +48,10 @@ struct ProfScope {
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+// v_exp_f32 / v_rcp_f32 form (~1e-7 relative): 6 instructions instead of ~45
+__device__ __forceinline__ float silu_fast(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

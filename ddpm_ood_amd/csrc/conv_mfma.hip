@@ -34,6 +34,8 @@ namespace ddpm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ unsigned g_cu_ticket[2048];  // experiment knob 64 only
+
 // native vector type: arrays of HIP's struct float4 stay in scratch (SROA does not split them)
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -47,6 +49,7 @@ struct ConvGeom {
   int pad;      // 1 for 3x3, 0 for 1x1
   int s;        // input step per output pixel (2 for stride-2)
   int Cin, nchunks;
+  int xflags;   // experiment knobs (env DDPM_CONV_X): 1 = fast SiLU, 2 = skew co-resident workgroups
 };
 
 static bool make_geom(const ddpm_conv_desc &d, ConvGeom &g) {
@@ -73,6 +76,8 @@ static bool make_geom(const ddpm_conv_desc &d, ConvGeom &g) {
   g.IRS = g.IR * g.RS;
   g.PS = g.TI * g.IRS;
   g.nchunks = Cin / kConvCc;
+  static const int xf = getenv("DDPM_CONV_X") ? atoi(getenv("DDPM_CONV_X")) : 0;
+  g.xflags = xf;
   return true;
 }
 
@@ -104,6 +109,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ddpm_conv_desc 
   const int nt = blockIdx.y;
   const int P0 = blockIdx.x * kConvMT;
 
+  if (g.xflags & 64) {
+    // experiment: skew by a per-CU arrival ticket (robust to whatever the dispatcher does)
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+    const unsigned key = ((xcc & 7) << 8) | ((hw >> 8) & 0xff);       // xcc | se,sh,cu
+    unsigned tk = 0;
+    if (threadIdx.x == 0) tk = atomicAdd(&g_cu_ticket[key & 2047], 1u);
+    unsigned *tks = reinterpret_cast<unsigned *>(smem);
+    if (threadIdx.x == 0) tks[0] = tk;
+    __syncthreads();
+    const unsigned t0 = tks[0];
+    __syncthreads();
+    if (t0 & 1) __builtin_amdgcn_s_sleep(127);
+  }
+  if ((g.xflags & 14) && (((blockIdx.x + blockIdx.y * gridDim.x) >> 8) & 1)) {
+    // experiment: offset every second 256-block "wave" of workgroups by ~half a chunk so that the two
+    // workgroups sharing a CU do not stage (no MFMA issue) at the same time (s_sleep n = 64 n cycles)
+    if (g.xflags & 2) __builtin_amdgcn_s_sleep(32);
+    if (g.xflags & 4) __builtin_amdgcn_s_sleep(64);
+    if (g.xflags & 8) __builtin_amdgcn_s_sleep(127);
+  }
   // ---- tile origin ---------------------------------------------------------------------
   int n0, h0;
   if (g.TI == 1) {
@@ -174,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ddpm_conv_desc 
   // global loads of chunk ch + 1, then runs the MFMAs of chunk ch while those loads fly.
   // (Written inline, not as lambdas: by-reference captures kept the prefetch arrays in scratch.)
   for (int ch = -1; ch < g.nchunks; ++ch) {
-    if (ch >= 0) {
+    if (ch >= 0 && !((g.xflags & 16) && ch > 0)) {
       __syncthreads();  // everyone finished reading the previous chunk
       v4f *wl4 = reinterpret_cast<v4f *>(Wl);
 #pragma unroll
@@ -192,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ddpm_conv_desc 
               const float sh = shreg[j][c >> 2][c & 3];
               v = v * sc + sh;
             }
-            if (a.act == DDPM_ACT_SILU) v = silu_f(v);
+            if (a.act == DDPM_ACT_SILU) v = (g.xflags & 1) ? silu_fast(v) : silu_f(v);
             Xl[c * g.PS + r] = valid ? v : 0.f;
           }
         }
@@ -200,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ddpm_conv_desc 
       __syncthreads();
     }
 
-    if (ch + 1 < g.nchunks) {
+    if (ch + 1 < g.nchunks && !((g.xflags & 16) && ch >= 0)) {
       const int cn = ch + 1;
       const v4f *wp = wsrc + (size_t)cn * (NTAPS * kConvCc * kConvNT / 4);
 #pragma unroll
@@ -232,43 +258,70 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ddpm_conv_desc 
       }
     }
 
-    if (ch >= 0) {
-#pragma unroll
-      for (int t = 0; t < NTAPS; ++t) {
+    if (ch >= 0 && !(g.xflags & 32)) {
+      // Operand fetch is software-pipelined one k-step ahead of the MFMAs: hipcc otherwise issues each
+      // step's ds_reads right in front of its four MFMAs and the matrix pipe idles for one LDS latency
+      // (~70 of every 256 cycles with one computing wave per SIMD).  sched_barrier pins the order.
+      constexpr int NSTEP = NTAPS * (kConvCc / 2);
+      float a0[2], a1[2], b0[2], b1[2];
+      auto fetch = [&](int st, int slot) {
+        const int t = st / (kConvCc / 2), kk = st % (kConvCc / 2);
         const int tapoff = (NTAPS == 9) ? ((t / 3) * g.RS + (t % 3)) : 0;
+        a0[slot] = Wl[wb + (t * kConvCc + 2 * kk) * kConvNT];
+        a1[slot] = Wl[wb + (t * kConvCc + 2 * kk) * kConvNT + 32];
+        b0[slot] = Xl[xb[0] + 2 * kk * g.PS + tapoff];
+        b1[slot] = Xl[xb[1] + 2 * kk * g.PS + tapoff];
+      };
+      fetch(0, 0);
 #pragma unroll
-        for (int kk = 0; kk < kConvCc / 2; ++kk) {
-          const float a0 = Wl[wb + (t * kConvCc + 2 * kk) * kConvNT];
-          const float a1 = Wl[wb + (t * kConvCc + 2 * kk) * kConvNT + 32];
-          const float b0 = Xl[xb[0] + 2 * kk * g.PS + tapoff];
-          const float b1 = Xl[xb[1] + 2 * kk * g.PS + tapoff];
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
+      for (int st = 0; st < NSTEP; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < NSTEP) fetch(st + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], b0[cur], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], b1[cur], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], b0[cur], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], b1[cur], acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
 
   // ---- epilogue: D[row = cout][col = pixel] -> NCHW, 128 B contiguous per (reg, half-wave) --
+  // Two-phase per pixel block: every addend (bias, temb, residual) is loaded BEFORE the first store.
+  // Interleaving "load residual -> add -> store" made each of the 64 stores wait for the previous one
+  // (out may alias the addends as far as the compiler knows): ~85k cycles per workgroup, 22 % of a
+  // 16-chunk convolution.  The restrict copies state the no-alias contract of the ABI.
+  const float *__restrict__ bias_p = a.bias;
+  const float *__restrict__ chan_p = a.chan_add;
+  const float *__restrict__ res_p = a.residual;
+  float *__restrict__ out_p = a.out;
+  const int co_base = nt * kConvNT + wn * 64 + 4 * lhi;
 #pragma unroll
   for (int bb = 0; bb < 2; ++bb) {
     const int P = P0 + (wm * 2 + bb) * 32 + l31;
-    if (P < g.M) {
+    if (P < g.M && !((g.xflags & 256) && blockIdx.x != 0xfffff)) {  // knob 256: drop the epilogue (timing only)
       const int n = P / g.HWo;
       const int p = P - n * g.HWo;
+      const size_t obase = ((size_t)n * a.Cout + co_base) * g.HWo + p;
 #pragma unroll
-      for (int ab = 0; ab < 2; ++ab) {
+      for (int ab = 0; ab < 2; ++ab) {  // 16 values at a time keeps the temporaries at 48 registers
+        float bv[16], cv[16], rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int co = nt * kConvNT + wn * 64 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          const size_t idx = ((size_t)n * a.Cout + co) * g.HWo + p;
+          const int dco = ab * 32 + (r & 3) + 8 * (r >> 2);
+          bv[r] = bias_p ? bias_p[co_base + dco] : 0.f;
+          cv[r] = chan_p ? chan_p[(size_t)n * a.chan_add_stride + co_base + dco] : 0.f;
+          rv[r] = res_p ? res_p[obase + (size_t)dco * g.HWo] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dco = ab * 32 + (r & 3) + 8 * (r >> 2);
           float v = acc[ab][bb][r];
-          if (a.bias) v += a.bias[co];
-          if (a.chan_add) v += a.chan_add[(size_t)n * a.chan_add_stride + co];
-          if (a.residual) v += a.residual[idx];
-          a.out[idx] = v;
+          if (bias_p) v += bv[r];
+          if (chan_p) v += cv[r];
+          if (res_p) v += rv[r];
+          out_p[obase + (size_t)dco * g.HWo] = v;
         }
       }
     }
@@ -277,12 +330,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ddpm_conv_desc 
 
 template <int NTAPS, int NPOS, bool AFFINE>
 static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_t s) {
-  const size_t lds = (size_t)(NTAPS * kConvCc * kConvNT + kConvCc * g.PS) * sizeof(float);
+  const size_t lds = (size_t)(NTAPS * kConvCc * kConvNT + kConvCc * g.PS) * sizeof(float) +
+                     ((g.xflags & 128) ? 48 * 1024 : 0);  // knob 128: pad LDS so only one workgroup fits a CU
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
+    if (getenv("DDPM_CONV_DEBUG")) {
+      int nb = -1;
+      hipFuncAttributes fa{};
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &nb, reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE>), 256, lds);
+      (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE>));
+      fprintf(stderr, "[conv_mfma<%d,%d,%d>] lds=%zu B, numRegs=%d, static LDS=%zu, occupancy=%d blocks/CU\n", NTAPS,
+              NPOS, (int)AFFINE, lds, fa.numRegs, fa.sharedSizeBytes, nb);
+    }
   }
   dim3 grid((g.M + kConvMT - 1) / kConvMT, d.Cout / kConvNT);
   // algorithmic work of this launch: 2*M*Cout*Cin*taps FLOP; input + output (+ residual)
