@@ -91,7 +91,7 @@ int launch_timestep_embedding(const int64_t *t, const float *freqs, float *out, 
 int launch_copy_f32(const float *src, float *dst, int64_t n, hipStream_t s);
 
 // MFMA conv tiling constants (shared by the packer and the kernel)
-constexpr int kConvCc = 8;     // input channels staged per chunk
+constexpr int kConvCc = 4;     // input channels staged per chunk
 constexpr int kConvNT = 128;   // output channels per workgroup
 constexpr int kConvMT = 128;   // output pixels per workgroup
 

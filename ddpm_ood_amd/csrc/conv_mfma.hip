@@ -12,36 +12,40 @@
 //     pixels of one channel plane -- exactly the contiguous direction of NCHW -- so operand
 //     fetches from LDS are bank-conflict-free ds_read_b32 and the D tile (rows = cout,
 //     cols = pixel) stores 128-byte contiguous rows back to NCHW.
-//   * f32-input MFMA is bit-exact fp32 FMA (k-ordered fmaf chain) at the fp32 vector peak
-//     (157 TF) but needs 1 LDS dword per operand per 2048 FLOP instead of 1 per 2 FLOP, so LDS
-//     and VGPR bandwidth stop being the limiter of a direct fp32 convolution.
-//   * Workgroup tile: 128 output pixels (whole rows of one image, or several whole images when
-//     H*W < 128) x 128 output channels, 4 waves as 2 (cout) x 2 (pixel), each wave 2x2 MFMA
-//     tiles = 64 accumulator registers.  Input channels are consumed in chunks of 8:
-//     the haloed input tile [8][rows+2][W+2] is staged ONCE per chunk and reused by all
-//     9 taps; weights arrive pre-packed as [cout_tile][chunk][tap][8][128] so the chunk is one
-//     contiguous 36 KB burst of coalesced 16-byte loads.
-//   * Next chunk's global loads are issued into registers before the current chunk's 144 MFMAs
-//     and written to LDS after them (async-stage split), so HBM/L2 latency hides under MFMA.
-//   * GroupNorm arrives as per-(image, channel) scale/shift and is applied, with SiLU, while
-//     staging; zero padding is applied AFTER the activation, as F.conv2d(pad=1) of the
-//     activated tensor does.
+//   * f32-input MFMA is bit-exact fp32 FMA (k-ordered fmaf chain) at the fp32 vector peak but
+//     needs 1 LDS dword per operand per 2048 FLOP instead of 1 per 2 FLOP, so LDS and VGPR
+//     bandwidth stop being the limiter of a direct fp32 convolution.
+//   * Workgroup tile: MT (128 or 64) output pixels -- whole rows of one image, or several whole
+//     images when H*W < MT -- x 128 output channels, 4 waves, each wave 64x64 (MT = 128) or
+//     64 px x 32 cout (MT = 64, used when the 128-pixel grid would leave CUs idle).
+//   * Input channels are consumed in chunks of 4.  LDS is double-buffered
+//     ([9][4][128] weights + [4][rows+2][W+2] haloed input per buffer, ~22 KB each): while the
+//     72 MFMAs of chunk q run from buffer q & 1, the same wave commits chunk q + 1 (already in
+//     registers; GroupNorm affine + SiLU applied here, zero halo written after the activation)
+//     into the other buffer and issues the global loads of chunk q + 2.  The staging work is
+//     spread over the chunk's k-steps in program order so that it issues in the shadow of the
+//     wave's own 64-cycle MFMAs (hipcc's scheduler is left free to move it: pinning the order with
+//     sched_barrier measured 2 % slower).  One barrier per chunk, three workgroups per CU.
+//   * Weights arrive pre-packed as [cout_tile][chunk][tap][4][128]: a chunk is one contiguous
+//     18 KB burst of coalesced 16-byte loads.  The input tile is loaded once per chunk and
+//     reused by all 9 taps.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "common.h"
 
 namespace ddpm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ unsigned g_cu_ticket[2048];  // experiment knob 64 only
-
-// native vector type: arrays of HIP's struct float4 stay in scratch (SROA does not split them)
+// native vector types: arrays of HIP's struct float4 stay in scratch (SROA does not split them)
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct ConvGeom {
   int M;        // B * Ho * Wo
   int HWo, HWi;
+  int MT;       // pixels per workgroup tile (128 or 64)
   int TI, TH;   // images per tile, output rows per tile (per image)
   int IR, RS;   // LDS rows per image slot, LDS row stride
   int IRS;      // IR * RS
@@ -49,25 +53,25 @@ struct ConvGeom {
   int pad;      // 1 for 3x3, 0 for 1x1
   int s;        // input step per output pixel (2 for stride-2)
   int Cin, nchunks;
-  int xflags;   // experiment knobs (env DDPM_CONV_X): 1 = fast SiLU, 2 = skew co-resident workgroups
 };
 
-static bool make_geom(const ddpm_conv_desc &d, ConvGeom &g) {
+static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g) {
   const int Cin = d.C1 + d.C2;
   g.Cin = Cin;
+  g.MT = MT;
   g.HWo = d.Ho * d.Wo;
   g.HWi = d.Hi * d.Wi;
   g.M = d.B * g.HWo;
   g.pad = d.ksize == 3 ? 1 : 0;
   g.s = d.mode == DDPM_CONV_STRIDE2 ? 2 : 1;
-  if (g.HWo >= kConvMT) {
-    if (kConvMT % d.Wo) return false;
+  if (g.HWo >= MT) {
+    if (MT % d.Wo) return false;
     g.TI = 1;
-    g.TH = kConvMT / d.Wo;
+    g.TH = MT / d.Wo;
     if (d.Ho % g.TH) return false;
   } else {
-    if (kConvMT % g.HWo) return false;
-    g.TI = kConvMT / g.HWo;
+    if (MT % g.HWo) return false;
+    g.TI = MT / g.HWo;
     g.TH = d.Ho;
   }
   const int IC = (g.s == 2) ? (2 * d.Wo + 1) : (d.Wo + 2 * g.pad);
@@ -76,8 +80,28 @@ static bool make_geom(const ddpm_conv_desc &d, ConvGeom &g) {
   g.IRS = g.IR * g.RS;
   g.PS = g.TI * g.IRS;
   g.nchunks = Cin / kConvCc;
-  static const int xf = getenv("DDPM_CONV_X") ? atoi(getenv("DDPM_CONV_X")) : 0;
-  g.xflags = xf;
+  return true;
+}
+
+static bool geom_ok(const ddpm_conv_desc &d, const ConvGeom &g) {
+  if (g.PS > 3 * 256) return false;
+  if (d.gscale && g.PS > 2 * 256) return false;  // instantiated AFFINE variants: NPOS <= 2
+  if (d.ksize == 1 && g.PS > 256) return false;
+  return true;
+}
+
+// Pick the pixel-tile size: 128 unless that grid cannot give every CU two workgroups.
+static bool pick_geom(const ddpm_conv_desc &d, ConvGeom &g) {
+  ConvGeom g128, g64;
+  const bool ok128 = make_geom(d, 128, g128) && geom_ok(d, g128);
+  const bool ok64 = make_geom(d, 64, g64) && geom_ok(d, g64);
+  if (!ok128 && !ok64) return false;
+  const long wg128 = ok128 ? (long)((g128.M + 127) / 128) * (d.Cout / kConvNT) : 0;
+  if (ok128 && (wg128 >= 512 || !ok64)) {
+    g = g128;
+  } else {
+    g = g64;
+  }
   return true;
 }
 
@@ -89,56 +113,34 @@ bool conv_mfma_supported(const ddpm_conv_desc &d) {
   if (Cin % kConvCc || d.Cout % kConvNT) return false;
   if (d.C2 > 0 && (d.C1 % kConvCc)) return false;
   ConvGeom g;
-  if (!make_geom(d, g)) return false;
-  if (g.PS > 3 * 256) return false;
-  if (d.gscale && g.PS > 2 * 256) return false;  // instantiated AFFINE variants: NPOS <= 2
-  if (d.ksize == 1 && g.PS > 256) return false;
-  return true;
+  return pick_geom(d, g);
 }
 
-template <int NTAPS, int NPOS, bool AFFINE>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ddpm_conv_desc a, const ConvGeom g) {
+template <int NTAPS, int NPOS, bool AFFINE, int MT>
+__global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(const ddpm_conv_desc a,
+                                                                             const ConvGeom g) {
+  constexpr int CC = kConvCc;                  // 4 input channels per chunk
+  constexpr int WF = NTAPS * CC * kConvNT;     // weight floats per chunk (4608 / 512)
+  constexpr int NW4 = WF / 1024;               // full 16-byte rounds per thread (4 / 0)
+  constexpr int NP = NW4 + 1 + NPOS;           // staging pieces per chunk
+  constexpr int NSTEP = NTAPS * (CC / 2);      // k-steps (4 or 2 MFMAs each) per chunk
+  constexpr int H = (NSTEP + 1) / 2;           // commit pieces go to steps [0, H), prefetch to [H, NSTEP)
+  constexpr int NAB = MT == 128 ? 2 : 1;       // 32-cout blocks per wave
+
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *Wl = smem;                               // [NTAPS][8][128]
-  float *Xl = smem + NTAPS * kConvCc * kConvNT;   // [8][PS]
+  const int bufsz = WF + CC * g.PS;            // floats per LDS buffer: [NTAPS][4][128] weights, [4][PS] input
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int wn = wave & 1, wm = wave >> 1;
+  const int wco = MT == 128 ? (wave & 1) * 64 : wave * 32;  // wave's first cout inside the tile
+  const int wpx = MT == 128 ? (wave >> 1) * 64 : 0;         // wave's first pixel inside the tile
   const int nt = blockIdx.y;
-  const int P0 = blockIdx.x * kConvMT;
+  const int P0 = blockIdx.x * MT;
 
-  if (g.xflags & 64) {
-    // experiment: skew by a per-CU arrival ticket (robust to whatever the dispatcher does)
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
-    const unsigned key = ((xcc & 7) << 8) | ((hw >> 8) & 0xff);       // xcc | se,sh,cu
-    unsigned tk = 0;
-    if (threadIdx.x == 0) tk = atomicAdd(&g_cu_ticket[key & 2047], 1u);
-    unsigned *tks = reinterpret_cast<unsigned *>(smem);
-    if (threadIdx.x == 0) tks[0] = tk;
-    __syncthreads();
-    const unsigned t0 = tks[0];
-    __syncthreads();
-    if (t0 & 1) __builtin_amdgcn_s_sleep(127);
-  }
-  if ((g.xflags & 14) && (((blockIdx.x + blockIdx.y * gridDim.x) >> 8) & 1)) {
-    // experiment: offset every second 256-block "wave" of workgroups by ~half a chunk so that the two
-    // workgroups sharing a CU do not stage (no MFMA issue) at the same time (s_sleep n = 64 n cycles)
-    if (g.xflags & 2) __builtin_amdgcn_s_sleep(32);
-    if (g.xflags & 4) __builtin_amdgcn_s_sleep(64);
-    if (g.xflags & 8) __builtin_amdgcn_s_sleep(127);
-  }
-  // ---- tile origin ---------------------------------------------------------------------
-  int n0, h0;
-  if (g.TI == 1) {
-    n0 = P0 / g.HWo;
-    h0 = (P0 - n0 * g.HWo) / a.Wo;
-  } else {
-    n0 = P0 / g.HWo;
-    h0 = 0;
-  }
+  // ---- tile origin -------------------------------------------------------------------------
+  const int n0 = P0 / g.HWo;
+  const int h0 = (g.TI == 1) ? (P0 - n0 * g.HWo) / a.Wo : 0;
 
   // ---- per-thread staging positions (chunk-invariant) -------------------------------------
   int soff[NPOS];   // offset inside one channel plane of the source, -1 => zero
@@ -166,72 +168,46 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ddpm_conv_desc 
     }
   }
 
-  // ---- per-lane MFMA operand bases -----------------------------------------------------------
+  // ---- per-lane MFMA operand bases (relative to an LDS buffer) --------------------------------
   int xb[2];
 #pragma unroll
   for (int bb = 0; bb < 2; ++bb) {
-    const int q = (wm * 2 + bb) * 32 + l31;
+    const int q = wpx + bb * 32 + l31;
     const int per_img = g.TH * a.Wo;
     const int ti = q / per_img;
     const int rem = q - ti * per_img;
     const int th = rem / a.Wo;
     const int tw = rem - th * a.Wo;
-    xb[bb] = lhi * g.PS + ti * g.IRS + th * g.s * g.RS + tw * g.s;
+    xb[bb] = WF + lhi * g.PS + ti * g.IRS + th * g.s * g.RS + tw * g.s;
   }
-  const int wb = lhi * kConvNT + wn * 64 + l31;
+  const int wb = lhi * kConvNT + wco + l31;
 
-  f32x16 acc[2][2];
+  f32x16 acc[NAB][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NAB; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- prefetch registers ---------------------------------------------------------------------
-  v4f wreg[NTAPS];
-  float xreg[NPOS][kConvCc];
-  v4f screg[NPOS][2], shreg[NPOS][2];
+  // ---- staging registers: one chunk in flight -----------------------------------------------
+  v4f w4[NW4 > 0 ? NW4 : 1];
+  v2f w2;
+  float xreg[NPOS][CC];
+  v4f screg[NPOS], shreg[NPOS];
 
-  const v4f *wsrc = reinterpret_cast<const v4f *>(a.w_packed) +
-                       (size_t)nt * g.nchunks * (NTAPS * kConvCc * kConvNT / 4);
+  const float *wsrc = a.w_packed + (size_t)nt * g.nchunks * WF;
 
-  // Software pipeline: iteration ch commits chunk ch (already in registers) to LDS, issues the
-  // global loads of chunk ch + 1, then runs the MFMAs of chunk ch while those loads fly.
-  // (Written inline, not as lambdas: by-reference captures kept the prefetch arrays in scratch.)
-  for (int ch = -1; ch < g.nchunks; ++ch) {
-    if (ch >= 0 && !((g.xflags & 16) && ch > 0)) {
-      __syncthreads();  // everyone finished reading the previous chunk
-      v4f *wl4 = reinterpret_cast<v4f *>(Wl);
-#pragma unroll
-      for (int i = 0; i < NTAPS; ++i) wl4[tid + 256 * i] = wreg[i];
-#pragma unroll
-      for (int j = 0; j < NPOS; ++j) {
-        const int r = tid + 256 * j;
-        if (r < g.PS) {
-          const bool valid = soff[j] >= 0;
-#pragma unroll
-          for (int c = 0; c < kConvCc; ++c) {
-            float v = xreg[j][c];
-            if (AFFINE) {
-              const float sc = screg[j][c >> 2][c & 3];
-              const float sh = shreg[j][c >> 2][c & 3];
-              v = v * sc + sh;
-            }
-            if (a.act == DDPM_ACT_SILU) v = (g.xflags & 1) ? silu_fast(v) : silu_f(v);
-            Xl[c * g.PS + r] = valid ? v : 0.f;
-          }
-        }
-      }
-      __syncthreads();
-    }
-
-    if (ch + 1 < g.nchunks && !((g.xflags & 16) && ch >= 0)) {
-      const int cn = ch + 1;
-      const v4f *wp = wsrc + (size_t)cn * (NTAPS * kConvCc * kConvNT / 4);
-#pragma unroll
-      for (int i = 0; i < NTAPS; ++i) wreg[i] = wp[tid + 256 * i];
-      const int cg0 = cn * kConvCc;
+  // piece p of chunk `ch`: global -> registers
+  auto prefetch_piece = [&](int p, int ch) {
+    const float *wp = wsrc + (size_t)ch * WF;
+    if (p < NW4) {
+      w4[p < NW4 ? p : 0] = reinterpret_cast<const v4f *>(wp)[tid + 256 * p];
+    } else if (p == NW4) {
+      w2 = reinterpret_cast<const v2f *>(wp)[NW4 * 512 + tid];
+    } else {
+      const int j = p - NW4 - 1;
+      const int cg0 = ch * CC;
       const float *base;
       int Cs, cl0;
       if (cg0 < a.C1) {
@@ -239,78 +215,126 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ddpm_conv_desc 
       } else {
         base = a.in2; Cs = a.C2; cl0 = cg0 - a.C1;
       }
+      if (soff[j] >= 0) {
+        const float *px = base + ((size_t)nimg[j] * Cs + cl0) * g.HWi + soff[j];
 #pragma unroll
-      for (int j = 0; j < NPOS; ++j) {
-        if (soff[j] >= 0) {
-          const float *p = base + ((size_t)nimg[j] * Cs + cl0) * g.HWi + soff[j];
+        for (int c = 0; c < CC; ++c) xreg[j][c] = px[(size_t)c * g.HWi];
+        if (AFFINE) {
+          screg[j] = *reinterpret_cast<const v4f *>(a.gscale + (size_t)nimg[j] * g.Cin + cg0);
+          shreg[j] = *reinterpret_cast<const v4f *>(a.gshift + (size_t)nimg[j] * g.Cin + cg0);
+        }
+      } else {
 #pragma unroll
-          for (int c = 0; c < kConvCc; ++c) xreg[j][c] = p[(size_t)c * g.HWi];
-          if (AFFINE) {
-            const v4f *sp = reinterpret_cast<const v4f *>(a.gscale + (size_t)nimg[j] * g.Cin + cg0);
-            const v4f *hp = reinterpret_cast<const v4f *>(a.gshift + (size_t)nimg[j] * g.Cin + cg0);
-            screg[j][0] = sp[0]; screg[j][1] = sp[1];
-            shreg[j][0] = hp[0]; shreg[j][1] = hp[1];
-          }
-        } else {
+        for (int c = 0; c < CC; ++c) xreg[j][c] = 0.f;
+      }
+    }
+  };
+
+  // piece p of the chunk held in registers -> LDS buffer at float offset `nb`
+  auto commit_piece = [&](int p, int nb) {
+    if (p < NW4) {
+      reinterpret_cast<v4f *>(smem + nb)[tid + 256 * p] = w4[p < NW4 ? p : 0];
+    } else if (p == NW4) {
+      reinterpret_cast<v2f *>(smem + nb)[NW4 * 512 + tid] = w2;
+    } else {
+      const int j = p - NW4 - 1;
+      const int r = tid + 256 * j;
+      if (r < g.PS) {
+        const bool valid = soff[j] >= 0;
 #pragma unroll
-          for (int c = 0; c < kConvCc; ++c) xreg[j][c] = 0.f;
+        for (int c = 0; c < CC; ++c) {
+          float v = xreg[j][c];
+          if (AFFINE) v = v * screg[j][c] + shreg[j][c];
+          // v_exp_f32 / v_rcp_f32 SiLU (6 instructions instead of ~45): end-to-end parity unchanged
+          // (Z-score error 2.4e-6 vs 3.4e-6 with expf + IEEE divide; profiles/r01_parity_report.txt)
+          if (a.act == DDPM_ACT_SILU) v = silu_fast(v);
+          smem[nb + WF + c * g.PS + r] = valid ? v : 0.f;
         }
       }
     }
+  };
 
-    if (ch >= 0 && !(g.xflags & 32)) {
-      // Operand fetch is software-pipelined one k-step ahead of the MFMAs: hipcc otherwise issues each
-      // step's ds_reads right in front of its four MFMAs and the matrix pipe idles for one LDS latency
-      // (~70 of every 256 cycles with one computing wave per SIMD).  sched_barrier pins the order.
-      constexpr int NSTEP = NTAPS * (kConvCc / 2);
-      float a0[2], a1[2], b0[2], b1[2];
-      auto fetch = [&](int st, int slot) {
-        const int t = st / (kConvCc / 2), kk = st % (kConvCc / 2);
-        const int tapoff = (NTAPS == 9) ? ((t / 3) * g.RS + (t % 3)) : 0;
-        a0[slot] = Wl[wb + (t * kConvCc + 2 * kk) * kConvNT];
-        a1[slot] = Wl[wb + (t * kConvCc + 2 * kk) * kConvNT + 32];
-        b0[slot] = Xl[xb[0] + 2 * kk * g.PS + tapoff];
-        b1[slot] = Xl[xb[1] + 2 * kk * g.PS + tapoff];
-      };
-      fetch(0, 0);
+  // ---- prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers ----------------------------------
 #pragma unroll
-      for (int st = 0; st < NSTEP; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < NSTEP) fetch(st + 1, cur ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], b0[cur], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], b1[cur], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], b0[cur], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], b1[cur], acc[1][1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+  for (int p = 0; p < NP; ++p) prefetch_piece(p, 0);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) commit_piece(p, 0);
+  if (g.nchunks > 1) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) prefetch_piece(p, 1);
+  }
+  __syncthreads();
+
+  // One chunk: MFMAs on buffer `cb`, with the commit of chunk q + 1 and the loads of chunk q + 2
+  // woven between the MFMA groups.
+  auto chunk = [&](auto commit_c, auto pref_c, int q) {
+    constexpr bool DO_COMMIT = decltype(commit_c)::value;
+    constexpr bool DO_PREF = decltype(pref_c)::value;
+    const int cb = (q & 1) * bufsz;
+    const int nb = bufsz - cb;
+    float av[2][NAB], bv[2][2];
+    auto fetch = [&](int st, int slot) {
+      const int t = st / (CC / 2), kk = st % (CC / 2);
+      const int tapoff = (NTAPS == 9) ? ((t / 3) * g.RS + (t % 3)) : 0;
+#pragma unroll
+      for (int ab = 0; ab < NAB; ++ab) av[slot][ab] = smem[cb + wb + (t * CC + 2 * kk) * kConvNT + ab * 32];
+      bv[slot][0] = smem[cb + xb[0] + 2 * kk * g.PS + tapoff];
+      bv[slot][1] = smem[cb + xb[1] + 2 * kk * g.PS + tapoff];
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      const int cur = st & 1;
+      if (st + 1 < NSTEP) fetch(st + 1, cur ^ 1);
+      if (DO_COMMIT) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          if ((p < H - 1 ? p : H - 1) == st) commit_piece(p, nb);
+      }
+      if (DO_PREF) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          if (H + (p < NSTEP - H - 1 ? p : NSTEP - H - 1) == st) prefetch_piece(p, q + 2);
+      }
+#pragma unroll
+      for (int ab = 0; ab < NAB; ++ab) {
+        acc[ab][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][ab], bv[cur][0], acc[ab][0], 0, 0, 0);
+        acc[ab][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][ab], bv[cur][1], acc[ab][1], 0, 0, 0);
       }
     }
+    __syncthreads();
+  };
+
+  int q = 0;
+  for (; q + 2 < g.nchunks; ++q) chunk(std::true_type{}, std::true_type{}, q);
+  if (q + 1 < g.nchunks) {
+    chunk(std::true_type{}, std::false_type{}, q);
+    ++q;
   }
+  chunk(std::false_type{}, std::false_type{}, q);
 
   // ---- epilogue: D[row = cout][col = pixel] -> NCHW, 128 B contiguous per (reg, half-wave) --
-  // Two-phase per pixel block: every addend (bias, temb, residual) is loaded BEFORE the first store.
-  // Interleaving "load residual -> add -> store" made each of the 64 stores wait for the previous one
-  // (out may alias the addends as far as the compiler knows): ~85k cycles per workgroup, 22 % of a
-  // 16-chunk convolution.  The restrict copies state the no-alias contract of the ABI.
+  // Every addend (bias, temb, residual) of a 16-value group is loaded before the group's first
+  // store; the restrict copies state the no-alias contract of the ABI.
   const float *__restrict__ bias_p = a.bias;
   const float *__restrict__ chan_p = a.chan_add;
   const float *__restrict__ res_p = a.residual;
   float *__restrict__ out_p = a.out;
-  const int co_base = nt * kConvNT + wn * 64 + 4 * lhi;
+  const int co_base = nt * kConvNT + wco + 4 * lhi;
 #pragma unroll
   for (int bb = 0; bb < 2; ++bb) {
-    const int P = P0 + (wm * 2 + bb) * 32 + l31;
-    if (P < g.M && !((g.xflags & 256) && blockIdx.x != 0xfffff)) {  // knob 256: drop the epilogue (timing only)
+    const int P = P0 + wpx + bb * 32 + l31;
+    if (P < g.M) {
       const int n = P / g.HWo;
       const int p = P - n * g.HWo;
       const size_t obase = ((size_t)n * a.Cout + co_base) * g.HWo + p;
 #pragma unroll
-      for (int ab = 0; ab < 2; ++ab) {  // 16 values at a time keeps the temporaries at 48 registers
-        float bv[16], cv[16], rv[16];
+      for (int ab = 0; ab < NAB; ++ab) {
+        float bvv[16], cv[16], rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dco = ab * 32 + (r & 3) + 8 * (r >> 2);
-          bv[r] = bias_p ? bias_p[co_base + dco] : 0.f;
+          bvv[r] = bias_p ? bias_p[co_base + dco] : 0.f;
           cv[r] = chan_p ? chan_p[(size_t)n * a.chan_add_stride + co_base + dco] : 0.f;
           rv[r] = res_p ? res_p[obase + (size_t)dco * g.HWo] : 0.f;
         }
@@ -318,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ddpm_conv_desc 
         for (int r = 0; r < 16; ++r) {
           const int dco = ab * 32 + (r & 3) + 8 * (r >> 2);
           float v = acc[ab][bb][r];
-          if (bias_p) v += bv[r];
+          if (bias_p) v += bvv[r];
           if (chan_p) v += cv[r];
           if (res_p) v += rv[r];
           out_p[obase + (size_t)dco * g.HWo] = v;
@@ -328,26 +352,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ddpm_conv_desc 
   }
 }
 
-template <int NTAPS, int NPOS, bool AFFINE>
+template <int NTAPS, int NPOS, bool AFFINE, int MT>
 static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_t s) {
-  const size_t lds = (size_t)(NTAPS * kConvCc * kConvNT + kConvCc * g.PS) * sizeof(float) +
-                     ((g.xflags & 128) ? 48 * 1024 : 0);  // knob 128: pad LDS so only one workgroup fits a CU
+  const size_t lds = (size_t)2 * (NTAPS * kConvCc * kConvNT + kConvCc * g.PS) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
     if (getenv("DDPM_CONV_DEBUG")) {
       int nb = -1;
       hipFuncAttributes fa{};
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
-          &nb, reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE>), 256, lds);
-      (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE>));
-      fprintf(stderr, "[conv_mfma<%d,%d,%d>] lds=%zu B, numRegs=%d, static LDS=%zu, occupancy=%d blocks/CU\n", NTAPS,
-              NPOS, (int)AFFINE, lds, fa.numRegs, fa.sharedSizeBytes, nb);
+          &nb, reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT>), 256, lds);
+      (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT>));
+      fprintf(stderr, "[conv_mfma<%d,%d,%d,%d>] lds=%zu B, numRegs=%d, occupancy=%d blocks/CU\n", NTAPS, NPOS,
+              (int)AFFINE, MT, lds, fa.numRegs, nb);
     }
   }
-  dim3 grid((g.M + kConvMT - 1) / kConvMT, d.Cout / kConvNT);
+  dim3 grid((g.M + MT - 1) / MT, d.Cout / kConvNT);
   // algorithmic work of this launch: 2*M*Cout*Cin*taps FLOP; input + output (+ residual)
   // + weights bytes, each counted once
   const double flops = 2.0 * g.M * d.Cout * (double)g.Cin * NTAPS;
@@ -357,37 +380,42 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_
                                   : (AFFINE ? "conv1x1_mfma_gn" : "conv1x1_mfma");
   char kshape[160];
   if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {  // development: one profile row per layer shape
-    snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d m%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo, d.mode);
+    snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d m%d t%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo, d.mode, MT);
     kname = kshape;
   }
   ProfScope prof(s, kname, flops, bytes);
-  hipLaunchKernelGGL((conv_mfma_kernel<NTAPS, NPOS, AFFINE>), grid, dim3(256), lds, s, d, g);
+  hipLaunchKernelGGL((conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT>), grid, dim3(256), lds, s, d, g);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
 
-int launch_conv_mfma(const ddpm_conv_desc &d, hipStream_t s) {
-  ConvGeom g;
-  if (!conv_mfma_supported(d) || !make_geom(d, g)) {
-    set_error("conv_mfma: unsupported shape");
-    return DDPM_EINVAL;
-  }
+template <int MT>
+static int launch_mt(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_t s) {
   const int npos = (g.PS + 255) / 256;
   const bool aff = d.gscale != nullptr;
   if (d.ksize == 3) {
     if (aff) {
-      if (npos == 1) return launch_variant<9, 1, true>(d, g, s);
-      return launch_variant<9, 2, true>(d, g, s);
+      if (npos == 1) return launch_variant<9, 1, true, MT>(d, g, s);
+      return launch_variant<9, 2, true, MT>(d, g, s);
     }
-    if (npos == 1) return launch_variant<9, 1, false>(d, g, s);
-    if (npos == 2) return launch_variant<9, 2, false>(d, g, s);
-    return launch_variant<9, 3, false>(d, g, s);
+    if (npos == 1) return launch_variant<9, 1, false, MT>(d, g, s);
+    if (npos == 2) return launch_variant<9, 2, false, MT>(d, g, s);
+    return launch_variant<9, 3, false, MT>(d, g, s);
   }
-  if (aff) return launch_variant<1, 1, true>(d, g, s);
-  return launch_variant<1, 1, false>(d, g, s);
+  if (aff) return launch_variant<1, 1, true, MT>(d, g, s);
+  return launch_variant<1, 1, false, MT>(d, g, s);
 }
 
-// ---- weight packing: torch [Cout][Cin][T] -> [cout_tile][chunk][tap][8][128] -----------------
+int launch_conv_mfma(const ddpm_conv_desc &d, hipStream_t s) {
+  ConvGeom g;
+  if (!conv_mfma_supported(d) || !pick_geom(d, g)) {
+    set_error("conv_mfma: unsupported shape");
+    return DDPM_EINVAL;
+  }
+  return g.MT == 128 ? launch_mt<128>(d, g, s) : launch_mt<64>(d, g, s);
+}
+
+// ---- weight packing: torch [Cout][Cin][T] -> [cout_tile][chunk][tap][4][128] -----------------
 __global__ void pack_conv_weight_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin,
                                         int T, int cout_offset) {
   const int64_t total = (int64_t)Cout * Cin * T;
@@ -411,7 +439,7 @@ size_t packed_conv_weight_floats(int Cout, int Cin, int ksize) {
 
 int launch_pack_conv_weight(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize, int cout_offset,
                             int Cout_total, hipStream_t s) {
-  DDPM_CHECK_ARG(packed_conv_weight_floats(Cout_total, Cin, ksize) != 0, "pack: Cout_total %% 128 or Cin %% 8 != 0");
+  DDPM_CHECK_ARG(packed_conv_weight_floats(Cout_total, Cin, ksize) != 0, "pack: Cout_total %% 128 or Cin %% 4 != 0");
   DDPM_CHECK_ARG(cout_offset >= 0 && cout_offset + Cout <= Cout_total, "pack: bad cout range");
   const int64_t total = (int64_t)Cout * Cin * ksize * ksize;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);

@@ -10,7 +10,16 @@ if str(ROOT) not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+def _cap_threads():
+    # The GPU box reports 256 logical CPUs; an OpenMP pool that wide makes the small oracle
+    # convolutions crawl (minutes instead of seconds).  32 threads is what bench.py uses too.
+    import torch
+
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+
+
 def pytest_configure(config):
+    _cap_threads()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
