@@ -189,7 +189,7 @@ def main():
     roofline = None
     if dom and dom["ms"] > 0:
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel<9,1,true> (3x3 conv, GN+SiLU prologue, fp32 MFMA)",
+        roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel<9,1,true,128> (3x3 conv, 128x128 tile, GN+SiLU prologue, fp32 MFMA)",
                     "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                     "launches_timed": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),

@@ -376,8 +376,10 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_
   const double flops = 2.0 * g.M * d.Cout * (double)g.Cin * NTAPS;
   const double bytes = 4.0 * ((double)d.B * g.Cin * g.HWi + (double)g.M * d.Cout * (d.residual ? 2 : 1) +
                               (double)d.Cout * g.Cin * NTAPS);
-  const char *kname = NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu" : "conv3x3_mfma")
-                                  : (AFFINE ? "conv1x1_mfma_gn" : "conv1x1_mfma");
+  const char *kname = MT == 128 ? (NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu" : "conv3x3_mfma")
+                                              : (AFFINE ? "conv1x1_mfma_gn" : "conv1x1_mfma"))
+                                : (NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu_t64" : "conv3x3_mfma_t64")
+                                              : (AFFINE ? "conv1x1_mfma_gn_t64" : "conv1x1_mfma_t64"));
   char kshape[160];
   if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {  // development: one profile row per layer shape
     snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d m%d t%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo, d.mode, MT);

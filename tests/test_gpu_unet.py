@@ -56,6 +56,22 @@ def test_unet_forward_generic_config_and_proj_attn(device):
     assert (yh - yr).abs().max().item() <= 1e-4 * (1 + yr.abs().max().item())
 
 
+def test_unet_forward_big_cfg4(device):
+    """BASELINE configs[3]: the attention-heavy `big` UNet (172.6 M params) at 64x64x3: attention at every
+    level (n = 4096 / 1024 / 256 tokens, 1 / 2 / 3 heads of 256), two res-blocks per level."""
+    from ddpm_ood_amd.trainer import MODEL_CONFIGS
+
+    ref, hip = _pair(device, 3, MODEL_CONFIGS["big"])
+    x = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(6))
+    t = torch.tensor([870])
+    with torch.no_grad():
+        yr = ref(x, timesteps=t)
+    yh = hip(x.to(device), timesteps=t.to(device)).cpu()
+    err = (yh - yr).abs().max().item()
+    assert math.isfinite(err) and err <= 1e-4 * (1 + yr.abs().max().item()), err
+    assert yr.abs().max() > 0.05
+
+
 def test_unet_missing_key_and_bad_shape(device):
     from ddpm_ood_amd import DiffusionModelUNet
 

@@ -1,0 +1,59 @@
+"""Aggregate rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE / SQ / GRBM runs of
+tools/microbench.py) into per-kernel HBM traffic and MFMA utilisation.
+
+    python tools/pmc_summary.py gpurun_out/pmc profiles/r01_pmc_per_kernel.csv profiles/pmc_traffic.json
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are KB; on gfx950
+FETCH_SIZE reports half of a wide coalesced read, so reads are 2 x FETCH_SIZE x 1024 (an upper
+estimate for this kernel's 4-byte input loads).  Only launches of the steady-state forwards are used.
+"""
+import json
+import sys
+
+import pandas as pd
+
+
+def load(root, d):
+    df = pd.read_csv(f"{root}/{d}/pmc_counter_collection.csv")
+    df["dur_us"] = (df.End_Timestamp - df.Start_Timestamp) / 1e3
+    return df[df.Kernel_Name.str.contains("ddpm")]
+
+
+def short(n):
+    n = n.replace("void ddpm::", "").replace("ddpm::", "")
+    return n.split("(")[0]
+
+
+def main(root, out_csv, out_json):
+    key = ["Kernel_Name"]
+    f, w = load(root, "FETCH_SIZE"), load(root, "WRITE_SIZE")
+    s, g = load(root, "SQ_WAVE_CYCLES"), load(root, "GRBM_GUI_ACTIVE")
+    m = f.groupby(key).agg(launches=("Counter_Value", "size"), fetch_kb=("Counter_Value", "mean"),
+                           dur_us=("dur_us", "mean")).reset_index()
+    m = m.merge(w.groupby(key).agg(write_kb=("Counter_Value", "mean")).reset_index(), on=key)
+    for df in (s, g):
+        pv = df.pivot_table(index=key + ["Dispatch_Id"], columns="Counter_Name", values="Counter_Value").reset_index()
+        m = m.merge(pv.groupby(key).mean(numeric_only=True).reset_index().drop(columns=["Dispatch_Id"]), on=key)
+    m["kernel"] = m.Kernel_Name.map(short)
+    m["hbm_read_MB_per_launch"] = m.fetch_kb * 2 * 1024 / 1e6
+    m["hbm_write_MB_per_launch"] = m.write_kb * 1024 / 1e6
+    m["hbm_MB_per_launch"] = m.hbm_read_MB_per_launch + m.hbm_write_MB_per_launch
+    m["clock_GHz"] = m.GRBM_GUI_ACTIVE / 8 / (m.dur_us * 1e3)          # GRBM counter summed over 8 XCDs
+    m["mfma_util"] = m.SQ_VALU_MFMA_BUSY_CYCLES / (1024 * m.dur_us * 1e3 * m.clock_GHz)  # 1024 SIMDs
+    m["l2_hit"] = m.TCC_HIT_sum / (m.TCC_HIT_sum + m.TCC_MISS_sum)
+    cols = ["kernel", "launches", "dur_us", "hbm_read_MB_per_launch", "hbm_write_MB_per_launch", "hbm_MB_per_launch",
+            "clock_GHz", "mfma_util", "l2_hit", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY",
+            "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU"]
+    m = m.sort_values("dur_us", ascending=False)[cols]
+    m.to_csv(out_csv, index=False, float_format="%.4g")
+    print(m.head(12).to_string())
+    dom = m[m.kernel.str.startswith("conv_mfma_kernel<9, 1, true, 128>")].iloc[0]
+    json.dump({"conv3x3_mfma_gn_silu_bytes_per_launch": float(dom.hbm_MB_per_launch * 1e6),
+               "conv3x3_mfma_gn_silu_mfma_util": float(dom.mfma_util),
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/microbench.py, B=256; "
+                         "reads = 2 x FETCH_SIZE KB (gfx950 correction), mean over the kernel's launches"},
+              open(out_json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
