@@ -116,19 +116,24 @@ bool conv_mfma_supported(const ddpm_conv_desc &d) {
   return pick_geom(d, g);
 }
 
-template <int NTAPS, int NPOS, bool AFFINE, int MT>
+template <int NTAPS, int NPOS, bool AFFINE, int MT, int KG>
 __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(const ddpm_conv_desc a,
                                                                              const ConvGeom g) {
-  constexpr int CC = kConvCc;                  // 4 input channels per chunk
-  constexpr int WF = NTAPS * CC * kConvNT;     // weight floats per chunk (4608 / 512)
-  constexpr int NW4 = WF / 1024;               // full 16-byte rounds per thread (4 / 0)
-  constexpr int NP = NW4 + 1 + NPOS;           // staging pieces per chunk
-  constexpr int NSTEP = NTAPS * (CC / 2);      // k-steps (4 or 2 MFMAs each) per chunk
+  // KG = groups of 4 input channels per chunk: 1 for 3x3 (72 MFMAs per chunk and barrier); 4 for plain
+  // 1x1 convs / Linears, whose single tap would otherwise give a barrier every 8 MFMAs.
+  constexpr int CC = kConvCc;                  // 4: granule of the packed weight layout
+  constexpr int CPC = CC * KG;                 // input channels per chunk
+  constexpr int WF = NTAPS * CPC * kConvNT;    // weight floats per chunk (4608 / 2048 / 512)
+  constexpr int NW4 = WF / 1024;               // full 16-byte rounds per thread
+  constexpr bool HASREM = (WF % 1024) != 0;    // + one 8-byte round (512 floats)
+  constexpr int NXP = NPOS * KG;               // input pieces: (position, channel group)
+  constexpr int NP = NW4 + (HASREM ? 1 : 0) + NXP;  // staging pieces per chunk
+  constexpr int NSTEP = NTAPS * (CPC / 2);     // k-steps (4 or 2 MFMAs each) per chunk
   constexpr int H = (NSTEP + 1) / 2;           // commit pieces go to steps [0, H), prefetch to [H, NSTEP)
   constexpr int NAB = MT == 128 ? 2 : 1;       // 32-cout blocks per wave
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int bufsz = WF + CC * g.PS;            // floats per LDS buffer: [NTAPS][4][128] weights, [4][PS] input
+  const int bufsz = WF + CPC * g.PS;           // floats per LDS buffer: [NTAPS][CPC][128] weights, [CPC][PS] input
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -193,8 +198,8 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   // ---- staging registers: one chunk in flight -----------------------------------------------
   v4f w4[NW4 > 0 ? NW4 : 1];
   v2f w2;
-  float xreg[NPOS][CC];
-  v4f screg[NPOS], shreg[NPOS];
+  float xreg[NXP][CC];
+  v4f screg[NXP], shreg[NXP];
 
   const float *wsrc = a.w_packed + (size_t)nt * g.nchunks * WF;
 
@@ -203,11 +208,12 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
     const float *wp = wsrc + (size_t)ch * WF;
     if (p < NW4) {
       w4[p < NW4 ? p : 0] = reinterpret_cast<const v4f *>(wp)[tid + 256 * p];
-    } else if (p == NW4) {
+    } else if (HASREM && p == NW4) {
       w2 = reinterpret_cast<const v2f *>(wp)[NW4 * 512 + tid];
     } else {
-      const int j = p - NW4 - 1;
-      const int cg0 = ch * CC;
+      const int xp = p - NW4 - (HASREM ? 1 : 0);
+      const int j = xp / KG, gk = xp % KG;
+      const int cg0 = ch * CPC + gk * CC;
       const float *base;
       int Cs, cl0;
       if (cg0 < a.C1) {
@@ -218,14 +224,14 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
       if (soff[j] >= 0) {
         const float *px = base + ((size_t)nimg[j] * Cs + cl0) * g.HWi + soff[j];
 #pragma unroll
-        for (int c = 0; c < CC; ++c) xreg[j][c] = px[(size_t)c * g.HWi];
+        for (int c = 0; c < CC; ++c) xreg[xp][c] = px[(size_t)c * g.HWi];
         if (AFFINE) {
-          screg[j] = *reinterpret_cast<const v4f *>(a.gscale + (size_t)nimg[j] * g.Cin + cg0);
-          shreg[j] = *reinterpret_cast<const v4f *>(a.gshift + (size_t)nimg[j] * g.Cin + cg0);
+          screg[xp] = *reinterpret_cast<const v4f *>(a.gscale + (size_t)nimg[j] * g.Cin + cg0);
+          shreg[xp] = *reinterpret_cast<const v4f *>(a.gshift + (size_t)nimg[j] * g.Cin + cg0);
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < CC; ++c) xreg[j][c] = 0.f;
+        for (int c = 0; c < CC; ++c) xreg[xp][c] = 0.f;
       }
     }
   };
@@ -234,21 +240,22 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   auto commit_piece = [&](int p, int nb) {
     if (p < NW4) {
       reinterpret_cast<v4f *>(smem + nb)[tid + 256 * p] = w4[p < NW4 ? p : 0];
-    } else if (p == NW4) {
+    } else if (HASREM && p == NW4) {
       reinterpret_cast<v2f *>(smem + nb)[NW4 * 512 + tid] = w2;
     } else {
-      const int j = p - NW4 - 1;
+      const int xp = p - NW4 - (HASREM ? 1 : 0);
+      const int j = xp / KG, gk = xp % KG;
       const int r = tid + 256 * j;
       if (r < g.PS) {
         const bool valid = soff[j] >= 0;
 #pragma unroll
         for (int c = 0; c < CC; ++c) {
-          float v = xreg[j][c];
-          if (AFFINE) v = v * screg[j][c] + shreg[j][c];
+          float v = xreg[xp][c];
+          if (AFFINE) v = v * screg[xp][c] + shreg[xp][c];
           // v_exp_f32 / v_rcp_f32 SiLU (6 instructions instead of ~45): end-to-end parity unchanged
-          // (Z-score error 2.4e-6 vs 3.4e-6 with expf + IEEE divide; profiles/r01_parity_report.txt)
+          // (Z-score error 2.4e-6 vs 3.4e-6 with expf + IEEE divide)
           if (a.act == DDPM_ACT_SILU) v = silu_fast(v);
-          smem[nb + WF + c * g.PS + r] = valid ? v : 0.f;
+          smem[nb + WF + (gk * CC + c) * g.PS + r] = valid ? v : 0.f;
         }
       }
     }
@@ -274,10 +281,10 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
     const int nb = bufsz - cb;
     float av[2][NAB], bv[2][2];
     auto fetch = [&](int st, int slot) {
-      const int t = st / (CC / 2), kk = st % (CC / 2);
+      const int t = st / (CPC / 2), kk = st % (CPC / 2);
       const int tapoff = (NTAPS == 9) ? ((t / 3) * g.RS + (t % 3)) : 0;
 #pragma unroll
-      for (int ab = 0; ab < NAB; ++ab) av[slot][ab] = smem[cb + wb + (t * CC + 2 * kk) * kConvNT + ab * 32];
+      for (int ab = 0; ab < NAB; ++ab) av[slot][ab] = smem[cb + wb + (t * CPC + 2 * kk) * kConvNT + ab * 32];
       bv[slot][0] = smem[cb + xb[0] + 2 * kk * g.PS + tapoff];
       bv[slot][1] = smem[cb + xb[1] + 2 * kk * g.PS + tapoff];
     };
@@ -289,12 +296,12 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
       if (DO_COMMIT) {
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-          if ((p < H - 1 ? p : H - 1) == st) commit_piece(p, nb);
+          if ((p * H) / NP == st) commit_piece(p, nb);
       }
       if (DO_PREF) {
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-          if (H + (p < NSTEP - H - 1 ? p : NSTEP - H - 1) == st) prefetch_piece(p, q + 2);
+          if (H + (p * (NSTEP - H)) / NP == st) prefetch_piece(p, q + 2);
       }
 #pragma unroll
       for (int ab = 0; ab < NAB; ++ab) {
@@ -352,20 +359,22 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   }
 }
 
-template <int NTAPS, int NPOS, bool AFFINE, int MT>
-static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_t s) {
-  const size_t lds = (size_t)2 * (NTAPS * kConvCc * kConvNT + kConvCc * g.PS) * sizeof(float);
+template <int NTAPS, int NPOS, bool AFFINE, int MT, int KG = 1>
+static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g_in, hipStream_t s) {
+  ConvGeom g = g_in;
+  g.nchunks = g.Cin / (kConvCc * KG);
+  const size_t lds = (size_t)2 * (NTAPS * kConvCc * KG * kConvNT + kConvCc * KG * g.PS) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT, KG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
     if (getenv("DDPM_CONV_DEBUG")) {
       int nb = -1;
       hipFuncAttributes fa{};
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
-          &nb, reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT>), 256, lds);
-      (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT>));
+          &nb, reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT, KG>), 256, lds);
+      (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT, KG>));
       fprintf(stderr, "[conv_mfma<%d,%d,%d,%d>] lds=%zu B, numRegs=%d, occupancy=%d blocks/CU\n", NTAPS, NPOS,
               (int)AFFINE, MT, lds, fa.numRegs, nb);
     }
@@ -386,7 +395,7 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_
     kname = kshape;
   }
   ProfScope prof(s, kname, flops, bytes);
-  hipLaunchKernelGGL((conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT>), grid, dim3(256), lds, s, d, g);
+  hipLaunchKernelGGL((conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT, KG>), grid, dim3(256), lds, s, d, g);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
@@ -405,6 +414,8 @@ static int launch_mt(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_t s) 
     return launch_variant<9, 3, false, MT>(d, g, s);
   }
   if (aff) return launch_variant<1, 1, true, MT>(d, g, s);
+  // plain 1x1 / Linear: 16 channels per chunk when the channel counts allow it
+  if (g.Cin % 16 == 0 && (d.C2 == 0 || d.C1 % 16 == 0)) return launch_variant<1, 1, false, MT, 4>(d, g, s);
   return launch_variant<1, 1, false, MT>(d, g, s);
 }
 
