@@ -30,6 +30,7 @@ class ConvDesc(C.Structure):
         ("B", C.c_int), ("Cout", C.c_int),
         ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
         ("ksize", C.c_int), ("mode", C.c_int), ("act", C.c_int), ("force_direct", C.c_int),
+        ("Di", C.c_int), ("Do", C.c_int), ("kd", C.c_int), ("accumulate", C.c_int),
     ]
 
 
@@ -76,6 +77,9 @@ SIGNATURES = {
     "ddpm_unet_param_numel": (C.c_int64, [C.c_void_p, C.c_int]),
     "ddpm_unet_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ddpm_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "ddpm_unet_workspace_bytes3d": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ddpm_unet_forward3d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddpm_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
 }

@@ -82,7 +82,7 @@ int launch_conv_mfma(const ddpm_conv_desc &d, hipStream_t s);
 int launch_conv_direct(const ddpm_conv_desc &d, hipStream_t s);
 size_t packed_conv_weight_floats(int Cout, int Cin, int ksize);
 int launch_pack_conv_weight(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize, int cout_offset,
-                            int Cout_total, hipStream_t s);
+                            int Cout_total, hipStream_t s, int src_taps = 0, int tap_off = 0);
 int launch_gn_scale_shift(const float *in1, const float *in2, int C1, int C2, const float *gamma, const float *beta,
                           float *scale, float *shift, int B, int HW, int groups, float eps, hipStream_t s);
 int launch_attention(const float *qkv, const float *residual, float *out, int B, int C, int N, int heads, float scale,

@@ -204,6 +204,12 @@ int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
   if (d.mode == DDPM_CONV_STRIDE2)
     DDPM_CHECK_ARG(d.Ho == (d.Hi + 1) / 2 && d.Wo == (d.Wi + 1) / 2 && d.ksize == 3,
                    "conv: stride-2 needs Ho == ceil(Hi / 2), k == 3");
+  if (d.Di > 1 || d.Do > 1) {
+    DDPM_CHECK_ARG(d.kd >= 0 && d.kd <= 2 && d.ksize == 3, "conv: a depth-tap launch needs kd in 0..2 and k == 3");
+    DDPM_CHECK_ARG(conv_mfma_supported(d), "conv3d: only shapes with an MFMA tiling are built (Cin %% 4, Cout %% 128)");
+    return launch_conv_mfma(d, s);
+  }
+  DDPM_CHECK_ARG(!d.accumulate, "conv: accumulate is only used by the depth-tap launches of a 3-D convolution");
   if (conv_mfma_supported(d)) return launch_conv_mfma(d, s);
   return launch_conv_direct(d, s);
 }

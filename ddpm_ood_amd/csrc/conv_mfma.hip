@@ -43,8 +43,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct ConvGeom {
-  int M;        // B * Ho * Wo
+  int M;        // B * Do * Ho * Wo
   int HWo, HWi;
+  int Di, Do;   // stored input / output depth (1 for 2-D); an "image" below is one (n, d) slice
+  int NI;       // B * Do slices
   int MT;       // pixels per workgroup tile (128 or 64)
   int TI, TH;   // images per tile, output rows per tile (per image)
   int IR, RS;   // LDS rows per image slot, LDS row stride
@@ -61,7 +63,10 @@ static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g) {
   g.MT = MT;
   g.HWo = d.Ho * d.Wo;
   g.HWi = d.Hi * d.Wi;
-  g.M = d.B * g.HWo;
+  g.Di = d.Di > 1 ? d.Di : 1;
+  g.Do = d.Do > 1 ? d.Do : 1;
+  g.NI = d.B * g.Do;
+  g.M = g.NI * g.HWo;
   g.pad = d.ksize == 3 ? 1 : 0;
   g.s = d.mode == DDPM_CONV_STRIDE2 ? 2 : 1;
   if (g.HWo >= MT) {
@@ -149,25 +154,39 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
 
   // ---- per-thread staging positions (chunk-invariant) -------------------------------------
   int soff[NPOS];   // offset inside one channel plane of the source, -1 => zero
-  int nimg[NPOS];
+  int nimg[NPOS];   // batch index of the position's slice
+  int dimg[NPOS];   // input depth index of the position's slice (0 for 2-D)
 #pragma unroll
   for (int j = 0; j < NPOS; ++j) {
     const int r = tid + 256 * j;
     soff[j] = -1;
     nimg[j] = 0;
+    dimg[j] = 0;
     if (r < g.PS) {
       const int ti = r / g.IRS;
       const int rr = r - ti * g.IRS;
       const int ir = rr / g.RS;
       const int ic = rr - ir * g.RS;
-      const int n = n0 + ti;
+      const int img = n0 + ti;       // (n, d_out) slice handled by this position
+      const int n = img / g.Do;
+      const int dz = img - n * g.Do;
+      // input depth of this launch's depth tap (3-D only): kd - 1 around the output slice
+      int din = 0;
+      bool dok = true;
+      if (g.Do > 1 || g.Di > 1) {
+        const int dv = g.s * dz + a.kd - 1;  // in the (virtual, for UPSAMPLE2: upsampled) input
+        const int Dv = (a.mode == DDPM_CONV_UPSAMPLE2) ? g.Do : g.Di;
+        dok = dv >= 0 && dv < Dv;
+        din = (a.mode == DDPM_CONV_UPSAMPLE2) ? (dv >> 1) : dv;
+      }
       const int hv = g.s * h0 + ir - g.pad;
       const int wv = ic - g.pad;
       // bounds of the (virtual) conv input: the upsampled extent for UPSAMPLE2, else Hi x Wi
       const int Hv = (a.mode == DDPM_CONV_UPSAMPLE2) ? a.Ho : a.Hi;
       const int Wv = (a.mode == DDPM_CONV_UPSAMPLE2) ? a.Wo : a.Wi;
-      if (n < a.B && hv >= 0 && hv < Hv && wv >= 0 && wv < Wv) {
+      if (img < g.NI && dok && hv >= 0 && hv < Hv && wv >= 0 && wv < Wv) {
         nimg[j] = n;
+        dimg[j] = din;
         soff[j] = (a.mode == DDPM_CONV_UPSAMPLE2) ? ((hv >> 1) * a.Wi + (wv >> 1)) : (hv * a.Wi + wv);
       }
     }
@@ -222,9 +241,9 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
         base = a.in2; Cs = a.C2; cl0 = cg0 - a.C1;
       }
       if (soff[j] >= 0) {
-        const float *px = base + ((size_t)nimg[j] * Cs + cl0) * g.HWi + soff[j];
+        const float *px = base + (((size_t)nimg[j] * Cs + cl0) * g.Di + dimg[j]) * g.HWi + soff[j];
 #pragma unroll
-        for (int c = 0; c < CC; ++c) xreg[xp][c] = px[(size_t)c * g.HWi];
+        for (int c = 0; c < CC; ++c) xreg[xp][c] = px[(size_t)c * g.Di * g.HWi];
         if (AFFINE) {
           screg[xp] = *reinterpret_cast<const v4f *>(a.gscale + (size_t)nimg[j] * g.Cin + cg0);
           shreg[xp] = *reinterpret_cast<const v4f *>(a.gshift + (size_t)nimg[j] * g.Cin + cg0);
@@ -326,15 +345,17 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   const float *__restrict__ bias_p = a.bias;
   const float *__restrict__ chan_p = a.chan_add;
   const float *__restrict__ res_p = a.residual;
-  float *__restrict__ out_p = a.out;
   const int co_base = nt * kConvNT + wco + 4 * lhi;
 #pragma unroll
   for (int bb = 0; bb < 2; ++bb) {
     const int P = P0 + wpx + bb * 32 + l31;
     if (P < g.M) {
-      const int n = P / g.HWo;
-      const int p = P - n * g.HWo;
-      const size_t obase = ((size_t)n * a.Cout + co_base) * g.HWo + p;
+      const int img = P / g.HWo;
+      const int p = P - img * g.HWo;
+      const int n = img / g.Do;
+      const int dz = img - n * g.Do;
+      const size_t cstride = (size_t)g.Do * g.HWo;  // channel stride of the NC(D)HW output
+      const size_t obase = (((size_t)n * a.Cout + co_base) * g.Do + dz) * g.HWo + p;
 #pragma unroll
       for (int ab = 0; ab < NAB; ++ab) {
         float bvv[16], cv[16], rv[16];
@@ -343,7 +364,8 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
           const int dco = ab * 32 + (r & 3) + 8 * (r >> 2);
           bvv[r] = bias_p ? bias_p[co_base + dco] : 0.f;
           cv[r] = chan_p ? chan_p[(size_t)n * a.chan_add_stride + co_base + dco] : 0.f;
-          rv[r] = res_p ? res_p[obase + (size_t)dco * g.HWo] : 0.f;
+          rv[r] = res_p ? res_p[obase + (size_t)dco * cstride] : 0.f;
+          if (a.accumulate) rv[r] += a.out[obase + (size_t)dco * cstride];  // 2nd / 3rd depth tap
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -351,8 +373,8 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
           float v = acc[ab][bb][r];
           if (bias_p) v += bvv[r];
           if (chan_p) v += cv[r];
-          if (res_p) v += rv[r];
-          out_p[obase + (size_t)dco * g.HWo] = v;
+          if (res_p || a.accumulate) v += rv[r];
+          a.out[obase + (size_t)dco * cstride] = v;
         }
       }
     }
@@ -383,7 +405,7 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g_in, hipStre
   // algorithmic work of this launch: 2*M*Cout*Cin*taps FLOP; input + output (+ residual)
   // + weights bytes, each counted once
   const double flops = 2.0 * g.M * d.Cout * (double)g.Cin * NTAPS;
-  const double bytes = 4.0 * ((double)d.B * g.Cin * g.HWi + (double)g.M * d.Cout * (d.residual ? 2 : 1) +
+  const double bytes = 4.0 * ((double)d.B * g.Cin * g.Di * g.HWi + (double)g.M * d.Cout * (d.residual ? 2 : 1) +
                               (double)d.Cout * g.Cin * NTAPS);
   const char *kname = MT == 128 ? (NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu" : "conv3x3_mfma")
                                               : (AFFINE ? "conv1x1_mfma_gn" : "conv1x1_mfma"))
@@ -429,8 +451,10 @@ int launch_conv_mfma(const ddpm_conv_desc &d, hipStream_t s) {
 }
 
 // ---- weight packing: torch [Cout][Cin][T] -> [cout_tile][chunk][tap][4][128] -----------------
+// `src_taps` / `tap_off` select T taps out of a wider torch kernel: the 9 (kh, kw) taps of depth tap kd
+// of a [Cout][Cin][3][3][3] conv3d weight are src_taps = 27, tap_off = 9 * kd.
 __global__ void pack_conv_weight_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin,
-                                        int T, int cout_offset) {
+                                        int T, int cout_offset, int src_taps, int tap_off) {
   const int64_t total = (int64_t)Cout * Cin * T;
   const int nchunks = Cin / kConvCc;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -441,7 +465,7 @@ __global__ void pack_conv_weight_kernel(const float *__restrict__ src, float *__
     const int tile = og / kConvNT, col = og % kConvNT;
     const int ch = ci / kConvCc, cl = ci % kConvCc;
     const size_t di = ((((size_t)tile * nchunks + ch) * T + t) * kConvCc + cl) * kConvNT + col;
-    dst[di] = src[i];
+    dst[di] = src[((size_t)o * Cin + ci) * src_taps + tap_off + t];
   }
 }
 
@@ -451,13 +475,14 @@ size_t packed_conv_weight_floats(int Cout, int Cin, int ksize) {
 }
 
 int launch_pack_conv_weight(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize, int cout_offset,
-                            int Cout_total, hipStream_t s) {
+                            int Cout_total, hipStream_t s, int src_taps, int tap_off) {
+  if (src_taps <= 0) src_taps = ksize * ksize;
   DDPM_CHECK_ARG(packed_conv_weight_floats(Cout_total, Cin, ksize) != 0, "pack: Cout_total %% 128 or Cin %% 4 != 0");
   DDPM_CHECK_ARG(cout_offset >= 0 && cout_offset + Cout <= Cout_total, "pack: bad cout range");
   const int64_t total = (int64_t)Cout * Cin * ksize * ksize;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, s, w_raw, w_packed, Cout, Cin,
-                     ksize * ksize, cout_offset);
+                     ksize * ksize, cout_offset, src_taps, tap_off);
   DDPM_CHECK_LAUNCH();
   return 0;
 }

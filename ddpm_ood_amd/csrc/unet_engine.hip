@@ -28,6 +28,7 @@ struct ParamSlot {
   bool is_conv = false;         // also packed for the MFMA kernel when the shape allows it
   size_t packed_base = 0;       // float offset of the (possibly shared) packed weight
   int Cout = 0, Cin = 0, ksize = 1, cout_offset = 0, Cout_total = 0;
+  int dims = 2;                 // 3: [Cout, Cin, k, k, k] packed as k slabs of 2-D taps (one per depth tap)
   bool optional = false;
   bool set = false;
 };
@@ -36,6 +37,7 @@ struct ConvRef {  // a conv-like op: weight (raw + packed) and bias locations in
   size_t w_raw = 0, w_packed = 0, bias = 0;
   bool has_packed = false;
   int Cin = 0, Cout = 0, ksize = 1;
+  int dims = 2;
 };
 
 struct GNRef {
@@ -104,10 +106,12 @@ struct ddpm_unet {
     return (int)params.size() - 1;
   }
   // conv / linear with its own weight and bias
-  ConvRef add_conv(const std::string &prefix, int Cout, int Cin, int k, bool optional = false) {
+  // `dims` = spatial rank of the kernel (1x1 convs and Linears are rank-free: pass 2)
+  ConvRef add_conv(const std::string &prefix, int Cout, int Cin, int k, bool optional = false, int dims = 2) {
     ConvRef r;
-    r.Cin = Cin; r.Cout = Cout; r.ksize = k;
-    const size_t n = (size_t)Cout * Cin * k * k;
+    if (k == 1) dims = 2;
+    r.Cin = Cin; r.Cout = Cout; r.ksize = k; r.dims = dims;
+    const size_t n = (size_t)Cout * Cin * (dims == 3 ? k * k * k : k * k);
     r.w_raw = alloc(n);
     r.has_packed = packed_conv_weight_floats(Cout, Cin, k) != 0;
     if (r.has_packed) r.w_packed = alloc(n);
@@ -116,7 +120,7 @@ struct ddpm_unet {
     params[wi].is_conv = r.has_packed;
     params[wi].packed_base = r.w_packed;
     params[wi].Cout = Cout; params[wi].Cin = Cin; params[wi].ksize = k;
-    params[wi].cout_offset = 0; params[wi].Cout_total = Cout;
+    params[wi].cout_offset = 0; params[wi].Cout_total = Cout; params[wi].dims = dims;
     add_raw(prefix + ".bias", Cout, r.bias, optional);
     return r;
   }
@@ -159,12 +163,12 @@ static ResRef build_res(ddpm_unet *u, const std::string &prefix, int Cin, int Co
   ResRef r;
   r.Cin = Cin; r.Cout = Cout;
   r.n1 = u->add_gn(prefix + ".norm1", Cin);
-  r.c1 = u->add_conv(prefix + ".conv1.conv", Cout, Cin, 3);
+  r.c1 = u->add_conv(prefix + ".conv1.conv", Cout, Cin, 3, false, u->cfg.spatial_dims);
   r.temb_off = temb_cursor;
   temb_members.emplace_back(prefix + ".time_emb_proj", Cout);
   temb_cursor += Cout;
   r.n2 = u->add_gn(prefix + ".norm2", Cout);
-  r.c2 = u->add_conv(prefix + ".conv2.conv", Cout, Cout, 3);
+  r.c2 = u->add_conv(prefix + ".conv2.conv", Cout, Cout, 3, false, u->cfg.spatial_dims);
   r.has_skip = Cin != Cout;
   if (r.has_skip) r.skip = u->add_conv(prefix + ".skip_connection.conv", Cout, Cin, 1);
   return r;
@@ -187,9 +191,18 @@ static AttnRef build_attn(ddpm_unet *u, const std::string &prefix, int C, int he
 
 extern "C" ddpm_unet *ddpm_unet_create(const ddpm_unet_config *cfg) {
   if (!cfg) { set_error("unet_create: cfg is NULL"); return nullptr; }
-  if (cfg->spatial_dims != 2) {
-    set_error("unet_create: spatial_dims = %d is reserved for the LDM row; only 2 is built", cfg->spatial_dims);
+  if (cfg->spatial_dims != 2 && cfg->spatial_dims != 3) {
+    set_error("unet_create: spatial_dims must be 2 or 3, got %d", cfg->spatial_dims);
     return nullptr;
+  }
+  if (cfg->spatial_dims == 3) {
+    // 3-D convolutions run as depth-tap launches of the MFMA kernel; there is no generic 3-D fallback
+    bool ok = cfg->in_channels % 4 == 0 && cfg->out_channels % 128 == 0;
+    for (int i = 0; i < cfg->num_levels; ++i) ok = ok && cfg->num_channels[i] % 128 == 0;
+    if (!ok) {
+      set_error("unet_create: spatial_dims = 3 needs in_channels %% 4 == 0 and out / num_channels %% 128 == 0");
+      return nullptr;
+    }
   }
   const int L = cfg->num_levels;
   if (L < 1 || L > DDPM_MAX_LEVELS) { set_error("unet_create: num_levels out of range"); return nullptr; }
@@ -207,7 +220,8 @@ extern "C" ddpm_unet *ddpm_unet_create(const ddpm_unet_config *cfg) {
 
   u->freqs_off = u->alloc(u->ch0 / 2);
   u->add_raw("freqs", u->ch0 / 2, u->freqs_off);
-  u->conv_in = u->add_conv("conv_in.conv", u->ch0, cfg->in_channels, 3);
+  const int sd = cfg->spatial_dims;
+  u->conv_in = u->add_conv("conv_in.conv", u->ch0, cfg->in_channels, 3, false, sd);
   u->te0 = u->add_conv("time_embed.0", u->ted, u->ch0, 1);
   u->te2 = u->add_conv("time_embed.2", u->ted, u->ted, 1);
 
@@ -228,7 +242,7 @@ extern "C" ddpm_unet *ddpm_unet_create(const ddpm_unet_config *cfg) {
       if (d.with_attn)
         d.att.push_back(build_attn(u, bp + ".attentions." + std::to_string(j), out_c, cfg->num_head_channels[i]));
     }
-    if (d.has_down) d.down = u->add_conv(bp + ".downsampler.op.conv", out_c, out_c, 3);
+    if (d.has_down) d.down = u->add_conv(bp + ".downsampler.op.conv", out_c, out_c, 3, false, sd);
     u->down.push_back(d);
   }
   const int cm = cfg->num_channels[L - 1];
@@ -255,11 +269,11 @@ extern "C" ddpm_unet *ddpm_unet_create(const ddpm_unet_config *cfg) {
       if (b.with_attn)
         b.att.push_back(build_attn(u, bp + ".attentions." + std::to_string(j), out_c, cfg->num_head_channels[ri]));
     }
-    if (b.has_up) b.up = u->add_conv(bp + ".upsampler.conv.conv", out_c, out_c, 3);
+    if (b.has_up) b.up = u->add_conv(bp + ".upsampler.conv.conv", out_c, out_c, 3, false, sd);
     u->up.push_back(b);
   }
   u->out_norm = u->add_gn("out.0", u->ch0);
-  u->conv_out = u->add_conv("out.2.conv", cfg->out_channels, u->ch0, 3);
+  u->conv_out = u->add_conv("out.2.conv", cfg->out_channels, u->ch0, 3, false, sd);
 
   // all time_emb_proj Linears share one [sum Cout, 4 ch0] GEMM (emb is loop-invariant in a forward)
   u->temb_total = temb_cursor;
@@ -309,7 +323,13 @@ extern "C" int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *
   hipStream_t s = as_stream(stream);
   int rc = launch_copy_f32(src, h->blob + p.raw_off, numel, s);
   if (rc) return rc;
-  if (p.is_conv) {
+  if (p.is_conv && p.dims == 3 && p.ksize == 3) {
+    const size_t slab = (size_t)p.Cout_total * p.Cin * 9;  // one packed 2-D weight per depth tap
+    for (int kd = 0; kd < 3 && !rc; ++kd)
+      rc = launch_pack_conv_weight(src, h->blob + p.packed_base + kd * slab, p.Cout, p.Cin, 3, p.cout_offset,
+                                   p.Cout_total, s, 27, 9 * kd);
+    if (rc) return rc;
+  } else if (p.is_conv) {
     rc = launch_pack_conv_weight(src, h->blob + p.packed_base, p.Cout, p.Cin, p.ksize, p.cout_offset, p.Cout_total, s);
     if (rc) return rc;
   }
@@ -334,9 +354,10 @@ struct Bump {
   void release(size_t m) { off = m; }
 };
 
-struct Act {  // an activation tensor [B, C, H, W]
+struct Act {  // an activation tensor [B, C, H, W] (D == 1) or [B, C, D, H, W]
   float *p = nullptr;
-  int C = 0, H = 0, W = 0;
+  int C = 0, H = 0, W = 0, D = 1;
+  size_t voxels() const { return (size_t)D * H * W; }
 };
 
 struct Runner {
@@ -350,7 +371,7 @@ struct Runner {
   const float *P(size_t off) const { return u->blob + off; }
 
   void conv(const ConvRef &c, const Act &in1, const Act *in2, const float *gsc, const float *gsh, int act, int mode,
-            const float *chan_add, int chan_stride, const float *residual, float *out, int Ho, int Wo) {
+            const float *chan_add, int chan_stride, const float *residual, float *out, int Ho, int Wo, int Do = 1) {
     if (ws.dry || rc) return;
     ddpm_conv_desc d{};
     d.in1 = in1.p; d.C1 = in1.C;
@@ -365,58 +386,81 @@ struct Runner {
     d.B = B; d.Cout = c.Cout;
     d.Hi = in1.H; d.Wi = in1.W; d.Ho = Ho; d.Wo = Wo;
     d.ksize = c.ksize; d.mode = mode; d.act = act;
+    if (in1.D > 1 || Do > 1) {
+      if (c.ksize == 1) {
+        // pointwise over a volume: the NCDHW tensor is an NCHW tensor of extent (D*H) x W
+        d.Hi = in1.D * in1.H; d.Ho = Do * Ho;
+      } else {
+        // F.conv3d as three depth-tap launches of the 2-D kernel (centre tap first: it is always in
+        // range and carries bias / temb / residual; the other two accumulate into `out`)
+        const size_t slab = (size_t)c.Cout * c.Cin * 9;
+        d.Di = in1.D; d.Do = Do;
+        static const int order[3] = {1, 0, 2};
+        for (int i = 0; i < 3 && !rc; ++i) {
+          d.kd = order[i];
+          d.w_packed = P(c.w_packed) + d.kd * slab;
+          if (i > 0) {
+            d.bias = nullptr; d.chan_add = nullptr; d.residual = nullptr;
+            d.accumulate = 1;
+          }
+          rc = conv_dispatch(d, s);
+        }
+        return;
+      }
+    }
     rc = conv_dispatch(d, s);
   }
 
   void gn(const GNRef &g, const Act &in1, const Act *in2, float *sc, float *sh) {
     if (ws.dry || rc) return;
     rc = launch_gn_scale_shift(in1.p, in2 ? in2->p : nullptr, in1.C, in2 ? in2->C : 0, P(g.gamma), P(g.beta), sc, sh,
-                               B, in1.H * in1.W, u->cfg.norm_num_groups, u->cfg.norm_eps, s);
+                               B, (int)in1.voxels(), u->cfg.norm_num_groups, u->cfg.norm_eps, s);
   }
 
   // out must be allocated by the caller (so that it survives the temporaries released here)
   void resnet(const ResRef &r, const Act &in1, const Act *in2, Act &out) {
     const size_t m = ws.mark();
-    const int H = in1.H, W = in1.W;
-    const size_t hw = (size_t)H * W;
+    const int H = in1.H, W = in1.W, D = in1.D;
+    const size_t hw = in1.voxels();
     float *sc1 = ws.get((size_t)B * r.Cin), *sh1 = ws.get((size_t)B * r.Cin);
     gn(r.n1, in1, in2, sc1, sh1);
-    Act h1{ws.get((size_t)B * r.Cout * hw), r.Cout, H, W};
+    Act h1{ws.get((size_t)B * r.Cout * hw), r.Cout, H, W, D};
     conv(r.c1, in1, in2, sc1, sh1, DDPM_ACT_SILU, DDPM_CONV_NORMAL, temb + r.temb_off, u->temb_total, nullptr, h1.p,
-         H, W);
+         H, W, D);
     float *sc2 = ws.get((size_t)B * r.Cout), *sh2 = ws.get((size_t)B * r.Cout);
     gn(r.n2, h1, nullptr, sc2, sh2);
     if (!r.has_skip) {
-      conv(r.c2, h1, nullptr, sc2, sh2, DDPM_ACT_SILU, DDPM_CONV_NORMAL, nullptr, 0, in1.p, out.p, H, W);
+      conv(r.c2, h1, nullptr, sc2, sh2, DDPM_ACT_SILU, DDPM_CONV_NORMAL, nullptr, 0, in1.p, out.p, H, W, D);
     } else {
-      Act h2{ws.get((size_t)B * r.Cout * hw), r.Cout, H, W};
-      conv(r.c2, h1, nullptr, sc2, sh2, DDPM_ACT_SILU, DDPM_CONV_NORMAL, nullptr, 0, nullptr, h2.p, H, W);
-      conv(r.skip, in1, in2, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, h2.p, out.p, H, W);
+      Act h2{ws.get((size_t)B * r.Cout * hw), r.Cout, H, W, D};
+      conv(r.c2, h1, nullptr, sc2, sh2, DDPM_ACT_SILU, DDPM_CONV_NORMAL, nullptr, 0, nullptr, h2.p, H, W, D);
+      conv(r.skip, in1, in2, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, h2.p, out.p, H, W, D);
     }
     ws.release(m);
   }
 
   void attention(const AttnRef &a, const Act &x, Act &out) {
     const size_t m = ws.mark();
-    const int N = x.H * x.W;
+    const int N = (int)x.voxels();
     float *sc = ws.get((size_t)B * a.C), *sh = ws.get((size_t)B * a.C);
     gn(a.norm, x, nullptr, sc, sh);
     float *qkv = ws.get((size_t)B * 3 * a.C * N);
-    conv(a.qkv, x, nullptr, sc, sh, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, nullptr, qkv, x.H, x.W);
+    conv(a.qkv, x, nullptr, sc, sh, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, nullptr, qkv, x.H, x.W, x.D);
     const float scale = 1.0f / sqrtf((float)a.C / (float)a.heads);
     if (!u->cfg.use_proj_attn) {
       if (!ws.dry && !rc) rc = launch_attention(qkv, x.p, out.p, B, a.C, N, a.heads, scale, s);
     } else {
-      Act o{ws.get((size_t)B * a.C * N), a.C, x.H, x.W};
+      Act o{ws.get((size_t)B * a.C * N), a.C, x.H, x.W, x.D};
       if (!ws.dry && !rc) rc = launch_attention(qkv, nullptr, o.p, B, a.C, N, a.heads, scale, s);
-      conv(a.proj, o, nullptr, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, x.p, out.p, x.H, x.W);
+      conv(a.proj, o, nullptr, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, x.p, out.p, x.H, x.W,
+           x.D);
     }
     ws.release(m);
   }
 
-  Act new_act(int C, int H, int W) { return Act{ws.get((size_t)B * C * H * W), C, H, W}; }
+  Act new_act(int C, int H, int W, int D = 1) { return Act{ws.get((size_t)B * C * D * H * W), C, H, W, D}; }
 
-  int run(const float *x, const int64_t *timesteps, float *out, int H, int W) {
+  int run(const float *x, const int64_t *timesteps, float *out, int H, int W, int D = 1) {
     const ddpm_unet_config &cfg = u->cfg;
     // ---- timestep embedding + MLP + all time projections ------------------------------------------
     Act temb0{ws.get((size_t)B * u->ch0), u->ch0, 1, 1};
@@ -430,39 +474,41 @@ struct Runner {
          1);
 
     // ---- conv_in + down path ------------------------------------------------------------------------
-    Act xin{const_cast<float *>(x), cfg.in_channels, H, W};
-    Act h = new_act(u->ch0, H, W);
-    conv(u->conv_in, xin, nullptr, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, nullptr, h.p, H, W);
+    Act xin{const_cast<float *>(x), cfg.in_channels, H, W, D};
+    Act h = new_act(u->ch0, H, W, D);
+    conv(u->conv_in, xin, nullptr, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, nullptr, h.p, H, W,
+         D);
     std::vector<Act> skips;
     skips.push_back(h);
     for (size_t i = 0; i < u->down.size(); ++i) {
       const DownRef &d = u->down[i];
       for (size_t j = 0; j < d.res.size(); ++j) {
-        Act o = new_act(d.res[j].Cout, h.H, h.W);
+        Act o = new_act(d.res[j].Cout, h.H, h.W, h.D);
         resnet(d.res[j], h, nullptr, o);
         h = o;
         if (d.with_attn) {
-          Act o2 = new_act(h.C, h.H, h.W);
+          Act o2 = new_act(h.C, h.H, h.W, h.D);
           attention(d.att[j], h, o2);
           h = o2;
         }
         skips.push_back(h);
       }
       if (d.has_down) {
-        const int Ho = (h.H + 1) / 2, Wo = (h.W + 1) / 2;
-        Act o = new_act(h.C, Ho, Wo);
-        conv(d.down, h, nullptr, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_STRIDE2, nullptr, 0, nullptr, o.p, Ho, Wo);
+        const int Ho = (h.H + 1) / 2, Wo = (h.W + 1) / 2, Do = h.D > 1 ? (h.D + 1) / 2 : 1;
+        Act o = new_act(h.C, Ho, Wo, Do);
+        conv(d.down, h, nullptr, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_STRIDE2, nullptr, 0, nullptr, o.p, Ho, Wo,
+             Do);
         h = o;
         skips.push_back(h);
       }
     }
     // ---- middle ----------------------------------------------------------------------------------------
     {
-      Act o = new_act(h.C, h.H, h.W);
+      Act o = new_act(h.C, h.H, h.W, h.D);
       resnet(u->mid1, h, nullptr, o);
-      Act o2 = new_act(h.C, h.H, h.W);
+      Act o2 = new_act(h.C, h.H, h.W, h.D);
       attention(u->mid_attn, o, o2);
-      Act o3 = new_act(h.C, h.H, h.W);
+      Act o3 = new_act(h.C, h.H, h.W, h.D);
       resnet(u->mid2, o2, nullptr, o3);
       h = o3;
     }
@@ -473,47 +519,64 @@ struct Runner {
         if (skips.empty()) { set_error("unet_forward: skip stack underflow"); return DDPM_EINVAL; }
         Act sk = skips.back();
         skips.pop_back();
-        if (sk.H != h.H || sk.W != h.W) {
+        if (sk.H != h.H || sk.W != h.W || sk.D != h.D) {
           set_error("unet_forward: skip extent %dx%d does not match %dx%d (input extent must be divisible by 2^%d)",
                     sk.H, sk.W, h.H, h.W, (int)u->down.size() - 1);
           return DDPM_EINVAL;
         }
-        Act o = new_act(b.res[j].Cout, h.H, h.W);
+        Act o = new_act(b.res[j].Cout, h.H, h.W, h.D);
         resnet(b.res[j], h, &sk, o);
         h = o;
         if (b.with_attn) {
-          Act o2 = new_act(h.C, h.H, h.W);
+          Act o2 = new_act(h.C, h.H, h.W, h.D);
           attention(b.att[j], h, o2);
           h = o2;
         }
       }
       if (b.has_up) {
-        Act o = new_act(h.C, 2 * h.H, 2 * h.W);
+        const int Do = h.D > 1 ? 2 * h.D : 1;
+        Act o = new_act(h.C, 2 * h.H, 2 * h.W, Do);
         conv(b.up, h, nullptr, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_UPSAMPLE2, nullptr, 0, nullptr, o.p, 2 * h.H,
-             2 * h.W);
+             2 * h.W, Do);
         h = o;
       }
     }
     // ---- out: GroupNorm + SiLU + conv ----------------------------------------------------------------
     float *sc = ws.get((size_t)B * u->ch0), *sh = ws.get((size_t)B * u->ch0);
     gn(u->out_norm, h, nullptr, sc, sh);
-    Act o{out, cfg.out_channels, H, W};
-    conv(u->conv_out, h, nullptr, sc, sh, DDPM_ACT_SILU, DDPM_CONV_NORMAL, nullptr, 0, nullptr, o.p, H, W);
+    Act o{out, cfg.out_channels, H, W, D};
+    conv(u->conv_out, h, nullptr, sc, sh, DDPM_ACT_SILU, DDPM_CONV_NORMAL, nullptr, 0, nullptr, o.p, H, W, D);
     return rc;
   }
 };
 
 }  // namespace ddpm
 
-extern "C" size_t ddpm_unet_workspace_bytes(const ddpm_unet *h, int B, int H, int W) {
-  if (!h || B <= 0 || H <= 0 || W <= 0) return 0;
+extern "C" size_t ddpm_unet_workspace_bytes3d(const ddpm_unet *h, int B, int D, int H, int W) {
+  if (!h || B <= 0 || H <= 0 || W <= 0 || D <= 0) return 0;
+  if ((h->cfg.spatial_dims == 3) != (D > 1) && !(h->cfg.spatial_dims == 3 && D == 1)) {
+    set_error("unet: a 2-D network takes D == 1");
+    return 0;
+  }
   Runner r{const_cast<ddpm_unet *>(h), Bump{nullptr, 0, 0, 0, true}, nullptr, B};
-  if (r.run(nullptr, nullptr, nullptr, H, W) != 0) return 0;
+  if (r.run(nullptr, nullptr, nullptr, H, W, D) != 0) return 0;
   return r.ws.peak + 256;
 }
 
+extern "C" size_t ddpm_unet_workspace_bytes(const ddpm_unet *h, int B, int H, int W) {
+  return ddpm_unet_workspace_bytes3d(h, B, 1, H, W);
+}
+
+extern "C" int ddpm_unet_forward3d(ddpm_unet *h, const float *x, const int64_t *timesteps, float *out, int B, int D,
+                                   int H, int W, void *workspace, size_t workspace_bytes, ddpm_stream_t stream);
+
 extern "C" int ddpm_unet_forward(ddpm_unet *h, const float *x, const int64_t *timesteps, float *out, int B, int H,
                                  int W, void *workspace, size_t workspace_bytes, ddpm_stream_t stream) {
+  return ddpm_unet_forward3d(h, x, timesteps, out, B, 1, H, W, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ddpm_unet_forward3d(ddpm_unet *h, const float *x, const int64_t *timesteps, float *out, int B, int D,
+                                   int H, int W, void *workspace, size_t workspace_bytes, ddpm_stream_t stream) {
   DDPM_CHECK_ARG(h && x && timesteps && out && workspace, "unet_forward: NULL argument");
   DDPM_CHECK_ARG(h->blob, "unet_forward: no parameter blob bound");
   for (auto &p : h->params) {
@@ -522,7 +585,7 @@ extern "C" int ddpm_unet_forward(ddpm_unet *h, const float *x, const int64_t *ti
       return DDPM_ENOPARAM;
     }
   }
-  const size_t need = ddpm_unet_workspace_bytes(h, B, H, W);
+  const size_t need = ddpm_unet_workspace_bytes3d(h, B, D, H, W);
   if (need == 0) return DDPM_EINVAL;
   if (workspace_bytes < need) {
     set_error("unet_forward: workspace too small: %zu < %zu bytes", workspace_bytes, need);
@@ -530,5 +593,5 @@ extern "C" int ddpm_unet_forward(ddpm_unet *h, const float *x, const int64_t *ti
   }
   char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
   Runner r{h, Bump{base, workspace_bytes, 0, 0, false}, as_stream(stream), B};
-  return r.run(x, timesteps, out, H, W);
+  return r.run(x, timesteps, out, H, W, D);
 }

@@ -246,13 +246,14 @@ class DiffusionModelUNet(nn.Module):
             raise ValueError("timesteps must have shape [B]")
         self._sync(x.device)
         lib = _lib.load()
-        B, _, H, W = x.shape
-        need = lib.ddpm_unet_workspace_bytes(self._engine, B, H, W)
+        B = x.shape[0]
+        D, H, W = ((1,) + tuple(x.shape[2:])) if self.spatial_dims == 2 else tuple(x.shape[2:])
+        need = lib.ddpm_unet_workspace_bytes3d(self._engine, B, D, H, W)
         if need == 0:
             raise ValueError("DiffusionModelUNet: " + lib.ddpm_last_error().decode())
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != x.device:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
-        out = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
-        check(lib.ddpm_unet_forward(self._engine, ptr(x), ptr(timesteps), ptr(out), B, H, W, ptr(self._workspace),
-                                    self._workspace.numel(), stream_ptr()), "unet_forward")
+        out = torch.empty((B, self.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        check(lib.ddpm_unet_forward3d(self._engine, ptr(x), ptr(timesteps), ptr(out), B, D, H, W,
+                                      ptr(self._workspace), self._workspace.numel(), stream_ptr()), "unet_forward")
         return out

@@ -76,6 +76,13 @@ typedef struct ddpm_conv_desc {
   int mode;              /* DDPM_CONV_*                                                  */
   int act;               /* DDPM_ACT_* applied after the affine                          */
   int force_direct;      /* 1: take the generic direct kernel even if MFMA tiling exists */
+  /* 3-D convolutions (F.conv3d in the LDM UNet) run as three launches of the 2-D kernel, one per
+   * depth tap kd: out[n, :, d] += conv2d(in[n, :, din(d, kd)], w[:, :, kd]) on NCDHW tensors.
+   * Di / Do = stored input / output depth (0 or 1 = plain 2-D), kd = 0..2, accumulate = 1 adds
+   * into `out` (used for the 2nd and 3rd tap; bias / chan_add / residual go with the first).     */
+  int Di, Do;
+  int kd;
+  int accumulate;
 } ddpm_conv_desc;
 
 int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream);
@@ -130,7 +137,7 @@ int ddpm_clamp_mse_f32(const float *orig, float *recon, float b_scale, float *ms
 #define DDPM_MAX_LEVELS 8
 
 typedef struct ddpm_unet_config {
-  int spatial_dims;                    /* 2 (3 is reserved for the LDM row)               */
+  int spatial_dims;                    /* 2, or 3 for the latent-diffusion UNet (NCDHW)   */
   int in_channels, out_channels;
   int num_levels;
   int num_channels[DDPM_MAX_LEVELS];
@@ -160,6 +167,10 @@ int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *src, int64_
  * ddpm_unet_set_param too; it is computed by the host exactly as the reference does.      */
 
 size_t ddpm_unet_workspace_bytes(const ddpm_unet *h, int B, int H, int W);
+/* spatial_dims == 3 (LDM latents, NCDHW): same calls with an explicit depth */
+size_t ddpm_unet_workspace_bytes3d(const ddpm_unet *h, int B, int D, int H, int W);
+int ddpm_unet_forward3d(ddpm_unet *h, const float *x, const int64_t *timesteps, float *out, int B, int D, int H,
+                        int W, void *workspace, size_t workspace_bytes, ddpm_stream_t stream);
 int ddpm_unet_forward(ddpm_unet *h, const float *x, const int64_t *timesteps, float *out, int B, int H, int W,
                       void *workspace, size_t workspace_bytes, ddpm_stream_t stream);
 

@@ -16,15 +16,15 @@ SMALL = dict(num_channels=(128, 256, 256), attention_levels=(False, False, True)
              num_head_channels=256)
 
 
-def _pair(device, channels=1, cfg=SMALL, seed=1, **extra):
+def _pair(device, channels=1, cfg=SMALL, seed=1, spatial_dims=2, **extra):
     import oracle
     from ddpm_ood_amd import DiffusionModelUNet
     from ddpm_ood_amd.synthetic import random_state_dict
 
-    sd = random_state_dict(channels=channels, seed=seed, config=cfg)
-    ref = oracle.DiffusionModelUNet(2, channels, channels, **cfg, **extra).eval()
+    sd = random_state_dict(channels=channels, seed=seed, config=cfg, spatial_dims=spatial_dims)
+    ref = oracle.DiffusionModelUNet(spatial_dims, channels, channels, **cfg, **extra).eval()
     ref.load_state_dict(sd)
-    hip = DiffusionModelUNet(2, channels, channels, **cfg, **extra)
+    hip = DiffusionModelUNet(spatial_dims, channels, channels, **cfg, **extra)
     hip.load_state_dict(sd)
     return ref, hip.to(device).eval()
 
@@ -64,6 +64,21 @@ def test_unet_forward_big_cfg4(device):
     ref, hip = _pair(device, 3, MODEL_CONFIGS["big"])
     x = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(6))
     t = torch.tensor([870])
+    with torch.no_grad():
+        yr = ref(x, timesteps=t)
+    yh = hip(x.to(device), timesteps=t.to(device)).cpu()
+    err = (yh - yr).abs().max().item()
+    assert math.isfinite(err) and err <= 1e-4 * (1 + yr.abs().max().item()), err
+    assert yr.abs().max() > 0.05
+
+
+@pytest.mark.parametrize("B,size", [(2, 8), (1, 16)])
+def test_unet_forward_3d_cfg5(device, B, size):
+    """BASELINE configs[4]: the `small` UNet over 3-D VQ-VAE latents [B, 128, 8, 8, 8] (47.5 M params).
+    conv3d runs as three depth-tap launches of the 2-D MFMA kernel; attention sees 2^3 = 8 tokens."""
+    ref, hip = _pair(device, 128, SMALL, spatial_dims=3)
+    x = torch.randn(B, 128, size, size, size, generator=torch.Generator().manual_seed(12))
+    t = torch.tensor([650, 30][:B])
     with torch.no_grad():
         yr = ref(x, timesteps=t)
     yh = hip(x.to(device), timesteps=t.to(device)).cpu()
