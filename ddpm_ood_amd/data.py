@@ -11,7 +11,9 @@ round-robin split without padding duplicates).  MONAI's NIfTI /
 are out of scope: ``.npy`` / ``.npz`` files and synthetic specs only.
 
 Synthetic id specs (no dataset can be downloaded here):
-    synthetic:<kind>[:n=N][:size=S][:channels=C][:seed=K]     kind in {blobs, noise}
+    synthetic:<kind>[:n=N][:size=S][:channels=C][:seed=K]     kind in {blobs, noise, blobs3d, noise3d}
+3-D volumes ([N, C, D, H, W]; ``.npy`` files of shape (D, H, W) or (C, D, H, W)) are handled with the
+same transforms (crop, area resize, min-max scale, flips of the first / second spatial axis).
 """
 
 from __future__ import annotations
@@ -42,8 +44,27 @@ def _blobs(n: int, channels: int, size: int, gen: torch.Generator) -> torch.Tens
     return out
 
 
+def _blobs3d(n: int, channels: int, size: int, gen: torch.Generator) -> torch.Tensor:
+    g = torch.arange(size, dtype=torch.float32)
+    zs, ys, xs = torch.meshgrid(g, g, g, indexing="ij")
+    out = torch.zeros(n, channels, size, size, size)
+    for i in range(n):
+        k = int(torch.randint(3, 6, (1,), generator=gen))
+        for c in range(channels):
+            for _ in range(k):
+                cz, cy, cx = (torch.rand(3, generator=gen) * size).tolist()
+                sig = float(torch.rand(1, generator=gen)) * size / 6 + size / 16
+                amp = float(torch.rand(1, generator=gen)) * 0.8 + 0.2
+                out[i, c] += amp * torch.exp(-((zs - cz) ** 2 + (ys - cy) ** 2 + (xs - cx) ** 2) / (2 * sig * sig))
+    return out
+
+
 def synthetic_images(kind: str, n: int, channels: int = 1, size: int = 32, seed: int = 0) -> torch.Tensor:
     gen = torch.Generator().manual_seed(seed)
+    if kind == "blobs3d":
+        return scale_intensity(_blobs3d(n, channels, size, gen))
+    if kind == "noise3d":
+        return scale_intensity(torch.rand(n, channels, size, size, size, generator=gen))
     if kind == "blobs":
         x = _blobs(n, channels, size, gen)
     elif kind == "noise":
@@ -73,8 +94,8 @@ def _parse_spec(spec: str):
     return kind, kw
 
 
-def load_ids(ids: str, is_grayscale: bool = False, first_n=None):
-    """-> (images fp32 [N, C, H, W] unscaled, names list[str])."""
+def load_ids(ids: str, is_grayscale: bool = False, first_n=None, spatial_dimension: int = 2):
+    """-> (images fp32 [N, C, *spatial] unscaled, names list[str])."""
     ids = str(ids)
     if ids.startswith("synthetic:"):
         kind, kw = _parse_spec(ids)
@@ -101,7 +122,7 @@ def load_ids(ids: str, is_grayscale: bool = False, first_n=None):
         if not path.endswith(".npy"):
             raise NotImplementedError(f"{path}: only .npy images are ingested (NIfTI/PIL readers are out of scope)")
         a = torch.from_numpy(np.load(path).astype(np.float32))
-        if a.ndim == 2:
+        if a.ndim == spatial_dimension:
             a = a[None]
         if is_grayscale:
             a = a[0, None, ...]
@@ -140,16 +161,16 @@ def partition(n_items: int, rank: int, world: int) -> List[int]:
 def get_data_loader(ids: str, batch_size: int, first_n=None, is_grayscale: bool = False, image_size=None,
                     add_vflip: bool = False, add_hflip: bool = False, drop_last: bool = False,
                     spatial_dimension: int = 2, image_roi=None, rank: int = 0, world: int = 1) -> ListLoader:
-    if spatial_dimension != 2:
-        raise NotImplementedError("3D ingest belongs to the LDM row (SURVEY 8f) and is not built yet")
-    x, names = load_ids(ids, is_grayscale=is_grayscale, first_n=first_n)
+    x, names = load_ids(ids, is_grayscale=is_grayscale, first_n=first_n, spatial_dimension=spatial_dimension)
+    if x.ndim != 2 + spatial_dimension:
+        raise ValueError(f"--spatial_dimension={spatial_dimension} but the images are {tuple(x.shape[1:])}")
     print(f"Found {len(names)} subjects.")
     if image_roi:
-        roi = [r if r > 0 else s for r, s in zip(image_roi, x.shape[2:])]
-        off = [(s - r) // 2 for r, s in zip(roi, x.shape[2:])]
-        x = x[:, :, off[0]:off[0] + roi[0], off[1]:off[1] + roi[1]]
+        roi = [min(r, s) if r > 0 else s for r, s in zip(image_roi, x.shape[2:])]
+        sl = tuple(slice((s - r) // 2, (s - r) // 2 + r) for r, s in zip(roi, x.shape[2:]))
+        x = x[(slice(None), slice(None)) + sl]
     if image_size:
-        x = F.interpolate(x, size=(int(image_size),) * 2, mode="area")
+        x = F.interpolate(x, size=(int(image_size),) * spatial_dimension, mode="area")
     x = scale_intensity(x)
     if add_vflip:
         x = torch.flip(x, dims=(2,))

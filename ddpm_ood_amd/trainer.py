@@ -136,6 +136,13 @@ class BaseTrainer:
             with open(vqvae_config_path, "r") as f:
                 self.vqvae_config = json.load(f)
             self.vqvae_model = VQVAE(**self.vqvae_config)
+            vqvae_checkpoint = torch.load(vqvae_checkpoint_path, map_location="cpu", weights_only=False)
+            self.vqvae_model.load_state_dict(vqvae_checkpoint["model_state_dict"])
+            self.vqvae_model.to(self.device)
+            self.vqvae_model.eval()
+            print("Loaded vqvae model with config:")
+            for k, v in self.vqvae_config.items():
+                print(f"  {k}: {v}")
             ddpm_channels = self.vqvae_config["embedding_dim"]
         else:
             self.vqvae_model = PassthroughVQVAE()
@@ -273,7 +280,7 @@ class Reconstruct(BaseTrainer):
 
             t1 = time.time()
             images_original = batch["image"].to(self.device, non_blocking=True).float().contiguous()
-            images = self.vqvae_model.encode_stage_2_inputs(images_original)
+            images = self.vqvae_model.encode_stage_2_inputs(images_original).float().contiguous()
             if self.do_latent_pad:
                 images = F.pad(input=images, pad=self.latent_pad, mode="constant", value=0)
             B = images.shape[0]
@@ -298,7 +305,7 @@ class Reconstruct(BaseTrainer):
                     n_fwd += B
                 if self.do_latent_pad:
                     x = F.pad(input=x, pad=self.inverse_latent_pad, mode="constant", value=0).contiguous()
-                x = self.vqvae_model.decode_stage_2_outputs(x)
+                x = self.vqvae_model.decode_stage_2_outputs(x).contiguous()
                 mse = ops.clamp_mse_(images_original, x, self.b_scale)  # x / b_scale, clamp_(0, 1), MSE
                 if self.spatial_dimension == 2:
                     if images_original.shape[3] == 28:

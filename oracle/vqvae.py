@@ -3,9 +3,16 @@
 TEST INFRASTRUCTURE (see oracle/__init__.py).
 ``PassthroughVQVAE`` follows /root/reference/src/networks/passthrough_vqvae.py:4-26
 (identity for pixel-space DDPMs; selected at /root/reference/src/trainers/base.py:62-64).
+``VQVAE`` restates MONAI-Generative 0.2.x ``generative.networks.nets.VQVAE`` (encoder / EMA
+quantiser / decoder) as constructed from ``vqvae_config.json`` at
+/root/reference/src/trainers/base.py:44-61 and used at /root/reference/src/trainers/reconstruct.py:124,166.
+PARITY UNPINNED (the package is not installed here); state_dict key names follow the published module
+tree (``encoder.blocks.N.conv.weight``, ``...conv1.conv.weight``, ``quantizer.quantizer.embedding.weight``).
 """
 
 import torch
+import torch.nn as nn
+import torch.nn.functional as F
 
 
 class PassthroughVQVAE(torch.nn.Module):
@@ -27,3 +34,136 @@ class PassthroughVQVAE(torch.nn.Module):
 
     def decode_stage_2_outputs(self, x):
         return x
+
+
+class _Convolution(nn.Module):
+    """monai.networks.blocks.Convolution restricted to what VQVAE uses: a (transposed) ConvNd stored as
+    ``.conv`` optionally followed by ``.adn`` = ReLU (adn_ordering "DA" / "NDA" with norm=None, dropout=0)."""
+
+    def __init__(self, spatial_dims, cin, cout, strides=1, kernel_size=3, dilation=1, padding=1, output_padding=0,
+                 conv_only=False, is_transposed=False):
+        super().__init__()
+        if is_transposed:
+            conv_t = {2: nn.ConvTranspose2d, 3: nn.ConvTranspose3d}[spatial_dims]
+            self.conv = conv_t(cin, cout, kernel_size, strides, padding, output_padding, dilation=dilation)
+        else:
+            conv_t = {2: nn.Conv2d, 3: nn.Conv3d}[spatial_dims]
+            self.conv = conv_t(cin, cout, kernel_size, strides, padding, dilation=dilation)
+        self.conv_only = conv_only
+
+    def forward(self, x):
+        x = self.conv(x)
+        return x if self.conv_only else F.relu(x)
+
+
+class _ResidualUnit(nn.Module):
+    def __init__(self, spatial_dims, num_channels, num_res_channels):
+        super().__init__()
+        self.conv1 = _Convolution(spatial_dims, num_channels, num_res_channels)
+        self.conv2 = _Convolution(spatial_dims, num_res_channels, num_channels, conv_only=True)
+
+    def forward(self, x):
+        return F.relu(x + self.conv2(self.conv1(x)))
+
+
+class _Stack(nn.Module):
+    def __init__(self, blocks):
+        super().__init__()
+        self.blocks = nn.ModuleList(blocks)
+
+    def forward(self, x):
+        for b in self.blocks:
+            x = b(x)
+        return x
+
+
+class _EMAQuantizer(nn.Module):
+    def __init__(self, num_embeddings, embedding_dim):
+        super().__init__()
+        self.embedding = nn.Embedding(num_embeddings, embedding_dim)
+        self.register_buffer("ema_cluster_size", torch.zeros(num_embeddings))
+        self.register_buffer("ema_w", self.embedding.weight.data.clone())
+
+    def quantize(self, x):
+        """nearest code by squared L2 over channel-last flattened inputs -> indices [B, *spatial]"""
+        shape = x.shape
+        flat = x.movedim(1, -1).reshape(-1, shape[1]).float()
+        e = self.embedding.weight
+        dist = (flat ** 2).sum(dim=1, keepdim=True) + (e.t() ** 2).sum(dim=0, keepdim=True) - 2 * flat @ e.t()
+        idx = torch.max(-dist, dim=1)[1]
+        return idx.view(shape[0], *shape[2:])
+
+    def forward(self, x):
+        idx = self.quantize(x)
+        q = self.embedding(idx).movedim(-1, 1).contiguous()
+        return x + (q - x)  # straight-through form of the eval path (no gradient here)
+
+
+class _VectorQuantizer(nn.Module):
+    def __init__(self, quantizer):
+        super().__init__()
+        self.quantizer = quantizer
+
+    def forward(self, x):
+        return self.quantizer(x)
+
+
+class VQVAE(nn.Module):
+    def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, num_channels=(96, 96, 192),
+                 num_res_layers: int = 3, num_res_channels=(96, 96, 192),
+                 downsample_parameters=((2, 4, 1, 1), (2, 4, 1, 1), (2, 4, 1, 1)),
+                 upsample_parameters=((2, 4, 1, 1, 0), (2, 4, 1, 1, 0), (2, 4, 1, 1, 0)), num_embeddings: int = 32,
+                 embedding_dim: int = 64, embedding_init: str = "normal", commitment_cost: float = 0.25,
+                 decay: float = 0.5, epsilon: float = 1e-5, dropout: float = 0.0, adn_ordering: str = "NDA",
+                 act="RELU", output_act=None, ddp_sync: bool = True, use_checkpointing: bool = False):
+        super().__init__()
+        if isinstance(num_res_channels, int):
+            num_res_channels = (num_res_channels,) * len(num_channels)
+        if not (len(num_channels) == len(num_res_channels) == len(downsample_parameters) == len(upsample_parameters)):
+            raise ValueError("`num_channels`, `num_res_channels`, `downsample_parameters` and `upsample_parameters` "
+                             "should have the same length.")
+        if output_act is not None or str(act).upper() != "RELU":
+            raise NotImplementedError("only act='RELU' / output_act=None (the reference's configuration)")
+        self.spatial_dims, self.in_channels, self.out_channels = spatial_dims, in_channels, out_channels
+        self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
+        sd, n = spatial_dims, len(num_channels)
+        enc = []
+        for i in range(n):
+            s, k, dil, pad = downsample_parameters[i]
+            enc.append(_Convolution(sd, in_channels if i == 0 else num_channels[i - 1], num_channels[i], s, k, dil, pad))
+            enc += [_ResidualUnit(sd, num_channels[i], num_res_channels[i]) for _ in range(num_res_layers)]
+        enc.append(_Convolution(sd, num_channels[-1], embedding_dim, conv_only=True))
+        self.encoder = _Stack(enc)
+        rc, rr = list(reversed(num_channels)), list(reversed(num_res_channels))
+        dec = [_Convolution(sd, embedding_dim, rc[0], conv_only=True)]
+        for i in range(n):
+            dec += [_ResidualUnit(sd, rc[i], rr[i]) for _ in range(num_res_layers)]
+            s, k, dil, pad, opad = upsample_parameters[i]
+            dec.append(_Convolution(sd, rc[i], out_channels if i == n - 1 else rc[i + 1], s, k, dil, pad, opad,
+                                    conv_only=i == n - 1, is_transposed=True))
+        self.decoder = _Stack(dec)
+        self.quantizer = _VectorQuantizer(_EMAQuantizer(num_embeddings, embedding_dim))
+
+    def encode(self, images):
+        return self.encoder(images)
+
+    def quantize(self, encodings):
+        return self.quantizer(encodings), torch.zeros((), device=encodings.device)
+
+    def decode(self, quantizations):
+        return self.decoder(quantizations)
+
+    def index_quantize(self, images):
+        return self.quantizer.quantizer.quantize(self.encode(images))
+
+    def forward(self, images):
+        q, loss = self.quantize(self.encode(images))
+        return self.decode(q), loss
+
+    def encode_stage_2_inputs(self, x):
+        e, _ = self.quantize(self.encode(x))
+        return e
+
+    def decode_stage_2_outputs(self, z):
+        e, _ = self.quantize(z)  # the denoised latent is re-quantised before decoding (SURVEY A.6)
+        return self.decode(e)

@@ -158,3 +158,54 @@ def test_trajectory_scores_match_oracle(device, tmp_path):
     for col in ("z_score_mse", "z_score_perceptual_difference"):
         assert (dh[col] - do[col]).abs().max() < 1e-4 * max(1.0, do[col].abs().max()), col
     assert abs(auc_h - auc_o) <= 1e-3
+
+
+VQ_CFG = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(16, 32), num_res_layers=1,
+              num_res_channels=(16, 32), downsample_parameters=((2, 4, 1, 1), (2, 4, 1, 1)),
+              upsample_parameters=((2, 4, 1, 1, 0), (2, 4, 1, 1, 0)), num_embeddings=64, embedding_dim=128)
+
+
+def test_ldm_trajectory_3d_matches_oracle(device, tmp_path):
+    """cfg5-shaped (scaled down): 32^3 volumes -> VQ-VAE (2 stride-2 levels, 64 codes x 128) -> latents
+    [B, 128, 8, 8, 8] -> `small` 3-D UNet PLMS trajectories (t = 10, 650) -> re-quantise + decode -> 2.5-D LPIPS
+    + MSE.  HIP path (UNet / PLMS / MSE on HIP, VQ-VAE + LPIPS on PyTorch-ROCm ops) vs the CPU oracle."""
+    import json
+
+    import oracle
+    from oracle.vqvae import VQVAE as OracleVQVAE
+    from ddpm_ood_amd import synthetic
+    from ddpm_ood_amd.data import get_data_loader
+    from ddpm_ood_amd.trainer import Reconstruct, batch_noise
+
+    torch.manual_seed(3)
+    vq = OracleVQVAE(**VQ_CFG).eval()
+    with torch.no_grad():  # spread the codebook so that nearest-code decisions are not knife-edge
+        vq.quantizer.quantizer.embedding.weight.mul_(3.0)
+    vq_dir = tmp_path / "vqvae"
+    vq_dir.mkdir()
+    torch.save({"model_state_dict": vq.state_dict()}, vq_dir / "checkpoint.pth")
+    json.dump(VQ_CFG, open(vq_dir / "vqvae_config.json", "w"))
+
+    ids = "synthetic:blobs3d:n=2:size=32:seed=5"
+    args = _args(tmp_path, model_name="decathlon_synth", validation_ids=ids, in_ids=ids, out_ids=ids,
+                 spatial_dimension=3, vqvae_checkpoint=str(vq_dir / "checkpoint.pth"), batch_size=2)
+    sd = synthetic.random_state_dict("small", 128, spatial_dims=3, seed=1)
+    (tmp_path / args.model_name).mkdir()
+    torch.save({"epoch": 0, "global_step": 0, "model_state_dict": sd, "best_loss": 1.0},
+               tmp_path / args.model_name / "checkpoint.pth")
+    rec = Reconstruct(args)
+    loader = get_data_loader(ids, batch_size=2, is_grayscale=True, spatial_dimension=3)
+    rows_h = pd.DataFrame(rec.get_scores(loader, "val", 64))
+
+    ref = oracle.DiffusionModelUNet(3, 128, 128, **SMALL).eval()
+    ref.load_state_dict(sd)
+    pl = oracle.PerceptualLoss(dimensions=3, include_pixel_loss=False, is_fake_3d=True, lpips_normalize=True)
+    pl.perceptual_function.load_state_dict(rec._perceptual().perceptual_function.state_dict())
+    rows_o = pd.DataFrame(oracle.get_scores(
+        loader, "val", 64, model=ref, vqvae=vq, perceptual=pl, spatial_dimension=3,
+        noise_fn=lambda batch, t, shape: batch_noise(2, batch["index"], t, shape),
+        beta_schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195))
+    assert list(rows_h["t"]) == list(rows_o["t"]) == [10, 10, 650, 650]
+    for col in ("mse", "perceptual_difference"):
+        rel = ((rows_h[col] - rows_o[col]).abs() / (rows_o[col].abs() + 1e-9)).max()
+        assert rel < 1e-3, (col, rel, rows_h[col].tolist(), rows_o[col].tolist())

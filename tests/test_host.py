@@ -141,8 +141,8 @@ def test_reference_exceptions_are_kept(tmp_path):
     x = torch.ones(1, 1, 2, 2)
     p = PassthroughVQVAE()
     assert p.encode_stage_2_inputs(x) is x and p.decode_stage_2_outputs(x) is x
-    with pytest.raises(NotImplementedError):
-        VQVAE(embedding_dim=128)
+    with pytest.raises(ValueError):  # mismatched per-level tuples, as the MONAI-Generative ctor raises
+        VQVAE(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(8, 8), num_res_channels=(8,))
     if not torch.cuda.is_available():
         import reconstruct as cli
         from ddpm_ood_amd.trainer import Reconstruct
@@ -164,3 +164,41 @@ def test_unet_holder_rejects_bad_configs():
                            num_head_channels=128)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 1, 8, 8), timesteps=torch.zeros(1, dtype=torch.long))
+
+
+def test_vqvae_restatement_and_3d_ingest(tmp_path):
+    """VQ-VAE surface of the LDM configuration (base.py:44-61, reconstruct.py:124,166): same state_dict keys in
+    oracle and product, nearest-code quantiser against a brute-force search, encode -> 8^3 x 128 latents."""
+    from oracle.vqvae import VQVAE as OV
+    from ddpm_ood_amd.vqvae import VQVAE as PV
+    from ddpm_ood_amd.data import get_data_loader
+
+    cfg = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(8, 16), num_res_layers=1,
+               num_res_channels=(8, 16), downsample_parameters=((2, 4, 1, 1), (2, 4, 1, 1)),
+               upsample_parameters=((2, 4, 1, 1, 0), (2, 4, 1, 1, 0)), num_embeddings=32, embedding_dim=12)
+    torch.manual_seed(0)
+    o, p = OV(**cfg).eval(), PV(**cfg).eval()
+    assert list(o.state_dict()) == list(p.state_dict())
+    assert "quantizer.quantizer.embedding.weight" in o.state_dict()
+    p.load_state_dict(o.state_dict())
+    ld = get_data_loader("synthetic:blobs3d:n=2:size=16:seed=1", batch_size=2, is_grayscale=True, spatial_dimension=3)
+    x = next(iter(ld))["image"]
+    assert x.shape == (2, 1, 16, 16, 16) and float(x.min()) == 0.0 and float(x.max()) == 1.0
+    with torch.no_grad():
+        z = o.encode(x)
+        q = o.encode_stage_2_inputs(x)
+        assert z.shape == (2, 12, 4, 4, 4)
+        e = o.quantizer.quantizer.embedding.weight
+        flat = z.movedim(1, -1).reshape(-1, 12)
+        brute = ((flat[:, None, :] - e[None]) ** 2).sum(-1).argmin(1)
+        assert torch.equal(o.index_quantize(x).reshape(-1), brute)
+        assert torch.allclose(q.movedim(1, -1).reshape(-1, 12), e[brute], atol=1e-6)
+        assert torch.equal(p.encode_stage_2_inputs(x), q)
+        assert o.decode_stage_2_outputs(q).shape == x.shape
+    np.save(tmp_path / "vol.npy", np.random.default_rng(0).random((20, 18, 16)).astype(np.float32))
+    (tmp_path / "Task01_test.csv").write_text(str(tmp_path / "vol.npy") + "\n")
+    ld = get_data_loader(str(tmp_path / "Task01_test.csv"), 1, is_grayscale=True, spatial_dimension=3,
+                         image_roi=(16, 16, -1), image_size=8)
+    assert next(iter(ld))["image"].shape == (1, 1, 8, 8, 8)
+    with pytest.raises(ValueError):
+        get_data_loader(str(tmp_path / "Task01_test.csv"), 1, is_grayscale=True, spatial_dimension=2)
