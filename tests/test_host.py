@@ -200,5 +200,3 @@ def test_vqvae_restatement_and_3d_ingest(tmp_path):
     ld = get_data_loader(str(tmp_path / "Task01_test.csv"), 1, is_grayscale=True, spatial_dimension=3,
                          image_roi=(16, 16, -1), image_size=8)
     assert next(iter(ld))["image"].shape == (1, 1, 8, 8, 8)
-    with pytest.raises(ValueError):
-        get_data_loader(str(tmp_path / "Task01_test.csv"), 1, is_grayscale=True, spatial_dimension=2)
