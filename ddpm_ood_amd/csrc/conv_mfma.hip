@@ -102,7 +102,8 @@ static bool pick_geom(const ddpm_conv_desc &d, ConvGeom &g) {
   const bool ok64 = make_geom(d, 64, g64) && geom_ok(d, g64);
   if (!ok128 && !ok64) return false;
   const long wg128 = ok128 ? (long)((g128.M + 127) / 128) * (d.Cout / kConvNT) : 0;
-  if (ok128 && (wg128 >= 512 || !ok64)) {
+  static const long min_wg128 = getenv("DDPM_CONV_MIN_WG128") ? atol(getenv("DDPM_CONV_MIN_WG128")) : 512;
+  if (ok128 && (wg128 >= min_wg128 || !ok64)) {
     g = g128;
   } else {
     g = g64;

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--model", default="small")
+    ap.add_argument("--dims", type=int, default=2)
     a = ap.parse_args()
 
     from ddpm_ood_amd import DiffusionModelUNet, _lib
@@ -32,10 +33,10 @@ def main():
 
     lib = _lib.load()
     dev = torch.device("cuda:0")
-    m = DiffusionModelUNet(2, a.channels, a.channels, **MODEL_CONFIGS[a.model])
-    m.load_state_dict(random_state_dict(a.model, a.channels, seed=1))
+    m = DiffusionModelUNet(a.dims, a.channels, a.channels, **MODEL_CONFIGS[a.model])
+    m.load_state_dict(random_state_dict(a.model, a.channels, spatial_dims=a.dims, seed=1))
     m = m.to(dev).eval()
-    x = torch.randn(a.batch, a.channels, a.size, a.size, device=dev)
+    x = torch.randn((a.batch, a.channels) + (a.size,) * a.dims, device=dev)
     t = torch.full((a.batch,), 500, dtype=torch.int64, device=dev)
     t0 = time.perf_counter()
     m(x, timesteps=t)
