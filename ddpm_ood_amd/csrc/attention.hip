@@ -4,15 +4,18 @@
 // (reference call site /root/reference/src/trainers/reconstruct.py:151-153).
 // q, k, v come straight from the fused QKV 1x1 convolution in channel-major NCHW form
 // [B, 3C, N]: q[d][i], k[d][j], v[d][j] with the token index contiguous.  That is already the
-// MFMA operand order (32 consecutive lanes = 32 consecutive tokens), so
-//   S[i][j]  = sum_d q[d][i] k[d][j]   takes A = q^T and B = k directly from global / L2,
-//   O[d][i]  = sum_j v[d][j] P[i][j]   takes A = v (staged through LDS with a +1 pad so the
-//                                       32 lanes that differ in d hit 32 different banks)
-//                                       and B = P^T from the score tile in LDS,
-// and the output tile O[d][i] stores 128-byte rows back into NCHW, fused with the residual.
+// MFMA operand order (32 consecutive lanes = 32 consecutive tokens):
+//   S[i][j]  = sum_d q[d][i] k[d][j]   A = q^T (LDS [256][64], loaded once per workgroup),
+//                                       B = k   (LDS [256][64], one key block at a time);
+//   O[d][i]  = sum_j v[d][j] P[i][j]   A = v   (same LDS buffer re-used after QK^T, row stride 65 so
+//                                       that the 32 lanes differing in d hit 32 banks),
+//                                       B = P^T from the score tile in LDS;
+// the output tile O[d][i] stores 128-byte rows back into NCHW, fused with the residual.
 // One workgroup = (image, head, 64 queries); keys are walked in blocks of 64 with an online
 // (running max / running sum) softmax, so n = 64 (small UNet @ 8x8) is a single block and
-// n = 4096 (big UNet @ 64x64) never materialises the n x n score matrix.
+// n = 4096 (big UNet @ 64x64) never materialises the n x n score matrix.  The next block's K (V)
+// is prefetched into registers while the PV (QK^T) MFMAs of the current block run, operand
+// ds_reads are software-pipelined one k-step ahead of the MFMAs.
 // Head dim is fixed at 256 (num_head_channels = 256 in both reference configs,
 // /root/reference/src/trainers/base.py:73,84).
 #include "common.h"
@@ -20,22 +23,27 @@
 namespace ddpm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kDH = 256;   // head dim
 constexpr int kQB = 64;    // queries per workgroup
 constexpr int kKB = 64;    // keys per block
-constexpr int kLd = 65;    // padded LDS leading dimension
+constexpr int kLd = 65;    // padded leading dimension (V tile, score tile)
+constexpr int kPF = kDH * kKB / 256;  // prefetch floats per thread for one K or V block (64)
 
+// VEC: N % 4 == 0 -> 16-byte global loads of K / V / Q rows
+template <bool VEC>
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ qkv,
                                                         const float *__restrict__ residual,
                                                         float *__restrict__ out, int C, int N, int heads,
                                                         float scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *Vl = smem;                    // [256][65]
-  float *Sl = Vl + kDH * kLd;          // [64][65]
-  float *mrow = Sl + kQB * kLd;        // [64]
-  float *lrow = mrow + kQB;            // [64]
-  float *arow = lrow + kQB;            // [64]
+  float *Ql = smem;                    // [256][64]   q tile, d-major
+  float *KVl = Ql + kDH * kQB;         // [256][65]   K block (row stride 64) then V block (row stride 65)
+  float *Sl = KVl + kDH * kLd;         // [64][65]    scores / probabilities
+  float *mrow = Sl + kQB * kLd;        // [64] running max
+  float *lrow = mrow + kQB;            // [64] running sum
+  float *arow = lrow + kQB;            // [64] rescale factor of this block
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -46,6 +54,48 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
   const float *kp = qp + (size_t)C * N;
   const float *vp = kp + (size_t)C * N;
 
+  // ---- block loaders: a [256 d][64 token] block, zero beyond N ------------------------------------
+  float pf[kPF];
+  auto load_block = [&](const float *src, int t0) {
+    if (VEC) {
+#pragma unroll
+      for (int r = 0; r < kPF / 4; ++r) {
+        const int e4 = tid + 256 * r;
+        const int d = e4 >> 4, j = (e4 & 15) * 4;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (t0 + j < N) v = *reinterpret_cast<const v4f *>(src + (size_t)d * N + t0 + j);
+        pf[4 * r + 0] = v[0]; pf[4 * r + 1] = v[1]; pf[4 * r + 2] = v[2]; pf[4 * r + 3] = v[3];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < kPF; ++r) {
+        const int e = tid + 256 * r;
+        const int d = e >> 6, j = e & 63;
+        pf[r] = (t0 + j < N) ? src[(size_t)d * N + t0 + j] : 0.f;
+      }
+    }
+  };
+  auto store_block = [&](float *dst, int ld) {
+    if (VEC) {
+#pragma unroll
+      for (int r = 0; r < kPF / 4; ++r) {
+        const int e4 = tid + 256 * r;
+        const int d = e4 >> 4, j = (e4 & 15) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[d * ld + j + c] = pf[4 * r + c];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < kPF; ++r) {
+        const int e = tid + 256 * r;
+        dst[(e >> 6) * ld + (e & 63)] = pf[r];
+      }
+    }
+  };
+
+  load_block(qp, i0);
+  store_block(Ql, kQB);
+  load_block(kp, 0);
   if (tid < kQB) {
     mrow[tid] = -INFINITY;
     lrow[tid] = 0.f;
@@ -60,30 +110,31 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
       for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
 
   const int qi = wave >> 1, kj = wave & 1;
-  const int iq = min(i0 + qi * 32 + l31, N - 1);  // clamped query index for operand reads
 
   for (int j0 = 0; j0 < N; j0 += kKB) {
-    __syncthreads();  // previous block's PV finished with Vl / Sl (also orders the m/l init)
-
-    // ---- stage V block [256 d][64 keys] ----------------------------------------------------
-    for (int e = tid; e < kDH * kKB; e += 256) {
-      const int d = e >> 6, j = e & 63;
-      Vl[d * kLd + j] = (j0 + j < N) ? vp[(size_t)d * N + j0 + j] : 0.f;
-    }
+    __syncthreads();            // previous PV finished with KVl / Sl; orders the Q tile and m / l init
+    store_block(KVl, kKB);      // K block, row stride 64
+    __syncthreads();
+    load_block(vp, j0);         // V of this block flies while QK^T runs
 
     // ---- S quadrant: rows = queries qi*32.., cols = keys kj*32.. ----------------------------
     {
       f32x16 sacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-      const int jk = min(j0 + kj * 32 + l31, N - 1);
-      const float *qa = qp + (size_t)lhi * N + iq;
-      const float *kb = kp + (size_t)lhi * N + jk;
-#pragma unroll 8
+      const float *qa = Ql + lhi * kQB + qi * 32 + l31;
+      const float *kb = KVl + lhi * kKB + kj * 32 + l31;
+      float av[2], bv[2];
+      av[0] = qa[0];
+      bv[0] = kb[0];
+#pragma unroll 16
       for (int d = 0; d < kDH; d += 2) {
-        const float av = qa[(size_t)d * N];
-        const float bv = kb[(size_t)d * N];
-        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, sacc, 0, 0, 0);
+        const int cur = (d >> 1) & 1;
+        if (d + 2 < kDH) {
+          av[cur ^ 1] = qa[(d + 2) * kQB];
+          bv[cur ^ 1] = kb[(d + 2) * kKB];
+        }
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur], sacc, 0, 0, 0);
       }
       const bool colok = (j0 + kj * 32 + l31) < N;
 #pragma unroll
@@ -92,7 +143,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
         Sl[row * kLd + kj * 32 + l31] = colok ? sacc[r] * scale : -INFINITY;
       }
     }
-    __syncthreads();
+    __syncthreads();            // scores complete; every wave is done reading the K block
 
     // ---- online softmax: 4 threads per query row, 16 keys each ------------------------------
     {
@@ -115,7 +166,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
       sum += __shfl_xor(sum, 1, 64);
       sum += __shfl_xor(sum, 2, 64);
       const float alpha = expf(mo - mn);  // exp(-inf) = 0 on the first block
-      __syncthreads();                    // all 4 readers of mrow[row] are done
+      store_block(KVl, kLd);              // V block over the K block, row stride 65
+      __syncthreads();                    // all 4 readers of mrow[row] are done; V and P are visible
       if (part == 0) {
         mrow[row] = mn;
         lrow[row] = lrow[row] * alpha + sum;
@@ -123,6 +175,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
       }
     }
     __syncthreads();
+    if (j0 + kKB < N) load_block(kp, j0 + kKB);  // next K block flies while PV runs
 
     // ---- O[d][i] = alpha_i * O[d][i] + sum_j V[d][j] P[i][j] --------------------------------
 #pragma unroll
@@ -133,18 +186,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[a][b][r] *= al;
     }
-    const float *va = Vl + ((wave * 2) * 32 + l31) * kLd + lhi;
+    const float *va = KVl + ((wave * 2) * 32 + l31) * kLd + lhi;
     const float *pb = Sl + l31 * kLd + lhi;
-#pragma unroll 4
+    float a0[2], a1[2], b0[2], b1[2];
+    a0[0] = va[0]; a1[0] = va[32 * kLd]; b0[0] = pb[0]; b1[0] = pb[32 * kLd];
+#pragma unroll 8
     for (int jj = 0; jj < kKB; jj += 2) {
-      const float a0 = va[jj];
-      const float a1 = va[32 * kLd + jj];
-      const float b0 = pb[jj];
-      const float b1 = pb[32 * kLd + jj];
-      o[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, o[0][0], 0, 0, 0);
-      o[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, o[0][1], 0, 0, 0);
-      o[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, o[1][0], 0, 0, 0);
-      o[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, o[1][1], 0, 0, 0);
+      const int cur = (jj >> 1) & 1;
+      if (jj + 2 < kKB) {
+        a0[cur ^ 1] = va[jj + 2];
+        a1[cur ^ 1] = va[32 * kLd + jj + 2];
+        b0[cur ^ 1] = pb[jj + 2];
+        b1[cur ^ 1] = pb[32 * kLd + jj + 2];
+      }
+      o[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], b0[cur], o[0][0], 0, 0, 0);
+      o[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], b1[cur], o[0][1], 0, 0, 0);
+      o[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], b0[cur], o[1][0], 0, 0, 0);
+      o[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], b1[cur], o[1][1], 0, 0, 0);
     }
   }
 
@@ -156,13 +214,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
       const float inv = 1.0f / lrow[b * 32 + l31];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
+        float rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int d = (wave * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          const size_t idx = ((size_t)n * C + hh * kDH + d) * N + i;
-          float v = o[a][b][r] * inv;
-          if (residual) v += residual[idx];
-          out[idx] = v;
+          rv[r] = residual ? residual[((size_t)n * C + hh * kDH + d) * N + i] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = (wave * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          out[((size_t)n * C + hh * kDH + d) * N + i] = o[a][b][r] * inv + rv[r];
         }
       }
     }
@@ -174,16 +235,21 @@ int launch_attention(const float *qkv, const float *residual, float *out, int B,
   DDPM_CHECK_ARG(qkv && out && B > 0 && N > 0 && heads > 0, "attention: null pointer or empty shape");
   DDPM_CHECK_ARG(C == heads * kDH, "attention: only head dim 256 is built (C = %d, heads = %d)", C, heads);
   DDPM_CHECK_ARG(B <= 65535 && heads <= 65535, "attention: grid too large");
-  const size_t lds = (size_t)(kDH * kLd + kQB * kLd + 3 * kQB) * sizeof(float);
+  const size_t lds = (size_t)(kDH * kQB + kDH * kLd + kQB * kLd + 3 * kQB) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   dim3 grid((N + kQB - 1) / kQB, heads, B);
   ProfScope prof(s, "attention", 4.0 * B * (double)N * N * C, 4.0 * B * C * (double)N * (residual ? 5 : 4));
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, residual, out, C, N, heads, scale);
+  if ((N & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv) & 15) == 0))
+    hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), lds, s, qkv, residual, out, C, N, heads, scale);
+  else
+    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), lds, s, qkv, residual, out, C, N, heads, scale);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
