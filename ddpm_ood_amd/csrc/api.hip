@@ -97,6 +97,16 @@ extern "C" int ddpm_pack_conv_weight_f32(const float *w_raw, float *w_packed, in
   return launch_pack_conv_weight(w_raw, w_packed, Cout, Cin, ksize, cout_offset, Cout_total, as_stream(stream));
 }
 
+extern "C" size_t ddpm_folded_upsample_weight_floats(int Cout, int Cin) {
+  return folded_upsample_weight_floats(Cout, Cin);
+}
+
+extern "C" int ddpm_fold_upsample_weight_f32(const float *w_raw, float *w_folded, int Cout, int Cin,
+                                             ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(w_raw && w_folded, "fold: NULL pointer");
+  return launch_fold_upsample_weight(w_raw, w_folded, Cout, Cin, as_stream(stream));
+}
+
 extern "C" int ddpm_gn_scale_shift_f32(const float *in1, const float *in2, int C1, int C2, const float *gamma,
                                        const float *beta, float *scale, float *shift, int B, int HW, int groups,
                                        float eps, ddpm_stream_t stream) {

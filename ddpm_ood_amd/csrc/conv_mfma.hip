@@ -55,6 +55,7 @@ struct ConvGeom {
   int pad;      // 1 for 3x3, 0 for 1x1
   int s;        // input step per output pixel (2 for stride-2)
   int Cin, nchunks;
+  int fold, up_dy, up_dx;  // folded nearest-x2 upsample: this launch computes output parity (dy, dx)
 };
 
 static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g) {
@@ -85,6 +86,7 @@ static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g) {
   g.IRS = g.IR * g.RS;
   g.PS = g.TI * g.IRS;
   g.nchunks = Cin / kConvCc;
+  g.fold = g.up_dy = g.up_dx = 0;
   return true;
 }
 
@@ -302,9 +304,11 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
     float av[2][NAB], bv[2][2];
     auto fetch = [&](int st, int slot) {
       const int t = st / (CPC / 2), kk = st % (CPC / 2);
-      const int tapoff = (NTAPS == 9) ? ((t / 3) * g.RS + (t % 3)) : 0;
+      const int tapoff = (NTAPS == 9) ? ((t / 3) * g.RS + (t % 3))
+                       : (NTAPS == 4) ? ((g.up_dy + (t >> 1)) * g.RS + g.up_dx + (t & 1)) : 0;
 #pragma unroll
-      for (int ab = 0; ab < NAB; ++ab) av[slot][ab] = smem[cb + wb + (t * CPC + 2 * kk) * kConvNT + ab * 32];
+      for (int ab = 0; ab < NAB; ++ab)  // LDS weights are [channel group][tap][4][128], as packed
+        av[slot][ab] = smem[cb + wb + (((kk >> 1) * NTAPS + t) * CC + 2 * (kk & 1)) * kConvNT + ab * 32];
       bv[slot][0] = smem[cb + xb[0] + 2 * kk * g.PS + tapoff];
       bv[slot][1] = smem[cb + xb[1] + 2 * kk * g.PS + tapoff];
     };
@@ -355,8 +359,13 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
       const int p = P - img * g.HWo;
       const int n = img / g.Do;
       const int dz = img - n * g.Do;
-      const size_t cstride = (size_t)g.Do * g.HWo;  // channel stride of the NC(D)HW output
-      const size_t obase = (((size_t)n * a.Cout + co_base) * g.Do + dz) * g.HWo + p;
+      size_t cstride = (size_t)g.Do * g.HWo;  // channel stride of the NC(D)HW output
+      size_t obase = (((size_t)n * a.Cout + co_base) * g.Do + dz) * g.HWo + p;
+      if (g.fold) {  // (h, w) of the low-res tile -> output pixel (2h + dy, 2w + dx) of the 2x larger plane
+        const int hl = p / a.Wo, wl = p - hl * a.Wo;
+        cstride = (size_t)4 * g.HWo;
+        obase = ((size_t)n * a.Cout + co_base) * cstride + (size_t)(2 * hl + g.up_dy) * (2 * a.Wo) + 2 * wl + g.up_dx;
+      }
 #pragma unroll
       for (int ab = 0; ab < NAB; ++ab) {
         float bvv[16], cv[16], rv[16];
@@ -405,10 +414,12 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g_in, hipStre
   dim3 grid((g.M + MT - 1) / MT, d.Cout / kConvNT);
   // algorithmic work of this launch: 2*M*Cout*Cin*taps FLOP; input + output (+ residual)
   // + weights bytes, each counted once
-  const double flops = 2.0 * g.M * d.Cout * (double)g.Cin * NTAPS;
+  // (a folded-upsample launch is one output parity = a quarter of the original conv's algorithmic work)
+  const double flops = 2.0 * g.M * d.Cout * (double)g.Cin * (NTAPS == 4 ? 9 : NTAPS);
   const double bytes = 4.0 * ((double)d.B * g.Cin * g.Di * g.HWi + (double)g.M * d.Cout * (d.residual ? 2 : 1) +
                               (double)d.Cout * g.Cin * NTAPS);
-  const char *kname = MT == 128 ? (NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu" : "conv3x3_mfma")
+  const char *kname = NTAPS == 4 ? (MT == 128 ? "conv3x3_mfma_up_folded" : "conv3x3_mfma_up_folded_t64")
+                      : MT == 128 ? (NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu" : "conv3x3_mfma")
                                               : (AFFINE ? "conv1x1_mfma_gn" : "conv1x1_mfma"))
                                 : (NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu_t64" : "conv3x3_mfma_t64")
                                               : (AFFINE ? "conv1x1_mfma_gn_t64" : "conv1x1_mfma_t64"));
@@ -442,7 +453,43 @@ static int launch_mt(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_t s) 
   return launch_variant<1, 1, false, MT>(d, g, s);
 }
 
+// 3x3 conv over a nearest-x2 upsampled image as four 2x2-tap convs over the low-res image (one per output
+// parity), weights pre-summed by fold_upsample_kernel: 16 instead of 36 multiply-adds per 4 outputs.
+static int launch_upsample_folded(const ddpm_conv_desc &d, hipStream_t s, bool &taken) {
+  taken = false;
+  const int Cin = d.C1 + d.C2;
+  if (!d.w_folded || d.gscale || d.Di > 1 || d.Do > 1 || Cin % 8 || (d.C2 > 0 && d.C1 % 8)) return 0;
+  ddpm_conv_desc lr = d;
+  lr.mode = DDPM_CONV_NORMAL;
+  lr.Ho = d.Hi;
+  lr.Wo = d.Wi;
+  lr.w_packed = d.w_folded;
+  ConvGeom g;
+  if (!pick_geom(lr, g) || g.PS > 2 * 256) return 0;
+  taken = true;
+  const size_t slab = (size_t)d.Cout * Cin * 4;
+  for (int par = 0; par < 4; ++par) {
+    g.fold = 1;
+    g.up_dy = par >> 1;
+    g.up_dx = par & 1;
+    lr.w_packed = d.w_folded + par * slab;
+    const int npos = (g.PS + 255) / 256;
+    int rc;
+    if (g.MT == 128)
+      rc = npos == 1 ? launch_variant<4, 1, false, 128, 2>(lr, g, s) : launch_variant<4, 2, false, 128, 2>(lr, g, s);
+    else
+      rc = npos == 1 ? launch_variant<4, 1, false, 64, 2>(lr, g, s) : launch_variant<4, 2, false, 64, 2>(lr, g, s);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 int launch_conv_mfma(const ddpm_conv_desc &d, hipStream_t s) {
+  if (d.mode == DDPM_CONV_UPSAMPLE2 && d.w_folded) {
+    bool taken = false;
+    const int rc = launch_upsample_folded(d, s, taken);
+    if (taken || rc) return rc;
+  }
   ConvGeom g;
   if (!conv_mfma_supported(d) || !pick_geom(d, g)) {
     set_error("conv_mfma: unsupported shape");
@@ -468,6 +515,41 @@ __global__ void pack_conv_weight_kernel(const float *__restrict__ src, float *__
     const size_t di = ((((size_t)tile * nchunks + ch) * T + t) * kConvCc + cl) * kConvNT + col;
     dst[di] = src[((size_t)o * Cin + ci) * src_taps + tap_off + t];
   }
+}
+
+// ---- folded upsample weights: torch [Cout][Cin][3][3] -> 4 x packed [cout_tile][chunk][2x2 tap][4][128] ----
+// parity dy = 0: source rows {y-1: w[0], y: w[1] + w[2]};  dy = 1: {y: w[0] + w[1], y+1: w[2]}; same for columns
+__global__ void fold_upsample_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin) {
+  const int64_t total = (int64_t)Cout * Cin * 16;
+  const int nchunks = Cin / kConvCc;
+  const size_t slab = (size_t)Cout * Cin * 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i & 3), par = (int)((i >> 2) & 3);
+    const int ci = (int)((i >> 4) % Cin), o = (int)((i >> 4) / Cin);
+    const int dy = par >> 1, dx = par & 1, r = t >> 1, c = t & 1;
+    const int kh0 = dy == 0 ? (r == 0 ? 0 : 1) : (r == 0 ? 0 : 2), kh1 = dy == 0 ? (r == 0 ? 0 : 2) : (r == 0 ? 1 : 2);
+    const int kw0 = dx == 0 ? (c == 0 ? 0 : 1) : (c == 0 ? 0 : 2), kw1 = dx == 0 ? (c == 0 ? 0 : 2) : (c == 0 ? 1 : 2);
+    const float *w = src + ((size_t)o * Cin + ci) * 9;
+    float acc = 0.f;
+    for (int kh = kh0; kh <= kh1; ++kh)
+      for (int kw = kw0; kw <= kw1; ++kw) acc += w[kh * 3 + kw];
+    const int tile = o / kConvNT, col = o % kConvNT, ch = ci / kConvCc, cl = ci % kConvCc;
+    dst[par * slab + ((((size_t)tile * nchunks + ch) * 4 + t) * kConvCc + cl) * kConvNT + col] = acc;
+  }
+}
+
+size_t folded_upsample_weight_floats(int Cout, int Cin) {
+  if (Cout % kConvNT || Cin % 8) return 0;
+  return (size_t)16 * Cout * Cin;
+}
+
+int launch_fold_upsample_weight(const float *w_raw, float *w_folded, int Cout, int Cin, hipStream_t s) {
+  DDPM_CHECK_ARG(folded_upsample_weight_floats(Cout, Cin) != 0, "fold: Cout %% 128 or Cin %% 8 != 0");
+  const int64_t total = (int64_t)Cout * Cin * 16;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(fold_upsample_kernel, dim3(blocks), dim3(256), 0, s, w_raw, w_folded, Cout, Cin);
+  DDPM_CHECK_LAUNCH();
+  return 0;
 }
 
 size_t packed_conv_weight_floats(int Cout, int Cin, int ksize) {

@@ -27,6 +27,8 @@ struct ParamSlot {
   size_t raw_off = 0;           // float offset of the torch-layout copy inside the blob
   bool is_conv = false;         // also packed for the MFMA kernel when the shape allows it
   size_t packed_base = 0;       // float offset of the (possibly shared) packed weight
+  bool has_folded = false;      // Upsample conv: also keep the folded (4 x 2x2-tap) form
+  size_t folded_base = 0;
   int Cout = 0, Cin = 0, ksize = 1, cout_offset = 0, Cout_total = 0;
   int dims = 2;                 // 3: [Cout, Cin, k, k, k] packed as k slabs of 2-D taps (one per depth tap)
   bool optional = false;
@@ -34,8 +36,8 @@ struct ParamSlot {
 };
 
 struct ConvRef {  // a conv-like op: weight (raw + packed) and bias locations in the blob
-  size_t w_raw = 0, w_packed = 0, bias = 0;
-  bool has_packed = false;
+  size_t w_raw = 0, w_packed = 0, bias = 0, w_folded = 0;
+  bool has_packed = false, has_folded = false;
   int Cin = 0, Cout = 0, ksize = 1;
   int dims = 2;
 };
@@ -269,7 +271,16 @@ extern "C" ddpm_unet *ddpm_unet_create(const ddpm_unet_config *cfg) {
       if (b.with_attn)
         b.att.push_back(build_attn(u, bp + ".attentions." + std::to_string(j), out_c, cfg->num_head_channels[ri]));
     }
-    if (b.has_up) b.up = u->add_conv(bp + ".upsampler.conv.conv", out_c, out_c, 3, false, sd);
+    if (b.has_up) {
+      b.up = u->add_conv(bp + ".upsampler.conv.conv", out_c, out_c, 3, false, sd);
+      if (sd == 2 && folded_upsample_weight_floats(out_c, out_c)) {  // nearest-x2 + 3x3 folded into 4 2x2 convs
+        b.up.has_folded = true;
+        b.up.w_folded = u->alloc(folded_upsample_weight_floats(out_c, out_c));
+        ParamSlot &ps = u->params[u->index[bp + ".upsampler.conv.conv.weight"]];
+        ps.has_folded = true;
+        ps.folded_base = b.up.w_folded;
+      }
+    }
     u->up.push_back(b);
   }
   u->out_norm = u->add_gn("out.0", u->ch0);
@@ -333,6 +344,10 @@ extern "C" int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *
     rc = launch_pack_conv_weight(src, h->blob + p.packed_base, p.Cout, p.Cin, p.ksize, p.cout_offset, p.Cout_total, s);
     if (rc) return rc;
   }
+  if (p.has_folded) {
+    rc = launch_fold_upsample_weight(src, h->blob + p.folded_base, p.Cout, p.Cin, s);
+    if (rc) return rc;
+  }
   p.set = true;
   return 0;
 }
@@ -386,6 +401,7 @@ struct Runner {
     d.B = B; d.Cout = c.Cout;
     d.Hi = in1.H; d.Wi = in1.W; d.Ho = Ho; d.Wo = Wo;
     d.ksize = c.ksize; d.mode = mode; d.act = act;
+    if (mode == DDPM_CONV_UPSAMPLE2 && c.has_folded) d.w_folded = P(c.w_folded);
     if (in1.D > 1 || Do > 1) {
       if (c.ksize == 1) {
         // pointwise over a volume: the NCDHW tensor is an NCHW tensor of extent (D*H) x W

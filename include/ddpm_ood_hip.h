@@ -83,6 +83,11 @@ typedef struct ddpm_conv_desc {
   int Di, Do;
   int kd;
   int accumulate;
+  /* Optional, 2-D DDPM_CONV_UPSAMPLE2 only: weights folded by ddpm_fold_upsample_weight_f32.  A 3x3
+   * conv over a nearest-x2 upsampled image is, for each of the 4 output parities (dy, dx), a 2x2 conv
+   * over the low-res image whose taps are sums of the 3x3 taps that read the same source pixel:
+   * 16 instead of 36 multiply-adds per 4 outputs, same result up to fp32 rounding of the tap sums.  */
+  const float *w_folded;
 } ddpm_conv_desc;
 
 int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream);
@@ -93,6 +98,10 @@ size_t ddpm_packed_conv_weight_floats(int Cout, int Cin, int ksize);
  * weight with `Cout_total` rows (lets q/k/v or all time_emb_proj share one GEMM).       */
 int ddpm_pack_conv_weight_f32(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize,
                               int cout_offset, int Cout_total, ddpm_stream_t stream);
+
+/* Folded form of an Upsample conv weight (see ddpm_conv_desc.w_folded): 4 packed 2x2-tap weights.     */
+size_t ddpm_folded_upsample_weight_floats(int Cout, int Cin);
+int ddpm_fold_upsample_weight_f32(const float *w_raw, float *w_folded, int Cout, int Cin, ddpm_stream_t stream);
 
 /* GroupNorm statistics -> per-(image, channel) scale/shift so that
  * y = x * scale + shift == F.group_norm(x, G, gamma, beta, eps).  cat(in1, in2) virtual. */

@@ -95,6 +95,30 @@ def test_conv(device, case, force_direct):
     _close(y, ref)
 
 
+@pytest.mark.parametrize("B,C1,C2,Cout,H", [(2, 256, 0, 256, 8), (3, 256, 0, 256, 16), (1, 128, 128, 128, 32),
+                                            (5, 256, 0, 128, 4)])
+def test_conv_upsample_folded(device, B, C1, C2, Cout, H):
+    """nearest-x2 + 3x3 as four 2x2-tap convs over the low-res image (weights pre-summed on the device): same
+    result as F.interpolate + F.conv2d up to the rounding of the tap sums."""
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(31)
+    Cin = C1 + C2
+    x = torch.randn(B, C1, H, H, generator=g)
+    x2 = torch.randn(B, C2, H, H, generator=g) if C2 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, 2 * H, 2 * H, generator=g)
+    ref = _ref_conv(x, x2, w, b, None, False, 2, None, res)
+    d = lambda t: None if t is None else t.to(device)
+    folded = ops.fold_upsample_weight(d(w))
+    assert folded is not None
+    y = ops.conv(d(x), d(w), d(b), x2=d(x2), mode=2, residual=d(res), folded=folded)
+    _close(y, ref)
+    y0 = ops.conv(d(x), d(w), d(b), x2=d(x2), mode=2, residual=d(res))  # unfolded path, same op
+    _close(y0, ref)
+
+
 @pytest.mark.parametrize("shape", [(2, 1, 128, 32), (2, 3, 128, 32), (2, 128, 1, 32), (2, 128, 3, 32),
                                    (2, 1, 128, 28), (1, 32, 64, 14), (2, 64, 64, 7)])
 def test_conv_direct_shapes(device, shape):
