@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void conv_smallco_kernel(const ddpm_conv_desc 
   const int tid = threadIdx.x;
   const int n = blockIdx.y;
   const int h0 = blockIdx.x * TH;
-  const int th = tid / a.Wo, tw = tid - th * a.Wo;
+  const bool live = tid < TH * a.Wo;  // ragged tiles (e.g. 9 x 28 = 252 pixels): the last threads only help staging
+  const int th = live ? tid / a.Wo : 0, tw = live ? tid - th * a.Wo : 0;
 
   int soff[NPOS];
 #pragma unroll
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_smallco_kernel(const ddpm_conv_desc 
     }
   }
   const int p = (h0 + th) * a.Wo + tw;
-  for (int co = 0; co < a.Cout; ++co) {
+  for (int co = 0; co < a.Cout && live; ++co) {
     const size_t idx = ((size_t)n * a.Cout + co) * HW + p;
     float v = acc[co];
     if (a.bias) v += a.bias[co];
@@ -152,9 +153,11 @@ __global__ __launch_bounds__(256) void conv_smallco_kernel(const ddpm_conv_desc 
 }
 
 static bool smallco_supported(const ddpm_conv_desc &d, int &TH, int &RS, int &PS) {
-  if (d.Cout > 4 || d.ksize != 3 || d.mode != DDPM_CONV_NORMAL || d.Wo > 256 || (256 % d.Wo)) return false;
-  TH = 256 / d.Wo;
-  if (d.Ho % TH) return false;
+  if (d.Cout > 4 || d.ksize != 3 || d.mode != DDPM_CONV_NORMAL || d.Wo > 256 || d.Di > 1 || d.Do > 1) return false;
+  TH = 0;
+  for (int th = 256 / d.Wo; th >= 1; --th)
+    if (d.Ho % th == 0) { TH = th; break; }
+  if (TH == 0 || 2 * TH * d.Wo < 256) return false;
   RS = d.Wo + 2;
   PS = (TH + 2) * RS;
   return PS <= 512;

@@ -49,6 +49,9 @@ struct ConvGeom {
   int NI;       // B * Do slices
   int MT;       // pixels per workgroup tile (128 or 64)
   int TI, TH;   // images per tile, output rows per tile (per image)
+  int TPX;      // valid output pixels per tile = TI * TH * Wo (<= MT; < MT for ragged extents such as 28 x 28)
+  int TPI;      // tiles per image (TI == 1) -- 0 when a tile holds several whole images
+  int ntiles;
   int IR, RS;   // LDS rows per image slot, LDS row stride
   int IRS;      // IR * RS
   int PS;       // LDS plane size (floats per channel)
@@ -70,16 +73,23 @@ static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g) {
   g.M = g.NI * g.HWo;
   g.pad = d.ksize == 3 ? 1 : 0;
   g.s = d.mode == DDPM_CONV_STRIDE2 ? 2 : 1;
-  if (g.HWo >= MT) {
-    if (MT % d.Wo) return false;
+  if (g.HWo > MT) {
+    // whole rows of one image: the largest divisor of Ho whose rows fit the tile
+    if (d.Wo > MT) return false;
     g.TI = 1;
-    g.TH = MT / d.Wo;
-    if (d.Ho % g.TH) return false;
+    g.TH = 0;
+    for (int th = MT / d.Wo; th >= 1; --th)
+      if (d.Ho % th == 0) { g.TH = th; break; }
+    g.TPI = d.Ho / g.TH;
+    g.ntiles = g.NI * g.TPI;
   } else {
-    if (MT % g.HWo) return false;
+    // several whole images per tile (the last tile may be short of images)
     g.TI = MT / g.HWo;
     g.TH = d.Ho;
+    g.TPI = 0;
+    g.ntiles = (g.NI + g.TI - 1) / g.TI;
   }
+  g.TPX = g.TI * g.TH * d.Wo;
   const int IC = (g.s == 2) ? (2 * d.Wo + 1) : (d.Wo + 2 * g.pad);
   g.IR = (g.s == 2) ? (2 * g.TH + 1) : (g.TH + 2 * g.pad);
   g.RS = IC;
@@ -94,6 +104,7 @@ static bool geom_ok(const ddpm_conv_desc &d, const ConvGeom &g) {
   if (g.PS > 3 * 256) return false;
   if (d.gscale && g.PS > 2 * 256) return false;  // instantiated AFFINE variants: NPOS <= 2
   if (d.ksize == 1 && g.PS > 256) return false;
+  if (4 * g.TPX < 3 * g.MT) return false;  // < 75 % of the tile's MFMA columns would carry real pixels
   return true;
 }
 
@@ -103,9 +114,11 @@ static bool pick_geom(const ddpm_conv_desc &d, ConvGeom &g) {
   const bool ok128 = make_geom(d, 128, g128) && geom_ok(d, g128);
   const bool ok64 = make_geom(d, 64, g64) && geom_ok(d, g64);
   if (!ok128 && !ok64) return false;
-  const long wg128 = ok128 ? (long)((g128.M + 127) / 128) * (d.Cout / kConvNT) : 0;
+  const long wg128 = ok128 ? (long)g128.ntiles * (d.Cout / kConvNT) : 0;
   static const long min_wg128 = getenv("DDPM_CONV_MIN_WG128") ? atol(getenv("DDPM_CONV_MIN_WG128")) : 512;
-  if (ok128 && (wg128 >= min_wg128 || !ok64)) {
+  // prefer 128-pixel tiles when they fill the chip and waste no more MFMA columns than 64-pixel tiles would
+  const bool fill128 = ok128 && (!ok64 || (long)g128.TPX * g64.MT >= (long)g64.TPX * g128.MT);
+  if (ok128 && ((wg128 >= min_wg128 && fill128) || !ok64)) {
     g = g128;
   } else {
     g = g64;
@@ -149,11 +162,17 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   const int wco = MT == 128 ? (wave & 1) * 64 : wave * 32;  // wave's first cout inside the tile
   const int wpx = MT == 128 ? (wave >> 1) * 64 : 0;         // wave's first pixel inside the tile
   const int nt = blockIdx.y;
-  const int P0 = blockIdx.x * MT;
 
   // ---- tile origin -------------------------------------------------------------------------
-  const int n0 = P0 / g.HWo;
-  const int h0 = (g.TI == 1) ? (P0 - n0 * g.HWo) / a.Wo : 0;
+  const int tile = blockIdx.x;
+  int n0, h0;  // first (n, d) slice of the tile, first output row inside it
+  if (g.TPI > 0) {
+    n0 = tile / g.TPI;
+    h0 = (tile - n0 * g.TPI) * g.TH;
+  } else {
+    n0 = tile * g.TI;
+    h0 = 0;
+  }
 
   // ---- per-thread staging positions (chunk-invariant) -------------------------------------
   int soff[NPOS];   // offset inside one channel plane of the source, -1 => zero
@@ -199,7 +218,8 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   int xb[2];
 #pragma unroll
   for (int bb = 0; bb < 2; ++bb) {
-    const int q = wpx + bb * 32 + l31;
+    const int qq = wpx + bb * 32 + l31;
+    const int q = qq < g.TPX ? qq : 0;  // lanes past a ragged tile's last pixel compute a dummy column
     const int per_img = g.TH * a.Wo;
     const int ti = q / per_img;
     const int rem = q - ti * per_img;
@@ -353,10 +373,12 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   const int co_base = nt * kConvNT + wco + 4 * lhi;
 #pragma unroll
   for (int bb = 0; bb < 2; ++bb) {
-    const int P = P0 + wpx + bb * 32 + l31;
-    if (P < g.M) {
-      const int img = P / g.HWo;
-      const int p = P - img * g.HWo;
+    const int q = wpx + bb * 32 + l31;
+    const int per_img = g.TH * a.Wo;
+    const int ti = q / per_img;
+    const int img = n0 + ti;
+    if (q < g.TPX && img < g.NI) {
+      const int p = h0 * a.Wo + (q - ti * per_img);  // flattened pixel inside the slice
       const int n = img / g.Do;
       const int dz = img - n * g.Do;
       size_t cstride = (size_t)g.Do * g.HWo;  // channel stride of the NC(D)HW output
@@ -411,7 +433,7 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g_in, hipStre
               (int)AFFINE, MT, lds, fa.numRegs, nb);
     }
   }
-  dim3 grid((g.M + MT - 1) / MT, d.Cout / kConvNT);
+  dim3 grid(g.ntiles, d.Cout / kConvNT);
   // algorithmic work of this launch: 2*M*Cout*Cin*taps FLOP; input + output (+ residual)
   // + weights bytes, each counted once
   // (a folded-upsample launch is one output parity = a quarter of the original conv's algorithmic work)

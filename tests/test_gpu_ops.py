@@ -60,6 +60,12 @@ CONV_CASES = [
     (1, 256, 0, 768, 8, 1, 0, True, False, False, False),    # fused QKV (affine, no SiLU), partial tile
     (5, 256, 256, 256, 8, 3, 0, True, True, True, False),   # odd batch: ragged last tile
     (1, 256, 0, 512, 64, 3, 0, True, True, False, False),   # W = 64 (two staging positions)
+    (3, 128, 0, 128, 28, 3, 0, True, True, True, False),    # native FashionMNIST 28x28: ragged 4-row tiles (112 / 128 px)
+    (3, 128, 0, 128, 28, 3, 1, False, False, False, False),  # 28 -> 14 downsample
+    (2, 256, 128, 256, 14, 3, 0, True, True, True, False),  # 14x14: 7-row tiles (98 px)
+    (5, 256, 256, 256, 7, 3, 0, True, True, True, False),   # 7x7: 2 images per tile (98 px), odd batch
+    (3, 256, 0, 256, 7, 3, 2, False, False, False, False),   # 7 -> 14 upsample (unfolded path)
+    (3, 256, 128, 128, 28, 1, 0, False, False, False, True),  # 1x1 skip at 28x28
 ]
 
 

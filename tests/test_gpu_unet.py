@@ -29,7 +29,7 @@ def _pair(device, channels=1, cfg=SMALL, seed=1, spatial_dims=2, **extra):
     return ref, hip.to(device).eval()
 
 
-@pytest.mark.parametrize("channels,B,H", [(1, 2, 32), (3, 3, 32), (1, 5, 16), (1, 1, 64)])
+@pytest.mark.parametrize("channels,B,H", [(1, 2, 32), (3, 3, 32), (1, 5, 16), (1, 1, 64), (1, 3, 28)])
 def test_unet_forward_small(device, channels, B, H):
     ref, hip = _pair(device, channels)
     g = torch.Generator().manual_seed(4)
@@ -209,3 +209,31 @@ def test_ldm_trajectory_3d_matches_oracle(device, tmp_path):
     for col in ("mse", "perceptual_difference"):
         rel = ((rows_h[col] - rows_o[col]).abs() / (rows_o[col].abs() + 1e-9)).max()
         assert rel < 1e-3, (col, rel, rows_h[col].tolist(), rows_o[col].tolist())
+
+
+def test_trajectory_native_28x28_lpips_pad_branch(device, tmp_path):
+    """The reference's README runs FashionMNIST at its native 28x28: the UNet sees 28 -> 14 -> 7 (ragged MFMA
+    tiles) and LPIPS gets both images zero-padded to 32 (reconstruct.py:171-178)."""
+    import oracle
+    from ddpm_ood_amd import synthetic
+    from ddpm_ood_amd.data import get_data_loader
+    from ddpm_ood_amd.trainer import Reconstruct, batch_noise
+
+    ids = "synthetic:blobs:n=3:size=28:seed=21"
+    args = _args(tmp_path, validation_ids=ids, in_ids=ids, out_ids=ids, batch_size=3)
+    sd = synthetic.write_checkpoint(tmp_path / args.model_name, "small", 1, seed=1)
+    rec = Reconstruct(args)
+    loader = get_data_loader(ids, batch_size=3, is_grayscale=True)
+    assert next(iter(loader))["image"].shape == (3, 1, 28, 28)
+    rows_h = pd.DataFrame(rec.get_scores(loader, "val", 64))
+    ref = oracle.DiffusionModelUNet(2, 1, 1, **SMALL).eval()
+    ref.load_state_dict(sd)
+    pl = oracle.PerceptualLoss(dimensions=2, include_pixel_loss=False, is_fake_3d=False, lpips_normalize=True)
+    pl.perceptual_function.load_state_dict(rec._perceptual().perceptual_function.state_dict())
+    rows_o = pd.DataFrame(oracle.get_scores(
+        loader, "val", 64, model=ref, vqvae=oracle.PassthroughVQVAE(), perceptual=pl,
+        noise_fn=lambda batch, t, shape: batch_noise(2, batch["index"], t, shape),
+        beta_schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195))
+    for col in ("mse", "perceptual_difference"):
+        rel = ((rows_h[col] - rows_o[col]).abs() / (rows_o[col].abs() + 1e-9)).max()
+        assert rel < 1e-4, (col, rel)
