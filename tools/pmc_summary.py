@@ -47,7 +47,7 @@ def main(root, out_csv, out_json):
     m = m.sort_values("dur_us", ascending=False)[cols]
     m.to_csv(out_csv, index=False, float_format="%.4g")
     print(m.head(12).to_string())
-    dom = m[m.kernel.str.startswith("conv_mfma_kernel<9, 1, true, 128>")].iloc[0]
+    dom = m[m.kernel.str.startswith("conv_mfma_kernel<9, 1, true, 128")].iloc[0]
     json.dump({"conv3x3_mfma_gn_silu_bytes_per_launch": float(dom.hbm_MB_per_launch * 1e6),
                "conv3x3_mfma_gn_silu_mfma_util": float(dom.mfma_util),
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/microbench.py, B=256; "
