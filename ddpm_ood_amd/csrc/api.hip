@@ -97,6 +97,13 @@ extern "C" int ddpm_pack_conv_weight_f32(const float *w_raw, float *w_packed, in
   return launch_pack_conv_weight(w_raw, w_packed, Cout, Cin, ksize, cout_offset, Cout_total, as_stream(stream));
 }
 
+extern "C" int ddpm_pack_conv_weight_taps_f32(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize,
+                                              int src_taps, int tap_off, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(w_raw && w_packed && src_taps >= ksize * ksize && tap_off >= 0 && tap_off + ksize * ksize <= src_taps,
+                 "pack_taps: bad argument");
+  return launch_pack_conv_weight(w_raw, w_packed, Cout, Cin, ksize, 0, Cout, as_stream(stream), src_taps, tap_off);
+}
+
 extern "C" size_t ddpm_folded_upsample_weight_floats(int Cout, int Cin) {
   return folded_upsample_weight_floats(Cout, Cin);
 }

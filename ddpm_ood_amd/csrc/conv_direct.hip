@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ddpm_conv_desc a
           v = up ? plane[(hv >> 1) * a.Wi + (wv >> 1)] : plane[hv * a.Wi + wv];
           if (a.gscale) v = v * sc + sh;
           if (a.act == DDPM_ACT_SILU) v = silu_f(v);
+          if (a.act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
         }
         const int t = kh * a.ksize + kw;
 #pragma unroll
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ddpm_conv_desc a
       if (a.bias) v += a.bias[co];
       if (a.chan_add) v += a.chan_add[(size_t)n * a.chan_add_stride + co];
       if (a.residual) v += a.residual[idx];
+      if (a.out_act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
       a.out[idx] = v;
     }
   }
@@ -118,6 +120,8 @@ __global__ __launch_bounds__(256) void conv_smallco_kernel(const ddpm_conv_desc 
             v = plane[soff[j]];
             if (a.gscale) v = v * a.gscale[(size_t)n * Cin + ci] + a.gshift[(size_t)n * Cin + ci];
             if (a.act == DDPM_ACT_SILU) v = silu_f(v);
+            if (a.act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
+          if (a.act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
           }
           tile[c * PS + r] = v;
         }
@@ -148,6 +152,7 @@ __global__ __launch_bounds__(256) void conv_smallco_kernel(const ddpm_conv_desc 
     if (a.bias) v += a.bias[co];
     if (a.chan_add) v += a.chan_add[(size_t)n * a.chan_add_stride + co];
     if (a.residual) v += a.residual[idx];
+    if (a.out_act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
     a.out[idx] = v;
   }
 }

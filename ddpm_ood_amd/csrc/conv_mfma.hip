@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
           // v_exp_f32 / v_rcp_f32 SiLU (6 instructions instead of ~45): end-to-end parity unchanged
           // (Z-score error 2.4e-6 vs 3.4e-6 with expf + IEEE divide)
           if (a.act == DDPM_ACT_SILU) v = silu_fast(v);
+          if (a.act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
           smem[nb + WF + (gk * CC + c) * g.PS + r] = valid ? v : 0.f;
         }
       }
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
           if (bias_p) v += bvv[r];
           if (chan_p) v += cv[r];
           if (res_p || a.accumulate) v += rv[r];
+          if (a.out_act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
           a.out[obase + (size_t)dco * cstride] = v;
         }
       }

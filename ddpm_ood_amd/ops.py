@@ -8,6 +8,7 @@ PyTorch ops.
 from __future__ import annotations
 
 import ctypes as C
+from ctypes import byref as C_byref
 
 import numpy as np
 import torch
@@ -16,7 +17,7 @@ from . import _lib
 from ._lib import ConvDesc, check, ptr, require_device_f32, stream_ptr
 
 CONV_NORMAL, CONV_STRIDE2, CONV_UPSAMPLE2 = 0, 1, 2
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 
 
 def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor | None:
@@ -98,6 +99,62 @@ def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NON
     d.w_folded = ptr(folded)
     check(lib.ddpm_conv_f32(C.byref(d), stream_ptr()), "conv")
     return out[:, :, 0, 0] if was_linear else out
+
+
+def conv3d_supported(weight: torch.Tensor) -> bool:
+    """3x3x3 stride-1 pad-1 weights with an MFMA tiling (Cin % 4 == 0, Cout % 128 == 0)."""
+    return (weight.ndim == 5 and tuple(weight.shape[2:]) == (3, 3, 3) and weight.shape[0] % 128 == 0
+            and weight.shape[1] % 4 == 0)
+
+
+def pack_conv3d_weight(weight: torch.Tensor) -> torch.Tensor:
+    """torch [Cout, Cin, 3, 3, 3] -> three MFMA-packed 2-D slabs, one per depth tap."""
+    lib = _lib.load()
+    w = require_device_f32(weight, "weight")
+    cout, cin = w.shape[:2]
+    slab = cout * cin * 9
+    out = torch.empty(3 * slab, dtype=torch.float32, device=w.device)
+    for kd in range(3):
+        check(lib.ddpm_pack_conv_weight_taps_f32(ptr(w), out.data_ptr() + 4 * kd * slab, cout, cin, 3, 27, 9 * kd,
+                                                 stream_ptr()), "pack_conv3d_weight")
+    return out
+
+
+def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=None, packed=None):
+    """F.conv3d(act(x), weight, bias, stride 1, pad 1) (+ residual, + output activation) on NCDHW tensors as three
+    depth-tap launches of the 2-D MFMA kernel (centre tap first; the last launch applies ``out_act``)."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    w = require_device_f32(weight, "weight")
+    if not conv3d_supported(w):
+        raise ValueError("conv3d: only 3x3x3 weights with Cin % 4 == 0 and Cout % 128 == 0 have an MFMA tiling")
+    B, C, D, H, W = x.shape
+    cout = w.shape[0]
+    if packed is None:
+        packed = pack_conv3d_weight(w)
+    out = torch.empty((B, cout, D, H, W), dtype=torch.float32, device=x.device)
+    if bias is not None:
+        bias = require_device_f32(bias, "bias")
+    if residual is not None:
+        residual = require_device_f32(residual, "residual")
+    slab = cout * C * 9
+    for i, kd in enumerate((1, 0, 2)):
+        d = ConvDesc()
+        d.in1, d.C1 = ptr(x), C
+        d.w_packed = packed.data_ptr() + 4 * kd * slab
+        d.w_raw = ptr(w)
+        d.out = ptr(out)
+        d.B, d.Cout, d.Hi, d.Wi, d.Ho, d.Wo = B, cout, H, W, H, W
+        d.ksize, d.mode, d.act = 3, CONV_NORMAL, act
+        d.Di, d.Do, d.kd = D, D, kd
+        if i == 0:
+            d.bias, d.residual = ptr(bias), ptr(residual)
+        else:
+            d.accumulate = 1
+        if i == 2:
+            d.out_act = out_act
+        check(lib.ddpm_conv_f32(C_byref(d), stream_ptr()), "conv3d")
+    return out
 
 
 def gn_scale_shift(x, gamma, beta, groups: int, eps: float, x2=None):

@@ -48,6 +48,7 @@ const char *ddpm_last_error(void);
 #define DDPM_CONV_UPSAMPLE2 2 /* nearest x2 folded into the input indexing (Upsample)     */
 #define DDPM_ACT_NONE 0
 #define DDPM_ACT_SILU 1
+#define DDPM_ACT_RELU 2
 
 /* Fused convolution / linear descriptor.  out = conv(act(affine(cat(in1,in2)))) + bias
  *                                               + chan_add[n, co] + residual
@@ -88,6 +89,10 @@ typedef struct ddpm_conv_desc {
    * over the low-res image whose taps are sums of the 3x3 taps that read the same source pixel:
    * 16 instead of 36 multiply-adds per 4 outputs, same result up to fp32 rounding of the tap sums.  */
   const float *w_folded;
+  /* Activation applied to the finished output element (after bias / chan_add / residual / accumulate):
+   * DDPM_ACT_NONE or DDPM_ACT_RELU.  Used by the VQ-VAE residual units, relu(x + conv2(relu(conv1(x)))).  */
+  int out_act;
+  int reserved;
 } ddpm_conv_desc;
 
 int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream);
@@ -98,6 +103,11 @@ size_t ddpm_packed_conv_weight_floats(int Cout, int Cin, int ksize);
  * weight with `Cout_total` rows (lets q/k/v or all time_emb_proj share one GEMM).       */
 int ddpm_pack_conv_weight_f32(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize,
                               int cout_offset, int Cout_total, ddpm_stream_t stream);
+
+/* Pack `ksize*ksize` taps starting at `tap_off` out of the `src_taps` taps of a wider torch kernel, e.g. depth
+ * tap kd of a conv3d weight [Cout, Cin, 3, 3, 3]: src_taps = 27, tap_off = 9 * kd.                       */
+int ddpm_pack_conv_weight_taps_f32(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize, int src_taps,
+                                   int tap_off, ddpm_stream_t stream);
 
 /* Folded form of an Upsample conv weight (see ddpm_conv_desc.w_folded): 4 packed 2x2-tap weights.     */
 size_t ddpm_folded_upsample_weight_floats(int Cout, int Cin);

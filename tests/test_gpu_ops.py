@@ -255,3 +255,44 @@ def test_no_cpu_fallback():
 
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.conv(torch.zeros(1, 8, 8, 8), torch.zeros(8, 8, 3, 3))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,D,H", [(1, 128, 256, 8, 8), (2, 256, 256, 4, 16), (1, 256, 128, 6, 12)])
+def test_conv3d_depth_taps_with_relu_epilogues(device, B, Cin, Cout, D, H):
+    """F.conv3d (3x3x3, pad 1) as three depth-tap launches, with the input / output ReLU and residual fusions the
+    VQ-VAE residual units use."""
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, Cin, D, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(Cin * 27)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, D, H, H, generator=g)
+    d = lambda t: t.to(device)
+    _close(ops.conv3d(d(x), d(w), d(b)), F.conv3d(x, w, b, padding=1))
+    _close(ops.conv3d(d(x), d(w), d(b), act=ops.ACT_RELU, out_act=ops.ACT_RELU, residual=d(res)),
+           F.relu(F.conv3d(F.relu(x), w, b, padding=1) + res))
+
+
+def test_vqvae_residual_units_on_hip_match_torch(device):
+    """The product VQ-VAE runs its 3x3x3 residual units on the MFMA kernel when the channel counts allow it;
+    result vs the CPU oracle restatement."""
+    from oracle.vqvae import VQVAE as OV
+    from ddpm_ood_amd.vqvae import VQVAE as PV
+
+    cfg = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(128, 128), num_res_layers=2,
+               num_res_channels=(128, 128), downsample_parameters=((2, 4, 1, 1), (2, 4, 1, 1)),
+               upsample_parameters=((2, 4, 1, 1, 0), (2, 4, 1, 1, 0)), num_embeddings=32, embedding_dim=128)
+    torch.manual_seed(1)
+    o = OV(**cfg).eval()
+    with torch.no_grad():
+        o.quantizer.quantizer.embedding.weight.mul_(3.0)
+    p = PV(**cfg)
+    p.load_state_dict(o.state_dict())
+    p = p.to(device).eval()
+    x = torch.rand(1, 1, 16, 16, 16, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        zo = o.encode_stage_2_inputs(x)
+        zp = p.encode_stage_2_inputs(x.to(device))
+        _close(zp, zo, tol=1e-5)
+        _close(p.decode_stage_2_outputs(zp), o.decode_stage_2_outputs(zo), tol=2e-5)
