@@ -55,8 +55,18 @@ class _Convolution(nn.Module):
             conv_t = {2: nn.Conv2d, 3: nn.Conv3d}[spatial_dims]
             self.conv = conv_t(cin, cout, kernel_size, strides, padding, dilation=dilation)
         self.conv_only = conv_only
+        self._hip_ok = (not is_transposed and spatial_dims == 3 and kernel_size == 3 and strides == 1
+                        and dilation == 1 and padding == 1)
+        self._packed = None
 
     def forward(self, x):
+        w = self.conv.weight
+        if self._hip_ok and x.is_cuda and ops.conv3d_supported(w):  # 3x3x3 stride 1: fp32-MFMA kernel
+            key = (w.data_ptr(), w._version)
+            if self._packed is None or self._packed[0] != key:
+                self._packed = (key, ops.pack_conv3d_weight(w.detach()))
+            return ops.conv3d(x.float().contiguous(), w.detach(), self.conv.bias.detach(), packed=self._packed[1],
+                              out_act=ops.ACT_NONE if self.conv_only else ops.ACT_RELU)
         x = self.conv(x)
         return x if self.conv_only else F.relu(x)
 
