@@ -78,7 +78,7 @@ def gather_scores(ids: torch.Tensor, scores: torch.Tensor):
     all_gather_object semantics, reconstruct.py:238-242, in 2 MB instead of 30 MB of pickles).
     Short shards are padded with id = -1 and dropped after the gather."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return ids, scores
+        return ids, scores, [int(ids.shape[0])]
     world = dist.get_world_size()
     n = torch.tensor([ids.shape[0]], dtype=torch.int64, device=ids.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
@@ -94,7 +94,27 @@ def gather_scores(ids: torch.Tensor, scores: torch.Tensor):
     allp = torch.cat(out, dim=0)
     keep = allp[:, 0] >= 0
     allp = allp[keep]
-    return allp[:, 0].to(torch.int32), allp[:, 1:].reshape(-1, n_t, 2)
+    return allp[:, 0].to(torch.int32), allp[:, 1:].reshape(-1, n_t, 2), [int(c) for c in counts]
+
+
+def rows_from_scores(ids, scores, counts, t_values, name_of, batch_size: int, dataset_name: str):
+    """Dense gathered scores -> the reference's row dicts, in the reference's order: rank-major
+    (all_gather_object, reconstruct.py:238-242), and inside a rank per batch, per t_start, per image
+    (reconstruct.py:128,192-204)."""
+    ids = [int(i) for i in ids]
+    results = []
+    start = 0
+    for n_rank in counts:
+        for s in range(start, start + n_rank, batch_size):
+            e = min(start + n_rank, s + batch_size)
+            for j, t in enumerate(t_values):
+                for b in range(s, e):
+                    filename = name_of.get(ids[b], str(ids[b]))
+                    stem = Path(filename).stem.replace(".nii", "").replace(".gz", "")
+                    results.append({"filename": stem, "type": dataset_name, "t": int(t),
+                                    "perceptual_difference": float(scores[b, j, 0]), "mse": float(scores[b, j, 1])})
+        start += n_rank
+    return results
 
 
 class BaseTrainer:
@@ -341,25 +361,16 @@ class Reconstruct(BaseTrainer):
             scores = torch.zeros((0, len(t_values), 2), dtype=torch.float32, device=self.device)
             ids = torch.zeros((0,), dtype=torch.int32, device=self.device)
         name_of = dict(zip((int(i) for i in ids.cpu()), names_all))
+        counts = [int(ids.shape[0])]
         if self.ddp:
-            ids, scores = gather_scores(ids, scores)
+            ids, scores, counts = gather_scores(ids, scores)
             # every rank can name every image: the id list is the same file on every rank
             name_of = {i: n for i, n in enumerate(loader.all_names)} if hasattr(loader, "all_names") else name_of
             if int(os.environ["LOCAL_RANK"]) != 0 and not quiet:
                 sys.stdout = sys.stderr = open(os.devnull, "w")
-        ids = ids.cpu().tolist()
-        scores = scores.cpu()  # the one device->host copy
-        results = []
-        # row order of the reference: per batch, per t_start, per image
-        bs = loader.batch_size
-        for s in range(0, len(ids), bs):
-            for j, t in enumerate(t_values):
-                for b in range(s, min(len(ids), s + bs)):
-                    filename = name_of.get(ids[b], str(ids[b]))
-                    stem = Path(filename).stem.replace(".nii", "").replace(".gz", "")
-                    results.append({"filename": stem, "type": dataset_name, "t": t,
-                                    "perceptual_difference": scores[b, j, 0].item(), "mse": scores[b, j, 1].item()})
-        return results
+        # the one device->host copy of the scores
+        return rows_from_scores(ids.cpu().tolist(), scores.cpu().numpy(), counts, t_values, name_of,
+                                loader.batch_size, dataset_name)
 
     def _write(self, results_list, name):
         if self.rank == 0:

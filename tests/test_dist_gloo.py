@@ -22,9 +22,13 @@ def _worker(rank, world, port, n_images, q):
     from ddpm_ood_amd.data import partition
     from ddpm_ood_amd.trainer import gather_scores
 
+    from ddpm_ood_amd.trainer import rows_from_scores
+
     ids = partition(n_images, rank, world)
-    gids, gsc = gather_scores(torch.tensor(ids, dtype=torch.int32), _fake_scores(ids))
-    q.put((rank, gids.tolist(), gsc))
+    gids, gsc, counts = gather_scores(torch.tensor(ids, dtype=torch.int32), _fake_scores(ids))
+    rows = rows_from_scores(gids.tolist(), gsc.numpy(), counts, [10, 50, 90], {i: f"img_{i}.npy" for i in range(99)},
+                            2, "in")
+    q.put((rank, gids.tolist(), gsc, rows))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -44,7 +48,15 @@ def test_two_rank_gather_equals_one_rank(n_images):
         p.join(timeout=60)
         assert p.exitcode == 0
     ref = _fake_scores(list(range(n_images)))
-    for rank, ids, sc in got:  # every rank holds every row (all_gather_object semantics of the reference)
+    for rank, ids, sc, rows in got:  # every rank holds every row (all_gather_object semantics of the reference)
+        assert len(rows) == 3 * n_images and {r["filename"] for r in rows} == {f"img_{i}" for i in range(n_images)}
+        one = _fake_scores(list(range(n_images)))
+        for r in rows:  # the (image, t) -> score association survives sharding + gather
+            i, j = int(r["filename"][4:]), [10, 50, 90].index(r["t"])
+            assert r["perceptual_difference"] == float(one[i, j, 0]) and r["mse"] == float(one[i, j, 1])
+        if n_images == 7:  # rank-major, then per batch (2), per t, per image -- rank 0 owns images 0 2 4 6
+            assert [r["filename"] for r in rows[:6]] == ["img_0", "img_2"] * 3
+            assert [r["t"] for r in rows[:6]] == [10, 10, 50, 50, 90, 90]
         assert sorted(ids) == list(range(n_images))  # ragged shards: no padding ids, no duplicates (Q6)
         order = torch.tensor(ids).argsort()
         assert torch.equal(sc[order], ref)
@@ -55,5 +67,5 @@ def test_single_process_gather_is_identity():
     from ddpm_ood_amd.trainer import gather_scores
 
     ids = torch.arange(4, dtype=torch.int32)
-    a, b = gather_scores(ids, _fake_scores([0, 1, 2, 3]))
-    assert a is ids and torch.equal(b, _fake_scores([0, 1, 2, 3]))
+    a, b, c = gather_scores(ids, _fake_scores([0, 1, 2, 3]))
+    assert a is ids and torch.equal(b, _fake_scores([0, 1, 2, 3])) and c == [4]
