@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
         ("ksize", C.c_int), ("mode", C.c_int), ("act", C.c_int), ("force_direct", C.c_int),
         ("Di", C.c_int), ("Do", C.c_int), ("kd", C.c_int), ("accumulate", C.c_int),
-        ("w_folded", C.c_void_p), ("out_act", C.c_int), ("reserved", C.c_int),
+        ("w_folded", C.c_void_p), ("out_act", C.c_int), ("reserved", C.c_int), ("w_wino", C.c_void_p),
     ]
 
 
@@ -58,6 +58,8 @@ SIGNATURES = {
                                             C.c_void_p]),
     "ddpm_pack_conv_weight_taps_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_void_p]),
+    "ddpm_wino_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "ddpm_pack_wino_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_folded_upsample_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_fold_upsample_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_gn_scale_shift_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -104,6 +104,13 @@ extern "C" int ddpm_pack_conv_weight_taps_f32(const float *w_raw, float *w_packe
   return launch_pack_conv_weight(w_raw, w_packed, Cout, Cin, ksize, 0, Cout, as_stream(stream), src_taps, tap_off);
 }
 
+extern "C" size_t ddpm_wino_weight_floats(int Cout, int Cin) { return wino_weight_floats(Cout, Cin); }
+
+extern "C" int ddpm_pack_wino_weight_f32(const float *w_raw, float *w_wino, int Cout, int Cin, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(w_raw && w_wino, "wino pack: NULL pointer");
+  return launch_pack_wino_weight(w_raw, w_wino, Cout, Cin, as_stream(stream));
+}
+
 extern "C" size_t ddpm_folded_upsample_weight_floats(int Cout, int Cin) {
   return folded_upsample_weight_floats(Cout, Cin);
 }

@@ -1,0 +1,383 @@
+// conv_wino.hip -- 3x3 stride-1 convolution as Winograd F(2x2, 3x3) on the fp32 MFMA pipe.
+//
+// Same fused op as conv_mfma.hip's 9-tap kernel (GroupNorm-affine + SiLU prologue, virtual concat, bias /
+// temb / residual epilogue; reference call site /root/reference/src/trainers/reconstruct.py:151-153) with
+// 2.25x fewer multiplies: every 2x2 output tile is  Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A  where d_c is
+// the 4x4 input patch of channel c.  The sum over channels at each of the 16 transform positions xi is a GEMM,
+//     M_xi[cout][tile] = sum_c U_xi[cout][c] * V_xi[c][tile],
+// and runs on v_mfma_f32_32x32x2_f32 exactly like the direct kernel: A = U_xi (weights, pre-transformed on the
+// device by wino_pack_kernel), B = V_xi (input patches transformed while they are staged into LDS).
+// fp32 throughout.  Rounding differs from the direct form (the transforms add values before multiplying):
+// measured max error of a 512-channel layer vs fp64 is 1.6e-6 against 0.9e-6 for the direct fp32 conv
+// (DESIGN.md section 3.3), far inside the 1e-4 parity bar.
+//
+// Workgroup = 64 output channels x 64 tiles (256 output pixels: whole tile rows of one image, or several
+// whole images), 4 waves as 2 (cout) x 2 (tile); a wave owns 32 couts x 32 tiles at all 16 positions =
+// 16 accumulator tiles = 256 accumulator registers, so the output transform is lane-local (a lane holds all
+// 16 M_xi of its (cout, tile) pairs).  Input channels advance in chunks of 8; LDS is double-buffered
+// ([16][8][64] U + [16][8][64] V = 64 KB per buffer): while the 64 MFMAs of chunk q run, the wave commits
+// chunk q + 1 (activation + B^T d B applied here) and issues the loads of chunk q + 2.  One barrier per chunk.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace ddpm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kWT = 64;    // tiles per workgroup
+constexpr int kWK = 64;    // output channels per workgroup
+constexpr int kWC = 8;     // input channels per chunk
+constexpr int kWUF = 16 * kWC * kWK;  // U floats per chunk (8192)
+constexpr int kWVF = 16 * kWC * kWT;  // V floats per chunk (8192)
+
+// The 16 accumulator tiles (256 registers) must live in the AGPR half of the unified register file: with the
+// builtin hipcc keeps them in arch VGPRs, funnels every MFMA through a[0:15] and spills 1.2 KB per lane.
+// The "+a" constraint pins each accumulator to its own AGPR tuple; successive MFMAs never share one (16 apart),
+// so no wait states are needed between them (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void mfma_agpr(f32x16 &c, float a, float b) {
+  asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+struct WinoGeom {
+  int TWc, THr;     // tile columns / rows per image (Wo / 2, Ho / 2)
+  int TI, TR;       // images per workgroup, tile rows per workgroup (per image)
+  int TPI;          // workgroups per image (0 when a workgroup holds several whole images)
+  int ntiles;       // workgroups along the tile axis
+  int Cin, nchunks, HW;
+};
+
+static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
+  const int Cin = d.C1 + d.C2;
+  if (d.ksize != 3 || d.mode != DDPM_CONV_NORMAL || d.Di > 1 || d.Do > 1 || d.accumulate || d.out_act) return false;
+  if (d.act == DDPM_ACT_RELU) return false;
+  if (Cin % kWC || (d.C2 > 0 && d.C1 % kWC) || d.Cout % kWK) return false;
+  if ((d.Ho & 1) || (d.Wo & 1)) return false;
+  g.TWc = d.Wo / 2;
+  g.THr = d.Ho / 2;
+  const int per_img = g.TWc * g.THr;
+  if (per_img >= kWT) {
+    if (kWT % g.TWc) return false;
+    g.TI = 1;
+    g.TR = kWT / g.TWc;
+    if (g.THr % g.TR) return false;
+    g.TPI = g.THr / g.TR;
+    g.ntiles = d.B * g.TPI;
+  } else {
+    if (kWT % per_img) return false;
+    g.TI = kWT / per_img;
+    g.TR = g.THr;
+    g.TPI = 0;
+    g.ntiles = (d.B + g.TI - 1) / g.TI;
+  }
+  g.Cin = Cin;
+  g.nchunks = Cin / kWC;
+  g.HW = d.Ho * d.Wo;
+  return true;
+}
+
+bool conv_wino_supported(const ddpm_conv_desc &d) {
+  static const bool enabled = !(getenv("DDPM_CONV_WINOGRAD") && atoi(getenv("DDPM_CONV_WINOGRAD")) == 0);
+  WinoGeom g;
+  return enabled && d.w_wino != nullptr && !d.force_direct && wino_geom(d, g);
+}
+
+template <bool AFFINE>
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ddpm_conv_desc a, const WinoGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BUF = kWUF + kWVF;  // floats per LDS buffer: U [16][8][64] then V [16][8][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int cb = wave & 1, tb = wave >> 1;  // wave's cout block / tile block
+  const int kt = blockIdx.y;
+
+  int n0, r0;  // first image of the workgroup, first tile row inside it
+  if (g.TPI > 0) {
+    n0 = blockIdx.x / g.TPI;
+    r0 = (blockIdx.x - n0 * g.TPI) * g.TR;
+  } else {
+    n0 = blockIdx.x * g.TI;
+    r0 = 0;
+  }
+
+  // ---- staging role of this thread: tile `st` (= lane), channels sc and sc + 4 of every chunk ----------
+  const int st = tid & 63, sc = tid >> 6;
+  int s_n, s_off;        // image and offset of the patch's top-left input pixel (may point outside the image)
+  unsigned s_mask = 0;   // bit (4 i + j): patch element (i, j) lies inside the image
+  {
+    const int per = g.TR * g.TWc;
+    const int ti = st / per, rem = st - ti * per;
+    const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
+    s_n = n0 + ti;
+    const int h = 2 * (r0 + tr) - 1, w = 2 * tc - 1;
+    s_off = h * a.Wo + w;
+    if (s_n < a.B) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (h + i >= 0 && h + i < a.Ho && w + j >= 0 && w + j < a.Wo) s_mask |= 1u << (4 * i + j);
+    }
+  }
+
+  // ---- MFMA operand bases ------------------------------------------------------------------------
+  const int ub = lhi * kWK + cb * 32 + l31;          // + (xi * 8 + 2 kk) * 64
+  const int vb = kWUF + lhi * kWT + tb * 32 + l31;   // + (xi * 8 + 2 kk) * 64
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int x = 0; x < 16; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+  // ---- staging registers ---------------------------------------------------------------------------
+  v4f ureg[8];
+  float dreg[2][16];
+  float gsc[2], gsh[2];
+  const float *usrc = a.w_wino + (size_t)kt * g.nchunks * kWUF;
+
+  auto prefetch_u = [&](int i, int ch) {
+    ureg[i] = reinterpret_cast<const v4f *>(usrc + (size_t)ch * kWUF)[tid + 256 * i];
+  };
+  auto prefetch_d = [&](int e, int ch) {
+    const int cg = ch * kWC + sc + 4 * e;
+    const float *base;
+    int Cs, cl;
+    if (cg < a.C1) {
+      base = a.in1; Cs = a.C1; cl = cg;
+    } else {
+      base = a.in2; Cs = a.C2; cl = cg - a.C1;
+    }
+    const float *p = base + ((size_t)s_n * Cs + cl) * g.HW + s_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        dreg[e][4 * i + j] = (s_mask >> (4 * i + j) & 1) ? p[i * a.Wo + j] : 0.f;
+    if (AFFINE && s_mask) {
+      gsc[e] = a.gscale[(size_t)s_n * g.Cin + cg];
+      gsh[e] = a.gshift[(size_t)s_n * g.Cin + cg];
+    }
+  };
+  auto commit_u = [&](int i, int nb) { reinterpret_cast<v4f *>(smem + nb)[tid + 256 * i] = ureg[i]; };
+  // activation (zero padding stays zero), then V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+  auto commit_d = [&](int e, int nb) {
+    float d[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      float v = dreg[e][x];
+      if (AFFINE) v = v * gsc[e] + gsh[e];
+      if (a.act == DDPM_ACT_SILU) v = silu_fast(v);
+      d[x] = (s_mask >> x & 1) ? v : 0.f;
+    }
+    float t[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // B^T d (combine rows)
+      t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+      t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+      t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+      t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+    }
+    float *vl = smem + nb + kWUF + (sc + 4 * e) * kWT + st;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // (B^T d) B (combine columns)
+      vl[(i * 4 + 0) * kWC * kWT] = t[i * 4 + 0] - t[i * 4 + 2];
+      vl[(i * 4 + 1) * kWC * kWT] = t[i * 4 + 1] + t[i * 4 + 2];
+      vl[(i * 4 + 2) * kWC * kWT] = t[i * 4 + 2] - t[i * 4 + 1];
+      vl[(i * 4 + 3) * kWC * kWT] = t[i * 4 + 1] - t[i * 4 + 3];
+    }
+  };
+
+  // ---- prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers -------------------------------------
+#pragma unroll
+  for (int i = 0; i < 8; ++i) prefetch_u(i, 0);
+  prefetch_d(0, 0);
+  prefetch_d(1, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) commit_u(i, 0);
+  commit_d(0, 0);
+  commit_d(1, 0);
+  if (g.nchunks > 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) prefetch_u(i, 1);
+    prefetch_d(0, 1);
+    prefetch_d(1, 1);
+  }
+  __syncthreads();
+
+  // One chunk: 16 positions x 4 k-pairs = 64 MFMAs, staging of the next chunks spread between them.
+  auto chunk = [&](auto commit_c, auto pref_c, int q) {
+    constexpr bool DO_COMMIT = decltype(commit_c)::value;
+    constexpr bool DO_PREF = decltype(pref_c)::value;
+    const int cbuf = (q & 1) * BUF;
+    const int nb = BUF - cbuf;
+    // operand ring, PFD steps ahead of the MFMAs: with one wave per SIMD nothing else hides the LDS latency
+    constexpr int PFD = 4;
+    float av[PFD], bv[PFD];
+#pragma unroll
+    for (int p = 0; p < PFD - 1; ++p) {
+      av[p] = smem[cbuf + ub + ((p >> 2) * kWC + 2 * (p & 3)) * kWK];
+      bv[p] = smem[cbuf + vb + ((p >> 2) * kWC + 2 * (p & 3)) * kWT];
+    }
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int s = x * 4 + k4;  // MFMA step inside the chunk
+      const int cur = s % PFD;
+      if (s + PFD - 1 < 64) {
+        const int xi = (s + PFD - 1) >> 2, kk = (s + PFD - 1) & 3;
+        av[(s + PFD - 1) % PFD] = smem[cbuf + ub + (xi * kWC + 2 * kk) * kWK];
+        bv[(s + PFD - 1) % PFD] = smem[cbuf + vb + (xi * kWC + 2 * kk) * kWT];
+      }
+      if (DO_COMMIT) {  // 10 pieces over steps 0..29
+        if (s % 3 == 0 && s / 3 < 8) commit_u(s / 3, nb);
+        if (s == 24) commit_d(0, nb);
+        if (s == 28) commit_d(1, nb);
+      }
+      if (DO_PREF) {    // 10 pieces over steps 32..61
+        if (s >= 32 && (s - 32) % 3 == 0 && (s - 32) / 3 < 8) prefetch_u((s - 32) / 3, q + 2);
+        if (s == 56) prefetch_d(0, q + 2);
+        if (s == 60) prefetch_d(1, q + 2);
+      }
+      mfma_agpr(acc[x], av[cur], bv[cur]);
+    }
+    }
+    __syncthreads();
+  };
+
+  int q = 0;
+  for (; q + 2 < g.nchunks; ++q) chunk(std::true_type{}, std::true_type{}, q);
+  if (q + 1 < g.nchunks) {
+    chunk(std::true_type{}, std::false_type{}, q);
+    ++q;
+  }
+  chunk(std::false_type{}, std::false_type{}, q);
+
+  // the last MFMAs are inline asm: give them their 16 passes before the accumulators are read back
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  // ---- epilogue: Y = A^T M A per (cout, tile), A^T = [1 1 1 0; 0 1 -1 -1]; lane-local ------------------
+  const int tq = tb * 32 + l31;  // this lane's tile
+  const int per = g.TR * g.TWc;
+  const int ti = tq / per, rem = tq - ti * per;
+  const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
+  const int n = n0 + ti;
+  if (n < a.B) {
+    const int co_base = kt * kWK + cb * 32 + 4 * lhi;
+    const size_t pix = (size_t)(2 * (r0 + tr)) * a.Wo + 2 * tc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co_base + (r & 3) + 8 * (r >> 2);
+      float s0[4], s1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s0[j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
+        s1[j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
+      }
+      float y[4] = {s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
+      float add = 0.f;
+      if (a.bias) add = a.bias[co];
+      const size_t o = ((size_t)n * a.Cout + co) * g.HW + pix;
+      float2 r0v = make_float2(0.f, 0.f), r1v = make_float2(0.f, 0.f);
+      if (a.residual) {
+        r0v = *reinterpret_cast<const float2 *>(a.residual + o);
+        r1v = *reinterpret_cast<const float2 *>(a.residual + o + a.Wo);
+      }
+      const float ca = a.chan_add ? a.chan_add[(size_t)n * a.chan_add_stride + co] : 0.f;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        if (a.bias) y[x] += add;
+        if (a.chan_add) y[x] += ca;
+      }
+      if (a.residual) {
+        y[0] += r0v.x; y[1] += r0v.y; y[2] += r1v.x; y[3] += r1v.y;
+      }
+      *reinterpret_cast<float2 *>(a.out + o) = make_float2(y[0], y[1]);
+      *reinterpret_cast<float2 *>(a.out + o + a.Wo) = make_float2(y[2], y[3]);
+    }
+  }
+}
+
+int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
+  WinoGeom g;
+  if (!d.w_wino || !wino_geom(d, g)) {
+    set_error("conv_wino: unsupported shape");
+    return DDPM_EINVAL;
+  }
+  const size_t lds = (size_t)2 * (kWUF + kWVF) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  dim3 grid(g.ntiles, d.Cout / kWK);
+  const double M = (double)d.B * g.HW;
+  // algorithmic work = the direct convolution's: 2*M*Cout*Cin*9; 16/36 of it is executed
+  const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9;
+  const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9);
+  const char *kname = d.gscale ? "conv3x3_wino_gn_silu" : "conv3x3_wino";
+  char kshape[160];
+  if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {
+    snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);
+    kname = kshape;
+  }
+  ProfScope prof(s, kname, flops, bytes);
+  if (d.gscale)
+    hipLaunchKernelGGL(conv_wino_kernel<true>, grid, dim3(256), lds, s, d, g);
+  else
+    hipLaunchKernelGGL(conv_wino_kernel<false>, grid, dim3(256), lds, s, d, g);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- weights: torch [Cout][Cin][3][3] -> U = G g G^T packed [cout_tile 64][chunk 8][xi 16][c 8][k 64] -------
+// G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+__global__ void wino_pack_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin) {
+  const int64_t total = (int64_t)Cout * Cin;
+  const int nchunks = Cin / kWC;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin), o = (int)(i / Cin);
+    const float *w = src + i * 9;
+    float t[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {  // G g
+      t[0][j] = w[0 * 3 + j];
+      t[1][j] = 0.5f * (w[0 * 3 + j] + w[1 * 3 + j] + w[2 * 3 + j]);
+      t[2][j] = 0.5f * (w[0 * 3 + j] - w[1 * 3 + j] + w[2 * 3 + j]);
+      t[3][j] = w[2 * 3 + j];
+    }
+    const int tile = o / kWK, k = o % kWK, ch = ci / kWC, cl = ci % kWC;
+    float *d = dst + ((size_t)tile * nchunks + ch) * kWUF + cl * kWK + k;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // (G g) G^T
+      d[(r * 4 + 0) * kWC * kWK] = t[r][0];
+      d[(r * 4 + 1) * kWC * kWK] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
+      d[(r * 4 + 2) * kWC * kWK] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
+      d[(r * 4 + 3) * kWC * kWK] = t[r][2];
+    }
+  }
+}
+
+size_t wino_weight_floats(int Cout, int Cin) {
+  if (Cout % kWK || Cin % kWC) return 0;
+  return (size_t)16 * Cout * Cin;
+}
+
+int launch_pack_wino_weight(const float *w_raw, float *w_wino, int Cout, int Cin, hipStream_t s) {
+  DDPM_CHECK_ARG(wino_weight_floats(Cout, Cin) != 0, "wino pack: Cout %% 64 or Cin %% 8 != 0");
+  const int64_t total = (int64_t)Cout * Cin;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, s, w_raw, w_wino, Cout, Cin);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace ddpm

@@ -29,6 +29,8 @@ struct ParamSlot {
   size_t packed_base = 0;       // float offset of the (possibly shared) packed weight
   bool has_folded = false;      // Upsample conv: also keep the folded (4 x 2x2-tap) form
   size_t folded_base = 0;
+  bool has_wino = false;        // 3x3 stride-1 conv: also keep the Winograd-domain form
+  size_t wino_base = 0;
   int Cout = 0, Cin = 0, ksize = 1, cout_offset = 0, Cout_total = 0;
   int dims = 2;                 // 3: [Cout, Cin, k, k, k] packed as k slabs of 2-D taps (one per depth tap)
   bool optional = false;
@@ -36,8 +38,8 @@ struct ParamSlot {
 };
 
 struct ConvRef {  // a conv-like op: weight (raw + packed) and bias locations in the blob
-  size_t w_raw = 0, w_packed = 0, bias = 0, w_folded = 0;
-  bool has_packed = false, has_folded = false;
+  size_t w_raw = 0, w_packed = 0, bias = 0, w_folded = 0, w_wino = 0;
+  bool has_packed = false, has_folded = false, has_wino = false;
   int Cin = 0, Cout = 0, ksize = 1;
   int dims = 2;
 };
@@ -171,6 +173,19 @@ static ResRef build_res(ddpm_unet *u, const std::string &prefix, int Cin, int Co
   temb_cursor += Cout;
   r.n2 = u->add_gn(prefix + ".norm2", Cout);
   r.c2 = u->add_conv(prefix + ".conv2.conv", Cout, Cout, 3, false, u->cfg.spatial_dims);
+  if (u->cfg.spatial_dims == 2) {  // both 3x3 convs of a ResnetBlock are stride 1: Winograd-domain weights too
+    ConvRef *cr[2] = {&r.c1, &r.c2};
+    const char *nm[2] = {".conv1.conv.weight", ".conv2.conv.weight"};
+    for (int i = 0; i < 2; ++i) {
+      const size_t nw = wino_weight_floats(cr[i]->Cout, cr[i]->Cin);
+      if (!nw) continue;
+      cr[i]->has_wino = true;
+      cr[i]->w_wino = u->alloc(nw);
+      ParamSlot &ps = u->params[u->index[prefix + nm[i]]];
+      ps.has_wino = true;
+      ps.wino_base = cr[i]->w_wino;
+    }
+  }
   r.has_skip = Cin != Cout;
   if (r.has_skip) r.skip = u->add_conv(prefix + ".skip_connection.conv", Cout, Cin, 1);
   return r;
@@ -344,6 +359,10 @@ extern "C" int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *
     rc = launch_pack_conv_weight(src, h->blob + p.packed_base, p.Cout, p.Cin, p.ksize, p.cout_offset, p.Cout_total, s);
     if (rc) return rc;
   }
+  if (p.has_wino) {
+    rc = launch_pack_wino_weight(src, h->blob + p.wino_base, p.Cout, p.Cin, s);
+    if (rc) return rc;
+  }
   if (p.has_folded) {
     rc = launch_fold_upsample_weight(src, h->blob + p.folded_base, p.Cout, p.Cin, s);
     if (rc) return rc;
@@ -402,6 +421,7 @@ struct Runner {
     d.Hi = in1.H; d.Wi = in1.W; d.Ho = Ho; d.Wo = Wo;
     d.ksize = c.ksize; d.mode = mode; d.act = act;
     if (mode == DDPM_CONV_UPSAMPLE2 && c.has_folded) d.w_folded = P(c.w_folded);
+    if (mode == DDPM_CONV_NORMAL && c.has_wino && in1.D == 1 && Do == 1) d.w_wino = P(c.w_wino);
     if (in1.D > 1 || Do > 1) {
       if (c.ksize == 1) {
         // pointwise over a volume: the NCDHW tensor is an NCHW tensor of extent (D*H) x W

@@ -93,6 +93,11 @@ typedef struct ddpm_conv_desc {
    * DDPM_ACT_NONE or DDPM_ACT_RELU.  Used by the VQ-VAE residual units, relu(x + conv2(relu(conv1(x)))).  */
   int out_act;
   int reserved;
+  /* Optional, 2-D 3x3 stride-1 only: weights pre-transformed by ddpm_pack_wino_weight_f32 (U = G g G^T).
+   * When present and the shape has a Winograd tiling (even H, W; Cin % 8 == 0; Cout % 64 == 0) the conv
+   * runs as Winograd F(2x2, 3x3) on the fp32 MFMA pipe: 2.25x fewer multiplies, fp32 rounding differs
+   * from the direct form by ~1e-6 relative.                                            */
+  const float *w_wino;
 } ddpm_conv_desc;
 
 int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream);
@@ -108,6 +113,10 @@ int ddpm_pack_conv_weight_f32(const float *w_raw, float *w_packed, int Cout, int
  * tap kd of a conv3d weight [Cout, Cin, 3, 3, 3]: src_taps = 27, tap_off = 9 * kd.                       */
 int ddpm_pack_conv_weight_taps_f32(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize, int src_taps,
                                    int tap_off, ddpm_stream_t stream);
+
+/* Winograd-domain form of a [Cout, Cin, 3, 3] weight (see ddpm_conv_desc.w_wino): 16 * Cout * Cin floats.  */
+size_t ddpm_wino_weight_floats(int Cout, int Cin);
+int ddpm_pack_wino_weight_f32(const float *w_raw, float *w_wino, int Cout, int Cin, ddpm_stream_t stream);
 
 /* Folded form of an Upsample conv weight (see ddpm_conv_desc.w_folded): 4 packed 2x2-tap weights.     */
 size_t ddpm_folded_upsample_weight_floats(int Cout, int Cin);

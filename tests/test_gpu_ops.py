@@ -296,3 +296,51 @@ def test_vqvae_residual_units_on_hip_match_torch(device):
         zp = p.encode_stage_2_inputs(x.to(device))
         _close(zp, zo, tol=1e-5)
         _close(p.decode_stage_2_outputs(zp), o.decode_stage_2_outputs(zo), tol=2e-5)
+
+
+WINO_CASES = [
+    # B, C1, C2, Cout, H, gn, chan_add, residual
+    (2, 128, 0, 128, 32, True, True, False),
+    (3, 128, 0, 128, 32, True, False, True),
+    (2, 256, 128, 128, 32, True, True, False),
+    (3, 256, 0, 256, 16, True, False, True),
+    (5, 256, 256, 256, 8, True, True, False),     # 4 images per workgroup, ragged last workgroup
+    (1, 128, 0, 64, 64, False, False, False),     # W = 64: two tile rows per workgroup, Cout = 64
+    (2, 8, 0, 64, 4, False, False, True),         # 4x4 images: 16 per workgroup
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv_winograd(device, case):
+    """3x3 stride-1 conv as Winograd F(2x2, 3x3) on the fp32 MFMA pipe vs F.conv2d; fp32 rounding of the transforms
+    costs ~2x the direct kernel's error (tolerance 4e-5 * (1 + max|ref|))."""
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, Cout, H, gn, chan, res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    Cin = C1 + C2
+    x = torch.randn(B, C1, H, H, generator=g)
+    x2 = torch.randn(B, C2, H, H, generator=g) * 1.5 + 0.3 if C2 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    G = 32 if Cin % 32 == 0 else 8
+    gamma = torch.randn(Cin, generator=g) * 0.2 + 1
+    beta = torch.randn(Cin, generator=g) * 0.2
+    chan_add = torch.randn(B, Cout + 64, generator=g) if chan else None
+    residual = torch.randn(B, Cout, H, H, generator=g) if res else None
+    ref = _ref_conv(x, x2, w, b, (gamma, beta, G, 1e-6) if gn else None, gn, 0,
+                    chan_add[:, 32:32 + Cout] if chan else None, residual)
+    d = lambda t: None if t is None else t.to(device)
+    gs = gh = None
+    if gn:
+        gs, gh = ops.gn_scale_shift(d(x), d(gamma), d(beta), G, 1e-6, x2=d(x2))
+    wino = ops.pack_wino_weight(d(w))
+    assert wino is not None
+    y = ops.conv(d(x), d(w), d(b), x2=d(x2), gscale=gs, gshift=gh, act=int(gn), chan_add=d(chan_add),
+                 chan_add_offset=32, residual=d(residual), wino=wino)
+    torch.cuda.synchronize()
+    _close(y, ref, tol=4e-5)
+    y_direct = ops.conv(d(x), d(w), d(b), x2=d(x2), gscale=gs, gshift=gh, act=int(gn), chan_add=d(chan_add),
+                        chan_add_offset=32, residual=d(residual)) if Cout % 128 == 0 else None
+    if y_direct is not None:
+        assert (y - y_direct).abs().max().item() < 4e-5 * (1 + ref.abs().max().item())
