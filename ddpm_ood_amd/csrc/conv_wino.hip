@@ -12,11 +12,14 @@
 // (DESIGN.md section 3.3), far inside the 1e-4 parity bar.
 //
 // Workgroup = 64 output channels x 64 tiles (256 output pixels: whole tile rows of one image, or several
-// whole images), 4 waves as 2 (cout) x 2 (tile); a wave owns 32 couts x 32 tiles at all 16 positions =
-// 16 accumulator tiles = 256 accumulator registers, so the output transform is lane-local (a lane holds all
-// 16 M_xi of its (cout, tile) pairs).  Input channels advance in chunks of 8; LDS is double-buffered
-// ([16][8][64] U + [16][8][64] V = 64 KB per buffer): while the 64 MFMAs of chunk q run, the wave commits
-// chunk q + 1 (activation + B^T d B applied here) and issues the loads of chunk q + 2.  One barrier per chunk.
+// whole images), 8 waves as 2 (cout) x 2 (tile) x 2 (transform rows): a wave owns 32 couts x 32 tiles at 8 of
+// the 16 positions = 8 accumulator tiles = 128 AGPRs, two waves per SIMD.  (A first version with 4 waves x 16
+// positions = 256 AGPRs made the output transform lane-local but ran one wave per SIMD: the ~1000 staging
+// instructions per chunk could not hide under that wave's own 64 MFMAs and the kernel only matched the direct
+// one.)  Input channels advance in chunks of 8; LDS is double-buffered ([16][8][64] U + [16][8][64] V = 64 KB
+// per buffer): while the 32 MFMAs of chunk q run, the wave commits its share of chunk q + 1 (activation +
+// B^T d B applied here) and issues the loads of chunk q + 2.  One barrier per chunk.  The output transform is
+// linear in M, so each wave transforms its own two rows and the pair sums through LDS.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -86,14 +89,16 @@ bool conv_wino_supported(const ddpm_conv_desc &d) {
 }
 
 template <bool AFFINE>
-__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ddpm_conv_desc a, const WinoGeom g) {
+__global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc a, const WinoGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BUF = kWUF + kWVF;  // floats per LDS buffer: U [16][8][64] then V [16][8][64]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int cb = wave & 1, tb = wave >> 1;  // wave's cout block / tile block
+  // 8 waves = 2 (cout block) x 2 (tile block) x 2 (transform rows {0,1} / {2,3}): two waves per SIMD, so one
+  // wave's staging instructions issue under the other's MFMAs; each wave keeps 8 positions = 128 AGPRs
+  const int cb = wave & 1, tb = (wave >> 1) & 1, hf = wave >> 2;
   const int kt = blockIdx.y;
 
   int n0, r0;  // first image of the workgroup, first tile row inside it
@@ -105,9 +110,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ddpm_conv_desc 
     r0 = 0;
   }
 
-  // ---- staging role of this thread: tile `st` (= lane), channels sc and sc + 4 of every chunk ----------
+  // ---- staging role of this thread: tile `st` (= lane), channel `sc` (= wave) of every chunk -----------
   const int st = tid & 63, sc = tid >> 6;
-  int s_n, s_off;        // image and offset of the patch's top-left input pixel (may point outside the image)
+  int s_n;               // image of the patch (clamped to a real image; s_mask == 0 if there is none)
+  int s_off;             // offset of patch element (1, 1) -- always inside the image
   unsigned s_mask = 0;   // bit (4 i + j): patch element (i, j) lies inside the image
   {
     const int per = g.TR * g.TWc;
@@ -115,37 +121,41 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ddpm_conv_desc 
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
     s_n = n0 + ti;
     const int h = 2 * (r0 + tr) - 1, w = 2 * tc - 1;
-    s_off = h * a.Wo + w;
+    s_off = (h + 1) * a.Wo + (w + 1);
     if (s_n < a.B) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (h + i >= 0 && h + i < a.Ho && w + j >= 0 && w + j < a.Wo) s_mask |= 1u << (4 * i + j);
+    } else {
+      s_n = a.B - 1;
     }
   }
 
-  // ---- MFMA operand bases ------------------------------------------------------------------------
-  const int ub = lhi * kWK + cb * 32 + l31;          // + (xi * 8 + 2 kk) * 64
-  const int vb = kWUF + lhi * kWT + tb * 32 + l31;   // + (xi * 8 + 2 kk) * 64
+  // ---- MFMA operand bases; this wave's positions are xi = 8 hf + x, x = 0..7 ------------------------------
+  const int ub = hf * 8 * kWC * kWK + lhi * kWK + cb * 32 + l31;          // + (x * 8 + 2 kk) * 64
+  const int vb = kWUF + hf * 8 * kWC * kWT + lhi * kWT + tb * 32 + l31;   // + (x * 8 + 2 kk) * 64
 
-  f32x16 acc[16];
+  f32x16 acc[8];
 #pragma unroll
-  for (int x = 0; x < 16; ++x)
+  for (int x = 0; x < 8; ++x)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
   // ---- staging registers ---------------------------------------------------------------------------
-  v4f ureg[8];
-  float dreg[2][16];
-  float gsc[2], gsh[2];
+  v4f ureg[4];
+  float dreg[16];
+  float gsc = 1.f, gsh = 0.f;
   const float *usrc = a.w_wino + (size_t)kt * g.nchunks * kWUF;
 
   auto prefetch_u = [&](int i, int ch) {
-    ureg[i] = reinterpret_cast<const v4f *>(usrc + (size_t)ch * kWUF)[tid + 256 * i];
+    ureg[i] = reinterpret_cast<const v4f *>(usrc + (size_t)ch * kWUF)[tid + 512 * i];
   };
-  auto prefetch_d = [&](int e, int ch) {
-    const int cg = ch * kWC + sc + 4 * e;
+  // unconditional loads: elements outside the image read the patch's (1, 1) element instead and are zeroed
+  // by the mask at commit time (no exec-mask juggling per element)
+  auto prefetch_d = [&](int ch) {
+    const int cg = ch * kWC + sc;
     const float *base;
     int Cs, cl;
     if (cg < a.C1) {
@@ -158,20 +168,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ddpm_conv_desc 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        dreg[e][4 * i + j] = (s_mask >> (4 * i + j) & 1) ? p[i * a.Wo + j] : 0.f;
-    if (AFFINE && s_mask) {
-      gsc[e] = a.gscale[(size_t)s_n * g.Cin + cg];
-      gsh[e] = a.gshift[(size_t)s_n * g.Cin + cg];
+        dreg[4 * i + j] = p[(s_mask >> (4 * i + j) & 1) ? (i - 1) * a.Wo + (j - 1) : 0];
+    if (AFFINE) {
+      gsc = a.gscale[(size_t)s_n * g.Cin + cg];
+      gsh = a.gshift[(size_t)s_n * g.Cin + cg];
     }
   };
-  auto commit_u = [&](int i, int nb) { reinterpret_cast<v4f *>(smem + nb)[tid + 256 * i] = ureg[i]; };
+  auto commit_u = [&](int i, int nb) { reinterpret_cast<v4f *>(smem + nb)[tid + 512 * i] = ureg[i]; };
   // activation (zero padding stays zero), then V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-  auto commit_d = [&](int e, int nb) {
+  auto commit_d = [&](int nb) {
     float d[16];
 #pragma unroll
     for (int x = 0; x < 16; ++x) {
-      float v = dreg[e][x];
-      if (AFFINE) v = v * gsc[e] + gsh[e];
+      float v = dreg[x];
+      if (AFFINE) v = v * gsc + gsh;
       if (a.act == DDPM_ACT_SILU) v = silu_fast(v);
       d[x] = (s_mask >> x & 1) ? v : 0.f;
     }
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ddpm_conv_desc 
       t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
       t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
     }
-    float *vl = smem + nb + kWUF + (sc + 4 * e) * kWT + st;
+    float *vl = smem + nb + kWUF + sc * kWT + st;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // (B^T d) B (combine columns)
       vl[(i * 4 + 0) * kWC * kWT] = t[i * 4 + 0] - t[i * 4 + 2];
@@ -195,29 +205,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ddpm_conv_desc 
 
   // ---- prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers -------------------------------------
 #pragma unroll
-  for (int i = 0; i < 8; ++i) prefetch_u(i, 0);
-  prefetch_d(0, 0);
-  prefetch_d(1, 0);
+  for (int i = 0; i < 4; ++i) prefetch_u(i, 0);
+  prefetch_d(0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) commit_u(i, 0);
-  commit_d(0, 0);
-  commit_d(1, 0);
+  for (int i = 0; i < 4; ++i) commit_u(i, 0);
+  commit_d(0);
   if (g.nchunks > 1) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) prefetch_u(i, 1);
-    prefetch_d(0, 1);
-    prefetch_d(1, 1);
+    for (int i = 0; i < 4; ++i) prefetch_u(i, 1);
+    prefetch_d(1);
   }
   __syncthreads();
 
-  // One chunk: 16 positions x 4 k-pairs = 64 MFMAs, staging of the next chunks spread between them.
+  // One chunk: 8 positions x 4 k-pairs = 32 MFMAs per wave, staging of the next chunks spread between them.
   auto chunk = [&](auto commit_c, auto pref_c, int q) {
     constexpr bool DO_COMMIT = decltype(commit_c)::value;
     constexpr bool DO_PREF = decltype(pref_c)::value;
     const int cbuf = (q & 1) * BUF;
     const int nb = BUF - cbuf;
-    // operand ring, PFD steps ahead of the MFMAs: with one wave per SIMD nothing else hides the LDS latency
-    constexpr int PFD = 4;
+    constexpr int PFD = 3;  // operand ring: loads run PFD - 1 steps ahead of the MFMAs
     float av[PFD], bv[PFD];
 #pragma unroll
     for (int p = 0; p < PFD - 1; ++p) {
@@ -225,28 +231,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ddpm_conv_desc 
       bv[p] = smem[cbuf + vb + ((p >> 2) * kWC + 2 * (p & 3)) * kWT];
     }
 #pragma unroll
-    for (int x = 0; x < 16; ++x) {
+    for (int x = 0; x < 8; ++x) {
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      const int s = x * 4 + k4;  // MFMA step inside the chunk
-      const int cur = s % PFD;
-      if (s + PFD - 1 < 64) {
-        const int xi = (s + PFD - 1) >> 2, kk = (s + PFD - 1) & 3;
-        av[(s + PFD - 1) % PFD] = smem[cbuf + ub + (xi * kWC + 2 * kk) * kWK];
-        bv[(s + PFD - 1) % PFD] = smem[cbuf + vb + (xi * kWC + 2 * kk) * kWT];
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int s = x * 4 + k4;  // MFMA step inside the chunk
+        const int cur = s % PFD;
+        if (s + PFD - 1 < 32) {
+          const int xn = (s + PFD - 1) >> 2, kk = (s + PFD - 1) & 3;
+          av[(s + PFD - 1) % PFD] = smem[cbuf + ub + (xn * kWC + 2 * kk) * kWK];
+          bv[(s + PFD - 1) % PFD] = smem[cbuf + vb + (xn * kWC + 2 * kk) * kWT];
+        }
+        if (DO_COMMIT) {
+          if ((s & 1) == 0 && s < 8) commit_u(s >> 1, nb);
+          if (s == 10) commit_d(nb);
+        }
+        if (DO_PREF) {
+          if ((s & 1) == 0 && s >= 16 && s < 24) prefetch_u((s - 16) >> 1, q + 2);
+          if (s == 26) prefetch_d(q + 2);
+        }
+        mfma_agpr(acc[x], av[cur], bv[cur]);
       }
-      if (DO_COMMIT) {  // 10 pieces over steps 0..29
-        if (s % 3 == 0 && s / 3 < 8) commit_u(s / 3, nb);
-        if (s == 24) commit_d(0, nb);
-        if (s == 28) commit_d(1, nb);
-      }
-      if (DO_PREF) {    // 10 pieces over steps 32..61
-        if (s >= 32 && (s - 32) % 3 == 0 && (s - 32) / 3 < 8) prefetch_u((s - 32) / 3, q + 2);
-        if (s == 56) prefetch_d(0, q + 2);
-        if (s == 60) prefetch_d(1, q + 2);
-      }
-      mfma_agpr(acc[x], av[cur], bv[cur]);
-    }
     }
     __syncthreads();
   };
@@ -261,7 +265,35 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ddpm_conv_desc 
 
   // the last MFMAs are inline asm: give them their 16 passes before the accumulators are read back
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-  // ---- epilogue: Y = A^T M A per (cout, tile), A^T = [1 1 1 0; 0 1 -1 -1]; lane-local ------------------
+
+  // ---- epilogue: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  The transform is linear in M, so each wave applies it
+  // to its own two rows of M (hf = 0: rows 0, 1; hf = 1: rows 2, 3); the hf = 1 wave hands its four partial
+  // outputs per (cout, tile) to its hf = 0 partner through LDS (the operand buffers are free by now).
+  float y[16][4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float s0[4], s1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ma = acc[j][r], mb = acc[4 + j][r];  // rows 2 hf and 2 hf + 1
+      s0[j] = hf == 0 ? ma + mb : ma;
+      s1[j] = hf == 0 ? mb : -ma - mb;
+    }
+    y[r][0] = s0[0] + s0[1] + s0[2];
+    y[r][1] = s0[1] - s0[2] - s0[3];
+    y[r][2] = s1[0] + s1[1] + s1[2];
+    y[r][3] = s1[1] - s1[2] - s1[3];
+  }
+  float *xch = smem + (wave & 3) * 64 * 64 + lane;  // [pair][r * 4 + x][lane]
+  if (hf == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) xch[(r * 4 + x) * 64] = y[r][x];
+  }
+  __syncthreads();
+  if (hf == 1) return;
+
   const int tq = tb * 32 + l31;  // this lane's tile
   const int per = g.TR * g.TWc;
   const int ti = tq / per, rem = tq - ti * per;
@@ -273,32 +305,27 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ddpm_conv_desc 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co_base + (r & 3) + 8 * (r >> 2);
-      float s0[4], s1[4];
+      float yy[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        s0[j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
-        s1[j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
-      }
-      float y[4] = {s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
-      float add = 0.f;
-      if (a.bias) add = a.bias[co];
+      for (int x = 0; x < 4; ++x) yy[x] = y[r][x] + xch[(r * 4 + x) * 64];
       const size_t o = ((size_t)n * a.Cout + co) * g.HW + pix;
       float2 r0v = make_float2(0.f, 0.f), r1v = make_float2(0.f, 0.f);
       if (a.residual) {
         r0v = *reinterpret_cast<const float2 *>(a.residual + o);
         r1v = *reinterpret_cast<const float2 *>(a.residual + o + a.Wo);
       }
+      const float add = a.bias ? a.bias[co] : 0.f;
       const float ca = a.chan_add ? a.chan_add[(size_t)n * a.chan_add_stride + co] : 0.f;
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        if (a.bias) y[x] += add;
-        if (a.chan_add) y[x] += ca;
+        if (a.bias) yy[x] += add;
+        if (a.chan_add) yy[x] += ca;
       }
       if (a.residual) {
-        y[0] += r0v.x; y[1] += r0v.y; y[2] += r1v.x; y[3] += r1v.y;
+        yy[0] += r0v.x; yy[1] += r0v.y; yy[2] += r1v.x; yy[3] += r1v.y;
       }
-      *reinterpret_cast<float2 *>(a.out + o) = make_float2(y[0], y[1]);
-      *reinterpret_cast<float2 *>(a.out + o + a.Wo) = make_float2(y[2], y[3]);
+      *reinterpret_cast<float2 *>(a.out + o) = make_float2(yy[0], yy[1]);
+      *reinterpret_cast<float2 *>(a.out + o + a.Wo) = make_float2(yy[2], yy[3]);
     }
   }
 }
@@ -331,9 +358,9 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   }
   ProfScope prof(s, kname, flops, bytes);
   if (d.gscale)
-    hipLaunchKernelGGL(conv_wino_kernel<true>, grid, dim3(256), lds, s, d, g);
+    hipLaunchKernelGGL(conv_wino_kernel<true>, grid, dim3(512), lds, s, d, g);
   else
-    hipLaunchKernelGGL(conv_wino_kernel<false>, grid, dim3(256), lds, s, d, g);
+    hipLaunchKernelGGL(conv_wino_kernel<false>, grid, dim3(512), lds, s, d, g);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
