@@ -59,6 +59,8 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   if (d.act == DDPM_ACT_RELU) return false;
   if (Cin % kWC || (d.C2 > 0 && d.C1 % kWC) || d.Cout % kWK) return false;
   if ((d.Ho & 1) || (d.Wo & 1)) return false;
+  // patches are fetched with 32-bit buffer offsets (12-bit immediate for the column)
+  if ((double)d.B * (d.C1 > d.C2 ? d.C1 : d.C2) * d.Ho * d.Wo * 4 >= 2147483648.0) return false;
   g.TWc = d.Wo / 2;
   g.THr = d.Ho / 2;
   const int per_img = g.TWc * g.THr;
@@ -88,13 +90,13 @@ bool conv_wino_supported(const ddpm_conv_desc &d) {
   return enabled && d.w_wino != nullptr && !d.force_direct && wino_geom(d, g);
 }
 
-template <bool AFFINE>
+template <bool AFFINE, bool SILU>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc a, const WinoGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BUF = kWUF + kWVF;  // floats per LDS buffer: U [16][8][64] then V [16][8][64]
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   // 8 waves = 2 (cout block) x 2 (tile block) x 2 (transform rows {0,1} / {2,3}): two waves per SIMD, so one
   // wave's staging instructions issue under the other's MFMAs; each wave keeps 8 positions = 128 AGPRs
@@ -111,9 +113,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   }
 
   // ---- staging role of this thread: tile `st` (= lane), channel `sc` (= wave) of every chunk -----------
-  const int st = tid & 63, sc = tid >> 6;
+  // Patches are read with buffer loads: an address outside the tensor returns 0 instead of faulting, so every
+  // element is loaded unconditionally; elements outside the IMAGE (which may alias a neighbouring channel's
+  // pixels) are zeroed by s_mask when the patch is committed.  A patch row is one dword (column 0) plus three
+  // consecutive dwords (columns 1..3, merged by the compiler): the offset of column 1 is never negative for a
+  // row inside the image, which matters because a multi-dword buffer load whose 32-bit offset starts "below
+  // zero" returns zeros for all its dwords (tools/ubench/bufload_probe.hip), and the row of the first image's
+  // first channel would otherwise lose its valid columns.  Column 0 of a left-edge tile is masked; its load is
+  // pointed at column 1.
+  const int st = lane, sc = wave;
   int s_n;               // image of the patch (clamped to a real image; s_mask == 0 if there is none)
-  int s_off;             // offset of patch element (1, 1) -- always inside the image
+  int s_v1, s_v2;        // byte offset of patch element (0, 1) of channel 0 of that image in in1 / in2
+  int s_c0;              // byte offset of element (i, 0) relative to (i, 1): -4, or 0 on the left edge
   unsigned s_mask = 0;   // bit (4 i + j): patch element (i, j) lies inside the image
   {
     const int per = g.TR * g.TWc;
@@ -121,7 +132,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
     s_n = n0 + ti;
     const int h = 2 * (r0 + tr) - 1, w = 2 * tc - 1;
-    s_off = (h + 1) * a.Wo + (w + 1);
     if (s_n < a.B) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -131,7 +141,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     } else {
       s_n = a.B - 1;
     }
+    s_v1 = (s_n * a.C1 * g.HW + h * a.Wo + w + 1) * 4;
+    s_v2 = (s_n * a.C2 * g.HW + h * a.Wo + w + 1) * 4;
+    s_c0 = w < 0 ? 0 : -4;
   }
+  const int bytes1 = a.B * a.C1 * g.HW * 4, bytes2 = a.B * a.C2 * g.HW * 4;
 
   // ---- MFMA operand bases; this wave's positions are xi = 8 hf + x, x = 0..7 ------------------------------
   const int ub = hf * 8 * kWC * kWK + lhi * kWK + cb * 32 + l31;          // + (x * 8 + 2 kk) * 64
@@ -143,114 +157,129 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
-  // ---- staging registers ---------------------------------------------------------------------------
+  // ---- staging registers, and the slices of staging work the chunk loop places between its MFMAs -----------
   v4f ureg[4];
-  float dreg[16];
+  float dreg[16], tt[16];
   float gsc = 1.f, gsh = 0.f;
+  int dvoff = 0;
+  __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in1), 0, bytes1, 0x00020000);
   const float *usrc = a.w_wino + (size_t)kt * g.nchunks * kWUF;
 
   auto prefetch_u = [&](int i, int ch) {
     ureg[i] = reinterpret_cast<const v4f *>(usrc + (size_t)ch * kWUF)[tid + 512 * i];
   };
-  // unconditional loads: elements outside the image read the patch's (1, 1) element instead and are zeroed
-  // by the mask at commit time (no exec-mask juggling per element)
-  auto prefetch_d = [&](int ch) {
-    const int cg = ch * kWC + sc;
-    const float *base;
-    int Cs, cl;
-    if (cg < a.C1) {
-      base = a.in1; Cs = a.C1; cl = cg;
-    } else {
-      base = a.in2; Cs = a.C2; cl = cg - a.C1;
+  auto commit_u = [&](int i, int nb) { reinterpret_cast<v4f *>(smem + nb)[tid + 512 * i] = ureg[i]; };
+  // patch row i of chunk ch; row 0 also sets up the chunk's source and fetches the channel's GroupNorm affine
+  auto prefetch_d = [&](int i, int ch) {
+    if (i == 0) {
+      const int cg = ch * kWC + sc;
+      const bool first = ch * kWC < a.C1;  // uniform over the workgroup: C1 is a multiple of the chunk
+      drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(first ? a.in1 : a.in2), 0,
+                                              first ? bytes1 : bytes2, 0x00020000);
+      dvoff = first ? s_v1 + cg * g.HW * 4 : s_v2 + (cg - a.C1) * g.HW * 4;
+      if (AFFINE) {
+        gsc = a.gscale[(size_t)s_n * g.Cin + cg];
+        gsh = a.gshift[(size_t)s_n * g.Cin + cg];
+      }
     }
-    const float *p = base + ((size_t)s_n * Cs + cl) * g.HW + s_off;
+    const int vo = dvoff + i * a.Wo * 4;
+    dreg[4 * i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, vo + s_c0, 0, 0));
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 1; j < 4; ++j)
+      dreg[4 * i + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, vo + 4 * (j - 1), 0, 0));
+  };
+  // activation of patch element x, in place (zero padding stays zero)
+  auto activate = [&](int x) {
+    float v = dreg[x];
+    if (AFFINE) v = v * gsc + gsh;
+    if (SILU) v = silu_fast(v);
+    dreg[x] = (s_mask >> x & 1) ? v : 0.f;
+  };
+  // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first ...
+  auto row_transform = [&]() {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        dreg[4 * i + j] = p[(s_mask >> (4 * i + j) & 1) ? (i - 1) * a.Wo + (j - 1) : 0];
-    if (AFFINE) {
-      gsc = a.gscale[(size_t)s_n * g.Cin + cg];
-      gsh = a.gshift[(size_t)s_n * g.Cin + cg];
+    for (int j = 0; j < 4; ++j) {
+      tt[0 * 4 + j] = dreg[0 * 4 + j] - dreg[2 * 4 + j];
+      tt[1 * 4 + j] = dreg[1 * 4 + j] + dreg[2 * 4 + j];
+      tt[2 * 4 + j] = dreg[2 * 4 + j] - dreg[1 * 4 + j];
+      tt[3 * 4 + j] = dreg[1 * 4 + j] - dreg[3 * 4 + j];
     }
   };
-  auto commit_u = [&](int i, int nb) { reinterpret_cast<v4f *>(smem + nb)[tid + 512 * i] = ureg[i]; };
-  // activation (zero padding stays zero), then V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-  auto commit_d = [&](int nb) {
-    float d[16];
-#pragma unroll
-    for (int x = 0; x < 16; ++x) {
-      float v = dreg[x];
-      if (AFFINE) v = v * gsc + gsh;
-      if (a.act == DDPM_ACT_SILU) v = silu_fast(v);
-      d[x] = (s_mask >> x & 1) ? v : 0.f;
-    }
-    float t[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {  // B^T d (combine rows)
-      t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
-      t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
-      t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
-      t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
-    }
+  // ... then the columns of row i, written to the four positions (i, 0..3) of the V image
+  auto col_commit = [&](int i, int nb) {
     float *vl = smem + nb + kWUF + sc * kWT + st;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {  // (B^T d) B (combine columns)
-      vl[(i * 4 + 0) * kWC * kWT] = t[i * 4 + 0] - t[i * 4 + 2];
-      vl[(i * 4 + 1) * kWC * kWT] = t[i * 4 + 1] + t[i * 4 + 2];
-      vl[(i * 4 + 2) * kWC * kWT] = t[i * 4 + 2] - t[i * 4 + 1];
-      vl[(i * 4 + 3) * kWC * kWT] = t[i * 4 + 1] - t[i * 4 + 3];
-    }
+    vl[(i * 4 + 0) * kWC * kWT] = tt[i * 4 + 0] - tt[i * 4 + 2];
+    vl[(i * 4 + 1) * kWC * kWT] = tt[i * 4 + 1] + tt[i * 4 + 2];
+    vl[(i * 4 + 2) * kWC * kWT] = tt[i * 4 + 2] - tt[i * 4 + 1];
+    vl[(i * 4 + 3) * kWC * kWT] = tt[i * 4 + 1] - tt[i * 4 + 3];
   };
 
   // ---- prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers -------------------------------------
 #pragma unroll
   for (int i = 0; i < 4; ++i) prefetch_u(i, 0);
-  prefetch_d(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) prefetch_d(i, 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) commit_u(i, 0);
-  commit_d(0);
+#pragma unroll
+  for (int x = 0; x < 16; ++x) activate(x);
+  row_transform();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) col_commit(i, 0);
   if (g.nchunks > 1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) prefetch_u(i, 1);
-    prefetch_d(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) prefetch_d(i, 1);
   }
   __syncthreads();
 
-  // One chunk: 8 positions x 4 k-pairs = 32 MFMAs per wave, staging of the next chunks spread between them.
+  // One chunk = 32 MFMA steps per wave (8 positions x 4 k-pairs).  The staging of chunk q + 1 (registers -> LDS)
+  // and the loads of chunk q + 2 are cut into 32 slices, one per step, and sched_barriers pin every slice to its
+  // MFMA: left to itself the compiler emits the ~200 activation / transform instructions as one block between
+  // two MFMAs and issues each operand read right before its use.  Operands come from LDS two step-pairs ahead.
+  //   step 0..3   U tile quarter s -> LDS, then the load of that quarter of chunk q + 2
+  //   step 4..19  activation of patch element s - 4
+  //   step 20     row transform;   step 21..24  column transform + LDS write of row s - 21
+  //   step 25..28 loads of patch row s - 25 of chunk q + 2
   auto chunk = [&](auto commit_c, auto pref_c, int q) {
     constexpr bool DO_COMMIT = decltype(commit_c)::value;
     constexpr bool DO_PREF = decltype(pref_c)::value;
     const int cbuf = (q & 1) * BUF;
     const int nb = BUF - cbuf;
-    constexpr int PFD = 3;  // operand ring: loads run PFD - 1 steps ahead of the MFMAs
-    float av[PFD], bv[PFD];
-#pragma unroll
-    for (int p = 0; p < PFD - 1; ++p) {
-      av[p] = smem[cbuf + ub + ((p >> 2) * kWC + 2 * (p & 3)) * kWK];
-      bv[p] = smem[cbuf + vb + ((p >> 2) * kWC + 2 * (p & 3)) * kWT];
-    }
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const int s = x * 4 + k4;  // MFMA step inside the chunk
-        const int cur = s % PFD;
-        if (s + PFD - 1 < 32) {
-          const int xn = (s + PFD - 1) >> 2, kk = (s + PFD - 1) & 3;
-          av[(s + PFD - 1) % PFD] = smem[cbuf + ub + (xn * kWC + 2 * kk) * kWK];
-          bv[(s + PFD - 1) % PFD] = smem[cbuf + vb + (xn * kWC + 2 * kk) * kWT];
-        }
-        if (DO_COMMIT) {
-          if ((s & 1) == 0 && s < 8) commit_u(s >> 1, nb);
-          if (s == 10) commit_d(nb);
-        }
-        if (DO_PREF) {
-          if ((s & 1) == 0 && s >= 16 && s < 24) prefetch_u((s - 16) >> 1, q + 2);
-          if (s == 26) prefetch_d(q + 2);
-        }
-        mfma_agpr(acc[x], av[cur], bv[cur]);
+    float av[3][2], bv[3][2];  // operand ring: three step-pairs
+    auto load_pair = [&](int slot, int p) {
+      const int x = p >> 1, kk = (p & 1) * 2;
+      av[slot][0] = smem[cbuf + ub + (x * kWC + 2 * kk) * kWK];
+      av[slot][1] = smem[cbuf + ub + (x * kWC + 2 * kk + 2) * kWK];
+      bv[slot][0] = smem[cbuf + vb + (x * kWC + 2 * kk) * kWT];
+      bv[slot][1] = smem[cbuf + vb + (x * kWC + 2 * kk + 2) * kWT];
+    };
+    auto slice = [&](int s) {
+      if (DO_COMMIT) {
+        if (s < 4) commit_u(s, nb);
+        else if (s < 20) activate(s - 4);
+        else if (s == 20) row_transform();
+        else if (s < 25) col_commit(s - 21, nb);
       }
+      if (DO_PREF) {
+        if (s < 4) prefetch_u(s, q + 2);
+        else if (s >= 25 && s < 29) prefetch_d(s - 25, q + 2);
+      }
+    };
+    load_pair(0, 0);
+    load_pair(1, 1);
+    load_pair(2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      mfma_agpr(acc[p >> 1], av[p % 3][0], bv[p % 3][0]);
+      slice(2 * p);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_agpr(acc[p >> 1], av[p % 3][1], bv[p % 3][1]);
+      if (p + 3 < 16) load_pair(p % 3, p + 3);
+      slice(2 * p + 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   };
@@ -337,11 +366,19 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
     return DDPM_EINVAL;
   }
   const size_t lds = (size_t)2 * (kWUF + kWVF) * sizeof(float);
+  const bool silu = d.act == DDPM_ACT_SILU;
+  void (*kern)(const ddpm_conv_desc, const WinoGeom) =
+      d.gscale ? (silu ? conv_wino_kernel<true, true> : conv_wino_kernel<true, false>)
+               : (silu ? conv_wino_kernel<false, true> : conv_wino_kernel<false, false>);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<true, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<true, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<false, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
@@ -357,10 +394,7 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
     kname = kshape;
   }
   ProfScope prof(s, kname, flops, bytes);
-  if (d.gscale)
-    hipLaunchKernelGGL(conv_wino_kernel<true>, grid, dim3(512), lds, s, d, g);
-  else
-    hipLaunchKernelGGL(conv_wino_kernel<false>, grid, dim3(512), lds, s, d, g);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, d, g);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
