@@ -248,12 +248,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     const int cbuf = (q & 1) * BUF;
     const int nb = BUF - cbuf;
     float av[3][2], bv[3][2];  // operand ring: three step-pairs
+    // step-pair p = k-pair (p >> 2) of positions 2 (p & 3) and 2 (p & 3) + 1: consecutive MFMAs never share an
+    // accumulator (a dependent f32 MFMA waits out the full 64-cycle latency of the one before it)
     auto load_pair = [&](int slot, int p) {
-      const int x = p >> 1, kk = (p & 1) * 2;
+      const int kk = p >> 2, x = 2 * (p & 3);
       av[slot][0] = smem[cbuf + ub + (x * kWC + 2 * kk) * kWK];
-      av[slot][1] = smem[cbuf + ub + (x * kWC + 2 * kk + 2) * kWK];
+      av[slot][1] = smem[cbuf + ub + ((x + 1) * kWC + 2 * kk) * kWK];
       bv[slot][0] = smem[cbuf + vb + (x * kWC + 2 * kk) * kWT];
-      bv[slot][1] = smem[cbuf + vb + (x * kWC + 2 * kk + 2) * kWT];
+      bv[slot][1] = smem[cbuf + vb + ((x + 1) * kWC + 2 * kk) * kWT];
     };
     auto slice = [&](int s) {
       if (DO_COMMIT) {
@@ -273,10 +275,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-      mfma_agpr(acc[p >> 1], av[p % 3][0], bv[p % 3][0]);
+      mfma_agpr(acc[2 * (p & 3)], av[p % 3][0], bv[p % 3][0]);
       slice(2 * p);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_agpr(acc[p >> 1], av[p % 3][1], bv[p % 3][1]);
+      mfma_agpr(acc[2 * (p & 3) + 1], av[p % 3][1], bv[p % 3][1]);
       if (p + 3 < 16) load_pair(p % 3, p + 3);
       slice(2 * p + 1);
       __builtin_amdgcn_sched_barrier(0);
