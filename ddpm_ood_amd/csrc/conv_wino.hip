@@ -51,6 +51,8 @@ struct WinoGeom {
   int TPI;          // workgroups per image (0 when a workgroup holds several whole images)
   int ntiles;       // workgroups along the tile axis
   int Cin, nchunks, HW;
+  int PW, PCH;      // pixel tile in LDS: padded row length (Wo + 2), floats per channel (TI * (2 TR + 2) rows)
+  int NRI;          // staging rounds of 64 pixels per image of the workgroup (TI * NRI <= 6)
 };
 
 static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
@@ -81,6 +83,12 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   g.Cin = Cin;
   g.nchunks = Cin / kWC;
   g.HW = d.Ho * d.Wo;
+  g.PW = d.Wo + 2;
+  g.PCH = g.TI * (2 * g.TR + 2) * g.PW;
+  const int rows = 2 * g.TR + 2 < d.Ho ? 2 * g.TR + 2 : d.Ho;  // in-image rows a workgroup reads, at most
+  g.NRI = (rows * d.Wo + 63) / 64;
+  if (g.TI * g.NRI > 6) return false;
+  if ((2 * (kWUF + kWVF) + 2 * kWC * g.PCH + 64) * sizeof(float) > 160 * 1024) return false;
   return true;
 }
 
@@ -90,18 +98,21 @@ bool conv_wino_supported(const ddpm_conv_desc &d) {
   return enabled && d.w_wino != nullptr && !d.force_direct && wino_geom(d, g);
 }
 
-template <bool AFFINE, bool SILU>
+template <bool AFFINE, int NR>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc a, const WinoGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int BUF = kWUF + kWVF;  // floats per LDS buffer: U [16][8][64] then V [16][8][64]
+  constexpr int BUF = kWUF + kWVF;  // floats per operand buffer: U [16][8][64] then V [16][8][64]
+  float *const P = smem + 2 * BUF;  // pixel tiles [2][8 channels][PCH] (zero-padded borders) + 64 dump floats
+  const int PB = kWC * g.PCH;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  // 8 waves = 2 (cout block) x 2 (tile block) x 2 (transform rows {0,1} / {2,3}): two waves per SIMD, so one
-  // wave's staging instructions issue under the other's MFMAs; each wave keeps 8 positions = 128 AGPRs
+  // 8 waves = 2 (cout block) x 2 (tile block) x 2 (transform rows {0,1} / {2,3}): two waves per SIMD, each wave
+  // keeps 8 positions = 128 AGPRs
   const int cb = wave & 1, tb = (wave >> 1) & 1, hf = wave >> 2;
   const int kt = blockIdx.y;
+  const bool silu = a.act == DDPM_ACT_SILU;
 
   int n0, r0;  // first image of the workgroup, first tile row inside it
   if (g.TPI > 0) {
@@ -112,40 +123,43 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     r0 = 0;
   }
 
-  // ---- staging role of this thread: tile `st` (= lane), channel `sc` (= wave) of every chunk -----------
-  // Patches are read with buffer loads: an address outside the tensor returns 0 instead of faulting, so every
-  // element is loaded unconditionally; elements outside the IMAGE (which may alias a neighbouring channel's
-  // pixels) are zeroed by s_mask when the patch is committed.  A patch row is one dword (column 0) plus three
-  // consecutive dwords (columns 1..3, merged by the compiler): the offset of column 1 is never negative for a
-  // row inside the image, which matters because a multi-dword buffer load whose 32-bit offset starts "below
-  // zero" returns zeros for all its dwords (tools/ubench/bufload_probe.hip), and the row of the first image's
-  // first channel would otherwise lose its valid columns.  Column 0 of a left-edge tile is masked; its load is
-  // pointed at column 1.
-  const int st = lane, sc = wave;
-  int s_n;               // image of the patch (clamped to a real image; s_mask == 0 if there is none)
-  int s_v1, s_v2;        // byte offset of patch element (0, 1) of channel 0 of that image in in1 / in2
-  int s_c0;              // byte offset of element (i, 0) relative to (i, 1): -4, or 0 on the left edge
-  unsigned s_mask = 0;   // bit (4 i + j): patch element (i, j) lies inside the image
+  // ---- staging roles ---------------------------------------------------------------------------------
+  // Pixels (stage A): wave = channel `sc` of the chunk; its lanes walk the channel's in-image pixels of this
+  // workgroup's rows (halo rows included) in NR rounds of 64, round k belonging to image n0 + k / NRI.  Every pixel
+  // is loaded, normalised and activated ONCE and stored into the zero-bordered tile P; f32 MFMAs share the SIMD's
+  // FMA hardware with the VALU (tools/ubench/mfma_valu_mix.hip: every VALU op next to an MFMA costs its ~2.4
+  // cycles, an exp / rcp ~9), so activating the 16 elements of every overlapping 4x4 patch -- each pixel four
+  // times -- cost a quarter of the kernel.
+  // Patches (stage T): lane = tile `st`, wave = channel: 16 LDS reads of the 4x4 patch out of P (no masks: the
+  // border is materialised), B^T d B, 16 LDS writes into the V image.
+  const int sc = wave, st = lane;
+  const int row_lo = max(0, 2 * r0 - 1), row_hi = min(a.Ho, 2 * (r0 + g.TR) + 1);  // real rows this workgroup reads
+  const int npx = (row_hi - row_lo) * a.Wo;
+  int pix[NR], pw[NR], nimg[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int ti = k / g.NRI, e = lane + 64 * (k - ti * g.NRI);
+    const bool valid = ti < g.TI && e < npx && n0 + ti < a.B;
+    const int row = row_lo + e / a.Wo, col = e % a.Wo;
+    nimg[k] = min(n0 + ti, a.B - 1);
+    pix[k] = valid ? (row * a.Wo + col) * 4 : (int)0x80000000;  // out of range: the buffer load returns 0
+    pw[k] = valid ? sc * g.PCH + (ti * (2 * g.TR + 2) + row - (2 * r0 - 1)) * g.PW + col + 1 : 2 * PB + lane;
+  }
+  int tbase;  // patch origin of tile st inside a channel tile of P
   {
     const int per = g.TR * g.TWc;
     const int ti = st / per, rem = st - ti * per;
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
-    s_n = n0 + ti;
-    const int h = 2 * (r0 + tr) - 1, w = 2 * tc - 1;
-    if (s_n < a.B) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (h + i >= 0 && h + i < a.Ho && w + j >= 0 && w + j < a.Wo) s_mask |= 1u << (4 * i + j);
-    } else {
-      s_n = a.B - 1;
-    }
-    s_v1 = (s_n * a.C1 * g.HW + h * a.Wo + w + 1) * 4;
-    s_v2 = (s_n * a.C2 * g.HW + h * a.Wo + w + 1) * 4;
-    s_c0 = w < 0 ? 0 : -4;
+    tbase = sc * g.PCH + (ti * (2 * g.TR + 2) + 2 * tr) * g.PW + 2 * tc;
   }
   const int bytes1 = a.B * a.C1 * g.HW * 4, bytes2 = a.B * a.C2 * g.HW * 4;
+  const __amdgpu_buffer_rsrc_t rs_sc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gscale), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_sh =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gshift), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
+  int vzero;  // a zero the compiler cannot see through: keeps the uniform scale / shift loads on the vector
+              // memory path (scalar loads share lgkmcnt with LDS and would force full LDS drains)
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
 
   // ---- MFMA operand bases; this wave's positions are xi = 8 hf + x, x = 0..7 ------------------------------
   const int ub = hf * 8 * kWC * kWK + lhi * kWK + cb * 32 + l31;          // + (x * 8 + 2 kk) * 64
@@ -159,41 +173,41 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
 
   // ---- staging registers, and the slices of staging work the chunk loop places between its MFMAs -----------
   v4f ureg[4];
-  float dreg[16], tt[16];
-  float gsc = 1.f, gsh = 0.f;
-  int dvoff = 0;
-  __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in1), 0, bytes1, 0x00020000);
+  float praw[NR], gs[NR], gh[NR], dreg[16], tt[16];
   const float *usrc = a.w_wino + (size_t)kt * g.nchunks * kWUF;
+  const int last = g.nchunks - 1;  // chunk indices past the end are clamped: their staging lands in buffers
+                                   // nobody reads, which keeps the loop body free of branches
 
   auto prefetch_u = [&](int i, int ch) {
-    ureg[i] = reinterpret_cast<const v4f *>(usrc + (size_t)ch * kWUF)[tid + 512 * i];
+    ureg[i] = reinterpret_cast<const v4f *>(usrc + (size_t)min(ch, last) * kWUF)[tid + 512 * i];
   };
   auto commit_u = [&](int i, int nb) { reinterpret_cast<v4f *>(smem + nb)[tid + 512 * i] = ureg[i]; };
-  // patch row i of chunk ch; row 0 also sets up the chunk's source and fetches the channel's GroupNorm affine
-  auto prefetch_d = [&](int i, int ch) {
-    if (i == 0) {
-      const int cg = ch * kWC + sc;
-      const bool first = ch * kWC < a.C1;  // uniform over the workgroup: C1 is a multiple of the chunk
-      drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(first ? a.in1 : a.in2), 0,
-                                              first ? bytes1 : bytes2, 0x00020000);
-      dvoff = first ? s_v1 + cg * g.HW * 4 : s_v2 + (cg - a.C1) * g.HW * 4;
-      if (AFFINE) {
-        gsc = a.gscale[(size_t)s_n * g.Cin + cg];
-        gsh = a.gshift[(size_t)s_n * g.Cin + cg];
-      }
+  // stage L: round k of chunk ch -> registers
+  auto load_px = [&](int k, int ch) {
+    const int cg = min(ch, last) * kWC + sc;
+    const bool first = cg < a.C1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
+    const int soff = first ? (nimg[k] * a.C1 + cg) * g.HW * 4 : (nimg[k] * a.C2 + cg - a.C1) * g.HW * 4;
+    praw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pix[k], soff, 0));
+    if (AFFINE) {
+      const int goff = (nimg[k] * g.Cin + cg) * 4;
+      gs[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
+      gh[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
     }
-    const int vo = dvoff + i * a.Wo * 4;
-    dreg[4 * i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, vo + s_c0, 0, 0));
-#pragma unroll
-    for (int j = 1; j < 4; ++j)
-      dreg[4 * i + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, vo + 4 * (j - 1), 0, 0));
   };
-  // activation of patch element x, in place (zero padding stays zero)
-  auto activate = [&](int x) {
-    float v = dreg[x];
-    if (AFFINE) v = v * gsc + gsh;
-    if (SILU) v = silu_fast(v);
-    dreg[x] = (s_mask >> x & 1) ? v : 0.f;
+  // stage A: round k -> pixel tile `pb` (float offset of the P buffer)
+  auto activate_px = [&](int k, int pb) {
+    float v = praw[k];
+    if (AFFINE) v = v * gs[k] + gh[k];
+    const float sv = silu_fast(v);
+    P[pb + pw[k]] = silu ? sv : v;
+  };
+  // stage T: patch row i out of pixel tile `pb`
+  auto read_patch = [&](int i, int pb) {
+    const float *p = P + pb + tbase + i * g.PW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dreg[4 * i + j] = p[j];
   };
   // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first ...
   auto row_transform = [&]() {
@@ -214,42 +228,48 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     vl[(i * 4 + 3) * kWC * kWT] = tt[i * 4 + 1] - tt[i * 4 + 3];
   };
 
-  // ---- prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers -------------------------------------
+  // ---- prologue: zero borders; pixel tiles of chunks 0 and 1; U and V of chunk 0; registers for chunks 1 / 2 ---
+  for (int i = tid; i < 2 * PB + 64; i += 512) P[i] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) prefetch_u(i, 0);
+  __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) prefetch_d(i, 0);
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) load_px(k, c);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) activate_px(k, c * PB);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) commit_u(i, 0);
+  __syncthreads();
 #pragma unroll
-  for (int x = 0; x < 16; ++x) activate(x);
+  for (int i = 0; i < 4; ++i) read_patch(i, 0);
   row_transform();
 #pragma unroll
   for (int i = 0; i < 4; ++i) col_commit(i, 0);
-  if (g.nchunks > 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) prefetch_u(i, 1);
+  for (int i = 0; i < 4; ++i) prefetch_u(i, 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) prefetch_d(i, 1);
-  }
+  for (int k = 0; k < NR; ++k) load_px(k, 2);
   __syncthreads();
 
-  // One chunk = 32 MFMA steps per wave (8 positions x 4 k-pairs).  The staging of chunk q + 1 (registers -> LDS)
-  // and the loads of chunk q + 2 are cut into 32 slices, one per step, and sched_barriers pin every slice to its
-  // MFMA: left to itself the compiler emits the ~200 activation / transform instructions as one block between
-  // two MFMAs and issues each operand read right before its use.  Operands come from LDS two step-pairs ahead.
-  //   step 0..3   U tile quarter s -> LDS, then the load of that quarter of chunk q + 2
-  //   step 4..19  activation of patch element s - 4
-  //   step 20     row transform;   step 21..24  column transform + LDS write of row s - 21
-  //   step 25..28 loads of patch row s - 25 of chunk q + 2
-  auto chunk = [&](auto commit_c, auto pref_c, int q) {
-    constexpr bool DO_COMMIT = decltype(commit_c)::value;
-    constexpr bool DO_PREF = decltype(pref_c)::value;
+  // One chunk = 32 MFMA steps per wave (4 k-pairs x 8 positions), with three stages of staging in flight:
+  //   T(q+1)  patches of chunk q + 1 out of P[(q+1) & 1] -> V of the other operand buffer
+  //   A(q+2)  pixels of chunk q + 2 (registers) -> P[q & 1]          L(q+3)  pixel loads of chunk q + 3
+  // plus the U tile of chunk q + 1 (registers -> LDS) and the U loads of chunk q + 2.  The work is cut into slices,
+  // one per MFMA step, and sched_barriers pin every slice to its MFMA: left to itself the compiler emits the
+  // staging as one block between two MFMAs and issues each operand read right before its use.
+  //   step 0..3    U quarter s -> LDS, load of that quarter of chunk q + 2, patch row s -> registers
+  //   step 6       row transform;   step 7..10  column transform + LDS write of row s - 7
+  //   step 12..    activation of pixel round s - 12 -> P;   step 20..  loads of pixel round s - 20
+  for (int q = 0; q < g.nchunks; ++q) {
     const int cbuf = (q & 1) * BUF;
     const int nb = BUF - cbuf;
+    const int pb_t = ((q + 1) & 1) * PB, pb_a = (q & 1) * PB;
     float av[3][2], bv[3][2];  // operand ring: three step-pairs
     // step-pair p = k-pair (p >> 2) of positions 2 (p & 3) and 2 (p & 3) + 1: consecutive MFMAs never share an
-    // accumulator (a dependent f32 MFMA waits out the full 64-cycle latency of the one before it)
+    // accumulator
     auto load_pair = [&](int slot, int p) {
       const int kk = p >> 2, x = 2 * (p & 3);
       av[slot][0] = smem[cbuf + ub + (x * kWC + 2 * kk) * kWK];
@@ -258,15 +278,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
       bv[slot][1] = smem[cbuf + vb + ((x + 1) * kWC + 2 * kk) * kWT];
     };
     auto slice = [&](int s) {
-      if (DO_COMMIT) {
-        if (s < 4) commit_u(s, nb);
-        else if (s < 20) activate(s - 4);
-        else if (s == 20) row_transform();
-        else if (s < 25) col_commit(s - 21, nb);
-      }
-      if (DO_PREF) {
-        if (s < 4) prefetch_u(s, q + 2);
-        else if (s >= 25 && s < 29) prefetch_d(s - 25, q + 2);
+      if (s < 4) {
+        commit_u(s, nb);
+        prefetch_u(s, q + 2);
+        read_patch(s, pb_t);
+      } else if (s == 6) {
+        row_transform();
+      } else if (s >= 7 && s < 11) {
+        col_commit(s - 7, nb);
+      } else if (s >= 12 && s < 12 + NR) {
+        activate_px(s - 12, pb_a);
+      } else if (s >= 20 && s < 20 + NR) {
+        load_px(s - 20, q + 3);
       }
     };
     load_pair(0, 0);
@@ -284,15 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-  };
-
-  int q = 0;
-  for (; q + 2 < g.nchunks; ++q) chunk(std::true_type{}, std::true_type{}, q);
-  if (q + 1 < g.nchunks) {
-    chunk(std::true_type{}, std::false_type{}, q);
-    ++q;
   }
-  chunk(std::false_type{}, std::false_type{}, q);
 
   // the last MFMAs are inline asm: give them their 16 passes before the accumulators are read back
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -367,23 +382,20 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
     set_error("conv_wino: unsupported shape");
     return DDPM_EINVAL;
   }
-  const size_t lds = (size_t)2 * (kWUF + kWVF) * sizeof(float);
-  const bool silu = d.act == DDPM_ACT_SILU;
-  void (*kern)(const ddpm_conv_desc, const WinoGeom) =
-      d.gscale ? (silu ? conv_wino_kernel<true, true> : conv_wino_kernel<true, false>)
-               : (silu ? conv_wino_kernel<false, true> : conv_wino_kernel<false, false>);
+  const size_t lds = ((size_t)2 * (kWUF + kWVF) + 2 * kWC * g.PCH + 64) * sizeof(float);
+  typedef void (*kern_t)(const ddpm_conv_desc, const WinoGeom);
+  static const kern_t kerns[2][3] = {
+      {conv_wino_kernel<false, 4>, conv_wino_kernel<false, 5>, conv_wino_kernel<false, 6>},
+      {conv_wino_kernel<true, 4>, conv_wino_kernel<true, 5>, conv_wino_kernel<true, 6>}};
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<true, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<true, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel<false, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int i = 0; i < 6; ++i)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[i / 3][i % 3]),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  const int rounds = g.TI * g.NRI;
+  const kern_t kern = kerns[d.gscale ? 1 : 0][rounds <= 4 ? 0 : rounds - 4];
   dim3 grid(g.ntiles, d.Cout / kWK);
   const double M = (double)d.B * g.HW;
   // algorithmic work = the direct convolution's: 2*M*Cout*Cin*9; 16/36 of it is executed
