@@ -26,6 +26,17 @@
 
 #include "common.h"
 
+#ifdef WINO_TRACE
+__device__ unsigned long long g_wino_trace[4];
+extern "C" int ddpm_debug_wino_trace(unsigned long long *out, int reset) {
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_trace), 32);
+}
+#endif
+
 namespace ddpm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -34,7 +45,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kWT = 64;    // tiles per workgroup
 constexpr int kWK = 64;    // output channels per workgroup
 constexpr int kWC = 8;     // input channels per chunk
-constexpr int kWUF = 16 * kWC * kWK;  // U floats per chunk (8192)
+constexpr int kWUF = 16 * kWC * kWK;  // U floats per chunk and cout tile (8192)
 constexpr int kWVF = 16 * kWC * kWT;  // V floats per chunk (8192)
 
 // The 16 accumulator tiles (256 registers) must live in the AGPR half of the unified register file: with the
@@ -101,7 +112,7 @@ bool conv_wino_supported(const ddpm_conv_desc &d) {
 template <bool AFFINE, int NR>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc a, const WinoGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int BUF = kWUF + kWVF;  // floats per operand buffer: U [16][8][64] then V [16][8][64]
+  constexpr int BUF = kWUF + kWVF;  // floats per operand buffer: U then V, both [xi 16][k-pair 2][k parity 2][64][2]
   float *const P = smem + 2 * BUF;  // pixel tiles [2][8 channels][PCH] (zero-padded borders) + 64 dump floats
   const int PB = kWC * g.PCH;
 
@@ -161,9 +172,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
               // memory path (scalar loads share lgkmcnt with LDS and would force full LDS drains)
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
 
-  // ---- MFMA operand bases; this wave's positions are xi = 8 hf + x, x = 0..7 ------------------------------
-  const int ub = hf * 8 * kWC * kWK + lhi * kWK + cb * 32 + l31;          // + (x * 8 + 2 kk) * 64
-  const int vb = kWUF + hf * 8 * kWC * kWT + lhi * kWT + tb * 32 + l31;   // + (x * 8 + 2 kk) * 64
+  // ---- MFMA operands.  This wave's positions are xi = 8 hf + x, x = 0..7; its 32 MFMAs of a chunk are 16 pairs
+  // p = (k-pair kp = p >> 3, position x = p & 7), the two MFMAs of a pair covering channels 4 kp + lhi and
+  // 4 kp + 2 + lhi of the chunk.  Both operand images are [xi][kp][lhi][cout or tile 64][2], so a pair's A and B
+  // values are one ds_read_b64 each (256 B/clk against ds_read_b32's 128).
+  const int ub = (lhi * kWK + cb * 32 + l31) * 2;         // + ((x + 8 hf) * 2 + kp) * 2 * 64 * 2
+  const int vb = kWUF + (lhi * kWT + tb * 32 + l31) * 2;  // likewise
+  // The U tile of a chunk (32 KB, already in LDS order in global memory) is copied by LDS-DMA: 4 x 1 KB per wave,
+  // no registers, no ds_write pass, and -- unlike loads into registers -- nothing in the loop has to wait for it
+  // before the chunk's closing barrier, so the (in-order) vmcnt waits never drag the slow pixel loads along.
+  const float *usrc = a.w_wino + (size_t)kt * g.nchunks * kWUF + wave * 4 * 256 + lane * 4;
 
   f32x16 acc[8];
 #pragma unroll
@@ -172,16 +190,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
   // ---- staging registers, and the slices of staging work the chunk loop places between its MFMAs -----------
-  v4f ureg[4];
   float praw[NR], gs[NR], gh[NR], dreg[16], tt[16];
-  const float *usrc = a.w_wino + (size_t)kt * g.nchunks * kWUF;
   const int last = g.nchunks - 1;  // chunk indices past the end are clamped: their staging lands in buffers
                                    // nobody reads, which keeps the loop body free of branches
-
-  auto prefetch_u = [&](int i, int ch) {
-    ureg[i] = reinterpret_cast<const v4f *>(usrc + (size_t)min(ch, last) * kWUF)[tid + 512 * i];
+  // quarter i of this wave's share of the U tile of chunk ch -> operand buffer at float offset nb
+  auto dma_u = [&](int i, int ch, int nb) {
+    __builtin_amdgcn_global_load_lds(usrc + (size_t)min(ch, last) * kWUF + i * 256,
+                                     smem + nb + (wave * 4 + i) * 256, 16, 0, 0);
   };
-  auto commit_u = [&](int i, int nb) { reinterpret_cast<v4f *>(smem + nb)[tid + 512 * i] = ureg[i]; };
   // stage L: round k of chunk ch -> registers
   auto load_px = [&](int k, int ch) {
     const int cg = min(ch, last) * kWC + sc;
@@ -221,17 +237,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   };
   // ... then the columns of row i, written to the four positions (i, 0..3) of the V image
   auto col_commit = [&](int i, int nb) {
-    float *vl = smem + nb + kWUF + sc * kWT + st;
+    // channel sc = 4 kp + 2 e + lhi  ->  V [xi][kp][lhi][tile][e]
+    float *vl = smem + nb + kWUF + (((sc >> 2) * 2 + (sc & 1)) * kWT + st) * 2 + ((sc >> 1) & 1);
     vl[(i * 4 + 0) * kWC * kWT] = tt[i * 4 + 0] - tt[i * 4 + 2];
     vl[(i * 4 + 1) * kWC * kWT] = tt[i * 4 + 1] + tt[i * 4 + 2];
     vl[(i * 4 + 2) * kWC * kWT] = tt[i * 4 + 2] - tt[i * 4 + 1];
     vl[(i * 4 + 3) * kWC * kWT] = tt[i * 4 + 1] - tt[i * 4 + 3];
   };
 
-  // ---- prologue: zero borders; pixel tiles of chunks 0 and 1; U and V of chunk 0; registers for chunks 1 / 2 ---
+  // ---- prologue: zero borders; pixel tiles of chunks 0 and 1; U and V of chunk 0; registers for chunk 2 -------
   for (int i = tid; i < 2 * PB + 64; i += 512) P[i] = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) prefetch_u(i, 0);
+  for (int i = 0; i < 4; ++i) dma_u(i, 0, 0);
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -240,8 +257,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
 #pragma unroll
     for (int k = 0; k < NR; ++k) activate_px(k, c * PB);
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) commit_u(i, 0);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) read_patch(i, 0);
@@ -249,38 +264,45 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
 #pragma unroll
   for (int i = 0; i < 4; ++i) col_commit(i, 0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) prefetch_u(i, 1);
-#pragma unroll
   for (int k = 0; k < NR; ++k) load_px(k, 2);
   __syncthreads();
 
-  // One chunk = 32 MFMA steps per wave (4 k-pairs x 8 positions), with three stages of staging in flight:
+  // One chunk = 32 MFMA steps per wave, with three stages of staging in flight:
   //   T(q+1)  patches of chunk q + 1 out of P[(q+1) & 1] -> V of the other operand buffer
   //   A(q+2)  pixels of chunk q + 2 (registers) -> P[q & 1]          L(q+3)  pixel loads of chunk q + 3
-  // plus the U tile of chunk q + 1 (registers -> LDS) and the U loads of chunk q + 2.  The work is cut into slices,
-  // one per MFMA step, and sched_barriers pin every slice to its MFMA: left to itself the compiler emits the
-  // staging as one block between two MFMAs and issues each operand read right before its use.
-  //   step 0..3    U quarter s -> LDS, load of that quarter of chunk q + 2, patch row s -> registers
+  // plus the LDS-DMA of the U tile of chunk q + 1.  The work is cut into slices, one per MFMA step, and
+  // sched_barriers pin every slice to its MFMA: left to itself the compiler emits the staging as one block between
+  // two MFMAs and issues each operand read right before its use.
+  //   step 0..3    U quarter s by DMA, patch row s -> registers
   //   step 6       row transform;   step 7..10  column transform + LDS write of row s - 7
   //   step 12..    activation of pixel round s - 12 -> P;   step 20..  loads of pixel round s - 20
+  // The chunk closes with a counted vmcnt (the DMAs are older than the pixel loads, which stay in flight) and a raw
+  // s_barrier: __syncthreads() would wait for vmcnt(0), i.e. for HBM, every chunk.
+#ifdef WINO_TRACE
+  unsigned long long tr_t0 = 0, tr_period = 0, tr_seg = 0;
+#endif
   for (int q = 0; q < g.nchunks; ++q) {
     const int cbuf = (q & 1) * BUF;
     const int nb = BUF - cbuf;
     const int pb_t = ((q + 1) & 1) * PB, pb_a = (q & 1) * PB;
-    float av[3][2], bv[3][2];  // operand ring: three step-pairs
-    // step-pair p = k-pair (p >> 2) of positions 2 (p & 3) and 2 (p & 3) + 1: consecutive MFMAs never share an
-    // accumulator
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 av[3], bv[3];  // operand ring: three pairs
     auto load_pair = [&](int slot, int p) {
-      const int kk = p >> 2, x = 2 * (p & 3);
-      av[slot][0] = smem[cbuf + ub + (x * kWC + 2 * kk) * kWK];
-      av[slot][1] = smem[cbuf + ub + ((x + 1) * kWC + 2 * kk) * kWK];
-      bv[slot][0] = smem[cbuf + vb + (x * kWC + 2 * kk) * kWT];
-      bv[slot][1] = smem[cbuf + vb + ((x + 1) * kWC + 2 * kk) * kWT];
+      const int off = (((p & 7) + 8 * hf) * 2 + (p >> 3)) * 2 * 64 * 2;
+      av[slot] = *reinterpret_cast<const f2 *>(smem + cbuf + ub + off);
+      bv[slot] = *reinterpret_cast<const f2 *>(smem + cbuf + vb + off);
     };
     auto slice = [&](int s) {
+#ifdef WINO_TRACE
+      if (s == 0) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if (q > 0) tr_period += t - tr_t0;
+        tr_t0 = t;
+      }
+      if (s == WINO_TRACE) tr_seg += __builtin_readcyclecounter() - tr_t0;
+#endif
       if (s < 4) {
-        commit_u(s, nb);
-        prefetch_u(s, q + 2);
+        dma_u(s, q + 1, nb);
         read_patch(s, pb_t);
       } else if (s == 6) {
         row_transform();
@@ -298,17 +320,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-      mfma_agpr(acc[2 * (p & 3)], av[p % 3][0], bv[p % 3][0]);
+      mfma_agpr(acc[p & 7], av[p % 3][0], bv[p % 3][0]);
       slice(2 * p);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_agpr(acc[2 * (p & 3) + 1], av[p % 3][1], bv[p % 3][1]);
+      mfma_agpr(acc[p & 7], av[p % 3][1], bv[p % 3][1]);
       if (p + 3 < 16) load_pair(p % 3, p + 3);
       slice(2 * p + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NR * (AFFINE ? 3 : 1)) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
   }
+  __syncthreads();
 
+#ifdef WINO_TRACE
+  if (tid == 0) {
+    atomicAdd(&g_wino_trace[0], tr_period);
+    atomicAdd(&g_wino_trace[1], tr_seg);
+    atomicAdd(&g_wino_trace[2], (unsigned long long)g.nchunks);
+  }
+#endif
   // the last MFMAs are inline asm: give them their 16 passes before the accumulators are read back
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
@@ -413,7 +444,8 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   return 0;
 }
 
-// ---- weights: torch [Cout][Cin][3][3] -> U = G g G^T packed [cout_tile 64][chunk 8][xi 16][c 8][k 64] -------
+// ---- weights: torch [Cout][Cin][3][3] -> U = G g G^T, packed as the LDS image the kernel's MFMAs read:
+//   [cout tile 64][chunk 8][xi 16][kp 2][lhi 2][cout 64][e 2],  channel of the chunk = 4 kp + 2 e + lhi
 // G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
 __global__ void wino_pack_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin) {
   const int64_t total = (int64_t)Cout * Cin;
@@ -429,8 +461,9 @@ __global__ void wino_pack_kernel(const float *__restrict__ src, float *__restric
       t[2][j] = 0.5f * (w[0 * 3 + j] - w[1 * 3 + j] + w[2 * 3 + j]);
       t[3][j] = w[2 * 3 + j];
     }
-    const int tile = o / kWK, k = o % kWK, ch = ci / kWC, cl = ci % kWC;
-    float *d = dst + ((size_t)tile * nchunks + ch) * kWUF + cl * kWK + k;
+    const int tile = o / kWK, k64 = o % kWK, ch = ci / kWC, cl = ci % kWC;
+    const int lhi = cl & 1, kp = cl >> 2, e = (cl >> 1) & 1;
+    float *d = dst + ((size_t)tile * nchunks + ch) * kWUF + ((kp * 2 + lhi) * kWK + k64) * 2 + e;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {  // (G g) G^T
       d[(r * 4 + 0) * kWC * kWK] = t[r][0];
