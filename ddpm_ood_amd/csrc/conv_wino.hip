@@ -11,60 +11,72 @@
 // measured max error of a 512-channel layer vs fp64 is 1.6e-6 against 0.9e-6 for the direct fp32 conv
 // (DESIGN.md section 3.3), far inside the 1e-4 parity bar.
 //
-// Workgroup = 64 output channels x 64 tiles (256 output pixels: whole tile rows of one image, or several
-// whole images), 8 waves as 2 (cout) x 2 (tile) x 2 (transform rows): a wave owns 32 couts x 32 tiles at 8 of
-// the 16 positions = 8 accumulator tiles = 128 AGPRs, two waves per SIMD.  (A first version with 4 waves x 16
-// positions = 256 AGPRs made the output transform lane-local but ran one wave per SIMD: the ~1000 staging
-// instructions per chunk could not hide under that wave's own 64 MFMAs and the kernel only matched the direct
-// one.)  Input channels advance in chunks of 8; LDS is double-buffered ([16][8][64] U + [16][8][64] V = 64 KB
-// per buffer): while the 32 MFMAs of chunk q run, the wave commits its share of chunk q + 1 (activation +
-// B^T d B applied here) and issues the loads of chunk q + 2.  One barrier per chunk.  The output transform is
-// linear in M, so each wave transforms its own two rows and the pair sums through LDS.
+// Work item = 64 output channels x 64 tiles (256 output pixels: whole tile rows of one image, or several whole
+// images) x all input channels, computed by 8 waves as 2 (cout) x 2 (tile) x 2 (transform rows): a wave owns
+// 32 couts x 32 tiles at 8 of the 16 positions = 8 accumulator tiles = 128 AGPRs, two waves per SIMD.  Input
+// channels advance in chunks of 8 through double-buffered LDS operand images.
+//
+// The kernel is persistent: a workgroup owns one (cout tile, image part) and walks a range of images, its items
+// forming ONE stream of chunks.  The staging pipeline (pixel loads three chunks ahead, activation two, patch
+// transform one, U tile by LDS-DMA one) simply runs across item boundaries, so the next item's first chunks are
+// already in LDS when the current item's last MFMA issues; only the output transform + store sits between two
+// items.  With one workgroup per launch slot (one per CU: 150 KB of LDS, 8 x 256 registers) the per-item prologue
+// and epilogue were a third of the time of a 128-channel layer (DESIGN.md 3.3 has the sampled timeline).
 #include <stdlib.h>
 
 #include <type_traits>
 
 #include "common.h"
 
-#ifdef WINO_TRACE
-__device__ unsigned long long g_wino_trace[4];
-extern "C" int ddpm_debug_wino_trace(unsigned long long *out, int reset) {
-  if (reset) {
-    unsigned long long z[4] = {0, 0, 0, 0};
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), z, sizeof(z));
-  }
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino_trace), 32);
-}
-#endif
-
 namespace ddpm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int kWT = 64;    // tiles per workgroup
-constexpr int kWK = 64;    // output channels per workgroup
+constexpr int kWT = 64;    // tiles per item
+constexpr int kWK = 64;    // output channels per item
 constexpr int kWC = 8;     // input channels per chunk
 constexpr int kWUF = 16 * kWC * kWK;  // U floats per chunk and cout tile (8192)
 constexpr int kWVF = 16 * kWC * kWT;  // V floats per chunk (8192)
 
-// The 16 accumulator tiles (256 registers) must live in the AGPR half of the unified register file: with the
-// builtin hipcc keeps them in arch VGPRs, funnels every MFMA through a[0:15] and spills 1.2 KB per lane.
-// The "+a" constraint pins each accumulator to its own AGPR tuple; successive MFMAs never share one (16 apart),
-// so no wait states are needed between them (cdna_hip_programming.md 5.7).
+// The accumulator tiles must live in the AGPR half of the unified register file: with the builtin hipcc keeps
+// them in arch VGPRs, funnels every MFMA through a[0:15] and spills.  The "+a" constraint pins each accumulator
+// to its own AGPR tuple.
 __device__ __forceinline__ void mfma_agpr(f32x16 &c, float a, float b) {
   asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// first MFMA of an item into an accumulator: C = 0.  (Zeroing the tuples element by element makes hipcc build
+// them in arch VGPRs first -- 128 of them inside the item loop -- and spill.)
+__device__ __forceinline__ void mfma_agpr_first(f32x16 &c, float a, float b) {
+  asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
 
 struct WinoGeom {
   int TWc, THr;     // tile columns / rows per image (Wo / 2, Ho / 2)
-  int TI, TR;       // images per workgroup, tile rows per workgroup (per image)
-  int TPI;          // workgroups per image (0 when a workgroup holds several whole images)
-  int ntiles;       // workgroups along the tile axis
+  int TI, TR;       // images per item, tile rows per item (per image)
+  int parts;        // items per image along the rows (1 when an item holds whole images)
   int Cin, nchunks, HW;
   int PW, PCH;      // pixel tile in LDS: padded row length (Wo + 2), floats per channel (TI * (2 TR + 2) rows)
-  int NRI;          // staging rounds of 64 pixels per image of the workgroup (TI * NRI <= 6)
+  int NRI;          // staging rounds of 64 pixels per image of an item (TI * NRI <= 6)
+  int KT;           // cout tiles
+  int NIT;          // items per (cout tile, part) = ceil(B / TI)
+  int IPW;          // items per workgroup
+  int NS;           // (part, image range) slots = parts * ceil(NIT / IPW)
+  int grid;         // KT * NS rounded up so that the cout tiles of one slot share an XCD
 };
+
+static int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
 
 static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   const int Cin = d.C1 + d.C2;
@@ -72,7 +84,7 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   if (d.act == DDPM_ACT_RELU) return false;
   if (Cin % kWC || (d.C2 > 0 && d.C1 % kWC) || d.Cout % kWK) return false;
   if ((d.Ho & 1) || (d.Wo & 1)) return false;
-  // patches are fetched with 32-bit buffer offsets (12-bit immediate for the column)
+  // pixels are fetched with 32-bit buffer offsets
   if ((double)d.B * (d.C1 > d.C2 ? d.C1 : d.C2) * d.Ho * d.Wo * 4 >= 2147483648.0) return false;
   g.TWc = d.Wo / 2;
   g.THr = d.Ho / 2;
@@ -82,24 +94,29 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
     g.TI = 1;
     g.TR = kWT / g.TWc;
     if (g.THr % g.TR) return false;
-    g.TPI = g.THr / g.TR;
-    g.ntiles = d.B * g.TPI;
+    g.parts = g.THr / g.TR;
   } else {
     if (kWT % per_img) return false;
     g.TI = kWT / per_img;
     g.TR = g.THr;
-    g.TPI = 0;
-    g.ntiles = (d.B + g.TI - 1) / g.TI;
+    g.parts = 1;
   }
   g.Cin = Cin;
   g.nchunks = Cin / kWC;
   g.HW = d.Ho * d.Wo;
   g.PW = d.Wo + 2;
   g.PCH = g.TI * (2 * g.TR + 2) * g.PW;
-  const int rows = 2 * g.TR + 2 < d.Ho ? 2 * g.TR + 2 : d.Ho;  // in-image rows a workgroup reads, at most
+  const int rows = 2 * g.TR + 2 < d.Ho ? 2 * g.TR + 2 : d.Ho;  // in-image rows an item reads, at most
   g.NRI = (rows * d.Wo + 63) / 64;
   if (g.TI * g.NRI > 6) return false;
   if ((2 * (kWUF + kWVF) + 2 * kWC * g.PCH + 64) * sizeof(float) > 160 * 1024) return false;
+  g.KT = d.Cout / kWK;
+  g.NIT = (d.B + g.TI - 1) / g.TI;
+  const long items = (long)g.KT * g.parts * g.NIT;
+  const int cus = device_cus();
+  g.IPW = (int)((items + cus - 1) / cus);
+  g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW);
+  g.grid = g.KT * ((g.NS + 7) / 8) * 8;
   return true;
 }
 
@@ -109,10 +126,12 @@ bool conv_wino_supported(const ddpm_conv_desc &d) {
   return enabled && d.w_wino != nullptr && !d.force_direct && wino_geom(d, g);
 }
 
-template <bool AFFINE, int NR>
+template <bool AFFINE, int NR, bool ONEIMG>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc a, const WinoGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BUF = kWUF + kWVF;  // floats per operand buffer: U then V, both [xi 16][k-pair 2][k parity 2][64][2]
+  constexpr int NGS = ONEIMG ? 1 : NR;             // GroupNorm scale / shift pairs per chunk: one per image
+  constexpr int NVM = NR + (AFFINE ? 2 * NGS : 0);  // vector-memory loads of one pixel stage
   float *const P = smem + 2 * BUF;  // pixel tiles [2][8 channels][PCH] (zero-padded borders) + 64 dump floats
   const int PB = kWC * g.PCH;
 
@@ -122,37 +141,40 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   // 8 waves = 2 (cout block) x 2 (tile block) x 2 (transform rows {0,1} / {2,3}): two waves per SIMD, each wave
   // keeps 8 positions = 128 AGPRs
   const int cb = wave & 1, tb = (wave >> 1) & 1, hf = wave >> 2;
-  const int kt = blockIdx.y;
   const bool silu = a.act == DDPM_ACT_SILU;
 
-  int n0, r0;  // first image of the workgroup, first tile row inside it
-  if (g.TPI > 0) {
-    n0 = blockIdx.x / g.TPI;
-    r0 = (blockIdx.x - n0 * g.TPI) * g.TR;
-  } else {
-    n0 = blockIdx.x * g.TI;
-    r0 = 0;
-  }
+  // ---- this workgroup's stream: cout tile kt, image part, images [n_first, n_end) in items of TI images.
+  // Workgroup ids that differ by a multiple of 8 run on the same XCD (one L2): the cout tiles of one slot, which
+  // read the same pixels, are placed there.
+  const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3;
+  const int kt = wj % g.KT, slot = (wj / g.KT) * 8 + xcd;
+  if (slot >= g.NS) return;
+  const int part = slot % g.parts, it0 = (slot / g.parts) * g.IPW;
+  const int nitems = min(g.IPW, g.NIT - it0);
+  const int r0 = part * g.TR;  // first tile row of the part
+  const int n_first = it0 * g.TI, n_end = n_first + nitems * g.TI;
+  const int last = g.nchunks - 1;
+  const int ctot = nitems * g.nchunks;
 
   // ---- staging roles ---------------------------------------------------------------------------------
-  // Pixels (stage A): wave = channel `sc` of the chunk; its lanes walk the channel's in-image pixels of this
-  // workgroup's rows (halo rows included) in NR rounds of 64, round k belonging to image n0 + k / NRI.  Every pixel
-  // is loaded, normalised and activated ONCE and stored into the zero-bordered tile P; f32 MFMAs share the SIMD's
-  // FMA hardware with the VALU (tools/ubench/mfma_valu_mix.hip: every VALU op next to an MFMA costs its ~2.4
-  // cycles, an exp / rcp ~9), so activating the 16 elements of every overlapping 4x4 patch -- each pixel four
-  // times -- cost a quarter of the kernel.
+  // Pixels (stage A): wave = channel `sc` of the chunk; its lanes walk the channel's in-image pixels of the item's
+  // rows (halo rows included) in NR rounds of 64, round k belonging to image n + k / NRI.  Every pixel is loaded,
+  // normalised and activated ONCE and stored into the zero-bordered tile P; f32 MFMAs share the SIMD's FMA
+  // hardware with the VALU (tools/ubench/mfma_valu_mix.hip: every VALU op next to an MFMA costs its ~3 cycles,
+  // an exp / rcp ~9), so activating the 16 elements of every overlapping 4x4 patch -- each pixel four times --
+  // is not free.
   // Patches (stage T): lane = tile `st`, wave = channel: 16 LDS reads of the 4x4 patch out of P (no masks: the
   // border is materialised), B^T d B, 16 LDS writes into the V image.
   const int sc = wave, st = lane;
-  const int row_lo = max(0, 2 * r0 - 1), row_hi = min(a.Ho, 2 * (r0 + g.TR) + 1);  // real rows this workgroup reads
+  const int row_lo = max(0, 2 * r0 - 1), row_hi = min(a.Ho, 2 * (r0 + g.TR) + 1);  // real rows an item reads
   const int npx = (row_hi - row_lo) * a.Wo;
-  int pix[NR], pw[NR], nimg[NR];
+  int pix[NR], pw[NR], tik[NR];
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
     const int ti = k / g.NRI, e = lane + 64 * (k - ti * g.NRI);
-    const bool valid = ti < g.TI && e < npx && n0 + ti < a.B;
+    const bool valid = ti < g.TI && e < npx;
     const int row = row_lo + e / a.Wo, col = e % a.Wo;
-    nimg[k] = min(n0 + ti, a.B - 1);
+    tik[k] = ti;
     pix[k] = valid ? (row * a.Wo + col) * 4 : (int)0x80000000;  // out of range: the buffer load returns 0
     pw[k] = valid ? sc * g.PCH + (ti * (2 * g.TR + 2) + row - (2 * r0 - 1)) * g.PW + col + 1 : 2 * PB + lane;
   }
@@ -181,41 +203,35 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   // The U tile of a chunk (32 KB, already in LDS order in global memory) is copied by LDS-DMA: 4 x 1 KB per wave,
   // no registers, no ds_write pass, and -- unlike loads into registers -- nothing in the loop has to wait for it
   // before the chunk's closing barrier, so the (in-order) vmcnt waits never drag the slow pixel loads along.
-  const float *usrc = a.w_wino + (size_t)kt * g.nchunks * kWUF + wave * 4 * 256 + lane * 4;
+  const float *usrc = a.w_wino + (size_t)kt * g.nchunks * kWUF + wave * 4 * 256;  // + lane * 4: per-lane offset
 
   f32x16 acc[8];
-#pragma unroll
-  for (int x = 0; x < 8; ++x)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
   // ---- staging registers, and the slices of staging work the chunk loop places between its MFMAs -----------
-  float praw[NR], gs[NR], gh[NR], dreg[16], tt[16];
-  const int last = g.nchunks - 1;  // chunk indices past the end are clamped: their staging lands in buffers
-                                   // nobody reads, which keeps the loop body free of branches
+  float praw[NR], gs[NGS], gh[NGS], dreg[16], tt[16];
   // quarter i of this wave's share of the U tile of chunk ch -> operand buffer at float offset nb
   auto dma_u = [&](int i, int ch, int nb) {
-    __builtin_amdgcn_global_load_lds(usrc + (size_t)min(ch, last) * kWUF + i * 256,
-                                     smem + nb + (wave * 4 + i) * 256, 16, 0, 0);
+    const float *ubase = usrc + (size_t)ch * kWUF + i * 256;  // uniform
+    __builtin_amdgcn_global_load_lds(ubase + lane * 4, smem + nb + (wave * 4 + i) * 256, 16, 0, 0);
   };
-  // stage L: round k of chunk ch -> registers
-  auto load_px = [&](int k, int ch) {
-    const int cg = min(ch, last) * kWC + sc;
+  // stage L: round k of chunk ch of the item at image n -> registers
+  auto load_px = [&](int k, int n, int ch) {
+    const int cg = ch * kWC + sc, ni = min(n + tik[k], a.B - 1);
     const bool first = cg < a.C1;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
-    const int soff = first ? (nimg[k] * a.C1 + cg) * g.HW * 4 : (nimg[k] * a.C2 + cg - a.C1) * g.HW * 4;
+    const int soff = first ? (ni * a.C1 + cg) * g.HW * 4 : (ni * a.C2 + cg - a.C1) * g.HW * 4;
     praw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pix[k], soff, 0));
-    if (AFFINE) {
-      const int goff = (nimg[k] * g.Cin + cg) * 4;
-      gs[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
-      gh[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
+    if (AFFINE && (!ONEIMG || k == 0)) {
+      const int goff = (ni * g.Cin + cg) * 4;
+      gs[ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
+      gh[ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
     }
   };
   // stage A: round k -> pixel tile `pb` (float offset of the P buffer)
   auto activate_px = [&](int k, int pb) {
     float v = praw[k];
-    if (AFFINE) v = v * gs[k] + gh[k];
+    if (AFFINE) v = v * gs[ONEIMG ? 0 : k] + gh[ONEIMG ? 0 : k];
     const float sv = silu_fast(v);
     P[pb + pw[k]] = silu ? sv : v;
   };
@@ -244,18 +260,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     vl[(i * 4 + 2) * kWC * kWT] = tt[i * 4 + 2] - tt[i * 4 + 1];
     vl[(i * 4 + 3) * kWC * kWT] = tt[i * 4 + 1] - tt[i * 4 + 3];
   };
+  // stream position -> next stream position; past the end it sticks to the last chunk (its staging lands in
+  // buffers nobody reads, which keeps the loop body free of branches)
+  auto advance = [&](int &n, int &ch) {
+    if (ch < last) {
+      ++ch;
+    } else if (n + g.TI < n_end) {
+      n += g.TI;
+      ch = 0;
+    }
+  };
 
-  // ---- prologue: zero borders; pixel tiles of chunks 0 and 1; U and V of chunk 0; registers for chunk 2 -------
+  // ---- prologue: zero borders; pixel tiles of stream chunks 0 and 1; U and V of chunk 0; registers for chunk 2
   for (int i = tid; i < 2 * PB + 64; i += 512) P[i] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) dma_u(i, 0, 0);
+  int nL = n_first, chL = 0;  // stream position of the pixel-load stage
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
 #pragma unroll
-    for (int k = 0; k < NR; ++k) load_px(k, c);
+    for (int k = 0; k < NR; ++k) load_px(k, nL, chL);
 #pragma unroll
     for (int k = 0; k < NR; ++k) activate_px(k, c * PB);
+    advance(nL, chL);
   }
   __syncthreads();
 #pragma unroll
@@ -264,13 +292,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
 #pragma unroll
   for (int i = 0; i < 4; ++i) col_commit(i, 0);
 #pragma unroll
-  for (int k = 0; k < NR; ++k) load_px(k, 2);
-  __syncthreads();
+  for (int k = 0; k < NR; ++k) load_px(k, nL, chL);
+  advance(nL, chL);
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NVM) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
 
-  // One chunk = 32 MFMA steps per wave, with three stages of staging in flight:
-  //   T(q+1)  patches of chunk q + 1 out of P[(q+1) & 1] -> V of the other operand buffer
-  //   A(q+2)  pixels of chunk q + 2 (registers) -> P[q & 1]          L(q+3)  pixel loads of chunk q + 3
-  // plus the LDS-DMA of the U tile of chunk q + 1.  The work is cut into slices, one per MFMA step, and
+  // One chunk = 32 MFMA steps per wave, with three stages of staging in flight (c = stream index):
+  //   T(c+1)  patches of chunk c + 1 out of P[(c+1) & 1] -> V of the other operand buffer
+  //   A(c+2)  pixels of chunk c + 2 (registers) -> P[c & 1]          L(c+3)  pixel loads of chunk c + 3
+  // plus the LDS-DMA of the U tile of chunk c + 1.  The work is cut into slices, one per MFMA step, and
   // sched_barriers pin every slice to its MFMA: left to itself the compiler emits the staging as one block between
   // two MFMAs and issues each operand read right before its use.
   //   step 0..3    U quarter s by DMA, patch row s -> registers
@@ -278,14 +308,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   //   step 12..    activation of pixel round s - 12 -> P;   step 20..  loads of pixel round s - 20
   // The chunk closes with a counted vmcnt (the DMAs are older than the pixel loads, which stay in flight) and a raw
   // s_barrier: __syncthreads() would wait for vmcnt(0), i.e. for HBM, every chunk.
-#ifdef WINO_TRACE
-  unsigned long long tr_t0 = 0, tr_period = 0, tr_seg = 0;
-#endif
-  for (int q = 0; q < g.nchunks; ++q) {
-    const int cbuf = (q & 1) * BUF;
+  int c = 0;  // stream index
+  auto chunk = [&](auto first_c, int ch_cur) {
+    constexpr bool FIRST = decltype(first_c)::value;  // first chunk of an item: its MFMAs start the accumulators
+    const int cbuf = (c & 1) * BUF;
     const int nb = BUF - cbuf;
-    const int pb_t = ((q + 1) & 1) * PB, pb_a = (q & 1) * PB;
-    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int pb_t = ((c + 1) & 1) * PB, pb_a = (c & 1) * PB;
+    const int ch_u = ch_cur < last ? ch_cur + 1 : 0;  // U depends on the chunk only, not on the image
     f2 av[3], bv[3];  // operand ring: three pairs
     auto load_pair = [&](int slot, int p) {
       const int off = (((p & 7) + 8 * hf) * 2 + (p >> 3)) * 2 * 64 * 2;
@@ -293,16 +322,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
       bv[slot] = *reinterpret_cast<const f2 *>(smem + cbuf + vb + off);
     };
     auto slice = [&](int s) {
-#ifdef WINO_TRACE
-      if (s == 0) {
-        const unsigned long long t = __builtin_readcyclecounter();
-        if (q > 0) tr_period += t - tr_t0;
-        tr_t0 = t;
-      }
-      if (s == WINO_TRACE) tr_seg += __builtin_readcyclecounter() - tr_t0;
-#endif
       if (s < 4) {
-        dma_u(s, q + 1, nb);
+        dma_u(s, ch_u, nb);
         read_patch(s, pb_t);
       } else if (s == 6) {
         row_transform();
@@ -311,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
       } else if (s >= 12 && s < 12 + NR) {
         activate_px(s - 12, pb_a);
       } else if (s >= 20 && s < 20 + NR) {
-        load_px(s - 20, q + 3);
+        load_px(s - 20, nL, chL);
       }
     };
     load_pair(0, 0);
@@ -320,7 +341,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-      mfma_agpr(acc[p & 7], av[p % 3][0], bv[p % 3][0]);
+      if (FIRST && p < 8)
+        mfma_agpr_first(acc[p & 7], av[p % 3][0], bv[p % 3][0]);
+      else
+        mfma_agpr(acc[p & 7], av[p % 3][0], bv[p % 3][0]);
       slice(2 * p);
       __builtin_amdgcn_sched_barrier(0);
       mfma_agpr(acc[p & 7], av[p % 3][1], bv[p % 3][1]);
@@ -328,83 +352,90 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
       slice(2 * p + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NR * (AFFINE ? 3 : 1)) : "memory");
+    advance(nL, chL);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NVM) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    ++c;
+  };
+
+  for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
+    chunk(std::true_type{}, 0);
+    for (int ch = 1; ch <= last; ++ch) chunk(std::false_type{}, ch);
+    const int cbuf = ((c - 1) & 1) * BUF;  // the operand buffer the item's last chunk consumed
+
+    // ---- end of an item: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  The transform is linear in M, so each wave
+    // applies it to its own two rows of M (hf = 0: rows 0, 1; hf = 1: rows 2, 3) and the two waves of a pair swap
+    // halves through LDS: wave hf finishes accumulator registers 8 hf .. 8 hf + 7 (8 of its 16 couts per lane) and
+    // sends the partial sums of the other eight.  The exchange uses the operand buffer the item's last chunk just
+    // consumed; the next item's first chunk is already staged in the other one.
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' 16 passes
+    // partial outputs of accumulator register r of this wave: its two rows of M through A^T (.) A
+    auto partial = [&](int r, float *y) {
+      float s0[4], s1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float ma = acc[j][r], mb = acc[4 + j][r];  // rows 2 hf and 2 hf + 1
+        s0[j] = hf == 0 ? ma + mb : ma;
+        s1[j] = hf == 0 ? mb : -ma - mb;
+      }
+      y[0] = s0[0] + s0[1] + s0[2];
+      y[1] = s0[1] - s0[2] - s0[3];
+      y[2] = s1[0] + s1[1] + s1[2];
+      y[3] = s1[1] - s1[2] - s1[3];
+    };
+    int elane = lane;  // re-derived here so that the epilogue's addressing is not hoisted out of (and kept live
+    asm volatile("" : "+v"(elane));  // across) the chunk loop
+    {
+      float *xw = smem + cbuf + (((wave & 3) * 2 + hf) * 32) * 64 + elane;  // [pair][from hf][rr * 4 + x][lane]
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        float ya[4], yb[4];
+        partial(rr, ya);
+        partial(rr + 8, yb);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) xw[(rr * 4 + x) * 64] = hf == 0 ? yb[x] : ya[x];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+      const float *xr = smem + cbuf + (((wave & 3) * 2 + (1 - hf)) * 32) * 64 + elane;
+      const int tq = tb * 32 + (elane & 31);  // this lane's tile
+      const int per = g.TR * g.TWc;
+      const int ti = tq / per, rem = tq - ti * per;
+      const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
+      const int n = n_cur + ti;
+      const int co_base = kt * kWK + cb * 32 + 4 * (elane >> 5) + 16 * hf;
+      const size_t pixo = (size_t)(2 * (r0 + tr)) * a.Wo + 2 * tc;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int co = co_base + (rr & 3) + 8 * (rr >> 2);
+        float ya[4], yb[4], yy[4];
+        partial(rr, ya);  // recomputed rather than kept across the barrier: registers are the scarce resource
+        partial(rr + 8, yb);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) yy[x] = (hf == 0 ? ya[x] : yb[x]) + xr[(rr * 4 + x) * 64];
+        if (n < a.B) {
+          const size_t o = ((size_t)n * a.Cout + co) * g.HW + pixo;
+          const float add = (a.bias ? a.bias[co] : 0.f) + (a.chan_add ? a.chan_add[(size_t)n * a.chan_add_stride + co] : 0.f);
+          if (a.bias || a.chan_add) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) yy[x] += add;
+          }
+          if (a.residual) {
+            const f2 ra = *reinterpret_cast<const f2 *>(a.residual + o);
+            const f2 rb = *reinterpret_cast<const f2 *>(a.residual + o + a.Wo);
+            yy[0] += ra[0]; yy[1] += ra[1]; yy[2] += rb[0]; yy[3] += rb[1];
+          }
+          *reinterpret_cast<f2 *>(a.out + o) = f2{yy[0], yy[1]};
+          *reinterpret_cast<f2 *>(a.out + o + a.Wo) = f2{yy[2], yy[3]};
+        }
+      }
+    }
+    // nobody may stage the next chunk into this buffer while a neighbour still reads its exchange data
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
-  __syncthreads();
-
-#ifdef WINO_TRACE
-  if (tid == 0) {
-    atomicAdd(&g_wino_trace[0], tr_period);
-    atomicAdd(&g_wino_trace[1], tr_seg);
-    atomicAdd(&g_wino_trace[2], (unsigned long long)g.nchunks);
-  }
-#endif
-  // the last MFMAs are inline asm: give them their 16 passes before the accumulators are read back
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-
-  // ---- epilogue: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  The transform is linear in M, so each wave applies it
-  // to its own two rows of M (hf = 0: rows 0, 1; hf = 1: rows 2, 3); the hf = 1 wave hands its four partial
-  // outputs per (cout, tile) to its hf = 0 partner through LDS (the operand buffers are free by now).
-  float y[16][4];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float s0[4], s1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float ma = acc[j][r], mb = acc[4 + j][r];  // rows 2 hf and 2 hf + 1
-      s0[j] = hf == 0 ? ma + mb : ma;
-      s1[j] = hf == 0 ? mb : -ma - mb;
-    }
-    y[r][0] = s0[0] + s0[1] + s0[2];
-    y[r][1] = s0[1] - s0[2] - s0[3];
-    y[r][2] = s1[0] + s1[1] + s1[2];
-    y[r][3] = s1[1] - s1[2] - s1[3];
-  }
-  float *xch = smem + (wave & 3) * 64 * 64 + lane;  // [pair][r * 4 + x][lane]
-  if (hf == 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-#pragma unroll
-      for (int x = 0; x < 4; ++x) xch[(r * 4 + x) * 64] = y[r][x];
-  }
-  __syncthreads();
-  if (hf == 1) return;
-
-  const int tq = tb * 32 + l31;  // this lane's tile
-  const int per = g.TR * g.TWc;
-  const int ti = tq / per, rem = tq - ti * per;
-  const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
-  const int n = n0 + ti;
-  if (n < a.B) {
-    const int co_base = kt * kWK + cb * 32 + 4 * lhi;
-    const size_t pix = (size_t)(2 * (r0 + tr)) * a.Wo + 2 * tc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co_base + (r & 3) + 8 * (r >> 2);
-      float yy[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) yy[x] = y[r][x] + xch[(r * 4 + x) * 64];
-      const size_t o = ((size_t)n * a.Cout + co) * g.HW + pix;
-      float2 r0v = make_float2(0.f, 0.f), r1v = make_float2(0.f, 0.f);
-      if (a.residual) {
-        r0v = *reinterpret_cast<const float2 *>(a.residual + o);
-        r1v = *reinterpret_cast<const float2 *>(a.residual + o + a.Wo);
-      }
-      const float add = a.bias ? a.bias[co] : 0.f;
-      const float ca = a.chan_add ? a.chan_add[(size_t)n * a.chan_add_stride + co] : 0.f;
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        if (a.bias) yy[x] += add;
-        if (a.chan_add) yy[x] += ca;
-      }
-      if (a.residual) {
-        yy[0] += r0v.x; yy[1] += r0v.y; yy[2] += r1v.x; yy[3] += r1v.y;
-      }
-      *reinterpret_cast<float2 *>(a.out + o) = make_float2(yy[0], yy[1]);
-      *reinterpret_cast<float2 *>(a.out + o + a.Wo) = make_float2(yy[2], yy[3]);
-    }
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
 int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
@@ -415,19 +446,20 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   }
   const size_t lds = ((size_t)2 * (kWUF + kWVF) + 2 * kWC * g.PCH + 64) * sizeof(float);
   typedef void (*kern_t)(const ddpm_conv_desc, const WinoGeom);
-  static const kern_t kerns[2][3] = {
-      {conv_wino_kernel<false, 4>, conv_wino_kernel<false, 5>, conv_wino_kernel<false, 6>},
-      {conv_wino_kernel<true, 4>, conv_wino_kernel<true, 5>, conv_wino_kernel<true, 6>}};
+  static const kern_t kerns[2][2][3] = {
+      {{conv_wino_kernel<false, 4, false>, conv_wino_kernel<false, 5, false>, conv_wino_kernel<false, 6, false>},
+       {conv_wino_kernel<false, 4, true>, conv_wino_kernel<false, 5, true>, conv_wino_kernel<false, 6, true>}},
+      {{conv_wino_kernel<true, 4, false>, conv_wino_kernel<true, 5, false>, conv_wino_kernel<true, 6, false>},
+       {conv_wino_kernel<true, 4, true>, conv_wino_kernel<true, 5, true>, conv_wino_kernel<true, 6, true>}}};
   static bool attr_done = false;
   if (!attr_done) {
-    for (int i = 0; i < 6; ++i)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[i / 3][i % 3]),
+    for (int i = 0; i < 12; ++i)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[i / 6][i / 3 % 2][i % 3]),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const int rounds = g.TI * g.NRI;
-  const kern_t kern = kerns[d.gscale ? 1 : 0][rounds <= 4 ? 0 : rounds - 4];
-  dim3 grid(g.ntiles, d.Cout / kWK);
+  const kern_t kern = kerns[d.gscale ? 1 : 0][g.TI == 1 ? 1 : 0][rounds <= 4 ? 0 : rounds - 4];
   const double M = (double)d.B * g.HW;
   // algorithmic work = the direct convolution's: 2*M*Cout*Cin*9; 16/36 of it is executed
   const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9;
@@ -439,7 +471,7 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
     kname = kshape;
   }
   ProfScope prof(s, kname, flops, bytes);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, d, g);
+  hipLaunchKernelGGL(kern, dim3(g.grid), dim3(512), lds, s, d, g);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
