@@ -101,8 +101,8 @@ def cpu_baseline(_state_dict=None):
 
 # kernels the roofline object may describe: profiler key -> (label, executed / algorithmic MFMA FLOPs)
 ROOFLINE_KERNELS = {
-    "conv3x3_wino_gn_silu": ("conv_wino_kernel<true> (3x3 conv as Winograd F(2x2,3x3): 64 couts x 64 tiles, "
-                             "GN+SiLU prologue, fp32 MFMA)", 16.0 / 36.0),
+    "conv3x3_wino_gn_silu": ("conv_wino_kernel<true, NR, ONEIMG> (3x3 conv as Winograd F(2x2,3x3), persistent: items of "
+                             "64 couts x 64 tiles, GN+SiLU prologue, fp32 MFMA)", 16.0 / 36.0),
     "conv3x3_mfma_gn_silu": ("conv_mfma_kernel<9,1,true,128> (3x3 conv, 128x128 tile, GN+SiLU prologue, fp32 MFMA)", 1.0),
 }
 

@@ -303,9 +303,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   // plus the LDS-DMA of the U tile of chunk c + 1.  The work is cut into slices, one per MFMA step, and
   // sched_barriers pin every slice to its MFMA: left to itself the compiler emits the staging as one block between
   // two MFMAs and issues each operand read right before its use.
-  //   step 0..3    U quarter s by DMA, patch row s -> registers
-  //   step 6       row transform;   step 7..10  column transform + LDS write of row s - 7
-  //   step 12..    activation of pixel round s - 12 -> P;   step 20..  loads of pixel round s - 20
+  //   step 0..     activation of pixel round s -> P (loaded a whole chunk ago; the vmcnt wait sees nothing younger)
+  //   step 6..     loads of pixel round s - 6;   step 12..15  U quarter s - 12 by DMA (17 steps to land)
+  //   step 16..19  patch row s - 16 -> registers;   step 22  row transform;   step 23..26  column transform + write
   // The chunk closes with a counted vmcnt (the DMAs are older than the pixel loads, which stay in flight) and a raw
   // s_barrier: __syncthreads() would wait for vmcnt(0), i.e. for HBM, every chunk.
   int c = 0;  // stream index
@@ -322,17 +322,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
       bv[slot] = *reinterpret_cast<const f2 *>(smem + cbuf + vb + off);
     };
     auto slice = [&](int s) {
-      if (s < 4) {
-        dma_u(s, ch_u, nb);
-        read_patch(s, pb_t);
-      } else if (s == 6) {
+      if (s < NR) {
+        activate_px(s, pb_a);
+      } else if (s >= 6 && s < 6 + NR) {
+        load_px(s - 6, nL, chL);
+      } else if (s >= 12 && s < 16) {
+        dma_u(s - 12, ch_u, nb);
+      } else if (s >= 16 && s < 20) {
+        read_patch(s - 16, pb_t);
+      } else if (s == 22) {
         row_transform();
-      } else if (s >= 7 && s < 11) {
-        col_commit(s - 7, nb);
-      } else if (s >= 12 && s < 12 + NR) {
-        activate_px(s - 12, pb_a);
-      } else if (s >= 20 && s < 20 + NR) {
-        load_px(s - 20, nL, chL);
+      } else if (s >= 23 && s < 27) {
+        col_commit(s - 23, nb);
       }
     };
     load_pair(0, 0);
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
       __builtin_amdgcn_sched_barrier(0);
     }
     advance(nL, chL);
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NVM) : "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // DMAs landed; pixel loads are older
     __builtin_amdgcn_sched_barrier(0);
     ++c;
   };
