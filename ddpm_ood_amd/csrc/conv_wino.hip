@@ -308,6 +308,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   //   step 16..19  patch row s - 16 -> registers;   step 22  row transform;   step 23..26  column transform + write
   // The chunk closes with a counted vmcnt (the DMAs are older than the pixel loads, which stay in flight) and a raw
   // s_barrier: __syncthreads() would wait for vmcnt(0), i.e. for HBM, every chunk.
+  // The two waves of a SIMD (w, w + 4) share its matrix pipe and VALU issue, arbitrated by priority, then age; the
+  // second-dispatched half loses every tie and trails its partner into each barrier.  One static priority bump for
+  // that half evens them out (MI355X_MICROARCH.md, "Two waves per SIMD").
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
   int c = 0;  // stream index
   auto chunk = [&](auto first_c, int ch_cur) {
     constexpr bool FIRST = decltype(first_c)::value;  // first chunk of an item: its MFMAs start the accumulators

@@ -47,12 +47,17 @@ def main(root, out_csv, out_json):
     m = m.sort_values("dur_us", ascending=False)[cols]
     m.to_csv(out_csv, index=False, float_format="%.4g")
     print(m.head(12).to_string())
-    dom = m[m.kernel.str.startswith("conv_mfma_kernel<9, 1, true, 128")].iloc[0]
-    json.dump({"conv3x3_mfma_gn_silu_bytes_per_launch": float(dom.hbm_MB_per_launch * 1e6),
-               "conv3x3_mfma_gn_silu_mfma_util": float(dom.mfma_util),
-               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/microbench.py, B=256; "
-                         "reads = 2 x FETCH_SIZE KB (gfx950 correction), mean over the kernel's launches"},
-              open(out_json, "w"), indent=1)
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/microbench.py, B=256; "
+                     "reads = 2 x FETCH_SIZE KB (gfx950 correction), launch-weighted mean over the kernel's launches"}
+    # profiler key of bench.py's roofline object -> the kernel instantiations behind it
+    for key, prefix in (("conv3x3_wino_gn_silu", "conv_wino_kernel<true"), ("conv3x3_mfma_gn_silu", "conv_mfma_kernel<9, 1, true, 128")):
+        sel = m[m.kernel.str.startswith(prefix)]
+        if len(sel):
+            wgt = sel.launches / sel.launches.sum()
+            out[key + "_bytes_per_launch"] = float((sel.hbm_MB_per_launch * wgt).sum() * 1e6)
+            out[key + "_mfma_util"] = float((sel.mfma_util * sel.dur_us * sel.launches).sum() / (sel.dur_us * sel.launches).sum())
+            out[key + "_avg_launch_us"] = float((sel.dur_us * wgt).sum())
+    json.dump(out, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
