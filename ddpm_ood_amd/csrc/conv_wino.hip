@@ -51,6 +51,23 @@ __device__ __forceinline__ void mfma_agpr(f32x16 &c, float a, float b) {
 __device__ __forceinline__ void mfma_agpr_first(f32x16 &c, float a, float b) {
   asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
+// The MFMA operands are fetched from LDS by inline-asm ds_read_b64 and waited for by hand.  hipcc's own waits around
+// the LDS-DMA and the staging reads were full lgkmcnt(0) drains several times per chunk; here the wait is "at most N
+// LDS operations still in flight", N = the operand reads issued after this pair's (4, 2, 0) -- staging LDS traffic
+// issued in between only makes the wait stricter, never wrong (the counter retires in order).
+template <int N>
+__device__ __forceinline__ void mfma_agpr_wait(f32x16 &c, float a, float b) {
+  asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b), "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void mfma_agpr_first_wait(f32x16 &c, float a, float b) {
+  asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b), "n"(N));
+}
+__device__ __forceinline__ f2 lds_read_b64(int byte_addr, int imm) {
+  f2 v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(imm));
+  return v;
+}
 
 struct WinoGeom {
   int TWc, THr;     // tile columns / rows per image (Wo / 2, Ho / 2)
@@ -320,10 +337,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     const int pb_t = ((c + 1) & 1) * PB, pb_a = (c & 1) * PB;
     const int ch_u = ch_cur < last ? ch_cur + 1 : 0;  // U depends on the chunk only, not on the image
     f2 av[3], bv[3];  // operand ring: three pairs
+    const int ua = (cbuf + ub + 8 * hf * 2 * 2 * 64 * 2) * 4, va = (cbuf + vb + 8 * hf * 2 * 2 * 64 * 2) * 4;  // bytes
     auto load_pair = [&](int slot, int p) {
-      const int off = (((p & 7) + 8 * hf) * 2 + (p >> 3)) * 2 * 64 * 2;
-      av[slot] = *reinterpret_cast<const f2 *>(smem + cbuf + ub + off);
-      bv[slot] = *reinterpret_cast<const f2 *>(smem + cbuf + vb + off);
+      const int imm = (((p & 7) * 2 + (p >> 3)) * 2 * 64 * 2) * 4;
+      av[slot] = lds_read_b64(ua, imm);
+      bv[slot] = lds_read_b64(va, imm);
     };
     auto slice = [&](int s) {
       if (s < NR) {
@@ -346,10 +364,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
+      // operand reads issued after this pair's: two more pairs (4 reads), one at p = 14, none at p = 15
       if (FIRST && p < 8)
-        mfma_agpr_first(acc[p & 7], av[p % 3][0], bv[p % 3][0]);
+        mfma_agpr_first_wait<4>(acc[p & 7], av[p % 3][0], bv[p % 3][0]);
+      else if (p < 14)
+        mfma_agpr_wait<4>(acc[p & 7], av[p % 3][0], bv[p % 3][0]);
+      else if (p == 14)
+        mfma_agpr_wait<2>(acc[p & 7], av[p % 3][0], bv[p % 3][0]);
       else
-        mfma_agpr(acc[p & 7], av[p % 3][0], bv[p % 3][0]);
+        mfma_agpr_wait<0>(acc[p & 7], av[p % 3][0], bv[p % 3][0]);
       slice(2 * p);
       __builtin_amdgcn_sched_barrier(0);
       mfma_agpr(acc[p & 7], av[p % 3][1], bv[p % 3][1]);
