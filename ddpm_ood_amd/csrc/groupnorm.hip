@@ -5,7 +5,9 @@
 // /root/reference/src/trainers/reconstruct.py:151-153).  The normalise + SiLU half is fused
 // into the consuming convolution's staging (conv_mfma.hip), so this kernel is the only extra
 // pass over the activation: one workgroup per (image, group), two-pass mean / variance in
-// fp32 (second pass re-reads the <= 64 KB group from L2), wave64 shuffle reductions.
+// fp32, wave64 shuffle reductions.  Groups of up to 12 288 values (every level of the 32x32 and
+// 3-D configurations) are held in registers between the passes -- all loads are issued before
+// the first use -- larger ones re-read the group from L2.
 // HBM-bound: algorithmic bytes = 4 * C * HW per image.  Handles a virtual torch.cat of two
 // sources, including groups that straddle the seam (384 = 256 + 128 channels, 12 per group).
 #include "common.h"
@@ -28,6 +30,42 @@ __global__ __launch_bounds__(256) void gn_scale_shift_kernel(const float *__rest
   auto plane = [&](int c) -> const float * {
     return (c < C1) ? in1 + ((size_t)n * C1 + c) * HW : in2 + ((size_t)n * C2 + (c - C1)) * HW;
   };
+
+  constexpr int kHold = 12;  // float4 per thread kept in registers
+  if ((HW & 3) == 0 && cpg * (HW >> 2) <= 256 * kHold) {
+    const int hw4 = HW >> 2, n4 = cpg * hw4;
+    float4 v[kHold];
+#pragma unroll
+    for (int i = 0; i < kHold; ++i) {
+      const int e = tid + 256 * i;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < n4) {
+        const int c = e / hw4, p4 = e - c * hw4;
+        v[i] = reinterpret_cast<const float4 *>(plane(c0 + c))[p4];
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kHold; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = block_sum_256(s, red) / (float)count;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kHold; ++i) {
+      if (tid + 256 * i < n4) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float var = block_sum_256(q, red) / (float)count;  // biased, as torch
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (tid < cpg) {
+      const int c = c0 + tid;
+      const float sc = rstd * gamma[c];
+      scale[(size_t)n * C + c] = sc;
+      shift[(size_t)n * C + c] = -sc * mean + beta[c];
+    }
+    return;
+  }
 
   float s = 0.f;
   if ((HW & 3) == 0) {
