@@ -62,7 +62,7 @@ def fold_upsample_weight(weight: torch.Tensor) -> torch.Tensor | None:
 
 def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NONE, mode=CONV_NORMAL,
          chan_add=None, chan_add_offset=0, residual=None, packed=None, force_direct=False, folded=None,
-         wino=None):
+         wino=None, out_act=ACT_NONE):
     """Fused conv / linear.  x: [B, C1, H, W]; x2: optional second source of a virtual concat."""
     lib = _lib.load()
     x = require_device_f32(x, "x")
@@ -113,6 +113,7 @@ def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NON
     d.ksize, d.mode, d.act, d.force_direct = k, mode, act, int(force_direct)
     d.w_folded = ptr(folded)
     d.w_wino = ptr(wino)
+    d.out_act = out_act
     check(lib.ddpm_conv_f32(C.byref(d), stream_ptr()), "conv")
     return out[:, :, 0, 0] if was_linear else out
 
@@ -257,3 +258,48 @@ def clamp_mse_(orig, recon, b_scale: float = 1.0):
     check(lib.ddpm_clamp_mse_f32(ptr(orig), ptr(recon), float(b_scale), ptr(mse), B, orig[0].numel(), stream_ptr()),
           "clamp_mse")
     return mse
+
+
+# ---- LPIPS-AlexNet pieces (src/losses/perceptual_loss.py:105-186) -------------------------------------
+
+def lpips_conv(x, weight, bias, stride: int, pad: int, relu: bool = True, in_scale=None, in_shift=None):
+    """relu(conv2d(x * in_scale[c] + in_shift[c], weight, bias, stride, pad)); a 1-channel x feeds every input
+    channel of the layer (the ScalingLayer's broadcast)."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    w = require_device_f32(weight, "weight")
+    N, Cx, H, W = x.shape
+    cout, cin, k, _ = w.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((N, cout, max(Ho, 0), max(Wo, 0)), dtype=torch.float32, device=x.device)
+    opt = [None if t is None else require_device_f32(t, "lpips_conv operand") for t in (bias, in_scale, in_shift)]
+    check(lib.ddpm_lpips_conv_f32(ptr(x), ptr(w), ptr(opt[0]), ptr(opt[1]), ptr(opt[2]), ptr(out), N, Cx, cin, H, W,
+                                  cout, k, stride, pad, int(relu), stream_ptr()), "lpips_conv")
+    return out
+
+
+def maxpool3s2(x):
+    """MaxPool2d(3, 2)."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, Cc, (H - 3) // 2 + 1, (W - 3) // 2 + 1), dtype=torch.float32, device=x.device)
+    check(lib.ddpm_maxpool3s2_f32(ptr(x), ptr(out), N * Cc, H, W, stream_ptr()), "maxpool3s2")
+    return out
+
+
+def lpips_layer(f0, f1, lin, out=None):
+    """out[n] (+)= spatial mean of the lin-weighted squared difference of the channel-normalised features."""
+    lib = _lib.load()
+    f0 = require_device_f32(f0, "f0")
+    f1 = require_device_f32(f1, "f1")
+    lin = require_device_f32(lin, "lin")
+    if f0.shape != f1.shape:
+        raise ValueError(f"feature maps differ in shape: {tuple(f0.shape)} vs {tuple(f1.shape)}")
+    N, Cc, H, W = f0.shape
+    acc = out is not None
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=f0.device)
+    check(lib.ddpm_lpips_layer_f32(ptr(f0), ptr(f1), ptr(lin), ptr(out), N, Cc, H * W, int(acc), stream_ptr()),
+          "lpips_layer")
+    return out

@@ -2,10 +2,11 @@
 
 Mirror of /root/reference/src/losses/perceptual_loss.py:47-186 over an in-tree restatement of
 ``lpips.LPIPS(net='alex', version='0.1', lpips=True, spatial=False)`` (the
-``lpips`` wheel is not installed here).  Per BASELINE.json's north_star and SURVEY.md 8(a)
-row a9 this similarity score stays on PyTorch-ROCm device ops (MIOpen) for now; fused HIP
-kernels for it are the "next" row f-2.  24 MFLOP per image pair at 32x32 -- 6e-5 of a
-reconstruction's cost.
+``lpips`` wheel is not installed here).  On a GPU the whole score runs on the library's HIP
+kernels (``csrc/lpips.hip`` for the 11x11 / 5x5 layers, max-pools and the
+normalise-diff-lin-mean reduction, the MFMA convolution with a ReLU epilogue for the three 3x3
+layers); CPU tensors take the plain PyTorch path below, which is what the oracle is checked
+against.  24 MFLOP per image pair at 32x32 -- 6e-5 of a reconstruction's cost.
 
 state_dict keys follow lpips (``net.slice1.0.weight`` ... ``lins.0.model.1.weight``,
 ``scaling_layer.shift/scale``) so real LPIPS weights can be loaded with ``--lpips_weights``;
@@ -82,8 +83,50 @@ class LPIPS(nn.Module):
         self.eval()
         for p in self.parameters():
             p.requires_grad_(False)
+        self._packed = {}  # MFMA-packed 3x3 weights, built on first device use
+
+    def _features_hip(self, x, normalize: bool):
+        """AlexNet slices 1-5 on the HIP kernels.  The "2x - 1" of normalize=True and the ScalingLayer
+        (x - shift) / scale are one per-channel affine applied while conv1 reads its input."""
+        from . import ops
+
+        shift, scale = self.scaling_layer.shift.reshape(-1), self.scaling_layer.scale.reshape(-1)
+        a = (2.0 if normalize else 1.0) / scale
+        b = ((-1.0 if normalize else 0.0) - shift) / scale
+        convs = [self.net.slice1[0], self.net.slice2[1], self.net.slice3[1], self.net.slice4[0], self.net.slice5[0]]
+        outs = []
+        h = ops.lpips_conv(x, convs[0].weight, convs[0].bias, 4, 2, True, a.contiguous(), b.contiguous())
+        outs.append(h)
+        h = ops.lpips_conv(ops.maxpool3s2(h), convs[1].weight, convs[1].bias, 1, 2, True)
+        outs.append(h)
+        h = ops.maxpool3s2(h)
+        for c in convs[2:]:
+            packed = self._packed.get(id(c))
+            if packed is None or packed.device != h.device:
+                packed = self._packed[id(c)] = ops.pack_conv_weight(c.weight)
+            if packed is not None:   # 3x3, Cin % 4 == 0, Cout % 128 == 0: the MFMA kernel, ReLU in its epilogue
+                h = ops.conv(h, c.weight, c.bias, packed=packed, out_act=ops.ACT_RELU)
+            else:
+                h = ops.lpips_conv(h, c.weight, c.bias, 1, 1, True)
+            outs.append(h)
+        return outs
+
+    def _forward_hip(self, in0, in1, normalize: bool):
+        from . import ops
+
+        n = in0.shape[0]
+        feats = self._features_hip(torch.cat([in0, in1], 0).contiguous(), normalize)
+        val = None
+        for k, f in enumerate(feats):
+            lin = self.lins[k].model[1].weight.reshape(-1)
+            val = ops.lpips_layer(f[:n], f[n:], lin, val)
+        return val.reshape(n, 1, 1, 1)
 
     def forward(self, in0, in1, normalize: bool = False):
+        if in0.is_cuda:
+            if in0.shape != in1.shape or in0.shape[1] not in (1, 3):
+                raise ValueError(f"LPIPS wants two equal [N, 1|3, H, W] batches, got {tuple(in0.shape)} and {tuple(in1.shape)}")
+            return self._forward_hip(in0.float(), in1.float(), normalize)
         if normalize:
             in0 = 2 * in0 - 1
             in1 = 2 * in1 - 1

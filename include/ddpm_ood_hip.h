@@ -159,6 +159,25 @@ int ddpm_clamp_mse_f32(const float *orig, float *recon, float b_scale, float *ms
                        ddpm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * LPIPS-AlexNet (PerceptualLoss.forward, src/losses/perceptual_loss.py:105-186; call site
+ * src/trainers/reconstruct.py:172-187).  The three 3x3 layers of AlexNet go through
+ * ddpm_conv_f32 with out_act = DDPM_ACT_RELU; these cover the rest.
+ * ---------------------------------------------------------------------------------- */
+/* out[N,Cout,Ho,Wo] = relu?(conv2d(in * in_scale[c] + in_shift[c], w[Cout,Cin,k,k], stride, pad) + bias).
+ * Cx = channels actually stored in `in` (Cin, or 1: the single plane feeds every input channel, the reference's
+ * 1 -> 3 broadcast in the ScalingLayer); in_scale / in_shift may be NULL; zero padding pads the scaled input. */
+int ddpm_lpips_conv_f32(const float *in, const float *w, const float *bias, const float *in_scale,
+                        const float *in_shift, float *out, int N, int Cx, int Cin, int H, int W, int Cout, int k,
+                        int stride, int pad, int relu, ddpm_stream_t stream);
+
+/* MaxPool2d(kernel 3, stride 2, no padding) over `planes` = N * C planes of H x W. */
+int ddpm_maxpool3s2_f32(const float *in, float *out, int64_t planes, int H, int W, ddpm_stream_t stream);
+
+/* One LPIPS layer: out[n] (+)= mean_hw( sum_c lin[c] * (f0[n,c]/(|f0[n,:]| + 1e-10) - f1[n,c]/(|f1[n,:]| + 1e-10))^2 ). */
+int ddpm_lpips_layer_f32(const float *f0, const float *f1, const float *lin, float *out, int N, int C, int HW,
+                         int accumulate, ddpm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * UNet engine: DiffusionModelUNet(x, timesteps) as one native call
  * (ctor kwargs: src/trainers/base.py:66-86; call: src/trainers/reconstruct.py:151-153).
  * ---------------------------------------------------------------------------------- */

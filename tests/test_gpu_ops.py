@@ -401,3 +401,78 @@ def test_conv_winograd_full_batch_matches_direct(device):
     torch.cuda.synchronize()
     assert torch.equal(y, y2)
     assert (y - y_direct).abs().max().item() < 4e-5 * (1 + y_direct.abs().max().item())
+
+
+# ---- LPIPS-AlexNet on the HIP kernels --------------------------------------------------
+
+@pytest.mark.parametrize("case", [
+    # N, Cx, Cin, H, W, Cout, k, stride, pad, affine
+    (5, 1, 3, 32, 32, 64, 11, 4, 2, True),      # AlexNet conv1 on a grey image (1 -> 3 broadcast)
+    (3, 3, 3, 64, 48, 64, 11, 4, 2, True),      # conv1, RGB, non-square
+    (4, 64, 64, 7, 7, 192, 5, 1, 2, False),     # conv2
+    (2, 10, 10, 5, 6, 7, 3, 1, 1, False),       # odd everything (Cout not a multiple of 4)
+])
+def test_lpips_conv(device, case):
+    from ddpm_ood_amd import ops
+
+    N, Cx, Cin, H, W, Cout, k, stride, pad, affine = case
+    g = torch.Generator().manual_seed(sum(case[:9]))
+    x = torch.rand(N, Cx, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    a = torch.rand(Cin, generator=g) + 0.5 if affine else None
+    s = torch.randn(Cin, generator=g) if affine else None
+    xin = x.expand(N, Cin, H, W) if Cx == 1 else x
+    if affine:
+        xin = xin * a[None, :, None, None] + s[None, :, None, None]
+    ref = F.relu(F.conv2d(xin, w, b, stride=stride, padding=pad))
+    d = lambda t: None if t is None else t.to(device)
+    y = ops.lpips_conv(d(x), d(w), d(b), stride, pad, True, d(a), d(s))
+    torch.cuda.synchronize()
+    _close(y, ref, tol=2e-5)
+
+
+def test_maxpool3s2(device):
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    for shape in ((3, 64, 7, 7), (2, 5, 15, 12), (1, 2, 3, 3)):
+        x = torch.randn(*shape, generator=g)
+        y = ops.maxpool3s2(x.to(device))
+        torch.cuda.synchronize()
+        assert torch.equal(y.cpu(), F.max_pool2d(x, 3, 2))
+
+
+def test_lpips_layer(device):
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(6)
+    val, ref = None, 0
+    for C, H, W in ((64, 7, 7), (192, 3, 3), (256, 1, 1), (32, 31, 31)):
+        f0, f1 = torch.rand(6, C, H, W, generator=g), torch.rand(6, C, H, W, generator=g)
+        f0[1] = 0  # an all-zero feature vector: the 1e-10 guard
+        lin = torch.rand(C, generator=g) / C
+        n0 = f0 / (torch.sqrt(torch.sum(f0 ** 2, dim=1, keepdim=True)) + 1e-10)
+        n1 = f1 / (torch.sqrt(torch.sum(f1 ** 2, dim=1, keepdim=True)) + 1e-10)
+        ref = ref + (((n0 - n1) ** 2) * lin[None, :, None, None]).sum(1).mean([1, 2])
+        val = ops.lpips_layer(f0.to(device), f1.to(device), lin.to(device), val)
+    torch.cuda.synchronize()
+    _close(val, ref, tol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(7, 1, 32, 32), (3, 3, 64, 64), (2, 1, 128, 96)])
+def test_lpips_score_vs_oracle(device, shape):
+    """Whole LPIPS(normalize=True) on the HIP kernels vs the CPU oracle with the same weights."""
+    import oracle
+    from ddpm_ood_amd.perceptual import LPIPS
+
+    g = torch.Generator().manual_seed(shape[2])
+    x, y = torch.rand(*shape, generator=g), torch.rand(*shape, generator=g)
+    hip = LPIPS(seed=3)
+    ref = oracle.LPIPSAlex()
+    ref.load_state_dict(hip.state_dict())
+    want = ref(x, y, normalize=True)
+    got = hip.to(device)(x.to(device), y.to(device), normalize=True)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape
+    _close(got, want, tol=2e-5)
