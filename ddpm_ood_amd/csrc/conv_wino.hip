@@ -44,7 +44,7 @@ constexpr int kWVF = 16 * kWC * kWT;  // V floats per chunk (8192)
 // them in arch VGPRs, funnels every MFMA through a[0:15] and spills.  The "+a" constraint pins each accumulator
 // to its own AGPR tuple.
 __device__ __forceinline__ void mfma_agpr(f32x16 &c, float a, float b) {
-  asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  asm volatile("s_setprio 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_setprio 0" : "+a"(c) : "v"(a), "v"(b));
 }
 // first MFMA of an item into an accumulator: C = 0.  (Zeroing the tuples element by element makes hipcc build
 // them in arch VGPRs first -- 128 of them inside the item loop -- and spill.)
@@ -57,11 +57,13 @@ __device__ __forceinline__ void mfma_agpr_first(f32x16 &c, float a, float b) {
 // issued in between only makes the wait stricter, never wrong (the counter retires in order).
 template <int N>
 __device__ __forceinline__ void mfma_agpr_wait(f32x16 &c, float a, float b) {
-  asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b), "n"(N));
+  asm volatile("s_setprio 1\n\ts_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_setprio 0"
+               : "+a"(c) : "v"(a), "v"(b), "n"(N));
 }
 template <int N>
 __device__ __forceinline__ void mfma_agpr_first_wait(f32x16 &c, float a, float b) {
-  asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b), "n"(N));
+  asm volatile("s_setprio 1\n\ts_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0\n\ts_setprio 0"
+               : "=a"(c) : "v"(a), "v"(b), "n"(N));
 }
 __device__ __forceinline__ f2 lds_read_b64(int byte_addr, int imm) {
   f2 v;
@@ -328,7 +330,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   // The two waves of a SIMD (w, w + 4) share its matrix pipe and VALU issue, arbitrated by priority, then age; the
   // second-dispatched half loses every tie and trails its partner into each barrier.  One static priority bump for
   // that half evens them out (MI355X_MICROARCH.md, "Two waves per SIMD").
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
   int c = 0;  // stream index
   auto chunk = [&](auto first_c, int ch_cur) {
     constexpr bool FIRST = decltype(first_c)::value;  // first chunk of an item: its MFMAs start the accumulators
