@@ -101,6 +101,7 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   const int Cin = d.C1 + d.C2;
   if (d.ksize != 3 || d.mode != DDPM_CONV_NORMAL || d.Di > 1 || d.Do > 1 || d.accumulate || d.out_act) return false;
   if (d.act == DDPM_ACT_RELU) return false;
+  if (d.gscale && d.act != DDPM_ACT_SILU) return false;  // the affine variant has SiLU built in
   if (Cin % kWC || (d.C2 > 0 && d.C1 % kWC) || d.Cout % kWK) return false;
   if ((d.Ho & 1) || (d.Wo & 1)) return false;
   // pixels are fetched with 32-bit buffer offsets
@@ -247,12 +248,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
       gh[ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
     }
   };
-  // stage A: round k -> pixel tile `pb` (float offset of the P buffer)
+  // stage A: round k -> pixel tile `pb` (float offset of the P buffer).  With the GroupNorm affine the SiLU argument
+  // is formed straight from the pixel: v = x a + b and t = -log2(e) v = x a' + b' are two independent fmas, then
+  // v * rcp(1 + exp2(t)): 4 VALU + 2 transcendental per pixel
   auto activate_px = [&](int k, int pb) {
-    float v = praw[k];
-    if (AFFINE) v = v * gs[ONEIMG ? 0 : k] + gh[ONEIMG ? 0 : k];
-    const float sv = silu_fast(v);
-    P[pb + pw[k]] = silu ? sv : v;
+    const float x = praw[k];
+    if (AFFINE) {
+      const float sa = gs[ONEIMG ? 0 : k], sb = gh[ONEIMG ? 0 : k];
+      const float v = __builtin_fmaf(x, sa, sb);
+      const float t = __builtin_fmaf(x, -1.44269504088896341f * sa, -1.44269504088896341f * sb);
+      P[pb + pw[k]] = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+    } else {
+      const float sv = silu_fast(x);
+      P[pb + pw[k]] = silu ? sv : x;
+    }
   };
   // stage T: patch row i out of pixel tile `pb`
   auto read_patch = [&](int i, int pb) {
