@@ -7,8 +7,11 @@ Restates the parts of /root/reference/src/data/get_train_and_val_dataloader.py t
 relies on: one-row CSV of file paths (:10-16, the row is read as the header), ``first_n``
 truncation before the rank split (:17-18), per-image min-max ScaleIntensity to [0, 1] (:76),
 optional area resize (:55-59), v/h flip variants (:77-82), rank partition (:21-31 -- here a
-round-robin split without padding duplicates).  MONAI's NIfTI / PIL readers
-are out of scope: ``.npy`` / ``.npz`` files and synthetic specs only.
+round-robin split without padding duplicates).  File formats:
+``.npy`` (the reference's computer-vision datasets), single-file NIfTI-1 ``.nii`` / ``.nii.gz`` (its
+Medical-Decathlon volumes; read here with numpy as nibabel's ``get_fdata`` would: Fortran order,
+``scl_slope`` / ``scl_inter`` applied, no reorientation -- what MONAI's ``LoadImage`` hands on), ``.npz``
+archives and synthetic specs.  PIL formats are not read.
 
 Synthetic id specs (no dataset can be downloaded here):
     synthetic:<kind>[:n=N][:size=S][:channels=C][:seed=K]     kind in {blobs, noise, blobs3d, noise3d}
@@ -94,6 +97,45 @@ def _parse_spec(spec: str):
     return kind, kw
 
 
+_NIFTI_DTYPES = {2: "u1", 4: "i2", 8: "i4", 16: "f4", 64: "f8", 256: "i1", 512: "u2", 768: "u4", 1024: "i8", 1280: "u8"}
+
+
+def read_nifti(path) -> np.ndarray:
+    """Single-file NIfTI-1 (.nii / .nii.gz) -> float32 array of shape dim[1..ndim] (x fastest on disk)."""
+    import gzip
+
+    path = str(path)
+    with (gzip.open(path, "rb") if path.endswith(".gz") else open(path, "rb")) as f:
+        raw = f.read()
+    if len(raw) < 352:
+        raise ValueError(f"{path}: too short for a NIfTI-1 header")
+    for order in ("<", ">"):
+        if int(np.frombuffer(raw, order + "i4", 1, 0)[0]) == 348:
+            break
+    else:
+        raise ValueError(f"{path}: not a NIfTI-1 file (sizeof_hdr != 348)")
+    if raw[344:347] not in (b"n+1",):
+        raise ValueError(f"{path}: only single-file NIfTI-1 ('n+1') is read, magic = {raw[344:348]!r}")
+    dim = np.frombuffer(raw, order + "i2", 8, 40)
+    ndim = int(dim[0])
+    if not 1 <= ndim <= 7:
+        raise ValueError(f"{path}: bad dim[0] = {ndim}")
+    shape = tuple(int(d) for d in dim[1:1 + ndim])
+    while len(shape) > 1 and shape[-1] == 1:  # trailing singleton axes (nibabel keeps them; LoadImage squeezes)
+        shape = shape[:-1]
+    code = int(np.frombuffer(raw, order + "i2", 1, 70)[0])
+    if code not in _NIFTI_DTYPES:
+        raise ValueError(f"{path}: unsupported NIfTI datatype code {code}")
+    vox_offset = int(np.frombuffer(raw, order + "f4", 1, 108)[0])
+    slope, inter = (float(v) for v in np.frombuffer(raw, order + "f4", 2, 112))
+    n = int(np.prod(shape))
+    data = np.frombuffer(raw, order + _NIFTI_DTYPES[code], n, max(vox_offset, 352)).reshape(shape, order="F")
+    data = data.astype(np.float32)
+    if slope != 0.0 and np.isfinite(slope) and np.isfinite(inter) and (slope != 1.0 or inter != 0.0):
+        data = data * np.float32(slope) + np.float32(inter)
+    return np.ascontiguousarray(data)
+
+
 def load_ids(ids: str, is_grayscale: bool = False, first_n=None, spatial_dimension: int = 2):
     """-> (images fp32 [N, C, *spatial] unscaled, names list[str])."""
     ids = str(ids)
@@ -119,9 +161,12 @@ def load_ids(ids: str, is_grayscale: bool = False, first_n=None, spatial_dimensi
         row = row[: int(first_n)]
     imgs = []
     for path in row:
-        if not path.endswith(".npy"):
-            raise NotImplementedError(f"{path}: only .npy images are ingested (NIfTI/PIL readers are out of scope)")
-        a = torch.from_numpy(np.load(path).astype(np.float32))
+        if path.endswith((".nii", ".nii.gz")):
+            a = torch.from_numpy(read_nifti(path))
+        elif path.endswith(".npy"):
+            a = torch.from_numpy(np.load(path).astype(np.float32))
+        else:
+            raise NotImplementedError(f"{path}: .npy and NIfTI-1 (.nii / .nii.gz) files are ingested; PIL formats are not")
         if a.ndim == spatial_dimension:
             a = a[None]
         if is_grayscale:

@@ -200,3 +200,52 @@ def test_vqvae_restatement_and_3d_ingest(tmp_path):
     ld = get_data_loader(str(tmp_path / "Task01_test.csv"), 1, is_grayscale=True, spatial_dimension=3,
                          image_roi=(16, 16, -1), image_size=8)
     assert next(iter(ld))["image"].shape == (1, 1, 8, 8, 8)
+
+
+def _write_nifti(path, data, slope=0.0, inter=0.0, big_endian=False):
+    """Minimal single-file NIfTI-1 writer for the ingest test (header fields as in the NIfTI-1 standard)."""
+    import gzip
+    import struct
+
+    e = ">" if big_endian else "<"
+    codes = {"uint8": 2, "int16": 4, "float32": 16, "float64": 64}
+    hdr = bytearray(352)
+    struct.pack_into(e + "i", hdr, 0, 348)
+    dim = [data.ndim] + list(data.shape) + [1] * (7 - data.ndim)
+    struct.pack_into(e + "8h", hdr, 40, *dim)
+    struct.pack_into(e + "h", hdr, 70, codes[str(data.dtype)])
+    struct.pack_into(e + "h", hdr, 72, data.dtype.itemsize * 8)
+    struct.pack_into(e + "f", hdr, 108, 352.0)
+    struct.pack_into(e + "ff", hdr, 112, slope, inter)
+    hdr[344:348] = b"n+1\0"
+    raw = bytes(hdr) + data.astype(data.dtype.newbyteorder(e)).tobytes(order="F")
+    with (gzip.open(path, "wb") if str(path).endswith(".gz") else open(path, "wb")) as f:
+        f.write(raw)
+
+
+def test_nifti_ingest(tmp_path):
+    """Row f-4: NIfTI-1 volumes listed in the reference's one-row CSV (get_train_and_val_dataloader.py:10-16,69-76)."""
+    from ddpm_ood_amd.data import get_data_loader, read_nifti
+
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 2000, size=(12, 10, 8)).astype(np.int16)
+    b = rng.random((12, 10, 8)).astype(np.float32)
+    _write_nifti(tmp_path / "a.nii.gz", a, slope=0.5, inter=-3.0)
+    _write_nifti(tmp_path / "b.nii", b, big_endian=True)
+    np.testing.assert_allclose(read_nifti(tmp_path / "a.nii.gz"), a.astype(np.float32) * 0.5 - 3.0)
+    np.testing.assert_array_equal(read_nifti(tmp_path / "b.nii"), b)
+    (tmp_path / "ids.csv").write_text(f"{tmp_path / 'a.nii.gz'},{tmp_path / 'b.nii'}\n")
+    loader = get_data_loader(str(tmp_path / "ids.csv"), batch_size=2, is_grayscale=True, spatial_dimension=3,
+                             image_roi=[8, 8, 8])
+    batch = next(iter(loader))
+    assert batch["image"].shape == (2, 1, 8, 8, 8)
+    assert float(batch["image"].min()) == 0.0 and float(batch["image"].max()) == 1.0   # ScaleIntensity per image
+    want = torch.from_numpy(b)[2:10, 1:9, :]  # centre crop, then min-max
+    want = (want - want.min()) / (want.max() - want.min())
+    assert torch.allclose(batch["image"][1, 0], want, atol=1e-6)
+    (tmp_path / "bad.nii").write_bytes(b"\0" * 400)
+    with pytest.raises(ValueError):
+        read_nifti(tmp_path / "bad.nii")
+    (tmp_path / "ids2.csv").write_text(f"{tmp_path / 'x.png'}\n")
+    with pytest.raises(NotImplementedError):
+        get_data_loader(str(tmp_path / "ids2.csv"), batch_size=1)
