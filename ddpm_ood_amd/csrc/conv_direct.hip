@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ddpm_conv_desc a
         if (hv >= 0 && hv < Hv && wv >= 0 && wv < Wv) {
           v = up ? plane[(hv >> 1) * a.Wi + (wv >> 1)] : plane[hv * a.Wi + wv];
           if (a.gscale) v = v * sc + sh;
-          if (a.act == DDPM_ACT_SILU) v = silu_f(v);
+          if (a.act == DDPM_ACT_SILU) v = silu_fast(v);
           if (a.act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
         }
         const int t = kh * a.ksize + kw;
@@ -104,6 +104,24 @@ __global__ __launch_bounds__(256) void conv_smallco_kernel(const ddpm_conv_desc 
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const int pix = th * RS + tw;  // top-left tap of this thread's 3x3 window inside the haloed plane
 
+  // chunk c0 + 8 is loaded into registers while chunk c0 is consumed from LDS (the kernel is latency-bound otherwise:
+  // 16 dependent load -> barrier -> compute rounds per workgroup)
+  float pre[NPOS][kSC_CH], psc[kSC_CH], psh[kSC_CH];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int c = 0; c < kSC_CH; ++c) {
+      const int ci = c0 + c;
+      const bool okc = ci < Cin;
+      const float *plane = !okc ? a.in1
+                           : (ci < a.C1) ? a.in1 + ((size_t)n * a.C1 + ci) * HW
+                                         : a.in2 + ((size_t)n * a.C2 + (ci - a.C1)) * HW;
+#pragma unroll
+      for (int j = 0; j < NPOS; ++j) pre[j][c] = (okc && soff[j] >= 0) ? plane[soff[j]] : 0.f;
+      psc[c] = (okc && a.gscale) ? a.gscale[(size_t)n * Cin + ci] : 1.f;
+      psh[c] = (okc && a.gscale) ? a.gshift[(size_t)n * Cin + ci] : 0.f;
+    }
+  };
+  fetch(0);
   for (int c0 = 0; c0 < Cin; c0 += kSC_CH) {
     __syncthreads();
 #pragma unroll
@@ -112,22 +130,19 @@ __global__ __launch_bounds__(256) void conv_smallco_kernel(const ddpm_conv_desc 
       if (r < PS) {
 #pragma unroll
         for (int c = 0; c < kSC_CH; ++c) {
-          const int ci = c0 + c;
           float v = 0.f;
-          if (soff[j] >= 0 && ci < Cin) {
-            const float *plane = (ci < a.C1) ? a.in1 + ((size_t)n * a.C1 + ci) * HW
-                                             : a.in2 + ((size_t)n * a.C2 + (ci - a.C1)) * HW;
-            v = plane[soff[j]];
-            if (a.gscale) v = v * a.gscale[(size_t)n * Cin + ci] + a.gshift[(size_t)n * Cin + ci];
-            if (a.act == DDPM_ACT_SILU) v = silu_f(v);
+          if (soff[j] >= 0 && c0 + c < Cin) {
+            v = pre[j][c];
+            if (a.gscale) v = v * psc[c] + psh[c];
+            if (a.act == DDPM_ACT_SILU) v = silu_fast(v);
             if (a.act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
-          if (a.act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
           }
           tile[c * PS + r] = v;
         }
       }
     }
     __syncthreads();
+    if (c0 + kSC_CH < Cin) fetch(c0 + kSC_CH);
 #pragma unroll
     for (int c = 0; c < kSC_CH; ++c) {
       const int ci = c0 + c;
