@@ -423,6 +423,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     };
     int elane = lane;  // re-derived here so that the epilogue's addressing is not hoisted out of (and kept live
     asm volatile("" : "+v"(elane));  // across) the chunk loop
+    const int tq = tb * 32 + (elane & 31);  // this lane's tile
+    const int per = g.TR * g.TWc;
+    const int ti = tq / per, rem = tq - ti * per;
+    const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
+    const int n = n_cur + ti;
+    const int co_base = kt * kWK + cb * 32 + 4 * (elane >> 5) + 16 * hf;
+    const size_t obase = ((size_t)min(n, a.B - 1) * a.Cout + co_base) * g.HW + (size_t)(2 * (r0 + tr)) * a.Wo + 2 * tc;
+    // the addends (residual, bias + temb) are requested first: their latency passes under the transform + exchange
+    f2 ra[8], rb[8];
+    float addv[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int cof = (rr & 3) + 8 * (rr >> 2);
+      const size_t o = obase + (size_t)cof * g.HW;
+      ra[rr] = rb[rr] = f2{0.f, 0.f};
+      if (a.residual) {
+        ra[rr] = *reinterpret_cast<const f2 *>(a.residual + o);
+        rb[rr] = *reinterpret_cast<const f2 *>(a.residual + o + a.Wo);
+      }
+      addv[rr] = (a.bias ? a.bias[co_base + cof] : 0.f) +
+                 (a.chan_add ? a.chan_add[(size_t)min(n, a.B - 1) * a.chan_add_stride + co_base + cof] : 0.f);
+    }
     {
       float *xw = smem + cbuf + (((wave & 3) * 2 + hf) * 32) * 64 + elane;  // [pair][from hf][rr * 4 + x][lane]
 #pragma unroll
@@ -437,33 +459,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     {
       const float *xr = smem + cbuf + (((wave & 3) * 2 + (1 - hf)) * 32) * 64 + elane;
-      const int tq = tb * 32 + (elane & 31);  // this lane's tile
-      const int per = g.TR * g.TWc;
-      const int ti = tq / per, rem = tq - ti * per;
-      const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
-      const int n = n_cur + ti;
-      const int co_base = kt * kWK + cb * 32 + 4 * (elane >> 5) + 16 * hf;
-      const size_t pixo = (size_t)(2 * (r0 + tr)) * a.Wo + 2 * tc;
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
-        const int co = co_base + (rr & 3) + 8 * (rr >> 2);
         float ya[4], yb[4], yy[4];
         partial(rr, ya);  // recomputed rather than kept across the barrier: registers are the scarce resource
         partial(rr + 8, yb);
 #pragma unroll
-        for (int x = 0; x < 4; ++x) yy[x] = (hf == 0 ? ya[x] : yb[x]) + xr[(rr * 4 + x) * 64];
+        for (int x = 0; x < 4; ++x) yy[x] = (hf == 0 ? ya[x] : yb[x]) + xr[(rr * 4 + x) * 64] + addv[rr];
+        yy[0] += ra[rr][0]; yy[1] += ra[rr][1]; yy[2] += rb[rr][0]; yy[3] += rb[rr][1];
         if (n < a.B) {
-          const size_t o = ((size_t)n * a.Cout + co) * g.HW + pixo;
-          const float add = (a.bias ? a.bias[co] : 0.f) + (a.chan_add ? a.chan_add[(size_t)n * a.chan_add_stride + co] : 0.f);
-          if (a.bias || a.chan_add) {
-#pragma unroll
-            for (int x = 0; x < 4; ++x) yy[x] += add;
-          }
-          if (a.residual) {
-            const f2 ra = *reinterpret_cast<const f2 *>(a.residual + o);
-            const f2 rb = *reinterpret_cast<const f2 *>(a.residual + o + a.Wo);
-            yy[0] += ra[0]; yy[1] += ra[1]; yy[2] += rb[0]; yy[3] += rb[1];
-          }
+          const size_t o = obase + (size_t)((rr & 3) + 8 * (rr >> 2)) * g.HW;
           *reinterpret_cast<f2 *>(a.out + o) = f2{yy[0], yy[1]};
           *reinterpret_cast<f2 *>(a.out + o + a.Wo) = f2{yy[2], yy[3]};
         }
