@@ -1,0 +1,179 @@
+// conv1x1_dma.hip -- plain 1x1 convolution (ResnetBlock skip connections, attention proj_attn) as a GEMM whose
+// two operands both arrive by LDS-DMA.
+//
+// Same op as conv_mfma.hip's single-tap variant without a GroupNorm / activation prologue (reference call site
+// /root/reference/src/trainers/reconstruct.py:151-153): out[n, co, p] = sum_c W[co, c] x[n, c, p] (+ bias, temb,
+// residual), x optionally a virtual concat of two tensors.  With no per-element work on the input, nothing has to
+// pass through registers on its way to LDS: NCHW already is the [k][pixel] image the MFMA B operand wants, the
+// packed weights (ddpm_pack_conv_weight_f32, [cout tile][k][128]) are the A image, so every chunk of 16 input
+// channels is 40 x global_load_lds_dwordx4 per workgroup (5 per wave) and the loop is MFMAs + operand ds_reads only.
+// conv_mfma's register-staged single-tap kernel ran these layers at ~50 % MFMA utilisation (32 MFMAs per barrier,
+// staging VALU beside them); see DESIGN.md 3.4.
+//
+// Workgroup = 128 output channels x 256 pixels (consecutive pixels of one image, or whole images), 4 waves as
+// 2 (cout halves) x 2 (pixel halves): a wave owns 64 couts x 128 pixels = 2 x 4 MFMA tiles (128 accumulator
+// registers), 64 MFMAs per chunk from 6 ds_read_b32 per k-step.  Three LDS buffers of 24 KB: while chunk q is
+// multiplied, chunk q + 1 has landed or is landing and chunk q + 2 is being requested; one barrier per chunk.
+// Two workgroups fit a CU, so one's epilogue (these layers move as many bytes in the epilogue -- residual in, result
+// out -- as in the main loop) overlaps the other's main loop; a 512-pixel / 8-wave version, one workgroup per CU,
+// measured the same 100 TFLOP/s with and without deeper operand prefetch: the layers are HBM-side bound.
+#include "common.h"
+
+namespace ddpm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kDC = 16;          // input channels per chunk
+constexpr int kDM = 128;         // output channels per workgroup
+constexpr int kDP = 256;         // pixels per workgroup
+constexpr int kDBuf = kDC * (kDM + kDP);  // floats per LDS buffer (6 144)
+
+bool conv1x1_dma_supported(const ddpm_conv_desc &d) {
+  static const bool enabled = !(getenv("DDPM_CONV1X1_DMA") && atoi(getenv("DDPM_CONV1X1_DMA")) == 0);
+  const int Cin = d.C1 + d.C2;
+  const long HW = (long)d.Ho * d.Wo;
+  if (!enabled || d.force_direct || !d.w_packed) return false;
+  if (d.ksize != 1 || d.mode != DDPM_CONV_NORMAL || d.gscale || d.act != DDPM_ACT_NONE) return false;
+  if (d.Di > 1 || d.Do > 1 || d.accumulate) return false;
+  if (Cin % kDC || (d.C2 > 0 && d.C1 % kDC) || d.Cout % kDM) return false;
+  // a tile is 256 consecutive pixels of one image or a whole number of images; rows of 4 pixels never straddle
+  if (HW % 4 || !((HW % kDP == 0) || (kDP % HW == 0))) return false;
+  const long tiles = ((long)d.B * HW + kDP - 1) / kDP;
+  return tiles * (d.Cout / kDM) >= 384;  // smaller launches stay with conv_mfma's 64 / 128-pixel tiles
+}
+
+__global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_desc a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][ A [16][128] | B [16][256] ]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int wco = (wave & 1) * 64, wpx = (wave >> 1) * 128;  // 4 waves: 2 x 2
+  const int HW = a.Ho * a.Wo, Cin = a.C1 + a.C2, nchunks = Cin / kDC;
+  const int nt = blockIdx.y;
+  const long t0 = (long)blockIdx.x * kDP;  // first pixel of the tile in the flattened (n, p) order
+  const long npix = (long)a.B * HW;
+
+  // ---- DMA roles.  A: the chunk's 16 x 128 weights are 8 KB contiguous -> pieces 2 wave, 2 wave + 1 of 8.
+  // B: one piece per channel (256 pixels = 1 KB); this wave copies channels 4 wave .. 4 wave + 3.  A lane copies 4
+  // consecutive pixels (16 B) of its channel row; pixels past the end re-read the last group.
+  const float *wsrc = a.w_packed + (size_t)nt * nchunks * kDC * kDM + wave * 512 + lane * 4;
+  size_t boff1, boff2;  // element offset of (image, channel 0, pixel) in in1 / in2
+  {
+    long t = t0 + lane * 4;
+    if (t >= npix) t = npix - 4;
+    const long n = t / HW, p = t - n * HW;
+    boff1 = ((size_t)n * a.C1) * HW + p;
+    boff2 = ((size_t)n * a.C2) * HW + p;
+  }
+  auto dma_chunk = [&](int q, int buf) {
+    float *dstA = smem + buf * kDBuf;
+    float *dstB = dstA + kDC * kDM;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds(wsrc + (size_t)q * kDC * kDM + j * 256, dstA + wave * 512 + j * 256, 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 4 * wave + j, cg = q * kDC + c;
+      const bool first = cg < a.C1;  // uniform (C1 % 16 == 0)
+      const float *src = first ? a.in1 + boff1 + (size_t)cg * HW : a.in2 + boff2 + (size_t)(cg - a.C1) * HW;
+      __builtin_amdgcn_global_load_lds(src, dstB + c * kDP, 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  dma_chunk(0, 0);
+  if (nchunks > 1) dma_chunk(1, 1);
+  for (int q = 0; q < nchunks; ++q) {
+    // chunk q's six pieces per wave are older than chunk q + 1's: a counted wait leaves the younger ones in flight
+    if (q + 1 < nchunks)
+      asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // everyone has left chunk q - 1: its buffer takes chunk q + 2
+    if (q + 2 < nchunks) dma_chunk(q + 2, (q + 2) % 3);
+    const float *A = smem + (q % 3) * kDBuf + lhi * kDM + wco + l31;
+    const float *Bm = A - (lhi * kDM + wco + l31) + kDC * kDM + lhi * kDP + wpx + l31;
+    // operands of k-step ks + 1 are requested before the 8 MFMAs of k-step ks (pinned: left alone, hipcc re-uses one
+    // register set and issues the reads one MFMA ahead of their use)
+    float av[2][2], bv[2][4];
+    auto fetch = [&](int ks, int slot) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[slot][i] = A[2 * ks * kDM + 32 * i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[slot][j] = Bm[2 * ks * kDP + 32 * j];
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < kDC / 2; ++ks) {
+      if (ks + 1 < kDC / 2) fetch(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][i], bv[ks & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: D[row = cout][col = pixel] -> NCHW, 128 B contiguous per (register, half-wave) -------------
+  const int co_base = nt * kDM + wco + 4 * lhi;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long t = t0 + wpx + 32 * j + l31;
+    if (t < npix) {
+      const long n = t / HW, p = t - n * HW;
+      const size_t obase = ((size_t)n * a.Cout + co_base) * HW + p;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float add[16], rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dco = 32 * i + (r & 3) + 8 * (r >> 2);
+          add[r] = (a.bias ? a.bias[co_base + dco] : 0.f) +
+                   (a.chan_add ? a.chan_add[(size_t)n * a.chan_add_stride + co_base + dco] : 0.f);
+          rv[r] = a.residual ? a.residual[obase + (size_t)dco * HW] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dco = 32 * i + (r & 3) + 8 * (r >> 2);
+          float v = acc[i][j][r];
+          if (a.bias || a.chan_add) v += add[r];
+          if (a.residual) v += rv[r];
+          if (a.out_act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
+          a.out[obase + (size_t)dco * HW] = v;
+        }
+      }
+    }
+  }
+}
+
+int launch_conv1x1_dma(const ddpm_conv_desc &d, hipStream_t s) {
+  if (!conv1x1_dma_supported(d)) {
+    set_error("conv1x1_dma: unsupported shape");
+    return DDPM_EINVAL;
+  }
+  const size_t lds = (size_t)3 * kDBuf * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_dma_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const long HW = (long)d.Ho * d.Wo, npix = (long)d.B * HW;
+  const int Cin = d.C1 + d.C2;
+  ProfScope prof(s, "conv1x1_dma", 2.0 * npix * d.Cout * Cin,
+                 4.0 * ((double)npix * Cin + (double)npix * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * Cin));
+  hipLaunchKernelGGL(conv1x1_dma_kernel, dim3((unsigned)((npix + kDP - 1) / kDP), d.Cout / kDM), dim3(256), lds, s, d);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace ddpm

@@ -234,6 +234,7 @@ int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
   }
   DDPM_CHECK_ARG(!d.accumulate, "conv: accumulate is only used by the depth-tap launches of a 3-D convolution");
   if (conv_wino_supported(d)) return launch_conv_wino(d, s);
+  if (conv1x1_dma_supported(d) && conv_mfma_supported(d)) return launch_conv1x1_dma(d, s);
   if (conv_mfma_supported(d)) return launch_conv_mfma(d, s);
   return launch_conv_direct(d, s);
 }

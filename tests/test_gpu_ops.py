@@ -476,3 +476,33 @@ def test_lpips_score_vs_oracle(device, shape):
     torch.cuda.synchronize()
     assert got.shape == want.shape
     _close(got, want, tol=2e-5)
+
+
+CONV1X1_DMA_CASES = [
+    # B, C1, C2, Cout, H, bias, chan_add, residual -- large enough for the DMA-fed 1x1 kernel (>= 384 workgroups)
+    (96, 256, 128, 128, 32, True, False, True),     # up-path skip connection with virtual concat
+    (256, 256, 256, 256, 16, True, True, False),    # one image per 256-pixel tile, two cout tiles
+    (1537, 128, 0, 128, 8, False, False, True),     # four images per tile, ragged last tile (384.25 tiles)
+]
+
+
+@pytest.mark.parametrize("case", CONV1X1_DMA_CASES)
+def test_conv1x1_dma(device, case):
+    """Plain 1x1 convolution with both operands fed by LDS-DMA vs F.conv2d and vs the register-staged kernel."""
+    import os
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, Cout, H, has_bias, chan, res = case
+    g = torch.Generator().manual_seed(B + C1 + H)
+    Cin = C1 + C2
+    x = torch.randn(B, C1, H, H, generator=g)
+    x2 = torch.randn(B, C2, H, H, generator=g) if C2 else None
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    b = torch.randn(Cout, generator=g) if has_bias else None
+    chan_add = torch.randn(B, Cout, generator=g) if chan else None
+    residual = torch.randn(B, Cout, H, H, generator=g) if res else None
+    ref = _ref_conv(x, x2, w, b, None, False, 0, chan_add, residual)
+    d = lambda t: None if t is None else t.to(device)
+    y = ops.conv(d(x), d(w), d(b), x2=d(x2), chan_add=d(chan_add), residual=d(residual))
+    torch.cuda.synchronize()
+    _close(y, ref, tol=2e-5)
