@@ -76,7 +76,9 @@ struct WinoGeom {
   int TI, TR;       // images per item, tile rows per item (per image)
   int parts;        // items per image along the rows (1 when an item holds whole images)
   int Cin, nchunks, HW;
-  int PW, PCH;      // pixel tile in LDS: padded row length (Wo + 2), floats per channel (TI * (2 TR + 2) rows)
+  int up;           // 1: DDPM_CONV_UPSAMPLE2 -- tiles are low-res pixels, the pixel tile holds low-res rows
+  int HWin;         // pixels of one input channel plane (Hi * Wi)
+  int PW, PCH;      // pixel tile in LDS: padded row length (W + 2), floats per channel (TI * (2 TR + 2) rows; TR + 2 if up)
   int NRI;          // staging rounds of 64 pixels per image of an item (TI * NRI <= 6)
   int KT;           // cout tiles
   int NIT;          // items per (cout tile, part) = ceil(B / TI)
@@ -99,7 +101,10 @@ static int device_cus() {
 
 static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   const int Cin = d.C1 + d.C2;
-  if (d.ksize != 3 || d.mode != DDPM_CONV_NORMAL || d.Di > 1 || d.Do > 1 || d.accumulate || d.out_act) return false;
+  if (d.ksize != 3 || d.Di > 1 || d.Do > 1 || d.accumulate || d.out_act) return false;
+  if (d.mode != DDPM_CONV_NORMAL && d.mode != DDPM_CONV_UPSAMPLE2) return false;
+  g.up = d.mode == DDPM_CONV_UPSAMPLE2;
+  if (g.up && (d.gscale || d.act != DDPM_ACT_NONE || d.Ho != 2 * d.Hi || d.Wo != 2 * d.Wi)) return false;
   if (d.act == DDPM_ACT_RELU) return false;
   if (d.gscale && d.act != DDPM_ACT_SILU) return false;  // the affine variant has SiLU built in
   if (Cin % kWC || (d.C2 > 0 && d.C1 % kWC) || d.Cout % kWK) return false;
@@ -124,10 +129,12 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   g.Cin = Cin;
   g.nchunks = Cin / kWC;
   g.HW = d.Ho * d.Wo;
-  g.PW = d.Wo + 2;
-  g.PCH = g.TI * (2 * g.TR + 2) * g.PW;
-  const int rows = 2 * g.TR + 2 < d.Ho ? 2 * g.TR + 2 : d.Ho;  // in-image rows an item reads, at most
-  g.NRI = (rows * d.Wo + 63) / 64;
+  g.HWin = d.Hi * d.Wi;
+  const int prow = g.up ? g.TR + 2 : 2 * g.TR + 2;  // pixel-tile rows per image of an item
+  g.PW = d.Wi + 2;
+  g.PCH = g.TI * prow * g.PW;
+  const int rows = prow < d.Hi ? prow : d.Hi;  // in-image rows an item reads, at most
+  g.NRI = (rows * d.Wi + 63) / 64;
   if (g.TI * g.NRI > 6) return false;
   if ((2 * (kWUF + kWVF) + 2 * kWC * g.PCH + 64) * sizeof(float) > 160 * 1024) return false;
   g.KT = d.Cout / kWK;
@@ -481,6 +488,294 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
+
+// ---- Upsample: nearest x2 followed by the 3x3 conv, in the Winograd domain ---------------------------------------
+// On a nearest-x2 image the 4x4 patch of the output tile (2 ty .. 2 ty + 1, 2 tx .. 2 tx + 1) has rows
+// [L(ty-1), L(ty), L(ty), L(ty+1)] of the low-res image (zero outside), and the same for columns, so
+//   B^T d = [L- - L0, 2 L0, 0, L0 - L+]:  row 2 and column 2 of V = B^T d B vanish.
+// Only the 9 positions (i, j) in {0, 1, 3}^2 carry work: 2.25 multiplies per output against 4 for the folded 2x2-tap
+// form (conv_mfma.hip) and 9 for the plain conv.  Tiles are low-res pixels (one 2x2 output tile each), so the item /
+// stream geometry is the one of the normal kernel with TWc = Wi; the pixel tile holds low-res rows (TR + 2 per item,
+// raw: Upsample has no GroupNorm / activation in front), a patch is 3x3 with stride 1.  The positions are dealt to
+// the two waves of a pair as 5 + 4 (they are independent GEMMs and the output transform is linear, so any split
+// works): wave half 0 takes xi = 0, 1, 3, 4, 5, half 1 takes 7, 12, 13, 15; 20 / 16 MFMAs per chunk.
+constexpr int kUpPos[2][5] = {{0, 1, 3, 4, 5}, {7, 12, 13, 15, 15}};
+constexpr int kUpNX[2] = {5, 4};
+constexpr int kUpIdx[3] = {0, 1, 3};                       // transform index of the three surviving rows / columns
+constexpr int kAT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};  // A^T
+
+template <int NR>
+__global__ __launch_bounds__(512, 2) void conv_wino_up_kernel(const ddpm_conv_desc a, const WinoGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BUF = kWUF + kWVF;
+  float *const P = smem + 2 * BUF;  // low-res pixel tiles [2][8 channels][PCH] (zero borders) + 64 dump floats
+  const int PB = kWC * g.PCH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int cb = wave & 1, tb = (wave >> 1) & 1, hf = wave >> 2;
+
+  const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3;
+  const int kt = wj % g.KT, slot = (wj / g.KT) * 8 + xcd;
+  if (slot >= g.NS) return;
+  const int part = slot % g.parts, it0 = (slot / g.parts) * g.IPW;
+  const int nitems = min(g.IPW, g.NIT - it0);
+  const int r0 = part * g.TR;  // first low-res row (= tile row) of the part
+  const int n_first = it0 * g.TI, n_end = n_first + nitems * g.TI;
+  const int last = g.nchunks - 1;
+
+  // ---- staging roles: wave = channel of the chunk; pixels in NR rounds of 64 lanes, patches one per lane ----
+  const int sc = wave, st = lane;
+  const int PR = g.TR + 2;
+  const int row_lo = max(0, r0 - 1), row_hi = min(a.Hi, r0 + g.TR + 1);  // low-res rows an item reads
+  const int npx = (row_hi - row_lo) * a.Wi;
+  int pix[NR], pw[NR], tik[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int ti = k / g.NRI, e = lane + 64 * (k - ti * g.NRI);
+    const bool valid = ti < g.TI && e < npx;
+    const int row = row_lo + e / a.Wi, col = e % a.Wi;
+    tik[k] = ti;
+    pix[k] = valid ? (row * a.Wi + col) * 4 : (int)0x80000000;
+    pw[k] = valid ? sc * g.PCH + (ti * PR + row - (r0 - 1)) * g.PW + col + 1 : 2 * PB + lane;
+  }
+  int tbase;  // 3x3 patch origin of tile st inside a channel tile of P
+  {
+    const int per = g.TR * g.TWc;
+    const int ti = st / per, rem = st - ti * per;
+    const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
+    tbase = sc * g.PCH + (ti * PR + tr) * g.PW + tc;
+  }
+  const int bytes1 = a.B * a.C1 * g.HWin * 4, bytes2 = a.B * a.C2 * g.HWin * 4;
+
+  const int ub = (lhi * kWK + cb * 32 + l31) * 2;
+  const int vb = kWUF + (lhi * kWT + tb * 32 + l31) * 2;
+  const float *usrc = a.w_wino + (size_t)kt * g.nchunks * kWUF + wave * 4 * 256;
+
+  f32x16 acc[5];
+  float praw[NR], dreg[9], vv[9];
+  auto dma_u = [&](int i, int ch, int nb) {
+    const float *ubase = usrc + (size_t)ch * kWUF + i * 256;  // uniform
+    __builtin_amdgcn_global_load_lds(ubase + lane * 4, smem + nb + (wave * 4 + i) * 256, 16, 0, 0);
+  };
+  auto load_px = [&](int k, int n, int ch) {
+    const int cg = ch * kWC + sc, ni = min(n + tik[k], a.B - 1);
+    const bool first = cg < a.C1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
+    const int soff = first ? (ni * a.C1 + cg) * g.HWin * 4 : (ni * a.C2 + cg - a.C1) * g.HWin * 4;
+    praw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pix[k], soff, 0));
+  };
+  auto store_px = [&](int k, int pb) { P[pb + pw[k]] = praw[k]; };
+  auto read_patch = [&](int i, int pb) {
+    const float *p = P + pb + tbase + i * g.PW;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dreg[3 * i + j] = p[j];
+  };
+  // V at the 9 surviving positions: rows (L- - L0, 2 L0, L0 - L+), then the same along the columns
+  auto transform = [&]() {
+    float t[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      t[0 * 3 + j] = dreg[0 * 3 + j] - dreg[1 * 3 + j];
+      t[1 * 3 + j] = dreg[1 * 3 + j] + dreg[1 * 3 + j];
+      t[2 * 3 + j] = dreg[1 * 3 + j] - dreg[2 * 3 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      vv[i * 3 + 0] = t[i * 3 + 0] - t[i * 3 + 1];
+      vv[i * 3 + 1] = t[i * 3 + 1] + t[i * 3 + 1];
+      vv[i * 3 + 2] = t[i * 3 + 1] - t[i * 3 + 2];
+    }
+  };
+  auto commit = [&](int i, int nb) {
+    float *vl = smem + nb + kWUF + (((sc >> 2) * 2 + (sc & 1)) * kWT + st) * 2 + ((sc >> 1) & 1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) vl[(kUpIdx[i] * 4 + kUpIdx[j]) * kWC * kWT] = vv[i * 3 + j];
+  };
+  auto advance = [&](int &n, int &ch) {
+    if (ch < last) {
+      ++ch;
+    } else if (n + g.TI < n_end) {
+      n += g.TI;
+      ch = 0;
+    }
+  };
+
+  // ---- prologue ----------------------------------------------------------------------------------------------
+  for (int i = tid; i < 2 * PB + 64; i += 512) P[i] = 0.f;
+  // positions 2, 6, 8..11, 14 of V are never written and never read; nothing to clear there
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_u(i, 0, 0);
+  int nL = n_first, chL = 0;
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) load_px(k, nL, chL);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) store_px(k, c * PB);
+    advance(nL, chL);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 3; ++i) read_patch(i, 0);
+  transform();
+#pragma unroll
+  for (int i = 0; i < 3; ++i) commit(i, 0);
+#pragma unroll
+  for (int k = 0; k < NR; ++k) load_px(k, nL, chL);
+  advance(nL, chL);
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NR) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- chunk: 2 NX pairs of MFMAs (NX positions x 2 k-pairs), staging slices pinned to the steps -----------------
+  //   step 0..3  U quarter by DMA;  step 0..2  patch row -> registers;  step 4  transform;  step 5..7  V writes
+  //   step 9..   pixel round s - 9 -> P;  step 10..  loads of pixel round s - 10 (three chunks ahead)
+  int c = 0;
+  auto chunk = [&](auto first_c, auto hf_c, int ch_cur) {
+    constexpr bool FIRST = decltype(first_c)::value;
+    constexpr int HF = decltype(hf_c)::value;
+    constexpr int NX = kUpNX[HF], NP = 2 * NX;
+    const int cbuf = (c & 1) * BUF;
+    const int nb = BUF - cbuf;
+    const int pb_t = ((c + 1) & 1) * PB, pb_a = (c & 1) * PB;
+    const int ch_u = ch_cur < last ? ch_cur + 1 : 0;
+    f2 av[3], bv[3];
+    const int ua = (cbuf + ub) * 4, va = (cbuf + vb) * 4;  // bytes
+    auto load_pair = [&](int slot, int p) {
+      const int imm = ((kUpPos[HF][p % NX] * 2 + p / NX) * 2 * 64 * 2) * 4;
+      av[slot] = lds_read_b64(ua, imm);
+      bv[slot] = lds_read_b64(va, imm);
+    };
+    auto slice = [&](int s) {
+      if (s < 4) dma_u(s, ch_u, nb);
+      if (s < 3) read_patch(s, pb_t);
+      if (s == 4) transform();
+      if (s >= 5 && s < 8) commit(s - 5, nb);
+      if (s >= 9 && s < 9 + NR) store_px(s - 9, pb_a);
+      if (s >= 10 && s < 10 + NR) load_px(s - 10, nL, chL);
+    };
+    load_pair(0, 0);
+    load_pair(1, 1);
+    load_pair(2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      f32x16 &ac = acc[p % NX];
+      if (FIRST && p < NX)
+        mfma_agpr_first_wait<4>(ac, av[p % 3][0], bv[p % 3][0]);
+      else if (p < NP - 2)
+        mfma_agpr_wait<4>(ac, av[p % 3][0], bv[p % 3][0]);
+      else if (p == NP - 2)
+        mfma_agpr_wait<2>(ac, av[p % 3][0], bv[p % 3][0]);
+      else
+        mfma_agpr_wait<0>(ac, av[p % 3][0], bv[p % 3][0]);
+      slice(2 * p);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_agpr(ac, av[p % 3][1], bv[p % 3][1]);
+      if (p + 3 < NP) load_pair(p % 3, p + 3);
+      slice(2 * p + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    advance(nL, chL);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    ++c;
+  };
+
+  for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
+    if (hf == 0) {
+      chunk(std::true_type{}, std::integral_constant<int, 0>{}, 0);
+      for (int ch = 1; ch <= last; ++ch) chunk(std::false_type{}, std::integral_constant<int, 0>{}, ch);
+    } else {
+      chunk(std::true_type{}, std::integral_constant<int, 1>{}, 0);
+      for (int ch = 1; ch <= last; ++ch) chunk(std::false_type{}, std::integral_constant<int, 1>{}, ch);
+    }
+    const int cbuf = ((c - 1) & 1) * BUF;
+
+    // ---- end of an item: Y = A^T M A restricted to this wave's positions; halves swapped as in the normal kernel --
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int tq = tb * 32 + (elane & 31);
+    const int per = g.TR * g.TWc;
+    const int ti = tq / per, rem = tq - ti * per;
+    const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
+    const int n = n_cur + ti;
+    const int co_base = kt * kWK + cb * 32 + 4 * (elane >> 5) + 16 * hf;
+    const size_t obase = ((size_t)min(n, a.B - 1) * a.Cout + co_base) * g.HW + (size_t)(2 * (r0 + tr)) * a.Wo + 2 * tc;
+    f2 ra[8], rb[8];
+    float addv[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int cof = (rr & 3) + 8 * (rr >> 2);
+      const size_t o = obase + (size_t)cof * g.HW;
+      ra[rr] = rb[rr] = f2{0.f, 0.f};
+      if (a.residual) {
+        ra[rr] = *reinterpret_cast<const f2 *>(a.residual + o);
+        rb[rr] = *reinterpret_cast<const f2 *>(a.residual + o + a.Wo);
+      }
+      addv[rr] = (a.bias ? a.bias[co_base + cof] : 0.f) +
+                 (a.chan_add ? a.chan_add[(size_t)min(n, a.B - 1) * a.chan_add_stride + co_base + cof] : 0.f);
+    }
+    // y[2 a + b] = sum over this wave's positions (i, j) of A^T[a][i] A^T[b][j] M_ij, coefficients in {-1, 0, 1}
+    auto partial = [&](auto hf_c, int r, float *y) {
+      constexpr int HF = decltype(hf_c)::value;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[q] = 0.f;
+#pragma unroll
+      for (int x = 0; x < kUpNX[HF]; ++x) {
+        const float m = acc[x][r];
+        const int i = kUpPos[HF][x] >> 2, j = kUpPos[HF][x] & 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cf = kAT[q >> 1][i] * kAT[q & 1][j];
+          if (cf == 1) y[q] += m;
+          if (cf == -1) y[q] -= m;
+        }
+      }
+    };
+    auto send = [&](auto hf_c) {
+      constexpr int HF = decltype(hf_c)::value;
+      float *xw = smem + cbuf + (((wave & 3) * 2 + HF) * 32) * 64 + elane;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        float y[4];
+        partial(hf_c, rr + 8 * (1 - HF), y);  // the register half the partner finishes
+#pragma unroll
+        for (int x = 0; x < 4; ++x) xw[(rr * 4 + x) * 64] = y[x];
+      }
+    };
+    if (hf == 0) send(std::integral_constant<int, 0>{});
+    else send(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    auto finish = [&](auto hf_c) {
+      constexpr int HF = decltype(hf_c)::value;
+      const float *xr = smem + cbuf + (((wave & 3) * 2 + (1 - HF)) * 32) * 64 + elane;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        float y[4], yy[4];
+        partial(hf_c, rr + 8 * HF, y);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) yy[x] = y[x] + xr[(rr * 4 + x) * 64] + addv[rr];
+        yy[0] += ra[rr][0]; yy[1] += ra[rr][1]; yy[2] += rb[rr][0]; yy[3] += rb[rr][1];
+        if (n < a.B) {
+          const size_t o = obase + (size_t)((rr & 3) + 8 * (rr >> 2)) * g.HW;
+          *reinterpret_cast<f2 *>(a.out + o) = f2{yy[0], yy[1]};
+          *reinterpret_cast<f2 *>(a.out + o + a.Wo) = f2{yy[2], yy[3]};
+        }
+      }
+    };
+    if (hf == 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   WinoGeom g;
   if (!d.w_wino || !wino_geom(d, g)) {
@@ -502,12 +797,23 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
     attr_done = true;
   }
   const int rounds = g.TI * g.NRI;
-  const kern_t kern = kerns[d.gscale ? 1 : 0][g.TI == 1 ? 1 : 0][rounds <= 4 ? 0 : rounds - 4];
+  kern_t kern = kerns[d.gscale ? 1 : 0][g.TI == 1 ? 1 : 0][rounds <= 4 ? 0 : rounds - 4];
+  if (g.up) {
+    static const kern_t up_kerns[2] = {conv_wino_up_kernel<2>, conv_wino_up_kernel<6>};
+    static bool up_attr_done = false;
+    if (!up_attr_done) {
+      for (int i = 0; i < 2; ++i)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(up_kerns[i]),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      up_attr_done = true;
+    }
+    kern = up_kerns[rounds <= 2 ? 0 : 1];
+  }
   const double M = (double)d.B * g.HW;
   // algorithmic work = the direct convolution's: 2*M*Cout*Cin*9; 16/36 of it is executed
   const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9;
   const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9);
-  const char *kname = d.gscale ? "conv3x3_wino_gn_silu" : "conv3x3_wino";
+  const char *kname = g.up ? "conv3x3_wino_up" : d.gscale ? "conv3x3_wino_gn_silu" : "conv3x3_wino";
   char kshape[160];
   if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {
     snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);

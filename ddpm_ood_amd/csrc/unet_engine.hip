@@ -294,6 +294,12 @@ extern "C" ddpm_unet *ddpm_unet_create(const ddpm_unet_config *cfg) {
         ParamSlot &ps = u->params[u->index[bp + ".upsampler.conv.conv.weight"]];
         ps.has_folded = true;
         ps.folded_base = b.up.w_folded;
+        if (const size_t nw = wino_weight_floats(out_c, out_c)) {  // Winograd on the upsampled image (9 of 16 positions)
+          b.up.has_wino = true;
+          b.up.w_wino = u->alloc(nw);
+          ps.has_wino = true;
+          ps.wino_base = b.up.w_wino;
+        }
       }
     }
     u->up.push_back(b);
@@ -421,7 +427,8 @@ struct Runner {
     d.Hi = in1.H; d.Wi = in1.W; d.Ho = Ho; d.Wo = Wo;
     d.ksize = c.ksize; d.mode = mode; d.act = act;
     if (mode == DDPM_CONV_UPSAMPLE2 && c.has_folded) d.w_folded = P(c.w_folded);
-    if (mode == DDPM_CONV_NORMAL && c.has_wino && in1.D == 1 && Do == 1) d.w_wino = P(c.w_wino);
+    if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino && in1.D == 1 && Do == 1)
+      d.w_wino = P(c.w_wino);
     if (in1.D > 1 || Do > 1) {
       if (c.ksize == 1) {
         // pointwise over a volume: the NCDHW tensor is an NCHW tensor of extent (D*H) x W

@@ -506,3 +506,37 @@ def test_conv1x1_dma(device, case):
     y = ops.conv(d(x), d(w), d(b), x2=d(x2), chan_add=d(chan_add), residual=d(residual))
     torch.cuda.synchronize()
     _close(y, ref, tol=2e-5)
+
+
+UP_WINO_CASES = [
+    # B, Cin, Cout, low-res H, bias/residual
+    (2, 256, 256, 16, False),     # the 16 -> 32 Upsample of the small UNet
+    (3, 256, 256, 8, True),       # 8 -> 16: one image per item
+    (5, 64, 128, 4, True),        # 4x4 low-res: four images per item, ragged last item
+    (1, 128, 64, 32, False),      # 32 -> 64: two tile rows per item
+    (44, 128, 128, 16, True),     # 2 x 4 x 44 = 352 items: several per persistent workgroup
+]
+
+
+@pytest.mark.parametrize("case", UP_WINO_CASES)
+def test_conv_upsample_winograd(device, case):
+    """nearest x2 + 3x3 conv on the 9 surviving Winograd positions vs F.interpolate + F.conv2d and vs the folded kernel."""
+    from ddpm_ood_amd import ops
+
+    B, Cin, Cout, H, extra = case
+    g = torch.Generator().manual_seed(B * 13 + H)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    residual = torch.randn(B, Cout, 2 * H, 2 * H, generator=g) if extra else None
+    ref = _ref_conv(x, None, w, b, None, False, 2, None, residual)
+    d = lambda t: None if t is None else t.to(device)
+    wino = ops.pack_wino_weight(d(w))
+    assert wino is not None
+    y = ops.conv(d(x), d(w), d(b), mode=ops.CONV_UPSAMPLE2, residual=d(residual), wino=wino)
+    torch.cuda.synchronize()
+    _close(y, ref, tol=4e-5)
+    if Cout % 128 == 0:
+        y_folded = ops.conv(d(x), d(w), d(b), mode=ops.CONV_UPSAMPLE2, residual=d(residual),
+                            folded=ops.fold_upsample_weight(d(w)))
+        assert (y - y_folded).abs().max().item() < 4e-5 * (1 + ref.abs().max().item())
