@@ -93,10 +93,11 @@ typedef struct ddpm_conv_desc {
    * DDPM_ACT_NONE or DDPM_ACT_RELU.  Used by the VQ-VAE residual units, relu(x + conv2(relu(conv1(x)))).  */
   int out_act;
   int reserved;
-  /* Optional, 2-D 3x3 stride-1 only: weights pre-transformed by ddpm_pack_wino_weight_f32 (U = G g G^T).
-   * When present and the shape has a Winograd tiling (even H, W; Cin % 8 == 0; Cout % 64 == 0) the conv
-   * runs as Winograd F(2x2, 3x3) on the fp32 MFMA pipe: 2.25x fewer multiplies, fp32 rounding differs
-   * from the direct form by ~1e-6 relative.                                            */
+  /* Optional, 2-D 3x3 only (DDPM_CONV_NORMAL or DDPM_CONV_UPSAMPLE2): weights pre-transformed by
+   * ddpm_pack_wino_weight_f32 (U = G g G^T).  When present and the shape has a Winograd tiling (even H, W;
+   * Cin % 8 == 0; Cout % 64 == 0) the conv runs as Winograd F(2x2, 3x3) on the fp32 MFMA pipe: 2.25x fewer
+   * multiplies (4x fewer for UPSAMPLE2, where 9 of the 16 transform positions are non-zero on a nearest-x2
+   * image); fp32 rounding differs from the direct form by ~1e-6 relative.                  */
   const float *w_wino;
 } ddpm_conv_desc;
 
