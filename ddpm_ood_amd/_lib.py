@@ -73,6 +73,7 @@ SIGNATURES = {
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int64,
                                      C.c_void_p]),
     "ddpm_clamp_mse_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "ddpm_vq_nearest_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "ddpm_lpips_conv_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 10 + [C.c_void_p]),
     "ddpm_maxpool3s2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_lpips_layer_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),

@@ -303,3 +303,21 @@ def lpips_layer(f0, f1, lin, out=None):
     check(lib.ddpm_lpips_layer_f32(ptr(f0), ptr(f1), ptr(lin), ptr(out), N, Cc, H * W, int(acc), stream_ptr()),
           "lpips_layer")
     return out
+
+
+def vq_nearest(x, codebook):
+    """VQ-VAE quantiser, eval path: (indices int64 [B, *spatial], x + (codebook[indices] - x) [B, D, *spatial])."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    e = require_device_f32(codebook, "codebook")
+    B, D = x.shape[:2]
+    S = x[0, 0].numel()
+    K = e.shape[0]
+    if e.shape[1] != D:
+        raise ValueError(f"codebook is [{K}, {e.shape[1]}] but the latent has {D} channels")
+    idx = torch.empty((B,) + tuple(x.shape[2:]), dtype=torch.int32, device=x.device)
+    out = torch.empty_like(x)
+    norms = torch.empty(K, dtype=torch.float32, device=x.device)
+    check(lib.ddpm_vq_nearest_f32(ptr(x), ptr(e), ptr(norms), idx.data_ptr(), ptr(out), B, D, S, K, stream_ptr()),
+          "vq_nearest")
+    return idx.long(), out

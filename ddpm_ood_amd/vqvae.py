@@ -117,8 +117,12 @@ class _EMAQuantizer(nn.Module):
         self.register_buffer("ema_cluster_size", torch.zeros(num_embeddings))
         self.register_buffer("ema_w", self.embedding.weight.data.clone())
 
+    _HIP_DIMS = (8, 16, 32, 64, 128)
+
     def quantize(self, x):
         """nearest code by squared L2 over channel-last flattened inputs -> indices [B, *spatial]"""
+        if x.is_cuda and x.shape[1] in self._HIP_DIMS:
+            return ops.vq_nearest(x.float().contiguous(), self.embedding.weight.detach())[0]
         shape = x.shape
         flat = x.movedim(1, -1).reshape(-1, shape[1]).float()
         e = self.embedding.weight
@@ -127,6 +131,8 @@ class _EMAQuantizer(nn.Module):
         return idx.view(shape[0], *shape[2:])
 
     def forward(self, x):
+        if x.is_cuda and x.shape[1] in self._HIP_DIMS:  # search + lookup + straight-through form in one HIP kernel
+            return ops.vq_nearest(x.float().contiguous(), self.embedding.weight.detach())[1]
         idx = self.quantize(x)
         q = self.embedding(idx).movedim(-1, 1).contiguous()
         return x + (q - x)  # straight-through form of the eval path (no gradient here)

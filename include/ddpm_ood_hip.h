@@ -159,6 +159,14 @@ int ddpm_plms_step_f32(const float *sample, const float *e0, const float *e1, co
 int ddpm_clamp_mse_f32(const float *orig, float *recon, float b_scale, float *mse, int B, int64_t chw,
                        ddpm_stream_t stream);
 
+/* VQ-VAE quantiser (EMAQuantizer.quantize + embedding lookup, eval path; reached from
+ * src/trainers/reconstruct.py:124,166 via vqvae.decode_stage_2_outputs): for every latent vector z = x[b, :, p],
+ * idx[b, p] = argmin_k |z|^2 + |e_k|^2 - 2 z.e_k (first on ties) and out[b, :, p] = z + (e_idx - z).
+ * x, out: [B, D, S] channel-first; codebook [K, D]; code_norms: K floats of scratch (|e_k|^2, rewritten every call).
+ * D in {8, 16, 32, 64, 128}.                                                                                  */
+int ddpm_vq_nearest_f32(const float *x, const float *codebook, float *code_norms, int *idx, float *out, int B, int D,
+                        int64_t S, int K, ddpm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * LPIPS-AlexNet (PerceptualLoss.forward, src/losses/perceptual_loss.py:105-186; call site
  * src/trainers/reconstruct.py:172-187).  The three 3x3 layers of AlexNet go through
