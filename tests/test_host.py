@@ -249,3 +249,17 @@ def test_nifti_ingest(tmp_path):
     (tmp_path / "ids2.csv").write_text(f"{tmp_path / 'x.png'}\n")
     with pytest.raises(NotImplementedError):
         get_data_loader(str(tmp_path / "ids2.csv"), batch_size=1)
+
+
+def test_product_code_never_imports_the_oracle():
+    """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use it."""
+    import re
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    pat = re.compile(r"^\s*(import\s+oracle\b|from\s+oracle\b)", re.M)
+    offenders = [str(p.relative_to(root)) for p in list((root / "ddpm_ood_amd").rglob("*.py")) +
+                 [root / "reconstruct.py", root / "ood_detection.py"] if pat.search(p.read_text())]
+    assert offenders == []
+    bench = (root / "bench.py").read_text()
+    assert len(pat.findall(bench)) == 1 and "def cpu_baseline_worker" in bench.split("import oracle")[0]
