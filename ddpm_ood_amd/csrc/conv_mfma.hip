@@ -87,13 +87,19 @@ static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g) {
     g.TI = MT / g.HWo;
     g.TH = d.Ho;
     g.TPI = 0;
-    g.ntiles = (g.NI + g.TI - 1) / g.TI;
   }
-  g.TPX = g.TI * g.TH * d.Wo;
   const int IC = (g.s == 2) ? (2 * d.Wo + 1) : (d.Wo + 2 * g.pad);
   g.IR = (g.s == 2) ? (2 * g.TH + 1) : (g.TH + 2 * g.pad);
   g.RS = IC;
   g.IRS = g.IR * g.RS;
+  if (g.TPI == 0) {
+    // tiny images (1x1, 2x2: the halo outweighs the pixels): cap the images per tile so that the staged
+    // plane still fits the instantiated variants (geom_ok); the tile then carries a few idle MFMA columns
+    const int max_ps = d.ksize == 1 ? 256 : (d.gscale ? 2 * 256 : 3 * 256);
+    if (g.TI * g.IRS > max_ps && max_ps / g.IRS >= 1) g.TI = max_ps / g.IRS;
+    g.ntiles = (g.NI + g.TI - 1) / g.TI;
+  }
+  g.TPX = g.TI * g.TH * d.Wo;
   g.PS = g.TI * g.IRS;
   g.nchunks = Cin / kConvCc;
   g.fold = g.up_dy = g.up_dx = 0;

@@ -429,6 +429,19 @@ struct Runner {
     if (mode == DDPM_CONV_UPSAMPLE2 && c.has_folded) d.w_folded = P(c.w_folded);
     if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino && in1.D == 1 && Do == 1)
       d.w_wino = P(c.w_wino);
+    if (c.dims == 3 && c.ksize == 3 && in1.D == 1 && Do == 1) {
+      // a 3-D convolution over a volume of depth 1 (input depth <= 2^(levels-1)): the depth taps kd = 0 and
+      // kd = 2 only ever see padding, so the op IS the 2-D convolution with the centre depth tap's weights
+      d.w_packed = P(c.w_packed) + (size_t)c.Cout * c.Cin * 9;
+      d.w_raw = nullptr;  // the torch-layout tensor has 27 taps: never hand it to a 9-tap kernel
+      if (!conv_mfma_supported(d)) {
+        set_error("unet_forward: no MFMA tiling for a depth-1 3-D convolution %d->%d at %dx%d", c.Cin, c.Cout, Ho, Wo);
+        rc = DDPM_EINVAL;
+        return;
+      }
+      rc = launch_conv_mfma(d, s);
+      return;
+    }
     if (in1.D > 1 || Do > 1) {
       if (c.ksize == 1) {
         // pointwise over a volume: the NCDHW tensor is an NCHW tensor of extent (D*H) x W
@@ -577,7 +590,7 @@ struct Runner {
         }
       }
       if (b.has_up) {
-        const int Do = h.D > 1 ? 2 * h.D : 1;
+        const int Do = cfg.spatial_dims == 3 ? 2 * h.D : 1;  // nearest x2 doubles a depth of 1 as well
         Act o = new_act(h.C, 2 * h.H, 2 * h.W, Do);
         conv(b.up, h, nullptr, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_UPSAMPLE2, nullptr, 0, nullptr, o.p, 2 * h.H,
              2 * h.W, Do);

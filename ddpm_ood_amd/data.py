@@ -5,16 +5,20 @@ The batch contract is the reference's (/root/reference/src/trainers/reconstruct.
 ``batch["image_meta_dict"]["filename_or_obj"][b]``.
 Restates the parts of /root/reference/src/data/get_train_and_val_dataloader.py the path
 relies on: one-row CSV of file paths (:10-16, the row is read as the header), ``first_n``
-truncation before the rank split (:17-18), per-image min-max ScaleIntensity to [0, 1] (:76),
-optional area resize (:55-59), v/h flip variants (:77-82), rank partition (:21-31 -- here a
-round-robin split without padding duplicates).  File formats:
+truncation before the rank split (:17-18), and the per-image ``val_transforms`` in the reference's
+order (:67-84): load, EnsureChannelFirst + ``x[0, None]`` for grayscale data (a 4-D BraTS NIfTI is
+channel-LAST on disk), CenterSpatialCrop (:61-65), area Resize (:55-59), min-max ScaleIntensity to
+[0, 1] (:76), v/h flips (:77-82) -- all BEFORE batching, so id lists whose volumes differ in native
+shape work; then the rank partition (:21-31 -- here a round-robin split without padding
+duplicates).  File formats:
 ``.npy`` (the reference's computer-vision datasets), single-file NIfTI-1 ``.nii`` / ``.nii.gz`` (its
 Medical-Decathlon volumes; read here with numpy as nibabel's ``get_fdata`` would: Fortran order,
 ``scl_slope`` / ``scl_inter`` applied, no reorientation -- what MONAI's ``LoadImage`` hands on), ``.npz``
 archives and synthetic specs.  PIL formats are not read.
 
 Synthetic id specs (no dataset can be downloaded here):
-    synthetic:<kind>[:n=N][:size=S][:channels=C][:seed=K]     kind in {blobs, noise, blobs3d, noise3d}
+    synthetic:<kind>[:n=N][:size=S][:channels=C][:seed=K][:mix=P][:name=X]
+        kind in {blobs, noise, speckle (blobs + P % uniform noise), blobs3d, noise3d}
 3-D volumes ([N, C, D, H, W]; ``.npy`` files of shape (D, H, W) or (C, D, H, W)) are handled with the
 same transforms (crop, area resize, min-max scale, flips of the first / second spatial axis).
 """
@@ -62,7 +66,9 @@ def _blobs3d(n: int, channels: int, size: int, gen: torch.Generator) -> torch.Te
     return out
 
 
-def synthetic_images(kind: str, n: int, channels: int = 1, size: int = 32, seed: int = 0) -> torch.Tensor:
+def synthetic_images(kind: str, n: int, channels: int = 1, size: int = 32, seed: int = 0, mix: int = 10) -> torch.Tensor:
+    """kind "speckle": blobs with ``mix`` percent of uniform noise blended in -- a near-distribution OOD set whose
+    AUROC against plain blobs is neither 0.5 nor saturated (used to make the AUROC checks sensitive)."""
     gen = torch.Generator().manual_seed(seed)
     if kind == "blobs3d":
         return scale_intensity(_blobs3d(n, channels, size, gen))
@@ -70,6 +76,9 @@ def synthetic_images(kind: str, n: int, channels: int = 1, size: int = 32, seed:
         return scale_intensity(torch.rand(n, channels, size, size, size, generator=gen))
     if kind == "blobs":
         x = _blobs(n, channels, size, gen)
+    elif kind == "speckle":
+        x = scale_intensity(_blobs(n, channels, size, gen))
+        x = (1 - mix / 100.0) * x + (mix / 100.0) * torch.rand(n, channels, size, size, generator=gen)
     elif kind == "noise":
         x = torch.rand(n, channels, size, size, generator=gen)
     else:
@@ -89,7 +98,7 @@ def scale_intensity(x: torch.Tensor) -> torch.Tensor:
 def _parse_spec(spec: str):
     parts = spec.split(":")
     kind = parts[1]
-    kw = {"n": 64, "size": 32, "channels": 1, "seed": 0}
+    kw = {"n": 64, "size": 32, "channels": 1, "seed": 0, "mix": 10}
     for p in parts[2:]:
         k, v = p.split("=")
         if k != "name":  # name= only labels the results file (trainer.dataset_stem)
@@ -136,14 +145,82 @@ def read_nifti(path) -> np.ndarray:
     return np.ascontiguousarray(data)
 
 
-def load_ids(ids: str, is_grayscale: bool = False, first_n=None, spatial_dimension: int = 2):
-    """-> (images fp32 [N, C, *spatial] unscaled, names list[str])."""
+def channel_first(a: torch.Tensor, path: str, is_grayscale: bool, spatial_dimension: int) -> torch.Tensor:
+    """``EnsureChannelFirstd`` + ``x[0, None]`` of the reference's grayscale pipeline
+    (/root/reference/src/data/get_train_and_val_dataloader.py:69-73), per image.
+
+    MONAI 1.2's readers decide where the channel is: a NIfTI keeps at most three spatial axes, any further
+    axis is the channel (BraTS: X x Y x Z x 4 -> channel LAST on disk); a ``.npy`` array carries no channel
+    information, so it is taken as channel-less.  Colour data (``is_grayscale=0``) gets no EnsureChannelFirst
+    in the reference: the file has to be channel-first already.  Anything else is ambiguous and raises."""
+    nifti = path.endswith((".nii", ".nii.gz"))
+    if is_grayscale:
+        if nifti and a.ndim == 4 and spatial_dimension == 3:
+            a = a.movedim(-1, 0)
+        elif a.ndim == spatial_dimension:
+            a = a[None]
+        else:
+            raise ValueError(f"{path}: array of shape {tuple(a.shape)} is ambiguous for --is_grayscale=1 "
+                             f"--spatial_dimension={spatial_dimension}: expected {spatial_dimension} spatial axes"
+                             + (" (or a 4-D NIfTI whose last axis is the modality)" if spatial_dimension == 3 else ""))
+        return a[0, None, ...]
+    if a.ndim != spatial_dimension + 1:
+        raise ValueError(f"{path}: array of shape {tuple(a.shape)} is not channel-first [C, *spatial{spatial_dimension}] "
+                         f"(--is_grayscale=0 applies no EnsureChannelFirst, as in the reference)")
+    return a
+
+
+def center_crop(a: torch.Tensor, image_roi) -> torch.Tensor:
+    """monai ``CenterSpatialCrop`` on [C, *spatial]: roi entries <= 0 keep the axis, larger-than-image entries are
+    clipped, start = size // 2 - roi // 2 (NOT (size - roi) // 2: they differ for even size / odd roi)."""
+    sp = a.shape[1:]
+    if len(image_roi) != len(sp):
+        raise ValueError(f"--image_roi {tuple(image_roi)} does not match the {len(sp)} spatial axes")
+    sl = [slice(None)]
+    for r, s in zip(image_roi, sp):
+        r = min(int(r), s) if int(r) > 0 else s
+        start = max(s // 2 - r // 2, 0)
+        sl.append(slice(start, start + r))
+    return a[tuple(sl)]
+
+
+def transform_image(a: torch.Tensor, image_roi=None, image_size=None, add_vflip=False, add_hflip=False) -> torch.Tensor:
+    """The reference's per-image ``val_transforms`` after the channel handling, in its order
+    (get_train_and_val_dataloader.py:74-82): centre crop, area resize, min-max scale to [0, 1], flips of the
+    first / second spatial axis.  a: fp32 [C, *spatial]."""
+    if image_roi:
+        a = center_crop(a, image_roi)
+    if image_size:
+        a = F.interpolate(a[None], size=(int(image_size),) * (a.ndim - 1), mode="area")[0]
+    a = scale_intensity(a[None])[0]
+    if add_vflip:
+        a = torch.flip(a, dims=(1,))
+    if add_hflip:
+        a = torch.flip(a, dims=(2,))
+    return a.contiguous()
+
+
+def read_image(path: str) -> torch.Tensor:
+    if path.endswith((".nii", ".nii.gz")):
+        return torch.from_numpy(read_nifti(path))
+    if path.endswith(".npy"):
+        return torch.from_numpy(np.load(path).astype(np.float32))
+    raise NotImplementedError(f"{path}: .npy and NIfTI-1 (.nii / .nii.gz) files are ingested; PIL formats are not")
+
+
+def load_ids(ids: str, is_grayscale: bool = False, first_n=None, spatial_dimension: int = 2, **transform):
+    """-> (images: list of transformed fp32 [C, *spatial] tensors, names list[str]).
+
+    Every image goes through the whole per-image pipeline (channel handling, crop, resize, scale, flips) BEFORE
+    anything is batched, like the reference's CacheDataset of transformed items: volumes of different native
+    shapes (the Decathlon out-sets) are fine as long as crop / resize bring them to one shape, and only the
+    transformed size is kept in memory."""
     ids = str(ids)
     if ids.startswith("synthetic:"):
         kind, kw = _parse_spec(ids)
         n = kw["n"] if not first_n else min(kw["n"], int(first_n))
-        x = synthetic_images(kind, kw["n"], kw["channels"], kw["size"], kw["seed"])[:n]
-        return x, [f"{kind}_{kw['seed']}_{i:06d}.npy" for i in range(n)]
+        x = synthetic_images(kind, kw["n"], kw["channels"], kw["size"], kw["seed"], kw["mix"])[:n]
+        return [transform_image(a, **transform) for a in x], [f"{kind}_{kw['seed']}_{i:06d}.npy" for i in range(n)]
     p = Path(ids)
     if not p.exists():
         raise FileNotFoundError(f"Cannot find id file {p}")
@@ -153,33 +230,24 @@ def load_ids(ids: str, is_grayscale: bool = False, first_n=None, spatial_dimensi
         names = [str(s) for s in z["names"]] if "names" in z else [f"{p.stem}_{i:06d}.npy" for i in range(len(x))]
         if first_n:
             x, names = x[: int(first_n)], names[: int(first_n)]
-        return x, names
+        return [transform_image(a, **transform) for a in x], names
     # reference format: a CSV whose single (header) row lists the image files
     with open(p, "r") as f:
         row = [s.strip() for s in f.readline().strip().split(",") if s.strip()]
     if first_n:
         row = row[: int(first_n)]
-    imgs = []
-    for path in row:
-        if path.endswith((".nii", ".nii.gz")):
-            a = torch.from_numpy(read_nifti(path))
-        elif path.endswith(".npy"):
-            a = torch.from_numpy(np.load(path).astype(np.float32))
-        else:
-            raise NotImplementedError(f"{path}: .npy and NIfTI-1 (.nii / .nii.gz) files are ingested; PIL formats are not")
-        if a.ndim == spatial_dimension:
-            a = a[None]
-        if is_grayscale:
-            a = a[0, None, ...]
-        imgs.append(a)
-    return torch.stack(imgs), row
+    imgs = [transform_image(channel_first(read_image(path), path, is_grayscale, spatial_dimension), **transform)
+            for path in row]
+    return imgs, row
 
 
 class ListLoader:
     """Minimal stand-in for monai ThreadDataLoader over a cached, transformed dataset."""
 
-    def __init__(self, images: torch.Tensor, names: List[str], batch_size: int, drop_last: bool = False,
+    def __init__(self, images, names: List[str], batch_size: int, drop_last: bool = False,
                  indices: List[int] = None, all_names: List[str] = None):
+        # images: one [N, C, *spatial] tensor, or a list of [C, *spatial] tensors when the transformed shapes
+        # differ (then a batch is stacked on demand and must be homogeneous, like torch's default collate)
         self.images, self.names, self.batch_size, self.drop_last = images, names, batch_size, drop_last
         self.indices = list(range(len(names))) if indices is None else list(indices)  # global image ids
         self.all_names = list(names) if all_names is None else list(all_names)
@@ -194,7 +262,13 @@ class ListLoader:
             e = min(n, s + self.batch_size)
             if self.drop_last and e - s < self.batch_size:
                 return
-            yield {"image": self.images[s:e], "image_meta_dict": {"filename_or_obj": self.names[s:e]},
+            image = self.images[s:e]
+            if isinstance(image, list):
+                if len({tuple(a.shape) for a in image}) != 1:
+                    raise RuntimeError(f"cannot batch images of different shapes {[tuple(a.shape) for a in image]}: "
+                                       "pass --image_roi / --image_size, or --batch_size=1")
+                image = torch.stack(image)
+            yield {"image": image, "image_meta_dict": {"filename_or_obj": self.names[s:e]},
                    "index": self.indices[s:e]}
 
 
@@ -206,21 +280,15 @@ def partition(n_items: int, rank: int, world: int) -> List[int]:
 def get_data_loader(ids: str, batch_size: int, first_n=None, is_grayscale: bool = False, image_size=None,
                     add_vflip: bool = False, add_hflip: bool = False, drop_last: bool = False,
                     spatial_dimension: int = 2, image_roi=None, rank: int = 0, world: int = 1) -> ListLoader:
-    x, names = load_ids(ids, is_grayscale=is_grayscale, first_n=first_n, spatial_dimension=spatial_dimension)
-    if x.ndim != 2 + spatial_dimension:
-        raise ValueError(f"--spatial_dimension={spatial_dimension} but the images are {tuple(x.shape[1:])}")
+    imgs, names = load_ids(ids, is_grayscale=is_grayscale, first_n=first_n, spatial_dimension=spatial_dimension,
+                           image_roi=image_roi, image_size=image_size, add_vflip=add_vflip, add_hflip=add_hflip)
+    for a, n in zip(imgs, names):
+        if a.ndim != 1 + spatial_dimension:
+            raise ValueError(f"--spatial_dimension={spatial_dimension} but {n} is {tuple(a.shape)}")
     print(f"Found {len(names)} subjects.")
-    if image_roi:
-        roi = [min(r, s) if r > 0 else s for r, s in zip(image_roi, x.shape[2:])]
-        sl = tuple(slice((s - r) // 2, (s - r) // 2 + r) for r, s in zip(roi, x.shape[2:]))
-        x = x[(slice(None), slice(None)) + sl]
-    if image_size:
-        x = F.interpolate(x, size=(int(image_size),) * spatial_dimension, mode="area")
-    x = scale_intensity(x)
-    if add_vflip:
-        x = torch.flip(x, dims=(2,))
-    if add_hflip:
-        x = torch.flip(x, dims=(3,))
     idx = partition(len(names), rank, world)
-    return ListLoader(x[idx].contiguous(), [names[i] for i in idx], batch_size, drop_last, indices=idx,
-                      all_names=names)
+    mine = [imgs[i] for i in idx]
+    if len({tuple(a.shape) for a in mine}) <= 1:
+        c = 1 if is_grayscale else 3
+        mine = torch.stack(mine) if mine else torch.zeros((0, c) + (0,) * spatial_dimension)
+    return ListLoader(mine, [names[i] for i in idx], batch_size, drop_last, indices=idx, all_names=names)

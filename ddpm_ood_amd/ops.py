@@ -155,7 +155,8 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
     if residual is not None:
         residual = require_device_f32(residual, "residual")
     slab = cout * C * 9
-    for i, kd in enumerate((1, 0, 2)):
+    taps = (1,) if D == 1 else (1, 0, 2)  # depth 1: the outer depth taps only ever see padding
+    for i, kd in enumerate(taps):
         d = ConvDesc()
         d.in1, d.C1 = ptr(x), C
         d.w_packed = packed.data_ptr() + 4 * kd * slab
@@ -164,11 +165,13 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
         d.B, d.Cout, d.Hi, d.Wi, d.Ho, d.Wo = B, cout, H, W, H, W
         d.ksize, d.mode, d.act = 3, CONV_NORMAL, act
         d.Di, d.Do, d.kd = D, D, kd
+        if D == 1:
+            d.w_raw = None  # 27-tap tensor: must not reach a 9-tap fallback kernel
         if i == 0:
             d.bias, d.residual = ptr(bias), ptr(residual)
         else:
             d.accumulate = 1
-        if i == 2:
+        if i == len(taps) - 1:
             d.out_act = out_act
         check(lib.ddpm_conv_f32(C_byref(d), stream_ptr()), "conv3d")
     return out

@@ -9,8 +9,10 @@ layers); CPU tensors take the plain PyTorch path below, which is what the oracle
 against.  24 MFLOP per image pair at 32x32 -- 6e-5 of a reconstruction's cost.
 
 state_dict keys follow lpips (``net.slice1.0.weight`` ... ``lins.0.model.1.weight``,
-``scaling_layer.shift/scale``) so real LPIPS weights can be loaded with ``--lpips_weights``;
-without them seeded synthetic weights are used (the trained ones need the network).
+``scaling_layer.shift/scale``) so real LPIPS weights can be loaded with ``--lpips_weights``
+(``LPIPS.load_pretrained_state_dict`` folds the package's duplicate ``linN`` aliases); without them
+seeded synthetic weights are used (the trained ones need the network) and the trainer says so loudly:
+the ``perceptual_difference`` column is then NOT an LPIPS value, only ``mse`` is meaningful.
 """
 
 from __future__ import annotations
@@ -84,6 +86,36 @@ class LPIPS(nn.Module):
         for p in self.parameters():
             p.requires_grad_(False)
         self._packed = {}  # MFMA-packed 3x3 weights, built on first device use
+        self.pretrained = False  # True once trained weights were loaded (load_pretrained_state_dict)
+
+    def load_pretrained_state_dict(self, state_dict) -> None:
+        """Load trained LPIPS-AlexNet weights saved from the real package: ``lpips.LPIPS(net="alex").state_dict()``
+        (keys ``scaling_layer.*``, ``net.sliceN.K.*``, ``lins.N.model.1.weight`` AND the duplicate aliases
+        ``linN.model.1.weight`` -- lpips 0.1.4 registers every lin layer twice), the reference's
+        ``PerceptualLoss(...).state_dict()`` (same keys under ``perceptual_function.``), or lpips' own
+        ``weights/v0.1/alex.pth`` merged with torchvision's AlexNet features.  Aliases are folded, every tensor this
+        module owns must be present with the right shape, and unknown keys raise."""
+        sd = {}
+        for k, v in state_dict.items():
+            if k.startswith("perceptual_function."):
+                k = k[len("perceptual_function."):]
+            for n in range(5):
+                if k.startswith(f"lin{n}."):
+                    k = f"lins.{n}." + k[len(f"lin{n}."):]
+            if k in sd and not torch.equal(sd[k], v):
+                raise ValueError(f"LPIPS state_dict: aliases of '{k}' disagree")
+            sd[k] = v
+        own = self.state_dict()
+        missing = sorted(set(own) - set(sd))
+        unexpected = sorted(set(sd) - set(own))
+        if missing or unexpected:
+            raise KeyError(f"LPIPS state_dict: missing {missing}, unexpected {unexpected}")
+        for k, v in sd.items():
+            if tuple(v.shape) != tuple(own[k].shape):
+                raise ValueError(f"LPIPS state_dict: {k} is {tuple(v.shape)}, expected {tuple(own[k].shape)}")
+        self.load_state_dict(sd, strict=True)
+        self._packed = {}
+        self.pretrained = True
 
     def _features_hip(self, x, normalize: bool):
         """AlexNet slices 1-5 on the HIP kernels.  The "2x - 1" of normalize=True and the ScalingLayer

@@ -111,6 +111,9 @@ class PNDMScheduler(Scheduler):
         else:
             plms = ts[::-1].copy()
         self.timesteps = torch.from_numpy(plms.astype(np.int64))  # host tensor: supports reversed(), masks, iteration
+        # the PLMS update steps by num_train_timesteps // (requested steps): the 101-entry diffusers list repeats
+        # one timestep, it does not change the ratio (diffusers keeps the requested count for it)
+        self._step_ratio = step_ratio
         self.num_inference_steps = len(self.timesteps)
         self.ets = []
         self.counter = 0
@@ -130,7 +133,7 @@ class PNDMScheduler(Scheduler):
         return (float(sample_coeff), float(a_p - a_t), float(denom), float(a_t ** 0.5), float(b_t ** 0.5))
 
     def step_plms(self, model_output: torch.Tensor, timestep: int, sample: torch.Tensor) -> torch.Tensor:
-        ratio = self.num_train_timesteps // self.num_inference_steps
+        ratio = self._step_ratio
         prev_timestep = timestep - ratio
         if self.counter != 1:
             self.ets = self.ets[-3:]

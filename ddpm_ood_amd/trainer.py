@@ -119,6 +119,11 @@ def rows_from_scores(ids, scores, counts, t_values, name_of, batch_size: int, da
 
 class BaseTrainer:
     def __init__(self, args):
+        # every rank reports a missing device / library BEFORE the non-zero ranks' output is silenced
+        if not torch.cuda.is_available():
+            raise RuntimeError("No ROCm device visible: the HIP reconstruction path has no CPU fallback "
+                               "(the CPU oracle under oracle/ is test infrastructure only)")
+        _lib.load()  # fail before any work if the native library is missing
         # initialise the process group if launched with torchrun (base.py:22-33)
         if "LOCAL_RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
             print("Setting up DDP.")
@@ -133,10 +138,6 @@ class BaseTrainer:
         else:
             self.ddp = False
             self.device = torch.device("cuda:0")
-        if not torch.cuda.is_available():
-            raise RuntimeError("No ROCm device visible: the HIP reconstruction path has no CPU fallback "
-                               "(the CPU oracle under oracle/ is test infrastructure only)")
-        _lib.load()  # fail before any work if the native library is missing
         torch.cuda.set_device(self.device)
         self.rank = dist.get_rank() if self.ddp else 0
         self.world = dist.get_world_size() if self.ddp else 1
@@ -265,7 +266,16 @@ class Reconstruct(BaseTrainer):
                                 is_fake_3d=True if self.spatial_dimension == 3 else False, lpips_normalize=True,
                                 spatial=False)
             if self.lpips_weights:
-                pl.perceptual_function.load_state_dict(torch.load(self.lpips_weights, map_location="cpu"))
+                pl.perceptual_function.load_pretrained_state_dict(
+                    torch.load(self.lpips_weights, map_location="cpu", weights_only=False))
+            elif self.rank == 0:
+                # the reference builds lpips.LPIPS(pretrained=True) (perceptual_loss.py:68-84); those weights
+                # cannot be fetched here, so say loudly that this column is not LPIPS
+                print("WARNING: no --lpips_weights given: LPIPS-AlexNet runs with SEEDED RANDOM weights, so the "
+                      "'perceptual_difference' column (and plot_target=perceptual_difference / mse+perceptual) is "
+                      "NOT an LPIPS value. Only 'mse' is comparable with the reference. Export weights on a "
+                      "machine with the lpips package: torch.save(lpips.LPIPS(net='alex').state_dict(), path).",
+                      file=sys.__stderr__, flush=True)
             self._pl = pl.to(self.device)
         return self._pl
 
@@ -350,7 +360,8 @@ class Reconstruct(BaseTrainer):
                 print(f"{self.rank}: Took {t2-t1}s for a batch size of {B}")
             else:
                 print(f"Took {t2-t1}s for a batch size of {B}")
-        self.last_stats = {"reconstructions": n_recon, "unet_forwards": n_fwd}
+        self.last_stats = {"reconstructions": n_recon, "unet_forwards": n_fwd,
+                           "lpips_pretrained": bool(pl.perceptual_function.pretrained)}
 
         if not scores_all and not self.ddp:
             return []

@@ -121,6 +121,10 @@ class PNDMScheduler(_Scheduler):
         else:
             plms = ts[::-1].copy()
         self.timesteps = torch.from_numpy(plms.astype(np.int64))
+        # MONAI-Generative re-derives num_inference_steps from the list length (a no-op for its 100-entry
+        # list); the diffusers variant keeps the REQUESTED count for the step ratio (its 101-entry list
+        # repeats one timestep), so the ratio is stored separately.
+        self._step_ratio = step_ratio
         self.num_inference_steps = len(self.timesteps)
         self.ets = []
         self.counter = 0
@@ -130,7 +134,7 @@ class PNDMScheduler(_Scheduler):
         return self.step_plms(model_output, int(timestep), sample), None
 
     def step_plms(self, model_output: torch.Tensor, timestep: int, sample: torch.Tensor) -> torch.Tensor:
-        ratio = self.num_train_timesteps // self.num_inference_steps
+        ratio = self._step_ratio
         prev_timestep = timestep - ratio
         if self.counter != 1:
             self.ets = self.ets[-3:]

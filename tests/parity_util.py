@@ -1,0 +1,91 @@
+"""Shared helpers of the workload-level parity tests (tests/test_gpu_configs.py, tests/test_gpu_unet.py).
+
+Both sides get the same images (synthetic id specs), the same weights (a checkpoint written from a seeded
+state_dict), the same per-image noise (``trainer.batch_noise``: a pure function of seed, image index and t_start)
+and the same LPIPS weights; the HIP side is the product (``Reconstruct.get_scores`` -> C ABI), the other side is
+the CPU fp32 oracle's restatement of the reference loop (/root/reference/src/trainers/reconstruct.py:72-250).
+"""
+
+from __future__ import annotations
+
+import argparse
+
+import pandas as pd
+import torch
+
+SCHED = dict(beta_schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195)
+
+
+def make_args(tmp_path, **kw):
+    d = dict(seed=2, output_dir=str(tmp_path), model_name="synth", validation_ids=None, in_ids=None, out_ids=None,
+             spatial_dimension=2, image_size=None, image_roi=None, latent_pad=None, vqvae_checkpoint=None,
+             ddpm_checkpoint_epoch=None, prediction_type="epsilon", model_type="small", b_scale=1.0, snr_shift=1,
+             simplex_noise=0, batch_size=4, augmentation=0, cache_data=1, num_workers=0, first_n_val=None,
+             first_n=None, eval_checkpoint=None, drop_last=False, is_grayscale=1, run_val=1, run_in=1, run_out=1,
+             num_inference_steps=100, inference_skip_factor=64, **SCHED)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def write_checkpoint(tmp_path, args, state_dict):
+    run = tmp_path / args.model_name
+    run.mkdir(parents=True, exist_ok=True)
+    torch.save({"epoch": 0, "global_step": 0, "model_state_dict": state_dict, "optimizer_state_dict": {},
+                "best_loss": 1000}, run / "checkpoint.pth")
+
+
+def loader_for(args, ids, **kw):
+    from ddpm_ood_amd.data import get_data_loader
+
+    return get_data_loader(ids, batch_size=args.batch_size, is_grayscale=bool(args.is_grayscale),
+                           spatial_dimension=args.spatial_dimension, image_size=args.image_size,
+                           image_roi=args.image_roi, **kw)
+
+
+def oracle_scores(args, rec, ids, name, *, model, vqvae=None, loader_kw=None):
+    """oracle.get_scores with everything that is an INPUT of the path taken from the product trainer ``rec``:
+    LPIPS weights, noise function, schedule parameters, step count."""
+    import oracle
+    from ddpm_ood_amd.trainer import batch_noise
+
+    pl = oracle.PerceptualLoss(dimensions=args.spatial_dimension, include_pixel_loss=False,
+                               is_fake_3d=args.spatial_dimension == 3, lpips_normalize=True)
+    pl.perceptual_function.load_state_dict(rec._perceptual().perceptual_function.state_dict())
+    loader = loader_for(args, ids, **(loader_kw or {}))
+    return pd.DataFrame(oracle.get_scores(
+        loader, name, args.inference_skip_factor, model=model, vqvae=vqvae or oracle.PassthroughVQVAE(),
+        perceptual=pl, spatial_dimension=args.spatial_dimension,
+        noise_fn=lambda batch, t, shape: batch_noise(args.seed, batch["index"], t, shape),
+        prediction_type=args.prediction_type, beta_schedule=args.beta_schedule, beta_start=args.beta_start,
+        beta_end=args.beta_end, b_scale=args.b_scale, snr_shift=args.snr_shift, latent_pad=args.latent_pad,
+        num_inference_steps=rec.num_inference_steps, timestep_list=rec.timestep_list))
+
+
+def hip_scores(args, rec, ids, name, loader_kw=None):
+    return pd.DataFrame(rec.get_scores(loader_for(args, ids, **(loader_kw or {})), name, args.inference_skip_factor))
+
+
+def assert_rows_close(h: pd.DataFrame, o: pd.DataFrame, rel: float, what=""):
+    assert list(h["filename"]) == list(o["filename"]) and list(h["t"]) == list(o["t"]), what
+    assert list(h["type"]) == list(o["type"]), what
+    worst = {}
+    for col in ("mse", "perceptual_difference"):
+        r = ((h[col] - o[col]).abs() / (o[col].abs() + 1e-6)).max()
+        worst[col] = float(r)
+        assert r < rel, (what, col, float(r))
+    return worst
+
+
+def assert_z_close(rows_h: dict, rows_o: dict, tol: float = 1e-4, auc_tol: float = 1e-3, plot_target="mse"):
+    """The north-star bar: per-image MSE / LPIPS Z-scores within 1e-4, AUROC within 1e-3 (BASELINE.json)."""
+    import oracle
+
+    dh, _, auc_h = oracle.z_scores_and_auroc(rows_h["val"], rows_h["in"], rows_h["out"], plot_target=plot_target)
+    do, _, auc_o = oracle.z_scores_and_auroc(rows_o["val"], rows_o["in"], rows_o["out"], plot_target=plot_target)
+    worst = 0.0
+    for col in ("z_score_mse", "z_score_perceptual_difference"):
+        err = float((dh[col] - do[col]).abs().max())
+        assert err < tol * max(1.0, float(do[col].abs().max())), (col, err)
+        worst = max(worst, err)
+    assert abs(auc_h - auc_o) <= auc_tol, (auc_h, auc_o)
+    return worst, auc_h, auc_o

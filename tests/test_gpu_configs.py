@@ -1,0 +1,310 @@
+"""-m gpu: workload-level parity for every BASELINE.json configuration, the committed golden fixtures against
+the HIP path, and the option branches of the reconstruction loop.
+
+    cfg2  FashionMNIST-shaped 32x32x1, inference_skip_factor = 4: all 25 chained t-starts (stale PLMS history
+          carried from every trajectory into the next, reference loop reconstruct.py:128-157)
+    cfg3  CIFAR-shaped 32x32x3: trajectories, 3-channel LPIPS, two OOD sets through the CLI-level scorer, with a
+          32 / 32 split whose oracle AUROC is neither 0.5-by-construction nor saturated
+    cfg4  CelebA-shaped 64x64x3 `big` UNet (attention at every level), skip factor 2, B = 2
+    cfg5  LDM path at the README VQ-VAE shape (4 stride-2 levels, 256 channels, 2 048 codes x 128;
+          /root/reference/README.md:153-158) -> 3-D `small` UNet -> re-quantise + decode -> 2.5-D LPIPS
+
+Tolerance: BASELINE.json north_star -- per-image MSE / LPIPS Z-scores within 1e-4 fp32, AUROC within 1e-3;
+raw scores are additionally held to a relative 2e-4.
+"""
+
+import json
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from parity_util import (assert_rows_close, assert_z_close, hip_scores, make_args, oracle_scores, write_checkpoint)
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+SMALL = dict(num_channels=(128, 256, 256), attention_levels=(False, False, True), num_res_blocks=1,
+             num_head_channels=256)
+
+
+def _setup(tmp_path, channels, model_type="small", spatial_dims=2, **kw):
+    import oracle
+    from ddpm_ood_amd import synthetic
+    from ddpm_ood_amd.trainer import MODEL_CONFIGS, Reconstruct
+
+    args = make_args(tmp_path, model_type=model_type, is_grayscale=int(channels == 1), spatial_dimension=spatial_dims,
+                     **kw)
+    sd = synthetic.random_state_dict(model_type, channels, spatial_dims=spatial_dims, seed=1)
+    write_checkpoint(tmp_path, args, sd)
+    rec = Reconstruct(args)
+    rec.quiet = True
+    ref = oracle.DiffusionModelUNet(spatial_dims, channels, channels, **MODEL_CONFIGS[model_type],
+                                    use_proj_attn=bool(getattr(args, "use_proj_attn", 0))).eval()
+    ref.load_state_dict(sd)
+    return args, rec, ref
+
+
+# ---- committed golden fixtures vs the HIP path (no oracle code runs here) -------------------------------------
+
+def test_golden_unet_forward_vs_hip(device):
+    """tests/golden/unet_forward.npz (x, t -> eps of the `small` UNet, seed-1 weights) against the HIP engine."""
+    from ddpm_ood_amd import DiffusionModelUNet
+    from ddpm_ood_amd.synthetic import random_state_dict
+
+    z = np.load(G / "unet_forward.npz")
+    hip = DiffusionModelUNet(2, 1, 1, **SMALL)
+    hip.load_state_dict(random_state_dict("small", 1, seed=1))
+    hip = hip.to(device).eval()
+    y = hip(torch.from_numpy(z["x"]).to(device), timesteps=torch.from_numpy(z["t"]).to(device)).cpu().numpy()
+    err = np.abs(y - z["eps"]).max()
+    assert err <= 1e-4 * (1 + np.abs(z["eps"]).max()), err
+    assert np.abs(z["eps"]).max() > 0.05
+
+
+def test_golden_ops_vs_hip(device):
+    """tests/golden/ops.npz: fused conv (GN + SiLU prologue over a virtual concat, bias, temb), nearest-x2 upsample
+    conv, stride-2 conv and attention, each through its C entry point."""
+    from ddpm_ood_amd import ops
+
+    z = {k: torch.from_numpy(v).to(device) for k, v in np.load(G / "ops.npz").items()}
+
+    def close(a, ref, tol=2e-5):
+        err = (a - ref).abs().max().item()
+        assert err <= tol * (1 + ref.abs().max().item()), err
+
+    sc, sh = ops.gn_scale_shift(z["res_x1"], z["res_gamma"], z["res_beta"], 32, 1e-6, x2=z["res_x2"])
+    y = ops.conv(z["res_x1"], z["res_w"], z["res_b"], x2=z["res_x2"], gscale=sc, gshift=sh, act=ops.ACT_SILU,
+                 chan_add=z["res_temb"])
+    close(y, z["res_y"])
+    close(ops.conv(z["up_x"], z["up_w"], z["up_b"], mode=ops.CONV_UPSAMPLE2), z["up_y"])
+    close(ops.conv(z["up_x"], z["up_w"], z["up_b"], mode=ops.CONV_STRIDE2), z["down_y"])
+    close(ops.attention(z["att_qkv"], None, 1, 1.0 / 16.0), z["att_y"])
+
+
+def test_golden_trajectory_rows_and_ood_scores_vs_hip(device, tmp_path):
+    """tests/golden/trajectory_rows.csv + ood_scores.json: 3 x 4 images, t in {10, 650}; the HIP path has to
+    reproduce the committed per-image scores, Z-scores and AUROC."""
+    import oracle  # only its pandas / sklearn scorer, on HIP-produced rows and on the committed rows
+
+    gold = pd.read_csv(G / "trajectory_rows.csv", index_col=0)
+    spec = json.load(open(G / "ood_scores.json"))
+    args, rec, _ = _setup(tmp_path, 1)
+    assert (spec["noise_seed"], spec["weight_seed"], spec["lpips_seed"]) == (args.seed, 1, 1234)
+    rows = {}
+    for name, ids in spec["specs"].items():
+        rows[name] = hip_scores(args, rec, ids, name)
+        g = gold[gold["type"] == name].reset_index(drop=True)
+        assert_rows_close(rows[name], g, 2e-4, name)
+    dh, _, auc = oracle.z_scores_and_auroc(rows["val"], rows["in"], rows["out"])
+    assert np.abs(dh["z_score_mse"].to_numpy() - np.asarray(spec["z_score_mse"])).max() < 1e-4 * max(
+        1.0, np.abs(spec["z_score_mse"]).max())
+    zp = np.asarray(spec["z_score_perceptual_difference"])
+    assert np.abs(dh["z_score_perceptual_difference"].to_numpy() - zp).max() < 1e-4 * max(1.0, np.abs(zp).max())
+    assert abs(auc - spec["auroc_mse"]) <= 1e-3
+
+
+# ---- cfg2 --------------------------------------------------------------------------------------------------------
+
+def test_cfg2_all_25_chained_t_starts(device, tmp_path):
+    """BASELINE configs[1]: inference_skip_factor = 4 -> t_start = 10, 50, ..., 970; 1 250 UNet forwards per image.
+    One scheduler per batch, so each of the 25 trajectories starts with the PLMS history the previous one left
+    behind (reconstruct.py:98-157).  val / in / out sets -> Z-scores <= 1e-4."""
+    args, rec, ref = _setup(tmp_path, 1, inference_skip_factor=4, batch_size=3)
+    sets = {"val": "synthetic:blobs:n=3:seed=10", "in": "synthetic:blobs:n=2:seed=11",
+            "out": "synthetic:speckle:n=2:seed=12:mix=10"}
+    rows_h, rows_o = {}, {}
+    for name, ids in sets.items():
+        rows_h[name] = hip_scores(args, rec, ids, name)
+        rows_o[name] = oracle_scores(args, rec, ids, name, model=ref)
+        assert sorted(set(rows_h[name]["t"])) == list(range(10, 1000, 40))
+        assert_rows_close(rows_h[name], rows_o[name], 2e-4, name)
+    assert rec.last_stats["unet_forwards"] == 2 * 1250
+    assert_z_close(rows_h, rows_o)
+
+
+# ---- cfg3 --------------------------------------------------------------------------------------------------------
+
+def test_cfg3_three_channel_two_ood_sets_and_sensitive_auroc(device, tmp_path):
+    """BASELINE configs[2]: 3-channel images (3-channel conv_in / conv_out, 3-channel LPIPS), CIFAR10-named run so
+    that ood_detection picks SVHN / CelebA (+ flips; ood_detection.py:91-135).  16 val / 32 in / 32 + 32 out
+    images: the AUROCs land strictly inside (0.2, 0.8), where one swapped pair moves them by 1e-3."""
+    import argparse
+
+    import oracle
+    from ddpm_ood_amd import ood
+
+    sets = {"val": "synthetic:blobs:n=16:channels=3:seed=10", "in": "synthetic:blobs:n=32:channels=3:seed=11",
+            "SVHN": "synthetic:speckle:n=32:channels=3:seed=13:mix=5:name=SVHN",
+            "CelebA": "synthetic:blobs:n=32:channels=3:seed=12:name=CelebA"}
+    args, rec, ref = _setup(tmp_path, 3, model_name="cifar10_synth", batch_size=32, validation_ids=sets["val"],
+                            in_ids=sets["in"], out_ids=",".join([sets["SVHN"], sets["CelebA"]]))
+    rec.reconstruct(args)  # the CLI-level driver: results_{val,in,SVHN,CelebA}.csv
+    out_dir = tmp_path / args.model_name / "ood"
+    rows_h = {n: pd.read_csv(out_dir / f"results_{n}.csv", index_col=0) for n in sets}
+    rows_o = {n: oracle_scores(args, rec, ids, "val" if n == "val" else "in" if n == "in" else "out", model=ref)
+              for n, ids in sets.items()}
+    for n in sets:
+        assert sorted(set(rows_h[n]["t"])) == [10, 650]
+        assert_rows_close(rows_h[n], rows_o[n], 2e-4, n)
+    aucs = ood.main(argparse.Namespace(output_dir=str(tmp_path), model_name=args.model_name, max_t=1000, min_t=0),
+                    out_data=("SVHN", "CelebA"))
+    for n in ("SVHN", "CelebA"):
+        hs = {"val": rows_h["val"], "in": rows_h["in"], "out": rows_h[n]}
+        os_ = {"val": rows_o["val"], "in": rows_o["in"], "out": rows_o[n]}
+        _, auc_h, auc_o = assert_z_close(hs, os_)
+        assert 0.2 < auc_o < 0.8, (n, auc_o)               # a split the check is sensitive on
+        assert abs(aucs[n] - auc_o) <= 1e-3, (n, aucs[n], auc_o)  # product scorer on product CSVs vs oracle on oracle rows
+        _, auc_hp, auc_op = assert_z_close(hs, os_, plot_target="perceptual_difference")
+        assert 0.2 < auc_op < 0.8
+
+
+# ---- cfg4 --------------------------------------------------------------------------------------------------------
+
+def test_cfg4_big_unet_trajectory(device, tmp_path):
+    """BASELINE configs[3]: `big` UNet (172.6 M parameters; attention over 4096 / 1024 / 256 tokens, 1 / 2 / 3
+    heads) at 64x64x3, inference_skip_factor = 2, B = 2.  The t-start list is shortened the only way the CLI offers
+    (--honour_num_inference_steps=1 --num_inference_steps=10 -> t_start = 100, 300, 500, 700, 900: five chained
+    trajectories, 30 UNet forwards per image) so that the CPU oracle finishes in seconds."""
+    args, rec, ref = _setup(tmp_path, 3, model_type="big", inference_skip_factor=2, batch_size=2,
+                            honour_num_inference_steps=1, num_inference_steps=10)
+    assert rec.num_inference_steps == 10
+    ids = "synthetic:blobs:n=2:channels=3:size=64:seed=31"
+    h = hip_scores(args, rec, ids, "in")
+    o = oracle_scores(args, rec, ids, "in", model=ref)
+    assert sorted(set(h["t"])) == [100, 300, 500, 700, 900]
+    assert rec.last_stats["unet_forwards"] == 2 * 30
+    assert_rows_close(h, o, 2e-4)
+
+
+# ---- cfg5 --------------------------------------------------------------------------------------------------------
+
+VQ_README = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(256, 256, 256, 256), num_res_layers=3,
+                 num_res_channels=(256, 256, 256, 256), downsample_parameters=((2, 4, 1, 1),) * 4,
+                 upsample_parameters=((2, 4, 1, 1, 0),) * 4, num_embeddings=2048, embedding_dim=128)
+
+
+@pytest.mark.parametrize("volume", [(32, 128, 128), (128, 128, 128)])
+def test_cfg5_readme_vqvae_ldm_trajectory(device, tmp_path, volume):
+    """BASELINE configs[4] at the README VQ-VAE shape.  (32, 128, 128) -> latents [128, 2, 8, 8]: the 3-D UNet's
+    lower levels have depth 1 (centre depth tap only); (128, 128, 128) -> [128, 8, 8, 8] is the
+    reference's own geometry.  encode (VQ-VAE + nearest-code search) -> PLMS trajectories at t = 10 and 650 ->
+    re-quantise + decode -> clamp, MSE, 2.5-D LPIPS over 128 slices."""
+    import oracle
+    from oracle.vqvae import VQVAE as OracleVQVAE
+    from ddpm_ood_amd import synthetic
+    from ddpm_ood_amd.data import ListLoader, synthetic_images
+    from ddpm_ood_amd.trainer import MODEL_CONFIGS, Reconstruct
+
+    torch.manual_seed(3)
+    vq = OracleVQVAE(**VQ_README).eval()
+    with torch.no_grad():  # spread the codebook so that nearest-code decisions are far from ties
+        vq.quantizer.quantizer.embedding.weight.mul_(3.0)
+    vq_dir = tmp_path / "vqvae"
+    vq_dir.mkdir()
+    torch.save({"model_state_dict": vq.state_dict()}, vq_dir / "checkpoint.pth")
+    json.dump(VQ_README, open(vq_dir / "vqvae_config.json", "w"))
+    args = make_args(tmp_path, model_name="decathlon_synth", spatial_dimension=3, batch_size=1,
+                     vqvae_checkpoint=str(vq_dir / "checkpoint.pth"), validation_ids="synthetic:blobs3d:n=1",
+                     in_ids="synthetic:blobs3d:n=1")
+    sd = synthetic.random_state_dict("small", 128, spatial_dims=3, seed=1)
+    write_checkpoint(tmp_path, args, sd)
+    rec = Reconstruct(args)
+    rec.quiet = True
+    ref = oracle.DiffusionModelUNet(3, 128, 128, **MODEL_CONFIGS["small"]).eval()
+    ref.load_state_dict(sd)
+
+    vol = synthetic_images("blobs3d", 1, 1, 128, seed=5)[:, :, : volume[0]].contiguous()
+    assert tuple(vol.shape[2:]) == volume
+    mk = lambda: ListLoader(vol, ["vol_000000.npy"], 1)  # noqa: E731
+    h = pd.DataFrame(rec.get_scores(mk(), "in", 64))
+
+    # the product's encoder really ran on the HIP kernels for this shape
+    with torch.no_grad():
+        z_h = rec.vqvae_model.encode_stage_2_inputs(vol.to(device)).cpu()
+        z_o = vq.encode_stage_2_inputs(vol)
+    assert z_h.shape == z_o.shape == (1, 128, volume[0] // 16, 8, 8)
+    assert torch.equal(rec.vqvae_model.index_quantize(vol.to(device)).cpu(), vq.index_quantize(vol))
+    assert (z_h - z_o).abs().max() < 1e-5
+
+    pl = oracle.PerceptualLoss(dimensions=3, include_pixel_loss=False, is_fake_3d=True, lpips_normalize=True)
+    pl.perceptual_function.load_state_dict(rec._perceptual().perceptual_function.state_dict())
+    from ddpm_ood_amd.trainer import batch_noise
+
+    o = pd.DataFrame(oracle.get_scores(
+        mk(), "in", 64, model=ref, vqvae=vq, perceptual=pl, spatial_dimension=3,
+        noise_fn=lambda batch, t, shape: batch_noise(2, batch["index"], t, shape),
+        beta_schedule=args.beta_schedule, beta_start=args.beta_start, beta_end=args.beta_end))
+    assert list(h["t"]) == list(o["t"]) == [10, 650]
+    assert_rows_close(h, o, 2e-4, str(volume))
+
+
+# ---- option branches of the loop ---------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case", ["latent_pad", "v_prediction", "image_size", "diffusers_list", "snr_shift_b_scale",
+                                  "reset_per_t"])
+def test_option_branches_in_a_trajectory(device, tmp_path, case):
+    """--latent_pad (reconstruct.py:125-126,160-163: 28-px images padded to the 32 the UNet wants, cropped back
+    before scoring; LPIPS then sees 28 px and takes its own zero-pad branch :171-178), prediction_type =
+    v_prediction (the v-branch of the PLMS transfer), --image_size (area resize 28 -> 32 in the loader),
+    --timestep_list=diffusers (101-entry list, ratio 10), --snr_shift / --b_scale (reconstruct.py:106-117,144,167),
+    --reset_scheduler_per_t."""
+    kw = dict(inference_skip_factor=32, batch_size=3)
+    ids = "synthetic:blobs:n=3:seed=21"
+    if case == "latent_pad":
+        kw.update(latent_pad=(2, 2, 2, 2))
+        ids = "synthetic:blobs:n=3:size=28:seed=21"
+    elif case == "v_prediction":
+        kw.update(prediction_type="v_prediction")
+    elif case == "image_size":
+        kw.update(image_size=32)
+        ids = "synthetic:blobs:n=3:size=28:seed=21"
+    elif case == "diffusers_list":
+        kw.update(timestep_list="diffusers")
+    elif case == "snr_shift_b_scale":
+        kw.update(snr_shift=0.5, b_scale=0.8)
+    elif case == "reset_per_t":
+        kw.update(reset_scheduler_per_t=1)
+    args, rec, ref = _setup(tmp_path, 1, **kw)
+    h = hip_scores(args, rec, ids, "in")
+    if case == "reset_per_t":
+        import oracle
+        from parity_util import loader_for
+        from ddpm_ood_amd.trainer import batch_noise
+
+        pl = oracle.PerceptualLoss(dimensions=2, include_pixel_loss=False, is_fake_3d=False, lpips_normalize=True)
+        pl.perceptual_function.load_state_dict(rec._perceptual().perceptual_function.state_dict())
+        o = pd.DataFrame(oracle.get_scores(
+            loader_for(args, ids), "in", 32, model=ref, vqvae=oracle.PassthroughVQVAE(), perceptual=pl,
+            noise_fn=lambda batch, t, shape: batch_noise(2, batch["index"], t, shape), reset_scheduler_per_t=True,
+            beta_schedule=args.beta_schedule, beta_start=args.beta_start, beta_end=args.beta_end))
+    else:
+        o = oracle_scores(args, rec, ids, "in", model=ref)
+    n_t = 5 if case == "diffusers_list" else 4
+    assert len(h) == 3 * n_t, sorted(set(h["t"]))
+    assert_rows_close(h, o, 2e-4, case)
+
+
+@pytest.mark.parametrize("B,D,H", [(2, 4, 8), (1, 1, 8), (2, 2, 16)])
+def test_unet_forward_3d_shallow_depth(device, B, D, H):
+    """a 3-D UNet whose activations reach depth 1 (input depth <= 2^(levels-1)).  The outer depth
+    taps then only see padding; the engine used to run such a level as a 2-D conv with the kd = 0 weights."""
+    import oracle
+    from ddpm_ood_amd import DiffusionModelUNet
+    from ddpm_ood_amd.synthetic import random_state_dict
+
+    sd = random_state_dict(channels=128, seed=1, config=SMALL, spatial_dims=3)
+    ref = oracle.DiffusionModelUNet(3, 128, 128, **SMALL).eval()
+    ref.load_state_dict(sd)
+    hip = DiffusionModelUNet(3, 128, 128, **SMALL)
+    hip.load_state_dict(sd)
+    hip = hip.to(device).eval()
+    x = torch.randn(B, 128, D, H, H, generator=torch.Generator().manual_seed(12))
+    t = torch.tensor([650, 30][:B])
+    with torch.no_grad():
+        yr = ref(x, timesteps=t)
+    yh = hip(x.to(device), timesteps=t.to(device)).cpu()
+    err = (yh - yr).abs().max().item()
+    assert err <= 1e-4 * (1 + yr.abs().max().item()), err
+    assert yr.abs().max() > 0.05

@@ -52,6 +52,16 @@ def test_product_scheduler_host_logic_equals_oracle():
     assert [int(t) for t in starts] == [10, 650]
     assert [int(s) for s in h.timesteps[h.timesteps <= starts[0]]] == [10, 0]
     h.betas = h.betas * 1.0  # assignable tables (SNR shift, reconstruct.py:106-117)
+    # --timestep_list=diffusers: 101 entries (the second timestep repeated), but the PLMS update still steps by
+    # 1000 // 100 = 10 (diffusers keeps the requested step count for the ratio), not 1000 // 101 = 9
+    for cls in (PNDMScheduler, oracle.PNDMScheduler):
+        d = cls(num_train_timesteps=1000, skip_prk_steps=True, timestep_list="diffusers", **SCHED)
+        d.set_timesteps(100)
+        assert [int(t) for t in d.timesteps[:4]] == [990, 980, 980, 970] and len(d.timesteps) == 101
+        assert d._step_ratio == 10
+    m = PNDMScheduler(num_train_timesteps=1000, skip_prk_steps=True, **SCHED)
+    m.set_timesteps(100)
+    assert m._step_ratio == 10 and len(m.timesteps) == 100
 
 
 def test_snr_shift_matches_oracle():
@@ -249,6 +259,83 @@ def test_nifti_ingest(tmp_path):
     (tmp_path / "ids2.csv").write_text(f"{tmp_path / 'x.png'}\n")
     with pytest.raises(NotImplementedError):
         get_data_loader(str(tmp_path / "ids2.csv"), batch_size=1)
+
+
+def test_ingest_follows_the_reference_transform_order(tmp_path):
+    """the Decathlon command line.  (1) BraTS NIfTI volumes are X x Y x Z x 4 -- channel LAST on
+    disk; EnsureChannelFirst + x[0, None] must pick modality 0, not slice the first spatial axis.  (2) crop / resize
+    run per image before batching, so out-sets whose volumes differ in native shape can be batched.  (3) ambiguous
+    layouts raise instead of producing 'valid' garbage.  (4) CenterSpatialCrop starts at s // 2 - r // 2."""
+    from ddpm_ood_amd.data import center_crop, get_data_loader
+
+    rng = np.random.default_rng(5)
+    brats = rng.random((12, 12, 10, 4)).astype(np.float32)
+    other = rng.random((14, 10, 9)).astype(np.float32)          # a Task0x out-set volume of another shape
+    _write_nifti(tmp_path / "brats.nii.gz", brats)
+    _write_nifti(tmp_path / "other.nii", other)
+    (tmp_path / "ids.csv").write_text(f"{tmp_path / 'brats.nii.gz'},{tmp_path / 'other.nii'}\n")
+    kw = dict(batch_size=2, is_grayscale=True, spatial_dimension=3)
+    ld = get_data_loader(str(tmp_path / "ids.csv"), image_roi=[8, 8, 8], image_size=4, **kw)
+    x = next(iter(ld))["image"]
+    assert x.shape == (2, 1, 4, 4, 4)
+    want = torch.from_numpy(brats[..., 0])[2:10, 2:10, 1:9]      # modality 0, centre crop 8^3
+    want = torch.nn.functional.interpolate(want[None, None], size=(4, 4, 4), mode="area")[0, 0]
+    want = (want - want.min()) / (want.max() - want.min())
+    assert torch.allclose(x[0, 0], want, atol=1e-6)
+    # without crop / resize the two volumes cannot share a batch -- the error says so -- but batch_size = 1 works
+    with pytest.raises(RuntimeError, match="different shapes"):
+        next(iter(get_data_loader(str(tmp_path / "ids.csv"), **kw)))
+    shapes = [tuple(b["image"].shape) for b in get_data_loader(str(tmp_path / "ids.csv"), **{**kw, "batch_size": 1})]
+    assert shapes == [(1, 1, 12, 12, 10), (1, 1, 14, 10, 9)]
+    # ambiguous layouts
+    np.save(tmp_path / "chw.npy", rng.random((4, 12, 12, 10)).astype(np.float32))
+    (tmp_path / "amb.csv").write_text(f"{tmp_path / 'chw.npy'}\n")
+    with pytest.raises(ValueError, match="ambiguous"):
+        get_data_loader(str(tmp_path / "amb.csv"), **kw)
+    np.save(tmp_path / "hw.npy", rng.random((8, 8)).astype(np.float32))
+    (tmp_path / "rgb.csv").write_text(f"{tmp_path / 'hw.npy'}\n")
+    with pytest.raises(ValueError, match="channel-first"):
+        get_data_loader(str(tmp_path / "rgb.csv"), batch_size=1, is_grayscale=False)
+    np.save(tmp_path / "rgb.npy", rng.integers(0, 255, (3, 8, 8), dtype=np.uint8))   # the reference's CIFAR layout
+    (tmp_path / "rgb2.csv").write_text(f"{tmp_path / 'rgb.npy'}\n")
+    assert next(iter(get_data_loader(str(tmp_path / "rgb2.csv"), batch_size=1)))["image"].shape == (1, 3, 8, 8)
+    # monai CenterSpatialCrop: even size, odd roi -> [1, 4), not [0, 3)
+    a = torch.arange(4.0).reshape(1, 4, 1)
+    assert center_crop(a, (3, -1)).flatten().tolist() == [1.0, 2.0, 3.0]
+    assert center_crop(a, (9, 1)).shape == (1, 4, 1)
+
+
+def test_lpips_loads_a_state_dict_shaped_like_the_real_package():
+    """lpips 0.1.4 registers each lin layer twice (lin0 ... lin4 AND lins.0 ... lins.4), so
+    ``lpips.LPIPS(net="alex").state_dict()`` carries duplicate keys; the reference's PerceptualLoss prefixes
+    everything with ``perceptual_function.``.  Both must load; missing / unknown / disagreeing keys must raise."""
+    from ddpm_ood_amd.perceptual import LPIPS
+
+    src = LPIPS(seed=7)
+    real = {}
+    for k, v in src.state_dict().items():
+        real[k] = v.clone()
+        if k.startswith("lins."):
+            n = k.split(".")[1]
+            real[f"lin{n}." + k.split(".", 2)[2]] = v.clone()
+    assert len(real) == len(src.state_dict()) + 5 and "lin3.model.1.weight" in real
+    dst = LPIPS(seed=1)
+    assert not dst.pretrained
+    dst.load_pretrained_state_dict(real)
+    assert dst.pretrained and all(torch.equal(a, b) for a, b in zip(dst.state_dict().values(), src.state_dict().values()))
+    dst2 = LPIPS(seed=2)
+    dst2.load_pretrained_state_dict({"perceptual_function." + k: v for k, v in real.items()})
+    assert torch.equal(dst2.lins[4].model[1].weight, src.lins[4].model[1].weight)
+    only_alias = {k: v for k, v in real.items() if not k.startswith("lins.")}  # lpips' own alex.pth naming
+    LPIPS(seed=3).load_pretrained_state_dict(only_alias)
+    bad = dict(real)
+    bad["lin2.model.1.weight"] = bad["lin2.model.1.weight"] + 1
+    with pytest.raises(ValueError, match="disagree"):
+        LPIPS().load_pretrained_state_dict(bad)
+    with pytest.raises(KeyError, match="missing"):
+        LPIPS().load_pretrained_state_dict({k: v for k, v in real.items() if "slice3" not in k})
+    with pytest.raises(KeyError, match="unexpected"):
+        LPIPS().load_pretrained_state_dict({**real, "net.slice6.0.weight": torch.zeros(1)})
 
 
 def test_product_code_never_imports_the_oracle():
