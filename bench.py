@@ -1,22 +1,34 @@
 """bench.py -- reconstructions/sec of the multi-t DDPM reconstruction hot path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): FashionMNIST-shaped 32x32x1 synthetic images, `small`
-UNet with seeded random weights, 100 PLMS timesteps, inference_skip_factor=4 -> 25 t-starts,
-1 250 UNet forwards per image, batch 256 per GPU.  One "step" = one batch of 256 images per
-rank through the whole hot path (noise, add_noise, every PLMS trajectory, clamp + MSE, LPIPS,
-score gather) = 6 400 reconstructions per rank, inputs resident in HBM when timing starts.
-Weak scaling: every rank gets its own 256-image shard of a 256*N-image set; the only
-collective is the per-step all_gather of the dense score tensor (RCCL).
+Default workload (BASELINE.json configs[1], the configuration the metric is quoted on): FashionMNIST-shaped
+32x32x1 synthetic images, `small` UNet with seeded random weights, 100 PLMS timesteps, inference_skip_factor=4
+-> 25 t-starts, 1 250 UNet forwards per image, batch 256 per GPU.  One "step" = one batch of 256 images per
+rank through the whole hot path (noise, add_noise, every PLMS trajectory, clamp + MSE, LPIPS, score gather)
+= 6 400 reconstructions per rank, inputs resident in HBM when timing starts.
 
-One JSON line on rank 0.  `roofline` = the dominant kernel (the 3x3 conv with the GroupNorm+SiLU
-prologue, Winograd F(2x2,3x3) on fp32 MFMA): algorithmic FLOPs / hipEvent-measured launch time, sampled in situ
-(first UNet step of each of the 25 t-starts of the LAST timed step), against the 157.3 TFLOP/s
-dense f32 MFMA peak.  `cpu_baseline` = the CPU oracle timed on this box's host cores on a
-bounded sample of the same workload (rank 0, N = 1 only).
+--scaling weak   (default) every rank gets its own 256-image shard of a 256*N-image set per step.
+--scaling strong a fixed --images set (default 2048 = 8 batches of 256) is split round-robin over the N
+                 ranks; a step is one pass over the whole set, so the work per step does not grow with N.
+The only collective is the per-step all_gather of the dense score tensor (RCCL).
+
+--config selects the other BASELINE configurations (same metric, their own `roofline`):
+    cfg3  32x32x3 `small`                       (batch 256, k = 4)
+    cfg4  64x64x3 `big` attention-heavy UNet    (batch 8,   k = 2: 50 t-starts, 2 550 forwards per image)
+    cfg5  128^3 volumes, README VQ-VAE (4 x stride 2, 256 ch, 2 048 codes) -> [128, 8, 8, 8] latents -> 3-D
+          `small` UNet -> re-quantise + decode -> 2.5-D LPIPS  (batch 2, k = 4)
+
+One JSON line on rank 0.  `roofline` describes the kernel class with the most time in the sampled launches
+(first UNet step -- and, for the LDM, the decode -- of each t-start of the LAST timed step, hipEvent-bracketed on
+the launch stream by the library): `achieved` = MFMA FLOPs actually EXECUTED per launch / launch time, `frac`
+= achieved / the 157.3 TFLOP/s dense f32 MFMA peak.  Winograd kernels execute 16/36 (9/36 for the upsample
+form) of the direct convolution's multiplies: the direct-conv-equivalent rate is reported separately as
+`algorithmic_equiv_tflops` and is NOT a roofline fraction.  `rooflines` lists every MFMA kernel class the same
+way (cfg4: the attention kernel; cfg5: the 3-D convolutions).  `cpu_baseline` = the CPU oracle timed on this
+box's host cores on a bounded sample of the same workload (rank 0, N = 1, default config only).
 """
 
 import argparse
@@ -37,20 +49,52 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
-BATCH = 256
-SKIP = 4
+HBM_PEAK_GBPS = 8000.0
 SCHED = dict(beta_schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195)
 
+VQ_README = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(256, 256, 256, 256), num_res_layers=3,
+                 num_res_channels=(256, 256, 256, 256), downsample_parameters=((2, 4, 1, 1),) * 4,
+                 upsample_parameters=((2, 4, 1, 1, 0),) * 4, num_embeddings=2048, embedding_dim=128)
 
-def make_args(run_root, n_images, batch):
-    ids = f"synthetic:blobs:n={n_images}:seed=0"
+CONFIGS = {
+    "cfg2": dict(model_type="small", channels=1, size=32, spatial=2, skip=4, batch=256, metric_tag="FashionMNIST 32x32",
+                 workload="BASELINE configs[1]: FashionMNIST-shaped 32x32x1, small UNet (17.7M params, random init), "
+                          "100 PLMS timesteps, inference_skip_factor=4 (25 t-starts, 1250 UNet forwards per image)"),
+    "cfg3": dict(model_type="small", channels=3, size=32, spatial=2, skip=4, batch=256, metric_tag="CIFAR10 32x32x3",
+                 workload="BASELINE configs[2]: CIFAR10-shaped 32x32x3, small UNet, 100 PLMS timesteps, "
+                          "inference_skip_factor=4 (25 t-starts, 1250 UNet forwards per image)"),
+    "cfg4": dict(model_type="big", channels=3, size=64, spatial=2, skip=2, batch=8, metric_tag="CelebA 64x64x3 big UNet",
+                 workload="BASELINE configs[3]: CelebA-shaped 64x64x3, big attention-heavy UNet (172.6M params, "
+                          "attention over 4096/1024/256 tokens), 100 PLMS timesteps, inference_skip_factor=2 "
+                          "(50 t-starts, 2550 UNet forwards per image)"),
+    "cfg5": dict(model_type="small", channels=1, size=128, spatial=3, skip=4, batch=2, vqvae=VQ_README,
+                 metric_tag="Decathlon-shaped 128^3 LDM",
+                 workload="BASELINE configs[4]: 128^3 volumes, README VQ-VAE (4 stride-2 levels, 256 ch, 2048 codes x "
+                          "128) -> [128,8,8,8] latents, small 3-D UNet (47.5M params), 100 PLMS timesteps, "
+                          "inference_skip_factor=4 (25 t-starts: 1250 UNet forwards + 25 re-quantise/decodes + 25 "
+                          "2.5-D LPIPS over 128 slices per volume)"),
+}
+
+
+def make_args(run_root, cfg, n_images, batch):
+    kind = "blobs3d" if cfg["spatial"] == 3 else "blobs"
+    ids = f"synthetic:{kind}:n={n_images}:size={cfg['size']}:channels={cfg['channels']}:seed=0"
     return argparse.Namespace(
-        seed=2, output_dir=str(run_root), model_name="fashionmnist_synthetic", validation_ids=ids, in_ids=ids,
-        out_ids=ids, spatial_dimension=2, image_size=None, image_roi=None, latent_pad=None, vqvae_checkpoint=None,
-        ddpm_checkpoint_epoch=None, prediction_type="epsilon", model_type="small", b_scale=1.0, snr_shift=1,
-        simplex_noise=0, batch_size=batch, augmentation=0, cache_data=1, num_workers=0, first_n_val=None, first_n=None,
-        eval_checkpoint=None, drop_last=False, is_grayscale=1, run_val=1, run_in=0, run_out=0,
-        num_inference_steps=100, inference_skip_factor=SKIP, **SCHED)
+        seed=2, output_dir=str(run_root), model_name="bench_synthetic", validation_ids=ids, in_ids=ids,
+        out_ids=ids, spatial_dimension=cfg["spatial"], image_size=None, image_roi=None, latent_pad=None,
+        vqvae_checkpoint=None, ddpm_checkpoint_epoch=None, prediction_type="epsilon", model_type=cfg["model_type"],
+        b_scale=1.0, snr_shift=1, simplex_noise=0, batch_size=batch, augmentation=0, cache_data=1, num_workers=0,
+        first_n_val=None, first_n=None, eval_checkpoint=None, drop_last=False, is_grayscale=int(cfg["channels"] == 1),
+        run_val=1, run_in=0, run_out=0, num_inference_steps=100, inference_skip_factor=cfg["skip"], **SCHED)
+
+
+def shard_sizes(scaling: str, world: int, batch: int, images: int):
+    """(total images per step, images of each rank) -- pure bookkeeping, tested on CPU (tests/test_dist_gloo.py)."""
+    if scaling == "weak":
+        return batch * world, [batch] * world
+    from ddpm_ood_amd.data import partition
+
+    return images, [len(partition(images, r, world)) for r in range(world)]
 
 
 def cpu_baseline_worker():
@@ -82,7 +126,7 @@ def cpu_baseline_worker():
                                 "oracle incl. LPIPS + MSE"}))
 
 
-def cpu_baseline(_state_dict=None):
+def cpu_baseline():
     """Oracle timing in a subprocess with a bounded thread count and a hard timeout: on the GPU
     box an OpenMP pool as wide as its 256 logical CPUs made these small convolutions crawl
     (> 8 min); min(cpu_count, 32) threads is what is used and reported as `cores`."""
@@ -99,40 +143,59 @@ def cpu_baseline(_state_dict=None):
                 "sample": f"failed: {type(e).__name__}: {e}"[:300]}
 
 
-# kernels the roofline object may describe: profiler key -> (label, executed / algorithmic MFMA FLOPs)
-ROOFLINE_KERNELS = {
-    "conv3x3_wino_gn_silu": ("conv_wino_kernel<true, NR, ONEIMG> (3x3 conv as Winograd F(2x2,3x3), persistent: items of "
-                             "64 couts x 64 tiles, GN+SiLU prologue, fp32 MFMA)", 16.0 / 36.0),
-    "conv3x3_mfma_gn_silu": ("conv_mfma_kernel<9,1,true,128> (3x3 conv, 128x128 tile, GN+SiLU prologue, fp32 MFMA)", 1.0),
-}
+# MFMA kernel classes by profiler-key prefix -> (description, executed / algorithmic MFMA FLOPs).
+# Longest prefix wins.  The library counts `flops` as the ALGORITHMIC (direct-form) work of the op.
+MFMA_KERNELS = [
+    ("conv3x3_wino_up", "conv_wino_up_kernel: nearest-x2 + 3x3 conv in the Winograd domain (9 of 16 positions), fp32 MFMA", 9.0 / 36.0),
+    ("conv3x3_wino", "conv_wino_kernel: 3x3 conv as Winograd F(2x2,3x3), persistent, GN+SiLU prologue, fp32 MFMA", 16.0 / 36.0),
+    ("conv3x3_mfma_up_folded", "conv_mfma_kernel<4>: nearest-x2 + 3x3 conv folded into four 2x2-tap convs, fp32 MFMA", 16.0 / 36.0),
+    ("conv3d_", "conv_mfma_kernel: 3-D convolution (depth taps merged into one chunk stream), fp32 MFMA", 1.0),
+    ("conv3x3_mfma", "conv_mfma_kernel<9>: direct 3x3 conv (stride 2, ragged extents, 3-D depth-tap launches), fp32 MFMA", 1.0),
+    ("conv1x1_dma", "conv1x1_dma_kernel: LDS-DMA-fed 1x1 conv, fp32 MFMA", 1.0),
+    ("conv1x1_mfma", "conv_mfma_kernel<1>: 1x1 conv / Linear (fused QKV, time MLP), fp32 MFMA", 1.0),
+    ("attention", "attention_kernel: QK^T, online softmax, AV (+ residual), fp32 MFMA", 1.0),
+]
 
 
-def roofline_of(prof):
-    """The dominant kernel = the profiler class with the most time in the sampled UNet steps.
-    `achieved` is ALGORITHMIC: the direct convolution's 2*9*Cin*Cout*pixels per launch
-    over the hipEvent launch time, so with the Winograd kernel (which executes 16/36 of those
-    multiplies) it may exceed what a direct convolution could reach; `mfma_executed_*` is the rate
-    of MFMA work actually issued, the number to read against the 157.3 TFLOP/s pipe."""
-    cands = [(v["ms"], k) for k, v in prof.items() if k in ROOFLINE_KERNELS and v["ms"] > 0]
-    if not cands:
-        return None
-    _, key = max(cands)
-    dom = prof[key]
-    label, executed = ROOFLINE_KERNELS[key]
-    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": label, "profile_key": key,
-                "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                "mfma_executed_tflops": round(achieved * executed, 2),
-                "mfma_executed_frac": round(achieved * executed / F32_MFMA_PEAK_TFLOPS, 4),
-                "launches_timed": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                "flops_per_launch": dom["flops"] / dom["launches"],
-                "algorithmic_GBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
-                "traffic": None}
-    pmc = ROOT / "profiles" / "pmc_traffic.json"  # written from a separate rocprofv3 --pmc pass, if any
-    if pmc.exists():
-        roofline["traffic"] = json.load(open(pmc)).get(key + "_bytes_per_launch")
-    return roofline
+def mfma_class(key):
+    for prefix, label, ratio in MFMA_KERNELS:
+        if key.startswith(prefix):
+            return prefix, label, ratio
+    return None
+
+
+def rooflines_of(prof):
+    """Aggregate the in-situ profile by MFMA kernel class.  Per class: executed-MFMA TFLOP/s against the f32 MFMA
+    peak (`frac`), the direct-conv-equivalent rate where the kernel executes fewer multiplies than the op it
+    replaces, and the algorithmic HBM rate."""
+    agg = {}
+    for key, v in prof.items():
+        cls = mfma_class(key)
+        if cls is None or v["ms"] <= 0:
+            continue
+        prefix, label, ratio = cls
+        a = agg.setdefault(prefix, {"label": label, "ratio": ratio, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        a["ms"] += v["ms"]; a["flops"] += v["flops"]; a["bytes"] += v["bytes"]; a["launches"] += v["launches"]
+    out = {}
+    pmc_path = ROOT / "profiles" / "pmc_traffic.json"  # builder-side rocprofv3 --pmc pass (tools/pmc_collect.sh)
+    pmc = json.load(open(pmc_path)) if pmc_path.exists() else {}
+    for prefix, a in agg.items():
+        alg = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        ex = alg * a["ratio"]
+        r = {"bound": "mfma", "kernel": a["label"], "profile_key": prefix, "achieved": round(ex, 2),
+             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ex / F32_MFMA_PEAK_TFLOPS, 4),
+             "executed_over_algorithmic_flops": round(a["ratio"], 4),
+             "algorithmic_equiv_tflops": round(alg, 2), "launches_timed": a["launches"],
+             "avg_launch_ms": round(a["ms"] / a["launches"], 4), "ms_in_sample": round(a["ms"], 3),
+             "flops_per_launch": a["flops"] / a["launches"],
+             "algorithmic_GBps": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1), "traffic": None}
+        for k in (prefix + "_gn_silu", prefix):
+            if k + "_bytes_per_launch" in pmc:
+                r["traffic"] = pmc[k + "_bytes_per_launch"]
+                r["traffic_source"] = "profiles/pmc_traffic.json (builder-side rocprofv3 --pmc pass, not this run)"
+                break
+        out[prefix] = r
+    return out
 
 
 _T0 = time.perf_counter()
@@ -144,17 +207,38 @@ def log(msg):
         print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def write_vqvae(run_root, cfg):
+    """Random-init VQ-VAE of the README shape (product class, CPU init), codebook spread so codes are used."""
+    from ddpm_ood_amd.vqvae import VQVAE
+
+    torch.manual_seed(3)
+    vq = VQVAE(**cfg).eval()
+    with torch.no_grad():
+        vq.quantizer.quantizer.embedding.weight.mul_(3.0)
+    d = run_root / "vqvae"
+    d.mkdir(parents=True, exist_ok=True)
+    torch.save({"model_state_dict": vq.state_dict()}, d / "checkpoint.pth")
+    json.dump(cfg, open(d / "vqvae_config.json", "w"))
+    return str(d / "checkpoint.pth")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step (256 = the reference default)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per batch (default: the config's)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--images", type=int, default=None,
+                    help="--scaling strong: size of the fixed image set (default 8 batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
         return cpu_baseline_worker()
+    cfg = CONFIGS[a.config]
+    batch = a.batch or cfg["batch"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -175,24 +259,34 @@ def main():
     from ddpm_ood_amd.trainer import Reconstruct
 
     lib = _lib.load()
+    n_images, per_rank = shard_sizes(a.scaling, world, batch, a.images or 8 * batch)
     run_root = Path(tempfile.mkdtemp(prefix=f"ddpm_bench_r{rank}_"))
-    args = make_args(run_root, a.batch * world, a.batch)
-    sd = synthetic.write_checkpoint(run_root / args.model_name, "small", 1, seed=1)
+    args = make_args(run_root, cfg, n_images, batch)
+    ddpm_channels = cfg["vqvae"]["embedding_dim"] if cfg.get("vqvae") else cfg["channels"]
+    sd = synthetic.random_state_dict(cfg["model_type"], ddpm_channels, spatial_dims=cfg["spatial"], seed=1)
+    (run_root / args.model_name).mkdir(parents=True)
+    torch.save({"epoch": 0, "global_step": 0, "model_state_dict": sd, "optimizer_state_dict": {}, "best_loss": 1000},
+               run_root / args.model_name / "checkpoint.pth")
+    del sd
+    if cfg.get("vqvae"):
+        args.vqvae_checkpoint = write_vqvae(run_root, cfg["vqvae"])
     out_stream = sys.stdout
     sys.stdout = open(os.devnull, "w")  # the trainer prints like the reference; keep stdout to ONE JSON line
     try:
         rec = Reconstruct(args)
         rec.quiet = True
-        loader = get_data_loader(args.validation_ids, batch_size=a.batch, is_grayscale=True, rank=rank, world=world)
+        loader = get_data_loader(args.validation_ids, batch_size=batch, is_grayscale=bool(args.is_grayscale),
+                                 spatial_dimension=cfg["spatial"], rank=rank, world=world)
+        assert len(loader.names) == per_rank[rank]
         loader.images = loader.images.to(rec.device)  # inputs resident in HBM before timing starts
 
         def step(profile=False):
             rec.profile_first_steps = profile
-            rows = rec.get_scores(loader, "val", SKIP)
+            rows = rec.get_scores(loader, "val", cfg["skip"])
             rec.profile_first_steps = False
             return rows
 
-        log(f"setup done (model on device, {a.batch} images resident)")
+        log(f"setup done ({a.config}: model on device, {per_rank[rank]} images resident on rank 0)")
         for i in range(a.warmup):
             step()
             log(f"warmup step {i} done")
@@ -215,32 +309,37 @@ def main():
         sys.stdout = out_stream
 
     n_t = len({r["t"] for r in rows})
-    recon_per_step = a.batch * world * n_t
+    assert len(rows) == n_images * n_t, (len(rows), n_images, n_t)  # every rank's scores came back through the gather
+    recon_per_step = n_images * n_t
     value = recon_per_step * a.steps / dt
 
     buf = ctypes.create_string_buffer(1 << 16)
     n = lib.ddpm_prof_report(buf, len(buf))
     prof = json.loads(buf.value.decode()) if n > 0 else {}
-    roofline = roofline_of(prof)
+    rooflines = rooflines_of(prof)
+    dominant = max(rooflines.values(), key=lambda r: r["ms_in_sample"]) if rooflines else None
 
     line = {
-        "metric": "reconstructions/sec (whole node), FashionMNIST 32x32", "value": round(value, 3),
+        "metric": f"reconstructions/sec (whole node), {cfg['metric_tag']}", "value": round(value, 3),
         "unit": "reconstructions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: FashionMNIST-shaped 32x32x1, small UNet (17.7M params, random "
-                               "init), 100 PLMS timesteps, inference_skip_factor=4 (25 t-starts, 1250 UNet forwards "
-                               "per image)",
-                   "images_per_gpu_per_step": a.batch, "reconstructions_per_step": recon_per_step,
-                   "unet_forwards_per_image": rec.last_stats["unet_forwards"] // a.batch, "sharding": f"images x{world}"},
-        "roofline": roofline,
+        "config": {"workload": cfg["workload"], "name": a.config, "images_per_gpu_per_batch": batch,
+                   "images_per_step": n_images, "reconstructions_per_step": recon_per_step,
+                   "unet_forwards_per_image": rec.last_stats["unet_forwards"] // max(per_rank[rank], 1),
+                   "sharding": f"images x{world} ({a.scaling})",
+                   "lpips_weights": "pretrained" if rec.last_stats.get("lpips_pretrained") else "seeded random"},
+        "roofline": dominant,
+        "rooflines": {k: {kk: r[kk] for kk in ("achieved", "frac", "algorithmic_equiv_tflops", "avg_launch_ms",
+                                                "launches_timed", "ms_in_sample", "algorithmic_GBps")}
+                      for k, r in rooflines.items()},
         "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                         "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
                         "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
                     for k, v in prof.items()},
     }
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(sd)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
+        line["cpu_baseline"] = cpu_baseline()
         log(f"cpu baseline done: {line['cpu_baseline']}")
     if world > 1:
         dist.barrier()

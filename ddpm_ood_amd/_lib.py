@@ -14,6 +14,7 @@ import torch
 
 _LIB = None
 LIB_NAME = "libddpm_ood_hip.so"
+ABI_VERSION = 2
 
 
 class HipLibraryMissing(RuntimeError):
@@ -30,7 +31,7 @@ class ConvDesc(C.Structure):
         ("B", C.c_int), ("Cout", C.c_int),
         ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
         ("ksize", C.c_int), ("mode", C.c_int), ("act", C.c_int), ("force_direct", C.c_int),
-        ("Di", C.c_int), ("Do", C.c_int), ("kd", C.c_int), ("accumulate", C.c_int),
+        ("Di", C.c_int), ("Do", C.c_int), ("dims", C.c_int), ("reserved0", C.c_int),
         ("w_folded", C.c_void_p), ("out_act", C.c_int), ("reserved", C.c_int), ("w_wino", C.c_void_p),
     ]
 
@@ -58,6 +59,11 @@ SIGNATURES = {
                                             C.c_void_p]),
     "ddpm_pack_conv_weight_taps_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_void_p]),
+    "ddpm_pack_conv3d_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_packed_convtr_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ddpm_pack_convtr_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_conv3d_k4s2_cin1_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
+    "ddpm_convtr3d_k4s2_cout1_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "ddpm_wino_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_wino_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_folded_upsample_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
@@ -116,8 +122,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.ddpm_abi_version() != 1:
-        raise HipLibraryMissing(f"{p}: ABI version {lib.ddpm_abi_version()} != 1")
+    if lib.ddpm_abi_version() != ABI_VERSION:
+        raise HipLibraryMissing(f"{p}: ABI version {lib.ddpm_abi_version()} != {ABI_VERSION}")
     _LIB = lib
     return lib
 

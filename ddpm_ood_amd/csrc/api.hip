@@ -104,6 +104,38 @@ extern "C" int ddpm_pack_conv_weight_taps_f32(const float *w_raw, float *w_packe
   return launch_pack_conv_weight(w_raw, w_packed, Cout, Cin, ksize, 0, Cout, as_stream(stream), src_taps, tap_off);
 }
 
+extern "C" int ddpm_pack_conv3d_weight_f32(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize,
+                                           ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(w_raw && w_packed && (ksize == 3 || ksize == 4), "pack_conv3d: NULL pointer or ksize not 3 / 4");
+  const size_t slab = (size_t)Cout * Cin * ksize * ksize;
+  for (int kd = 0; kd < ksize; ++kd) {
+    const int rc = launch_pack_conv_weight(w_raw, w_packed + kd * slab, Cout, Cin, ksize, 0, Cout, as_stream(stream),
+                                           ksize * ksize * ksize, ksize * ksize * kd);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" size_t ddpm_packed_convtr_weight_floats(int Cout, int Cin, int dims) {
+  return packed_convT_weight_floats(Cout, Cin, dims);
+}
+
+extern "C" int ddpm_pack_convtr_weight_f32(const float *w_raw, float *w_packed, int Cin, int Cout, int dims,
+                                          ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(w_raw && w_packed, "pack_convT: NULL pointer");
+  return launch_pack_convT_weight(w_raw, w_packed, Cin, Cout, dims, as_stream(stream));
+}
+
+extern "C" int ddpm_conv3d_k4s2_cin1_f32(const float *in, const float *w, const float *bias, float *out, int B,
+                                         int Cout, int D, int H, int W, int relu, ddpm_stream_t stream) {
+  return launch_conv3d_k4s2_cin1(in, w, bias, out, B, Cout, D, H, W, relu, as_stream(stream));
+}
+
+extern "C" int ddpm_convtr3d_k4s2_cout1_f32(const float *in, const float *w, const float *bias, float *out, int B,
+                                           int Cin, int D, int H, int W, ddpm_stream_t stream) {
+  return launch_convT3d_k4s2_cout1(in, w, bias, out, B, Cin, D, H, W, as_stream(stream));
+}
+
 extern "C" size_t ddpm_wino_weight_floats(int Cout, int Cin) { return wino_weight_floats(Cout, Cin); }
 
 extern "C" int ddpm_pack_wino_weight_f32(const float *w_raw, float *w_wino, int Cout, int Cin, ddpm_stream_t stream) {

@@ -91,6 +91,12 @@ int launch_pack_wino_weight(const float *w_raw, float *w_wino, int Cout, int Cin
 int launch_fold_upsample_weight(const float *w_raw, float *w_folded, int Cout, int Cin, hipStream_t s);
 int launch_pack_conv_weight(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize, int cout_offset,
                             int Cout_total, hipStream_t s, int src_taps = 0, int tap_off = 0);
+size_t packed_convT_weight_floats(int Cout, int Cin, int dims);
+int launch_pack_convT_weight(const float *w_raw, float *w_packed, int Cin, int Cout, int dims, hipStream_t s);
+int launch_conv3d_k4s2_cin1(const float *in, const float *w, const float *bias, float *out, int B, int Cout, int D,
+                            int H, int W, int relu, hipStream_t s);
+int launch_convT3d_k4s2_cout1(const float *in, const float *w, const float *bias, float *out, int B, int Cin, int D,
+                              int H, int W, hipStream_t s);
 int launch_gn_scale_shift(const float *in1, const float *in2, int C1, int C2, const float *gamma, const float *beta,
                           float *scale, float *shift, int B, int HW, int groups, float eps, hipStream_t s);
 int launch_attention(const float *qkv, const float *residual, float *out, int B, int C, int N, int heads, float scale,

@@ -34,7 +34,7 @@ bool conv1x1_dma_supported(const ddpm_conv_desc &d) {
   const long HW = (long)d.Ho * d.Wo;
   if (!enabled || d.force_direct || !d.w_packed) return false;
   if (d.ksize != 1 || d.mode != DDPM_CONV_NORMAL || d.gscale || d.act != DDPM_ACT_NONE) return false;
-  if (d.Di > 1 || d.Do > 1 || d.accumulate) return false;
+  if (d.Di > 1 || d.Do > 1) return false;
   if (Cin % kDC || (d.C2 > 0 && d.C1 % kDC) || d.Cout % kDM) return false;
   // a tile is 256 consecutive pixels of one image or a whole number of images; rows of 4 pixels never straddle
   if (HW % 4 || !((HW % kDP == 0) || (kDP % HW == 0))) return false;

@@ -1,0 +1,128 @@
+// conv3d_edge.hip -- the two VQ-VAE layers that have no MFMA tiling: the first encoder convolution
+// (Conv3d 1 -> C, kernel 4, stride 2, pad 1) and the last decoder convolution (ConvTranspose3d C -> 1, kernel 4,
+// stride 2, pad 1) of generative.networks.nets.VQVAE as configured at /root/reference/README.md:153-158 and
+// reached from /root/reference/src/trainers/reconstruct.py:124 (encode_stage_2_inputs) and :166
+// (decode_stage_2_outputs).  Both are HBM-bound (one side of the layer is a single-channel volume): 8.6 GFLOP
+// against 268 MB of activation traffic at 128^3 / 256 channels.  Weights are wave-uniform (scalar loads), the
+// 64 (27) input values of a thread stay in registers across all output (input) channels.
+#include "common.h"
+
+namespace ddpm {
+
+// out[n, co, z, y, x] = relu?(bias[co] + sum_{kz,ky,kx} w[co, 0, kz, ky, kx] * in[n, 0, 2z+kz-1, 2y+ky-1, 2x+kx-1])
+__global__ __launch_bounds__(256) void conv3d_k4s2_cin1_kernel(const float *__restrict__ in,
+                                                               const float *__restrict__ w,
+                                                               const float *__restrict__ bias, float *__restrict__ out,
+                                                               int Cout, int D, int H, int W, int relu) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const int npos = Do * Ho * Wo;
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (pos >= npos) return;
+  const int x = pos % Wo, y = (pos / Wo) % Ho, z = pos / (Wo * Ho);
+  const float *src = in + (size_t)n * D * H * W;
+  float v[64];
+#pragma unroll
+  for (int kz = 0; kz < 4; ++kz)
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int iz = 2 * z + kz - 1, iy = 2 * y + ky - 1, ix = 2 * x + kx - 1;
+        const bool ok = iz >= 0 && iz < D && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        v[(kz * 4 + ky) * 4 + kx] = ok ? src[((size_t)iz * H + iy) * W + ix] : 0.f;
+      }
+  float *dst = out + (size_t)n * Cout * npos + pos;
+  for (int co = 0; co < Cout; ++co) {
+    const float *wc = w + (size_t)co * 64;  // wave-uniform: scalar loads
+    // torch's own accumulation order is unspecified; a fixed k-ascending fmaf chain keeps the result deterministic
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) acc = fmaf(v[k], wc[k], acc);
+    if (bias) acc += bias[co];
+    dst[(size_t)co * npos] = relu ? fmaxf(acc, 0.f) : acc;
+  }
+}
+
+// out[n, 0, 2z+pz, 2y+py, 2x+px] = bias + sum_c sum_{a,r,s in {0,1}} in[n, c, z-1+pz+a, y-1+py+r, x-1+px+s]
+//                                                  * w[c, 0, 3-pz-2a, 3-py-2r, 3-px-2s]
+// A thread owns one low-res position and its eight output voxels: 27 neighbour loads and 64 FMAs per channel.
+__global__ __launch_bounds__(256) void convT3d_k4s2_cout1_kernel(const float *__restrict__ in,
+                                                                 const float *__restrict__ w,
+                                                                 const float *__restrict__ bias,
+                                                                 float *__restrict__ out, int Cin, int D, int H, int W) {
+  const int npos = D * H * W;
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (pos >= npos) return;
+  const int x = pos % W, y = (pos / W) % H, z = pos / (W * H);
+  int off[27];
+#pragma unroll
+  for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int iz = z + dz - 1, iy = y + dy - 1, ix = x + dx - 1;
+        const bool ok = iz >= 0 && iz < D && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        off[(dz * 3 + dy) * 3 + dx] = ok ? (iz * H + iy) * W + ix : -1;
+      }
+  float acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) acc[p] = 0.f;
+  const float *src = in + (size_t)n * Cin * npos;
+  for (int c = 0; c < Cin; ++c) {
+    const float *sc = src + (size_t)c * npos;
+    const float *wc = w + (size_t)c * 64;  // wave-uniform: scalar loads
+    float v[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) v[i] = off[i] >= 0 ? sc[off[i]] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int px = p & 1, py = (p >> 1) & 1, pz = p >> 2;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            acc[p] = fmaf(v[((pz + a) * 3 + py + r) * 3 + px + s],
+                          wc[((3 - pz - 2 * a) * 4 + 3 - py - 2 * r) * 4 + 3 - px - 2 * s], acc[p]);
+    }
+  }
+  const float b = bias ? bias[0] : 0.f;
+  float *dst = out + (size_t)n * 8 * npos;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int px = p & 1, py = (p >> 1) & 1, pz = p >> 2;
+    dst[((size_t)(2 * z + pz) * (2 * H) + 2 * y + py) * (2 * W) + 2 * x + px] = acc[p] + b;
+  }
+}
+
+int launch_conv3d_k4s2_cin1(const float *in, const float *w, const float *bias, float *out, int B, int Cout, int D,
+                            int H, int W, int relu, hipStream_t s) {
+  DDPM_CHECK_ARG(in && w && out && B > 0 && Cout > 0, "conv3d_k4s2_cin1: null tensor or empty shape");
+  DDPM_CHECK_ARG(D >= 2 && H >= 2 && W >= 2 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && B <= 65535,
+                 "conv3d_k4s2_cin1: extents must be even and >= 2");
+  const long npos = (long)(D / 2) * (H / 2) * (W / 2);
+  ProfScope prof(s, "conv3d_k4s2_cin1", 2.0 * B * npos * Cout * 64, 4.0 * B * ((double)D * H * W + (double)npos * Cout));
+  hipLaunchKernelGGL(conv3d_k4s2_cin1_kernel, dim3((unsigned)((npos + 255) / 256), B), dim3(256), 0, s, in, w, bias, out,
+                     Cout, D, H, W, relu);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_convT3d_k4s2_cout1(const float *in, const float *w, const float *bias, float *out, int B, int Cin, int D,
+                              int H, int W, hipStream_t s) {
+  DDPM_CHECK_ARG(in && w && out && B > 0 && Cin > 0 && D > 0 && H > 0 && W > 0 && B <= 65535,
+                 "convT3d_k4s2_cout1: null tensor or empty shape");
+  const long npos = (long)D * H * W;
+  DDPM_CHECK_ARG(npos * 8 < (1L << 31), "convT3d_k4s2_cout1: volume too large for 32-bit voxel offsets");
+  ProfScope prof(s, "convT3d_k4s2_cout1", 2.0 * B * npos * 8 * Cin * 8, 4.0 * B * ((double)npos * Cin + 8.0 * npos));
+  hipLaunchKernelGGL(convT3d_k4s2_cout1_kernel, dim3((unsigned)((npos + 255) / 256), B), dim3(256), 0, s, in, w, bias,
+                     out, Cin, D, H, W);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace ddpm

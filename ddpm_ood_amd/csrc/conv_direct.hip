@@ -224,15 +224,24 @@ int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
     DDPM_CHECK_ARG(d.Hi == d.Ho && d.Wi == d.Wo, "conv: normal mode needs Hi == Ho, Wi == Wo");
   if (d.mode == DDPM_CONV_UPSAMPLE2)
     DDPM_CHECK_ARG(d.Ho == 2 * d.Hi && d.Wo == 2 * d.Wi && d.ksize == 3, "conv: upsample needs Ho == 2 Hi, k == 3");
-  if (d.mode == DDPM_CONV_STRIDE2)
-    DDPM_CHECK_ARG(d.Ho == (d.Hi + 1) / 2 && d.Wo == (d.Wi + 1) / 2 && d.ksize == 3,
-                   "conv: stride-2 needs Ho == ceil(Hi / 2), k == 3");
-  if (d.Di > 1 || d.Do > 1) {
-    DDPM_CHECK_ARG(d.kd >= 0 && d.kd <= 2 && d.ksize == 3, "conv: a depth-tap launch needs kd in 0..2 and k == 3");
-    DDPM_CHECK_ARG(conv_mfma_supported(d), "conv3d: only shapes with an MFMA tiling are built (Cin %% 4, Cout %% 128)");
+  if (d.mode == DDPM_CONV_STRIDE2 && d.ksize == 3)
+    DDPM_CHECK_ARG(d.Ho == (d.Hi + 1) / 2 && d.Wo == (d.Wi + 1) / 2, "conv: stride-2 k3 needs Ho == ceil(Hi / 2)");
+  if (d.mode == DDPM_CONV_STRIDE2 && d.ksize == 4)
+    DDPM_CHECK_ARG(d.Ho == d.Hi / 2 && d.Wo == d.Wi / 2 && d.Ho > 0 && d.Wo > 0, "conv: stride-2 k4 needs Ho == Hi / 2");
+  DDPM_CHECK_ARG(d.mode != DDPM_CONV_STRIDE2 || d.ksize == 3 || d.ksize == 4, "conv: stride-2 needs k == 3 or 4");
+  const bool is3d = d.dims == 3 && d.ksize != 1;
+  if (is3d || d.mode == DDPM_CONV_TRANSPOSE2 || d.ksize == 4) {
+    // 3-D convolutions, k4 s2 and ConvTranspose only exist on the MFMA kernel (no generic fallback)
+    const int Di = d.Di > 1 ? d.Di : 1, Do = d.Do > 1 ? d.Do : 1;
+    if (is3d && d.mode == DDPM_CONV_NORMAL) DDPM_CHECK_ARG(Di == Do, "conv3d: normal mode needs Di == Do");
+    if (is3d && d.mode == DDPM_CONV_UPSAMPLE2) DDPM_CHECK_ARG(Do == 2 * Di, "conv3d: upsample needs Do == 2 Di");
+    if (is3d && d.mode == DDPM_CONV_STRIDE2)
+      DDPM_CHECK_ARG(Do == (d.ksize == 3 ? (Di + 1) / 2 : Di / 2) && Do > 0, "conv3d: stride-2 output depth");
+    DDPM_CHECK_ARG(conv_mfma_supported(d),
+                   "conv: 3-D / k4 / transposed convolutions need an MFMA tiling (Cin %% 4 (8), Cout %% 128, packed weights)");
     return launch_conv_mfma(d, s);
   }
-  DDPM_CHECK_ARG(!d.accumulate, "conv: accumulate is only used by the depth-tap launches of a 3-D convolution");
+  DDPM_CHECK_ARG(d.Di <= 1 && d.Do <= 1, "conv: Di / Do > 1 needs dims == 3");
   if (conv_wino_supported(d)) return launch_conv_wino(d, s);
   if (conv1x1_dma_supported(d) && conv_mfma_supported(d)) return launch_conv1x1_dma(d, s);
   if (conv_mfma_supported(d)) return launch_conv_mfma(d, s);

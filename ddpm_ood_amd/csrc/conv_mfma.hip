@@ -43,10 +43,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct ConvGeom {
-  int M;        // B * Do * Ho * Wo
+  int M;        // output pixels of the launch: B * (output slices) * Ho * Wo (per parity for TRANSPOSE2 / folded)
   int HWo, HWi;
   int Di, Do;   // stored input / output depth (1 for 2-D); an "image" below is one (n, d) slice
-  int NI;       // B * Do slices
+  int NI;       // B * DS slices walked by the tiles
+  int DS;       // slices per batch item: Do, or the LOW-RES depth Di for a 3-D TRANSPOSE2 (output slice 2 d + pz)
   int MT;       // pixels per workgroup tile (128 or 64)
   int TI, TH;   // images per tile, output rows per tile (per image)
   int TPX;      // valid output pixels per tile = TI * TH * Wo (<= MT; < MT for ragged extents such as 28 x 28)
@@ -55,10 +56,20 @@ struct ConvGeom {
   int IR, RS;   // LDS rows per image slot, LDS row stride
   int IRS;      // IR * RS
   int PS;       // LDS plane size (floats per channel)
-  int pad;      // 1 for 3x3, 0 for 1x1
+  int pad;      // 1 for 3x3 / 4x4, 0 for 1x1
   int s;        // input step per output pixel (2 for stride-2)
   int Cin, nchunks;
-  int fold, up_dy, up_dx;  // folded nearest-x2 upsample: this launch computes output parity (dy, dx)
+  // ---- 3-D: the depth taps are part of the chunk stream (chunk = (depth tap, channel group)) ----------------
+  int is3d;     // the depth logic below is active
+  int kd0, nkd; // depth taps walked by this launch: kd0 .. kd0 + nkd - 1 (a depth-1 volume only has its centre tap)
+  int nchunks_c;  // channel chunks per depth tap; nchunks = nkd * nchunks_c
+  long long slab;      // floats between two depth-tap slabs of w_packed
+  // input depth of tap kd for output slice dz: dv = dmul * dz + kd + doff (valid in [0, Dv)), stored slice dv >> dshift
+  int dmul, doff, Dv, dshift;
+  // ---- output parities (blockIdx.z): folded nearest-x2 upsample (4), ConvTranspose k4 s2 p1 (4 in 2-D, 8 in 3-D):
+  // the tile walks LOW-RES pixels, tap (r, c) reads LDS at (py + r, px + c), the output pixel is (2h + py, 2w + px)
+  int npar;
+  long long par_slab;  // floats between two parity slabs of w_packed
 };
 
 static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g) {
@@ -69,9 +80,13 @@ static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g) {
   g.HWi = d.Hi * d.Wi;
   g.Di = d.Di > 1 ? d.Di : 1;
   g.Do = d.Do > 1 ? d.Do : 1;
-  g.NI = d.B * g.Do;
+  g.is3d = d.dims == 3 && d.ksize != 1;
+  g.npar = 1;
+  g.par_slab = 0;
+  g.DS = g.Do;
+  g.NI = d.B * g.DS;
   g.M = g.NI * g.HWo;
-  g.pad = d.ksize == 3 ? 1 : 0;
+  g.pad = d.ksize == 1 ? 0 : 1;
   g.s = d.mode == DDPM_CONV_STRIDE2 ? 2 : 1;
   if (g.HWo > MT) {
     // whole rows of one image: the largest divisor of Ho whose rows fit the tile
@@ -88,8 +103,9 @@ static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g) {
     g.TH = d.Ho;
     g.TPI = 0;
   }
-  const int IC = (g.s == 2) ? (2 * d.Wo + 1) : (d.Wo + 2 * g.pad);
-  g.IR = (g.s == 2) ? (2 * g.TH + 1) : (g.TH + 2 * g.pad);
+  // stride 2: k = 3 reads input columns 2x-1 .. 2x+1, k = 4 reads 2x-1 .. 2x+2
+  const int IC = (g.s == 2) ? (2 * d.Wo + d.ksize - 2) : (d.Wo + 2 * g.pad);
+  g.IR = (g.s == 2) ? (2 * g.TH + d.ksize - 2) : (g.TH + 2 * g.pad);
   g.RS = IC;
   g.IRS = g.IR * g.RS;
   if (g.TPI == 0) {
@@ -101,8 +117,19 @@ static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g) {
   }
   g.TPX = g.TI * g.TH * d.Wo;
   g.PS = g.TI * g.IRS;
-  g.nchunks = Cin / kConvCc;
-  g.fold = g.up_dy = g.up_dx = 0;
+  g.nchunks_c = Cin / kConvCc;
+  // depth taps
+  g.kd0 = 0;
+  g.nkd = 1;
+  g.slab = 0;
+  g.dmul = g.s; g.doff = -1; g.Dv = g.Di; g.dshift = 0;
+  if (g.is3d) {
+    g.nkd = d.ksize;
+    g.slab = (long long)d.Cout * Cin * d.ksize * d.ksize;
+    if (d.mode == DDPM_CONV_UPSAMPLE2) { g.dmul = 1; g.Dv = g.Do; g.dshift = 1; }
+    if (d.ksize == 3 && g.Di == 1 && g.Do == 1) { g.kd0 = 1; g.nkd = 1; }  // the outer taps only see padding
+  }
+  g.nchunks = g.nkd * g.nchunks_c;
   return true;
 }
 
@@ -132,25 +159,70 @@ static bool pick_geom(const ddpm_conv_desc &d, ConvGeom &g) {
   return true;
 }
 
+// The low-res view of a parity launch (folded nearest-x2 upsample, ConvTranspose k4 s2 p1): tiles walk the INPUT
+// pixels; every workgroup of grid.z computes one output parity with 2 x 2 (x 2) taps.
+static ddpm_conv_desc lowres_view(const ddpm_conv_desc &d) {
+  ddpm_conv_desc lr = d;
+  lr.mode = DDPM_CONV_NORMAL;
+  lr.ksize = 3;  // halo of one pixel on each side, as for a 3x3
+  lr.Ho = d.Hi;
+  lr.Wo = d.Wi;
+  lr.Do = d.Di;
+  return lr;
+}
+
+static bool transpose_geom(const ddpm_conv_desc &d, ConvGeom &g) {
+  const int Cin = d.C1 + d.C2;
+  if (d.ksize != 4 || d.gscale || d.C2 || Cin % 8 || d.Cout % kConvNT) return false;
+  if (d.Ho != 2 * d.Hi || d.Wo != 2 * d.Wi) return false;
+  const bool is3d = d.dims == 3;
+  if (is3d && d.Do != 2 * (d.Di > 1 ? d.Di : 1)) return false;
+  ddpm_conv_desc lr = lowres_view(d);
+  lr.dims = 0;  // geometry of the in-plane tiling only; the depth walk is set below
+  if (!pick_geom(lr, g) || g.PS > 2 * 256) return false;
+  g.npar = is3d ? 8 : 4;
+  g.nchunks_c = Cin / 8;               // KG = 2: eight channels per chunk
+  g.par_slab = (long long)d.Cout * Cin * (is3d ? 8 : 4);
+  if (is3d) {
+    g.is3d = 1;
+    g.Di = d.Di > 1 ? d.Di : 1;
+    g.Do = d.Do;
+    g.DS = g.Di;
+    g.NI = d.B * g.DS;
+    // pick_geom above tiled B * 1 slices: redo the tile count for B * Di slices
+    g.ntiles = g.TPI > 0 ? g.NI * g.TPI : (g.NI + g.TI - 1) / g.TI;
+    g.kd0 = 0; g.nkd = 2;
+    g.slab = (long long)d.Cout * Cin * 4;
+    g.dmul = 1; g.doff = -1; g.Dv = g.Di; g.dshift = 0;  // + pz, added in the kernel
+  }
+  g.M = g.NI * g.HWo;
+  g.nchunks = g.nkd * g.nchunks_c;
+  return true;
+}
+
 bool conv_mfma_supported(const ddpm_conv_desc &d) {
   if (!d.w_packed || d.force_direct) return false;
   const int Cin = d.C1 + d.C2;
-  if (d.ksize != 1 && d.ksize != 3) return false;
-  if (d.mode != DDPM_CONV_NORMAL && d.ksize != 3) return false;
+  ConvGeom g;
+  if (d.mode == DDPM_CONV_TRANSPOSE2) return transpose_geom(d, g);
+  if (d.ksize != 1 && d.ksize != 3 && d.ksize != 4) return false;
+  if (d.ksize == 4 && d.mode != DDPM_CONV_STRIDE2) return false;
+  if (d.mode != DDPM_CONV_NORMAL && d.ksize == 1) return false;
   if (Cin % kConvCc || d.Cout % kConvNT) return false;
   if (d.C2 > 0 && (d.C1 % kConvCc)) return false;
-  ConvGeom g;
+  if (d.dims == 3 && d.ksize != 1 && d.mode == DDPM_CONV_UPSAMPLE2 && d.ksize != 3) return false;
   return pick_geom(d, g);
 }
 
 template <int NTAPS, int NPOS, bool AFFINE, int MT, int KG>
 __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(const ddpm_conv_desc a,
                                                                              const ConvGeom g) {
-  // KG = groups of 4 input channels per chunk: 1 for 3x3 (72 MFMAs per chunk and barrier); 4 for plain
-  // 1x1 convs / Linears, whose single tap would otherwise give a barrier every 8 MFMAs.
+  // KG = groups of 4 input channels per chunk: 1 for 3x3 / 4x4 (72 / 128 MFMAs per chunk and barrier); 4 for plain
+  // 1x1 convs / Linears, whose single tap would otherwise give a barrier every 8 MFMAs; 2 for the 2x2-tap
+  // parity launches (folded upsample, ConvTranspose).
   constexpr int CC = kConvCc;                  // 4: granule of the packed weight layout
   constexpr int CPC = CC * KG;                 // input channels per chunk
-  constexpr int WF = NTAPS * CPC * kConvNT;    // weight floats per chunk (4608 / 2048 / 512)
+  constexpr int WF = NTAPS * CPC * kConvNT;    // weight floats per chunk (4608 / 8192 / 2048 / 512)
   constexpr int NW4 = WF / 1024;               // full 16-byte rounds per thread
   constexpr bool HASREM = (WF % 1024) != 0;    // + one 8-byte round (512 floats)
   constexpr int NXP = NPOS * KG;               // input pieces: (position, channel group)
@@ -158,6 +230,7 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   constexpr int NSTEP = NTAPS * (CPC / 2);     // k-steps (4 or 2 MFMAs each) per chunk
   constexpr int H = (NSTEP + 1) / 2;           // commit pieces go to steps [0, H), prefetch to [H, NSTEP)
   constexpr int NAB = MT == 128 ? 2 : 1;       // 32-cout blocks per wave
+  constexpr bool PARITY = NTAPS == 4;          // low-res tiles, one output parity per blockIdx.z
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bufsz = WF + CPC * g.PS;           // floats per LDS buffer: [NTAPS][CPC][128] weights, [CPC][PS] input
@@ -168,6 +241,9 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   const int wco = MT == 128 ? (wave & 1) * 64 : wave * 32;  // wave's first cout inside the tile
   const int wpx = MT == 128 ? (wave >> 1) * 64 : 0;         // wave's first pixel inside the tile
   const int nt = blockIdx.y;
+  // output parity of this workgroup (PARITY launches): out pixel (2 d + pz, 2 h + py, 2 w + px)
+  const int par = PARITY ? blockIdx.z : 0;
+  const int px = par & 1, py = (par >> 1) & 1, pz = par >> 2;
 
   // ---- tile origin -------------------------------------------------------------------------
   const int tile = blockIdx.x;
@@ -183,38 +259,29 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   // ---- per-thread staging positions (chunk-invariant) -------------------------------------
   int soff[NPOS];   // offset inside one channel plane of the source, -1 => zero
   int nimg[NPOS];   // batch index of the position's slice
-  int dimg[NPOS];   // input depth index of the position's slice (0 for 2-D)
+  int dzb[NPOS];    // dmul * (slice depth index) + doff (+ pz): add the depth tap to get the virtual input depth
 #pragma unroll
   for (int j = 0; j < NPOS; ++j) {
     const int r = tid + 256 * j;
     soff[j] = -1;
     nimg[j] = 0;
-    dimg[j] = 0;
+    dzb[j] = 0;
     if (r < g.PS) {
       const int ti = r / g.IRS;
       const int rr = r - ti * g.IRS;
       const int ir = rr / g.RS;
       const int ic = rr - ir * g.RS;
-      const int img = n0 + ti;       // (n, d_out) slice handled by this position
-      const int n = img / g.Do;
-      const int dz = img - n * g.Do;
-      // input depth of this launch's depth tap (3-D only): kd - 1 around the output slice
-      int din = 0;
-      bool dok = true;
-      if (g.Do > 1 || g.Di > 1) {
-        const int dv = g.s * dz + a.kd - 1;  // in the (virtual, for UPSAMPLE2: upsampled) input
-        const int Dv = (a.mode == DDPM_CONV_UPSAMPLE2) ? g.Do : g.Di;
-        dok = dv >= 0 && dv < Dv;
-        din = (a.mode == DDPM_CONV_UPSAMPLE2) ? (dv >> 1) : dv;
-      }
+      const int img = n0 + ti;       // (n, d) slice handled by this position
+      const int n = img / g.DS;
+      const int dz = img - n * g.DS;
       const int hv = g.s * h0 + ir - g.pad;
       const int wv = ic - g.pad;
       // bounds of the (virtual) conv input: the upsampled extent for UPSAMPLE2, else Hi x Wi
       const int Hv = (a.mode == DDPM_CONV_UPSAMPLE2) ? a.Ho : a.Hi;
       const int Wv = (a.mode == DDPM_CONV_UPSAMPLE2) ? a.Wo : a.Wi;
-      if (img < g.NI && dok && hv >= 0 && hv < Hv && wv >= 0 && wv < Wv) {
+      if (img < g.NI && hv >= 0 && hv < Hv && wv >= 0 && wv < Wv) {
         nimg[j] = n;
-        dimg[j] = din;
+        dzb[j] = g.dmul * dz + g.doff + pz;
         soff[j] = (a.mode == DDPM_CONV_UPSAMPLE2) ? ((hv >> 1) * a.Wi + (wv >> 1)) : (hv * a.Wi + wv);
       }
     }
@@ -248,12 +315,18 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   v2f w2;
   float xreg[NXP][CC];
   v4f screg[NXP], shreg[NXP];
+  unsigned xok = 0;  // bit xp: the staged piece is a real pixel (inside the image AND inside the depth range)
 
-  const float *wsrc = a.w_packed + (size_t)nt * g.nchunks * WF;
+  const float *wsrc = a.w_packed + (size_t)par * g.par_slab + (size_t)nt * g.nchunks_c * WF;
 
-  // piece p of chunk `ch`: global -> registers
+  // piece p of chunk `ch` = (depth tap kdi, channel chunk cc): global -> registers
   auto prefetch_piece = [&](int p, int ch) {
-    const float *wp = wsrc + (size_t)ch * WF;
+    int kdi = 0, cc = ch;
+    if (g.nkd > 1) {  // wave-uniform: scalar ALU
+      kdi = ch / g.nchunks_c;
+      cc = ch - kdi * g.nchunks_c;
+    }
+    const float *wp = wsrc + (size_t)(g.kd0 + kdi) * g.slab + (size_t)cc * WF;
     if (p < NW4) {
       w4[p < NW4 ? p : 0] = reinterpret_cast<const v4f *>(wp)[tid + 256 * p];
     } else if (HASREM && p == NW4) {
@@ -261,7 +334,7 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
     } else {
       const int xp = p - NW4 - (HASREM ? 1 : 0);
       const int j = xp / KG, gk = xp % KG;
-      const int cg0 = ch * CPC + gk * CC;
+      const int cg0 = cc * CPC + gk * CC;
       const float *base;
       int Cs, cl0;
       if (cg0 < a.C1) {
@@ -269,17 +342,26 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
       } else {
         base = a.in2; Cs = a.C2; cl0 = cg0 - a.C1;
       }
-      if (soff[j] >= 0) {
-        const float *px = base + (((size_t)nimg[j] * Cs + cl0) * g.Di + dimg[j]) * g.HWi + soff[j];
+      bool ok = soff[j] >= 0;
+      int din = 0;
+      if (g.is3d) {
+        const int dv = dzb[j] + g.kd0 + kdi;
+        ok = ok && dv >= 0 && dv < g.Dv;
+        din = dv >> g.dshift;
+      }
+      if (ok) {
+        const float *px_ = base + (((size_t)nimg[j] * Cs + cl0) * g.Di + din) * g.HWi + soff[j];
 #pragma unroll
-        for (int c = 0; c < CC; ++c) xreg[xp][c] = px[(size_t)c * g.Di * g.HWi];
+        for (int c = 0; c < CC; ++c) xreg[xp][c] = px_[(size_t)c * g.Di * g.HWi];
         if (AFFINE) {
           screg[xp] = *reinterpret_cast<const v4f *>(a.gscale + (size_t)nimg[j] * g.Cin + cg0);
           shreg[xp] = *reinterpret_cast<const v4f *>(a.gshift + (size_t)nimg[j] * g.Cin + cg0);
         }
+        xok |= 1u << xp;
       } else {
 #pragma unroll
         for (int c = 0; c < CC; ++c) xreg[xp][c] = 0.f;
+        xok &= ~(1u << xp);
       }
     }
   };
@@ -295,7 +377,7 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
       const int j = xp / KG, gk = xp % KG;
       const int r = tid + 256 * j;
       if (r < g.PS) {
-        const bool valid = soff[j] >= 0;
+        const bool valid = (xok >> xp) & 1u;
 #pragma unroll
         for (int c = 0; c < CC; ++c) {
           float v = xreg[xp][c];
@@ -332,7 +414,8 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
     auto fetch = [&](int st, int slot) {
       const int t = st / (CPC / 2), kk = st % (CPC / 2);
       const int tapoff = (NTAPS == 9) ? ((t / 3) * g.RS + (t % 3))
-                       : (NTAPS == 4) ? ((g.up_dy + (t >> 1)) * g.RS + g.up_dx + (t & 1)) : 0;
+                       : (NTAPS == 16) ? ((t >> 2) * g.RS + (t & 3))
+                       : (NTAPS == 4) ? ((py + (t >> 1)) * g.RS + px + (t & 1)) : 0;
 #pragma unroll
       for (int ab = 0; ab < NAB; ++ab)  // LDS weights are [channel group][tap][4][128], as packed
         av[slot][ab] = smem[cb + wb + (((kk >> 1) * NTAPS + t) * CC + 2 * (kk & 1)) * kConvNT + ab * 32];
@@ -386,14 +469,16 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
     const int img = n0 + ti;
     if (q < g.TPX && img < g.NI) {
       const int p = h0 * a.Wo + (q - ti * per_img);  // flattened pixel inside the slice
-      const int n = img / g.Do;
-      const int dz = img - n * g.Do;
+      const int n = img / g.DS;
+      const int dz = img - n * g.DS;
       size_t cstride = (size_t)g.Do * g.HWo;  // channel stride of the NC(D)HW output
       size_t obase = (((size_t)n * a.Cout + co_base) * g.Do + dz) * g.HWo + p;
-      if (g.fold) {  // (h, w) of the low-res tile -> output pixel (2h + dy, 2w + dx) of the 2x larger plane
+      if (PARITY) {  // (d, h, w) of the low-res tile -> output voxel (2d + pz, 2h + py, 2w + px) of the 2x larger extent
         const int hl = p / a.Wo, wl = p - hl * a.Wo;
-        cstride = (size_t)4 * g.HWo;
-        obase = ((size_t)n * a.Cout + co_base) * cstride + (size_t)(2 * hl + g.up_dy) * (2 * a.Wo) + 2 * wl + g.up_dx;
+        const int dout = g.is3d ? 2 * dz + pz : 0;
+        cstride = (size_t)g.Do * 4 * g.HWo;
+        obase = (((size_t)n * a.Cout + co_base) * g.Do + dout) * (4 * (size_t)g.HWo) +
+                (size_t)(2 * hl + py) * (2 * a.Wo) + 2 * wl + px;
       }
 #pragma unroll
       for (int ab = 0; ab < NAB; ++ab) {
@@ -404,7 +489,6 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
           bvv[r] = bias_p ? bias_p[co_base + dco] : 0.f;
           cv[r] = chan_p ? chan_p[(size_t)n * a.chan_add_stride + co_base + dco] : 0.f;
           rv[r] = res_p ? res_p[obase + (size_t)dco * cstride] : 0.f;
-          if (a.accumulate) rv[r] += a.out[obase + (size_t)dco * cstride];  // 2nd / 3rd depth tap
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -412,7 +496,7 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
           float v = acc[ab][bb][r];
           if (bias_p) v += bvv[r];
           if (chan_p) v += cv[r];
-          if (res_p || a.accumulate) v += rv[r];
+          if (res_p) v += rv[r];
           if (a.out_act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
           a.out[obase + (size_t)dco * cstride] = v;
         }
@@ -424,7 +508,8 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
 template <int NTAPS, int NPOS, bool AFFINE, int MT, int KG = 1>
 static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g_in, hipStream_t s) {
   ConvGeom g = g_in;
-  g.nchunks = g.Cin / (kConvCc * KG);
+  g.nchunks_c = g.Cin / (kConvCc * KG);
+  g.nchunks = g.nkd * g.nchunks_c;
   const size_t lds = (size_t)2 * (NTAPS * kConvCc * KG * kConvNT + kConvCc * KG * g.PS) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -441,21 +526,33 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g_in, hipStre
               (int)AFFINE, MT, lds, fa.numRegs, nb);
     }
   }
-  dim3 grid(g.ntiles, d.Cout / kConvNT);
-  // algorithmic work of this launch: 2*M*Cout*Cin*taps FLOP; input + output (+ residual)
-  // + weights bytes, each counted once
-  // (a folded-upsample launch is one output parity = a quarter of the original conv's algorithmic work)
-  const double flops = 2.0 * g.M * d.Cout * (double)g.Cin * (NTAPS == 4 ? 9 : NTAPS);
-  const double bytes = 4.0 * ((double)d.B * g.Cin * g.Di * g.HWi + (double)g.M * d.Cout * (d.residual ? 2 : 1) +
-                              (double)d.Cout * g.Cin * NTAPS);
-  const char *kname = NTAPS == 4 ? (MT == 128 ? "conv3x3_mfma_up_folded" : "conv3x3_mfma_up_folded_t64")
-                      : MT == 128 ? (NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu" : "conv3x3_mfma")
-                                              : (AFFINE ? "conv1x1_mfma_gn" : "conv1x1_mfma"))
-                                : (NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu_t64" : "conv3x3_mfma_t64")
-                                              : (AFFINE ? "conv1x1_mfma_gn_t64" : "conv1x1_mfma_t64"));
+  dim3 grid(g.ntiles, d.Cout / kConvNT, g.npar);
+  // algorithmic work of this launch: 2 * (output pixels) * Cout * Cin * taps FLOP, counted as the
+  // op the launch replaces (a folded nearest-x2 upsample counts the 9 taps of the unfolded 3x3; a ConvTranspose
+  // k4 s2 has 2 x 2 (x 2) live taps per output); bytes = input + output (+ residual) + weights, once each
+  const bool transposed = d.mode == DDPM_CONV_TRANSPOSE2;
+  const double out_px = (double)g.M * g.npar;
+  const double taps = (NTAPS == 4 && !transposed) ? 9.0 : (double)NTAPS * g.nkd;
+  const double flops = 2.0 * out_px * d.Cout * (double)g.Cin * taps;
+  const double bytes = 4.0 * ((double)d.B * g.Cin * g.Di * g.HWi + out_px * d.Cout * (d.residual ? 2 : 1) +
+                              (double)d.Cout * g.Cin * NTAPS * g.nkd * g.npar);
+  const char *kname;
+  if (g.is3d)
+    kname = transposed ? "conv3d_transpose_k4s2" : NTAPS == 16 ? "conv3d_k4s2" : AFFINE ? "conv3d_k3_gn_silu" : "conv3d_k3";
+  else if (transposed)
+    kname = "conv2d_transpose_k4s2";
+  else if (NTAPS == 16)
+    kname = "conv2d_k4s2";
+  else
+    kname = NTAPS == 4 ? (MT == 128 ? "conv3x3_mfma_up_folded" : "conv3x3_mfma_up_folded_t64")
+            : MT == 128 ? (NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu" : "conv3x3_mfma")
+                                      : (AFFINE ? "conv1x1_mfma_gn" : "conv1x1_mfma"))
+                        : (NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu_t64" : "conv3x3_mfma_t64")
+                                      : (AFFINE ? "conv1x1_mfma_gn_t64" : "conv1x1_mfma_t64"));
   char kshape[160];
   if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {  // development: one profile row per layer shape
-    snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d m%d t%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo, d.mode, MT);
+    snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%dx%d m%d t%d", kname, d.C1, d.C2, d.Cout, g.Do, d.Ho, d.Wo, d.mode,
+             MT);
     kname = kshape;
   }
   ProfScope prof(s, kname, flops, bytes);
@@ -468,6 +565,11 @@ template <int MT>
 static int launch_mt(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_t s) {
   const int npos = (g.PS + 255) / 256;
   const bool aff = d.gscale != nullptr;
+  if (d.ksize == 4) {  // k4 s2 p1 (VQ-VAE downsampling): 16 in-plane taps per depth tap
+    if (npos == 1) return launch_variant<16, 1, false, MT>(d, g, s);
+    if (npos == 2) return launch_variant<16, 2, false, MT>(d, g, s);
+    return launch_variant<16, 3, false, MT>(d, g, s);
+  }
   if (d.ksize == 3) {
     if (aff) {
       if (npos == 1) return launch_variant<9, 1, true, MT>(d, g, s);
@@ -483,38 +585,45 @@ static int launch_mt(const ddpm_conv_desc &d, const ConvGeom &g, hipStream_t s) 
   return launch_variant<1, 1, false, MT>(d, g, s);
 }
 
+// One launch, grid.z = output parity, 2 x 2 in-plane taps (x 2 depth taps in the chunk stream), 8 channels per chunk.
+static int launch_parity(const ddpm_conv_desc &lr, const ConvGeom &g, hipStream_t s) {
+  const int npos = (g.PS + 255) / 256;
+  if (g.MT == 128)
+    return npos == 1 ? launch_variant<4, 1, false, 128, 2>(lr, g, s) : launch_variant<4, 2, false, 128, 2>(lr, g, s);
+  return npos == 1 ? launch_variant<4, 1, false, 64, 2>(lr, g, s) : launch_variant<4, 2, false, 64, 2>(lr, g, s);
+}
+
 // 3x3 conv over a nearest-x2 upsampled image as four 2x2-tap convs over the low-res image (one per output
 // parity), weights pre-summed by fold_upsample_kernel: 16 instead of 36 multiply-adds per 4 outputs.
 static int launch_upsample_folded(const ddpm_conv_desc &d, hipStream_t s, bool &taken) {
   taken = false;
   const int Cin = d.C1 + d.C2;
-  if (!d.w_folded || d.gscale || d.Di > 1 || d.Do > 1 || Cin % 8 || (d.C2 > 0 && d.C1 % 8)) return 0;
-  ddpm_conv_desc lr = d;
-  lr.mode = DDPM_CONV_NORMAL;
-  lr.Ho = d.Hi;
-  lr.Wo = d.Wi;
+  if (!d.w_folded || d.gscale || d.dims == 3 || d.Di > 1 || d.Do > 1 || Cin % 8 || (d.C2 > 0 && d.C1 % 8)) return 0;
+  ddpm_conv_desc lr = lowres_view(d);
   lr.w_packed = d.w_folded;
   ConvGeom g;
   if (!pick_geom(lr, g) || g.PS > 2 * 256) return 0;
   taken = true;
-  const size_t slab = (size_t)d.Cout * Cin * 4;
-  for (int par = 0; par < 4; ++par) {
-    g.fold = 1;
-    g.up_dy = par >> 1;
-    g.up_dx = par & 1;
-    lr.w_packed = d.w_folded + par * slab;
-    const int npos = (g.PS + 255) / 256;
-    int rc;
-    if (g.MT == 128)
-      rc = npos == 1 ? launch_variant<4, 1, false, 128, 2>(lr, g, s) : launch_variant<4, 2, false, 128, 2>(lr, g, s);
-    else
-      rc = npos == 1 ? launch_variant<4, 1, false, 64, 2>(lr, g, s) : launch_variant<4, 2, false, 64, 2>(lr, g, s);
-    if (rc) return rc;
+  g.npar = 4;
+  g.par_slab = (long long)d.Cout * Cin * 4;
+  return launch_parity(lr, g, s);
+}
+
+// ConvTranspose k4 s2 p1 (VQ-VAE upsampling), 2-D or 3-D: out[2i + p] = sum over the two input positions
+// i - 1 + p + r (r = 0, 1) with kernel index 3 - p - 2r, per axis -> one 2x2(x2)-tap conv per output parity.
+static int launch_transpose(const ddpm_conv_desc &d, hipStream_t s) {
+  ConvGeom g;
+  if (!transpose_geom(d, g)) {
+    set_error("conv_mfma: ConvTranspose k4 s2 p1 needs Cin %% 8 == 0, Cout %% 128 == 0 and Ho = 2 Hi, Wo = 2 Wi");
+    return DDPM_EINVAL;
   }
-  return 0;
+  ddpm_conv_desc lr = lowres_view(d);
+  lr.mode = DDPM_CONV_TRANSPOSE2;
+  return launch_parity(lr, g, s);
 }
 
 int launch_conv_mfma(const ddpm_conv_desc &d, hipStream_t s) {
+  if (d.mode == DDPM_CONV_TRANSPOSE2) return launch_transpose(d, s);
   if (d.mode == DDPM_CONV_UPSAMPLE2 && d.w_folded) {
     bool taken = false;
     const int rc = launch_upsample_folded(d, s, taken);
@@ -583,8 +692,45 @@ int launch_fold_upsample_weight(const float *w_raw, float *w_folded, int Cout, i
 }
 
 size_t packed_conv_weight_floats(int Cout, int Cin, int ksize) {
-  if (Cout % kConvNT || Cin % kConvCc || (ksize != 1 && ksize != 3)) return 0;
+  if (Cout % kConvNT || Cin % kConvCc || (ksize != 1 && ksize != 3 && ksize != 4)) return 0;
   return (size_t)Cout * Cin * ksize * ksize;
+}
+
+// ---- ConvTranspose k4 s2 p1 weights: torch [Cin][Cout][4][4]([4]) -> [parity][depth tap a][cout_tile][chunk][2x2 tap]
+// [4][128]; tap (a, r, c) of parity (pz, py, px) is kernel element (3 - pz - 2a, 3 - py - 2r, 3 - px - 2c) ----------
+__global__ void pack_convT_weight_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cin, int Cout,
+                                         int dims) {
+  const int npar = dims == 3 ? 8 : 4, nd = dims == 3 ? 2 : 1, K = dims == 3 ? 64 : 16;
+  const int64_t total = (int64_t)Cout * Cin * npar * nd * 4;
+  const int nchunks = Cin / kConvCc;
+  const size_t slab = (size_t)Cout * Cin * 4, par_slab = slab * nd;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r_ = i;
+    const int t = (int)(r_ & 3); r_ >>= 2;
+    const int a = (int)(r_ % nd); r_ /= nd;
+    const int par = (int)(r_ % npar); r_ /= npar;
+    const int ci = (int)(r_ % Cin), o = (int)(r_ / Cin);
+    const int px = par & 1, py = (par >> 1) & 1, pz = par >> 2;
+    const int ky = 3 - py - 2 * (t >> 1), kx = 3 - px - 2 * (t & 1), kz = 3 - pz - 2 * a;
+    const int kidx = dims == 3 ? (kz * 16 + ky * 4 + kx) : (ky * 4 + kx);
+    const int tile = o / kConvNT, col = o % kConvNT, ch = ci / kConvCc, cl = ci % kConvCc;
+    dst[par * par_slab + a * slab + ((((size_t)tile * nchunks + ch) * 4 + t) * kConvCc + cl) * kConvNT + col] =
+        src[((size_t)ci * Cout + o) * K + kidx];
+  }
+}
+
+size_t packed_convT_weight_floats(int Cout, int Cin, int dims) {
+  if (Cout % kConvNT || Cin % 8 || (dims != 2 && dims != 3)) return 0;
+  return (size_t)Cout * Cin * (dims == 3 ? 64 : 16);
+}
+
+int launch_pack_convT_weight(const float *w_raw, float *w_packed, int Cin, int Cout, int dims, hipStream_t s) {
+  DDPM_CHECK_ARG(packed_convT_weight_floats(Cout, Cin, dims) != 0, "pack convT: Cout %% 128, Cin %% 8 or dims");
+  const int64_t total = (int64_t)packed_convT_weight_floats(Cout, Cin, dims);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_convT_weight_kernel, dim3(blocks), dim3(256), 0, s, w_raw, w_packed, Cin, Cout, dims);
+  DDPM_CHECK_LAUNCH();
+  return 0;
 }
 
 int launch_pack_conv_weight(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize, int cout_offset,

@@ -101,7 +101,7 @@ static int device_cus() {
 
 static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   const int Cin = d.C1 + d.C2;
-  if (d.ksize != 3 || d.Di > 1 || d.Do > 1 || d.accumulate || d.out_act) return false;
+  if (d.ksize != 3 || d.dims == 3 || d.Di > 1 || d.Do > 1 || d.out_act) return false;
   if (d.mode != DDPM_CONV_NORMAL && d.mode != DDPM_CONV_UPSAMPLE2) return false;
   g.up = d.mode == DDPM_CONV_UPSAMPLE2;
   if (g.up && (d.gscale || d.act != DDPM_ACT_NONE || d.Ho != 2 * d.Hi || d.Wo != 2 * d.Wi)) return false;

@@ -427,42 +427,17 @@ struct Runner {
     d.Hi = in1.H; d.Wi = in1.W; d.Ho = Ho; d.Wo = Wo;
     d.ksize = c.ksize; d.mode = mode; d.act = act;
     if (mode == DDPM_CONV_UPSAMPLE2 && c.has_folded) d.w_folded = P(c.w_folded);
-    if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino && in1.D == 1 && Do == 1)
+    if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino && c.dims == 2)
       d.w_wino = P(c.w_wino);
-    if (c.dims == 3 && c.ksize == 3 && in1.D == 1 && Do == 1) {
-      // a 3-D convolution over a volume of depth 1 (input depth <= 2^(levels-1)): the depth taps kd = 0 and
-      // kd = 2 only ever see padding, so the op IS the 2-D convolution with the centre depth tap's weights
-      d.w_packed = P(c.w_packed) + (size_t)c.Cout * c.Cin * 9;
+    if (c.dims == 3 && c.ksize == 3) {
+      // F.conv3d: ONE launch walks the (depth tap, channel group) chunks (w_packed = three depth slabs); a
+      // volume of depth 1 (input depth <= 2^(levels-1)) only has its centre tap
+      d.dims = 3;
+      d.Di = in1.D; d.Do = Do;
       d.w_raw = nullptr;  // the torch-layout tensor has 27 taps: never hand it to a 9-tap kernel
-      if (!conv_mfma_supported(d)) {
-        set_error("unet_forward: no MFMA tiling for a depth-1 3-D convolution %d->%d at %dx%d", c.Cin, c.Cout, Ho, Wo);
-        rc = DDPM_EINVAL;
-        return;
-      }
-      rc = launch_conv_mfma(d, s);
-      return;
-    }
-    if (in1.D > 1 || Do > 1) {
-      if (c.ksize == 1) {
-        // pointwise over a volume: the NCDHW tensor is an NCHW tensor of extent (D*H) x W
-        d.Hi = in1.D * in1.H; d.Ho = Do * Ho;
-      } else {
-        // F.conv3d as three depth-tap launches of the 2-D kernel (centre tap first: it is always in
-        // range and carries bias / temb / residual; the other two accumulate into `out`)
-        const size_t slab = (size_t)c.Cout * c.Cin * 9;
-        d.Di = in1.D; d.Do = Do;
-        static const int order[3] = {1, 0, 2};
-        for (int i = 0; i < 3 && !rc; ++i) {
-          d.kd = order[i];
-          d.w_packed = P(c.w_packed) + d.kd * slab;
-          if (i > 0) {
-            d.bias = nullptr; d.chan_add = nullptr; d.residual = nullptr;
-            d.accumulate = 1;
-          }
-          rc = conv_dispatch(d, s);
-        }
-        return;
-      }
+    } else if (in1.D > 1 || Do > 1) {
+      // pointwise over a volume: the NCDHW tensor is an NCHW tensor of extent (D*H) x W
+      d.Hi = in1.D * in1.H; d.Ho = Do * Ho;
     }
     rc = conv_dispatch(d, s);
   }
@@ -576,8 +551,8 @@ struct Runner {
         Act sk = skips.back();
         skips.pop_back();
         if (sk.H != h.H || sk.W != h.W || sk.D != h.D) {
-          set_error("unet_forward: skip extent %dx%d does not match %dx%d (input extent must be divisible by 2^%d)",
-                    sk.H, sk.W, h.H, h.W, (int)u->down.size() - 1);
+          set_error("unet_forward: skip extent %dx%dx%d does not match %dx%dx%d (every input extent must be divisible "
+                    "by 2^%d)", sk.D, sk.H, sk.W, h.D, h.H, h.W, (int)u->down.size() - 1);
           return DDPM_EINVAL;
         }
         Act o = new_act(b.res[j].Cout, h.H, h.W, h.D);

@@ -118,62 +118,137 @@ def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NON
     return out[:, :, 0, 0] if was_linear else out
 
 
-def conv3d_supported(weight: torch.Tensor) -> bool:
-    """3x3x3 stride-1 pad-1 weights with an MFMA tiling (Cin % 4 == 0, Cout % 128 == 0)."""
-    return (weight.ndim == 5 and tuple(weight.shape[2:]) == (3, 3, 3) and weight.shape[0] % 128 == 0
-            and weight.shape[1] % 4 == 0)
+CONV_TRANSPOSE2 = 3
+
+
+def conv3d_supported(weight: torch.Tensor, stride: int = 1, transposed: bool = False) -> bool:
+    """Does this conv3d / conv_transpose3d weight have an MFMA tiling?  k3 s1 p1 and k4 s2 p1 need Cin % 4 == 0 and
+    Cout % 128 == 0; the transposed k4 s2 p1 (weight [Cin, Cout, 4, 4, 4]) needs Cin % 8 == 0 and Cout % 128 == 0."""
+    if weight.ndim != 5:
+        return False
+    k = tuple(weight.shape[2:])
+    if transposed:
+        return k == (4, 4, 4) and stride == 2 and weight.shape[0] % 8 == 0 and weight.shape[1] % 128 == 0
+    if not ((k == (3, 3, 3) and stride == 1) or (k == (4, 4, 4) and stride == 2)):
+        return False
+    return weight.shape[0] % 128 == 0 and weight.shape[1] % 4 == 0
 
 
 def pack_conv3d_weight(weight: torch.Tensor) -> torch.Tensor:
-    """torch [Cout, Cin, 3, 3, 3] -> three MFMA-packed 2-D slabs, one per depth tap."""
+    """torch [Cout, Cin, k, k, k] (k = 3 or 4) -> k MFMA-packed slabs of k x k taps, one per depth tap."""
     lib = _lib.load()
     w = require_device_f32(weight, "weight")
-    cout, cin = w.shape[:2]
-    slab = cout * cin * 9
-    out = torch.empty(3 * slab, dtype=torch.float32, device=w.device)
-    for kd in range(3):
-        check(lib.ddpm_pack_conv_weight_taps_f32(ptr(w), out.data_ptr() + 4 * kd * slab, cout, cin, 3, 27, 9 * kd,
-                                                 stream_ptr()), "pack_conv3d_weight")
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    out = torch.empty(cout * cin * k ** 3, dtype=torch.float32, device=w.device)
+    check(lib.ddpm_pack_conv3d_weight_f32(ptr(w), ptr(out), cout, cin, k, stream_ptr()), "pack_conv3d_weight")
     return out
 
 
-def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=None, packed=None):
-    """F.conv3d(act(x), weight, bias, stride 1, pad 1) (+ residual, + output activation) on NCDHW tensors as three
-    depth-tap launches of the 2-D MFMA kernel (centre tap first; the last launch applies ``out_act``)."""
+def pack_convT_weight(weight: torch.Tensor) -> torch.Tensor:
+    """torch ConvTranspose weight [Cin, Cout, 4, 4(, 4)] -> per-output-parity 2 x 2 (x 2)-tap packed weights."""
+    lib = _lib.load()
+    w = require_device_f32(weight, "weight")
+    cin, cout, dims = w.shape[0], w.shape[1], w.ndim - 2
+    n = lib.ddpm_packed_convtr_weight_floats(cout, cin, dims)
+    if n == 0 or tuple(w.shape[2:]) != (4,) * dims:
+        raise ValueError("pack_convT_weight: needs a [Cin % 8 == 0, Cout % 128 == 0, 4, 4(, 4)] weight")
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib.ddpm_pack_convtr_weight_f32(ptr(w), ptr(out), cin, cout, dims, stream_ptr()), "pack_convT_weight")
+    return out
+
+
+def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=None, packed=None, stride: int = 1):
+    """F.conv3d(act(x), weight, bias, stride, padding=1) (+ residual, + output activation) on NCDHW tensors:
+    kernel 3 stride 1, or kernel 4 stride 2.  ONE launch of the MFMA kernel: the depth taps are part of its chunk
+    stream (chunk = (depth tap, channel group)), so the output is written once."""
     lib = _lib.load()
     x = require_device_f32(x, "x")
     w = require_device_f32(weight, "weight")
-    if not conv3d_supported(w):
-        raise ValueError("conv3d: only 3x3x3 weights with Cin % 4 == 0 and Cout % 128 == 0 have an MFMA tiling")
-    B, C, D, H, W = x.shape
-    cout = w.shape[0]
+    if not conv3d_supported(w, stride):
+        raise ValueError("conv3d: only k3 s1 / k4 s2 weights with Cin % 4 == 0 and Cout % 128 == 0 have an MFMA tiling")
+    B, Cc, D, H, W = x.shape
+    cout, k = w.shape[0], w.shape[2]
+    if Cc != w.shape[1]:
+        raise ValueError(f"conv3d: input has {Cc} channels, weight expects {w.shape[1]}")
+    if stride == 2 and (D < 2 or H < 2 or W < 2):
+        raise ValueError("conv3d k4 s2: every extent must be >= 2")
+    Do, Ho, Wo = (D, H, W) if stride == 1 else (D // 2, H // 2, W // 2)
     if packed is None:
         packed = pack_conv3d_weight(w)
-    out = torch.empty((B, cout, D, H, W), dtype=torch.float32, device=x.device)
+    out = torch.empty((B, cout, Do, Ho, Wo), dtype=torch.float32, device=x.device)
     if bias is not None:
         bias = require_device_f32(bias, "bias")
     if residual is not None:
         residual = require_device_f32(residual, "residual")
-    slab = cout * C * 9
-    taps = (1,) if D == 1 else (1, 0, 2)  # depth 1: the outer depth taps only ever see padding
-    for i, kd in enumerate(taps):
-        d = ConvDesc()
-        d.in1, d.C1 = ptr(x), C
-        d.w_packed = packed.data_ptr() + 4 * kd * slab
-        d.w_raw = ptr(w)
-        d.out = ptr(out)
-        d.B, d.Cout, d.Hi, d.Wi, d.Ho, d.Wo = B, cout, H, W, H, W
-        d.ksize, d.mode, d.act = 3, CONV_NORMAL, act
-        d.Di, d.Do, d.kd = D, D, kd
-        if D == 1:
-            d.w_raw = None  # 27-tap tensor: must not reach a 9-tap fallback kernel
-        if i == 0:
-            d.bias, d.residual = ptr(bias), ptr(residual)
-        else:
-            d.accumulate = 1
-        if i == len(taps) - 1:
-            d.out_act = out_act
-        check(lib.ddpm_conv_f32(C_byref(d), stream_ptr()), "conv3d")
+    d = ConvDesc()
+    d.in1, d.C1 = ptr(x), Cc
+    d.w_packed = ptr(packed)
+    d.bias, d.residual, d.out = ptr(bias), ptr(residual), ptr(out)
+    d.B, d.Cout, d.Hi, d.Wi, d.Ho, d.Wo = B, cout, H, W, Ho, Wo
+    d.ksize, d.mode, d.act, d.out_act = k, (CONV_NORMAL if stride == 1 else CONV_STRIDE2), act, out_act
+    d.Di, d.Do, d.dims = D, Do, 3
+    check(lib.ddpm_conv_f32(C_byref(d), stream_ptr()), "conv3d")
+    return out
+
+
+def conv_transpose(x, weight, bias=None, *, out_act=ACT_NONE, packed=None):
+    """F.conv_transpose{2,3}d(x, weight, bias, stride=2, padding=1) (+ output activation) for kernel 4: one launch,
+    grid.z = output parity, each parity a 2 x 2 (x 2)-tap convolution over the input."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    w = require_device_f32(weight, "weight")
+    dims = x.ndim - 2
+    if w.ndim != x.ndim or x.shape[1] != w.shape[0]:
+        raise ValueError(f"conv_transpose: input {tuple(x.shape)} does not match weight {tuple(w.shape)}")
+    if packed is None:
+        packed = pack_convT_weight(w)
+    B, Cc = x.shape[:2]
+    D, H, W = ((1,) + tuple(x.shape[2:])) if dims == 2 else tuple(x.shape[2:])
+    cout = w.shape[1]
+    out = torch.empty((B, cout) + tuple(2 * e for e in x.shape[2:]), dtype=torch.float32, device=x.device)
+    if bias is not None:
+        bias = require_device_f32(bias, "bias")
+    d = ConvDesc()
+    d.in1, d.C1 = ptr(x), Cc
+    d.w_packed = ptr(packed)
+    d.bias, d.out = ptr(bias), ptr(out)
+    d.B, d.Cout, d.Hi, d.Wi, d.Ho, d.Wo = B, cout, H, W, 2 * H, 2 * W
+    d.ksize, d.mode, d.out_act = 4, CONV_TRANSPOSE2, out_act
+    if dims == 3:
+        d.Di, d.Do, d.dims = D, 2 * D, 3
+    check(lib.ddpm_conv_f32(C_byref(d), stream_ptr()), "conv_transpose")
+    return out
+
+
+def conv3d_k4s2_cin1(x, weight, bias=None, relu: bool = False):
+    """First VQ-VAE encoder layer: relu?(F.conv3d(x[B, 1, D, H, W], weight[Cout, 1, 4, 4, 4], bias, stride 2, pad 1))."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    w = require_device_f32(weight, "weight")
+    if x.ndim != 5 or x.shape[1] != 1 or tuple(w.shape[1:]) != (1, 4, 4, 4):
+        raise ValueError("conv3d_k4s2_cin1: needs x [B, 1, D, H, W] and weight [Cout, 1, 4, 4, 4]")
+    B, _, D, H, W = x.shape
+    out = torch.empty((B, w.shape[0], D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    if bias is not None:
+        bias = require_device_f32(bias, "bias")
+    check(lib.ddpm_conv3d_k4s2_cin1_f32(ptr(x), ptr(w), ptr(bias), ptr(out), B, w.shape[0], D, H, W, int(relu),
+                                        stream_ptr()), "conv3d_k4s2_cin1")
+    return out
+
+
+def convT3d_k4s2_cout1(x, weight, bias=None):
+    """Last VQ-VAE decoder layer: F.conv_transpose3d(x[B, Cin, D, H, W], weight[Cin, 1, 4, 4, 4], bias, stride 2, pad 1)."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    w = require_device_f32(weight, "weight")
+    if x.ndim != 5 or tuple(w.shape) != (x.shape[1], 1, 4, 4, 4):
+        raise ValueError("convT3d_k4s2_cout1: needs x [B, Cin, D, H, W] and weight [Cin, 1, 4, 4, 4]")
+    B, Cc, D, H, W = x.shape
+    out = torch.empty((B, 1, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    if bias is not None:
+        bias = require_device_f32(bias, "bias")
+    check(lib.ddpm_convtr3d_k4s2_cout1_f32(ptr(x), ptr(w), ptr(bias), ptr(out), B, Cc, D, H, W, stream_ptr()),
+          "convT3d_k4s2_cout1")
     return out
 
 

@@ -13,8 +13,9 @@ What is MI355X-native here (and differs in mechanism, not in results, from the r
   * noise is an explicit, host-generated, per-image seeded input (``--seed`` finally has an
     effect, Q2), so results do not depend on batch composition or rank count;
   * images are sharded round-robin over ranks and scores return through a single RCCL
-    all_gather of a dense [n, n_t, 2] fp32 tensor (+ int32 ids) instead of
-    all_gather_object of pickled dict rows; only rank 0 writes the CSV (Q6).
+    all_gather of a dense [ceil(n / world), n_t * 2 + 1] fp32 tensor per rank (ids ride in column 0; the
+    shard capacity is static, so no size exchange precedes it) instead of all_gather_object of pickled
+    dict rows; only rank 0 writes the CSV (Q6).
 """
 
 from __future__ import annotations
@@ -70,31 +71,32 @@ def snr_shift_tables(scheduler, snr_shift: float) -> None:
     scheduler.alphas_cumprod = new_alphas_cumprod
 
 
-def gather_scores(ids: torch.Tensor, scores: torch.Tensor):
-    """Single all_gather of dense per-image scores.
+def gather_scores(ids: torch.Tensor, scores: torch.Tensor, n_max: int = None):
+    """ONE all_gather of dense per-image scores (RCCL over xGMI; gloo in the CPU tests).
 
-    ids: int32 [n_local] global image indices; scores: fp32 [n_local, n_t, 2].
-    Returns (ids, scores) concatenated rank-major on every rank (the reference's
-    all_gather_object semantics, reconstruct.py:238-242, in 2 MB instead of 30 MB of pickles).
-    Short shards are padded with id = -1 and dropped after the gather."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    ids: int32 [n_local] global image indices; scores: fp32 [n_local, n_t, 2]; n_max: the static shard capacity
+    ceil(n_images / world) -- every rank can compute it from the id list, so no size exchange is needed.
+    Returns (ids, scores, counts) concatenated rank-major on every rank (the reference's all_gather_object
+    semantics, reconstruct.py:238-242, in 2 MB instead of 30 MB of pickles).  Short shards are padded with
+    id = -1; the padding is dropped after the gather and ``counts`` (rows per rank) is read off the ids."""
+    if not dist.is_initialized():
         return ids, scores, [int(ids.shape[0])]
-    world = dist.get_world_size()
-    n = torch.tensor([ids.shape[0]], dtype=torch.int64, device=ids.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    n_max = int(max(int(c) for c in counts))
+    world = dist.get_world_size()  # a 1-rank group still goes through the collective (same code path as N ranks)
+    if n_max is None:
+        n_max = int(ids.shape[0]) if world == 1 else None
+    if n_max is None or ids.shape[0] > n_max:
+        raise ValueError(f"gather_scores: shard of {ids.shape[0]} rows does not fit the static capacity {n_max}")
     n_t = scores.shape[1]
     # ids travel inside the same fp32 payload (exact for ids < 2^24): one collective, not two
     payload = torch.full((n_max, n_t * 2 + 1), -1.0, dtype=torch.float32, device=scores.device)
     payload[: ids.shape[0], 0] = ids.to(torch.float32)
     payload[: ids.shape[0], 1:] = scores.reshape(ids.shape[0], n_t * 2)  # (an empty shard has 0 rows)
-    out = [torch.empty_like(payload) for _ in range(world)]
-    dist.all_gather(out, payload)
-    allp = torch.cat(out, dim=0)
-    keep = allp[:, 0] >= 0
-    allp = allp[keep]
-    return allp[:, 0].to(torch.int32), allp[:, 1:].reshape(-1, n_t, 2), [int(c) for c in counts]
+    out = torch.empty((world * n_max, n_t * 2 + 1), dtype=torch.float32, device=scores.device)
+    dist.all_gather_into_tensor(out, payload)
+    valid = out[:, 0] >= 0
+    counts = valid.reshape(world, n_max).sum(dim=1).tolist()
+    out = out[valid]
+    return out[:, 0].to(torch.int32), out[:, 1:].reshape(-1, n_t, 2), [int(c) for c in counts]
 
 
 def rows_from_scores(ids, scores, counts, t_values, name_of, batch_size: int, dataset_name: str):
@@ -335,7 +337,12 @@ class Reconstruct(BaseTrainer):
                     n_fwd += B
                 if self.do_latent_pad:
                     x = F.pad(input=x, pad=self.inverse_latent_pad, mode="constant", value=0).contiguous()
+                prof_decode = self.profile_first_steps and not isinstance(self.vqvae_model, PassthroughVQVAE)
+                if prof_decode:
+                    _lib.load().ddpm_prof_enable(1)
                 x = self.vqvae_model.decode_stage_2_outputs(x).contiguous()
+                if prof_decode:
+                    _lib.load().ddpm_prof_enable(0)
                 mse = ops.clamp_mse_(images_original, x, self.b_scale)  # x / b_scale, clamp_(0, 1), MSE
                 if self.spatial_dimension == 2:
                     if images_original.shape[3] == 28:
@@ -374,7 +381,9 @@ class Reconstruct(BaseTrainer):
         name_of = dict(zip((int(i) for i in ids.cpu()), names_all))
         counts = [int(ids.shape[0])]
         if self.ddp:
-            ids, scores, counts = gather_scores(ids, scores)
+            n_total = len(loader.all_names) if hasattr(loader, "all_names") else None
+            n_max = -(-n_total // self.world) if n_total is not None else None
+            ids, scores, counts = gather_scores(ids, scores, n_max)
             # every rank can name every image: the id list is the same file on every rank
             name_of = {i: n for i, n in enumerate(loader.all_names)} if hasattr(loader, "all_names") else name_of
             if int(os.environ["LOCAL_RANK"]) != 0 and not quiet:

@@ -6,9 +6,12 @@
 
 ``VQVAE`` mirrors ``generative.networks.nets.VQVAE`` for the latent-diffusion
 configuration: ctor from ``vqvae_config.json`` + ``load_state_dict`` (base.py:44-61),
-``encode_stage_2_inputs`` / ``decode_stage_2_outputs`` (reconstruct.py:124,166).  Per SURVEY.md 8(f) row
-f-1 the stage-1 model still runs on PyTorch-ROCm device ops (MIOpen conv3d / conv_transpose3d); its HIP
-kernels are the next row.  The 3-D UNet that consumes the latents IS on the HIP engine.
+``encode_stage_2_inputs`` / ``decode_stage_2_outputs`` (reconstruct.py:124,166).  SURVEY.md 8(f) row f-1: on a
+ROCm device every layer of the reference configuration (README.md:153-158: 4 stride-2 levels, 256 channels,
+embedding 128 x 2 048) runs on the library's HIP kernels -- the 3x3x3 convolutions, the k4 s2 down-convolutions and
+the k4 s2 transposed convolutions on the fp32-MFMA kernel (one launch each, depth taps / output parities inside),
+the single-channel first / last layers on ``conv3d_edge.hip``, the nearest-code search on ``vq.hip``.  Shapes
+without an MFMA tiling (channel counts not multiples of 128 / 8) fall back to PyTorch-ROCm ops and say so once.
 """
 
 import torch
@@ -41,6 +44,17 @@ class PassthroughVQVAE(torch.nn.Module):
         return x
 
 
+_FALLBACK_WARNED = set()
+
+
+def _warn_fallback(what: str) -> None:
+    if what not in _FALLBACK_WARNED:
+        _FALLBACK_WARNED.add(what)
+        import sys
+
+        print(f"WARNING: VQ-VAE layer {what} has no HIP tiling; it runs on PyTorch-ROCm ops", file=sys.stderr, flush=True)
+
+
 class _Convolution(nn.Module):
     """monai.networks.blocks.Convolution restricted to what VQVAE uses: a (transposed) ConvNd stored as
     ``.conv`` optionally followed by ``.adn`` = ReLU (adn_ordering "DA" / "NDA" with norm=None, dropout=0)."""
@@ -55,18 +69,52 @@ class _Convolution(nn.Module):
             conv_t = {2: nn.Conv2d, 3: nn.Conv3d}[spatial_dims]
             self.conv = conv_t(cin, cout, kernel_size, strides, padding, dilation=dilation)
         self.conv_only = conv_only
-        self._hip_ok = (not is_transposed and spatial_dims == 3 and kernel_size == 3 and strides == 1
-                        and dilation == 1 and padding == 1)
+        self.is_transposed = is_transposed
+        self.geom = (spatial_dims, kernel_size, strides, dilation, padding, output_padding)
         self._packed = None
 
-    def forward(self, x):
+    def _hip_kind(self, x):
+        """Which HIP kernel computes this layer for input x (None: PyTorch-ROCm fallback)."""
+        sd, k, s, dil, pad, opad = self.geom
         w = self.conv.weight
-        if self._hip_ok and x.is_cuda and ops.conv3d_supported(w):  # 3x3x3 stride 1: fp32-MFMA kernel
+        if not x.is_cuda or sd != 3 or dil != 1 or pad != 1 or opad != 0:
+            return None
+        even = all(e % 2 == 0 and e >= 2 for e in x.shape[2:])
+        if self.is_transposed:
+            if (k, s) != (4, 2):
+                return None
+            if ops.conv3d_supported(w, 2, transposed=True):
+                return "convT"
+            return "convT_cout1" if w.shape[1] == 1 else None
+        if (k, s) == (3, 1):
+            return "conv" if ops.conv3d_supported(w, 1) else None
+        if (k, s) == (4, 2) and even:
+            if ops.conv3d_supported(w, 2):
+                return "conv"
+            return "conv_cin1" if w.shape[1] == 1 else None
+        return None
+
+    def forward(self, x):
+        w, b = self.conv.weight, self.conv.bias
+        kind = self._hip_kind(x)
+        out_act = ops.ACT_NONE if self.conv_only else ops.ACT_RELU
+        if kind in ("conv", "convT"):
             key = (w.data_ptr(), w._version)
             if self._packed is None or self._packed[0] != key:
-                self._packed = (key, ops.pack_conv3d_weight(w.detach()))
-            return ops.conv3d(x.float().contiguous(), w.detach(), self.conv.bias.detach(), packed=self._packed[1],
-                              out_act=ops.ACT_NONE if self.conv_only else ops.ACT_RELU)
+                pack = ops.pack_conv3d_weight if kind == "conv" else ops.pack_convT_weight
+                self._packed = (key, pack(w.detach()))
+            x = x.float().contiguous()
+            if kind == "conv":
+                return ops.conv3d(x, w.detach(), b.detach(), packed=self._packed[1], out_act=out_act,
+                                  stride=self.geom[2])
+            return ops.conv_transpose(x, w.detach(), b.detach(), packed=self._packed[1], out_act=out_act)
+        if kind == "conv_cin1":
+            return ops.conv3d_k4s2_cin1(x.float().contiguous(), w.detach(), b.detach(), relu=not self.conv_only)
+        if kind == "convT_cout1":
+            y = ops.convT3d_k4s2_cout1(x.float().contiguous(), w.detach(), b.detach())
+            return y if self.conv_only else F.relu(y)
+        if x.is_cuda:
+            _warn_fallback(f"{type(self.conv).__name__}{tuple(w.shape)}")
         x = self.conv(x)
         return x if self.conv_only else F.relu(x)
 
@@ -89,8 +137,8 @@ class _ResidualUnit(nn.Module):
     def forward(self, x):
         w1, w2 = self.conv1.conv.weight, self.conv2.conv.weight
         if x.is_cuda and x.ndim == 5 and ops.conv3d_supported(w1) and ops.conv3d_supported(w2):
-            # 95 % of the decoder's FLOPs: both 3x3x3 convolutions on the fp32-MFMA kernel (three depth-tap
-            # launches each), ReLU / residual fused into the epilogues
+            # 95 % of the decoder's FLOPs: both 3x3x3 convolutions on the fp32-MFMA kernel (one launch each),
+            # ReLU / residual fused into the epilogues
             p1, p2 = self._hip_weights()
             x = x.float().contiguous()
             h = ops.conv3d(x, w1.detach(), self.conv1.conv.bias.detach(), out_act=ops.ACT_RELU, packed=p1)

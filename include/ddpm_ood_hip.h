@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDPM_ABI_VERSION 1
+#define DDPM_ABI_VERSION 2
 
 #define DDPM_EINVAL (-1)      /* bad argument / unsupported shape      */
 #define DDPM_ENOPARAM (-2)    /* unknown or missing parameter name     */
@@ -46,6 +46,8 @@ const char *ddpm_last_error(void);
 #define DDPM_CONV_NORMAL 0
 #define DDPM_CONV_STRIDE2 1   /* kernel 3, stride 2, pad 1  (Downsample.op)               */
 #define DDPM_CONV_UPSAMPLE2 2 /* nearest x2 folded into the input indexing (Upsample)     */
+#define DDPM_CONV_TRANSPOSE2 3 /* ConvTranspose kernel 4, stride 2, pad 1 (VQ-VAE decoder upsampling); w_packed from
+                                  ddpm_pack_convtr_weight_f32                                */
 #define DDPM_ACT_NONE 0
 #define DDPM_ACT_SILU 1
 #define DDPM_ACT_RELU 2
@@ -73,17 +75,20 @@ typedef struct ddpm_conv_desc {
   int B, Cout;
   int Hi, Wi;            /* stored input extent                                          */
   int Ho, Wo;            /* output extent                                                */
-  int ksize;             /* 1 or 3                                                       */
+  int ksize;             /* 1, 3, or 4 (4: DDPM_CONV_STRIDE2 = kernel 4 stride 2 pad 1, or
+                            DDPM_CONV_TRANSPOSE2)                                        */
   int mode;              /* DDPM_CONV_*                                                  */
   int act;               /* DDPM_ACT_* applied after the affine                          */
   int force_direct;      /* 1: take the generic direct kernel even if MFMA tiling exists */
-  /* 3-D convolutions (F.conv3d in the LDM UNet) run as three launches of the 2-D kernel, one per
-   * depth tap kd: out[n, :, d] += conv2d(in[n, :, din(d, kd)], w[:, :, kd]) on NCDHW tensors.
-   * Di / Do = stored input / output depth (0 or 1 = plain 2-D), kd = 0..2, accumulate = 1 adds
-   * into `out` (used for the 2nd and 3rd tap; bias / chan_add / residual go with the first).     */
+  /* 3-D convolutions (F.conv3d of the LDM UNet, conv3d / conv_transpose3d of the VQ-VAE;
+   * src/trainers/reconstruct.py:124,151-153,166) on NCDHW tensors: dims = 3, Di / Do = stored input / output
+   * depth, kernel k x k x k.  w_packed then holds k depth slabs of k x k taps (ddpm_pack_conv3d_weight_f32) and
+   * ONE launch walks (depth tap, channel group) chunks: out[n, :, d] = sum_kd conv2d(in[n, :, din(d, kd)],
+   * w[:, :, kd]).  Supported: k = 3 with NORMAL / STRIDE2 / UPSAMPLE2, k = 4 with STRIDE2 / TRANSPOSE2; a 1x1x1
+   * conv is the 2-D op over an (D*H) x W image.  dims = 0 or 2: plain 2-D (Di = Do = 0).                     */
   int Di, Do;
-  int kd;
-  int accumulate;
+  int dims;
+  int reserved0;
   /* Optional, 2-D DDPM_CONV_UPSAMPLE2 only: weights folded by ddpm_fold_upsample_weight_f32.  A 3x3
    * conv over a nearest-x2 upsampled image is, for each of the 4 output parities (dy, dx), a 2x2 conv
    * over the low-res image whose taps are sums of the 3x3 taps that read the same source pixel:
@@ -109,6 +114,25 @@ size_t ddpm_packed_conv_weight_floats(int Cout, int Cin, int ksize);
  * weight with `Cout_total` rows (lets q/k/v or all time_emb_proj share one GEMM).       */
 int ddpm_pack_conv_weight_f32(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize,
                               int cout_offset, int Cout_total, ddpm_stream_t stream);
+
+/* [Cout, Cin, k, k, k] (k = 3 or 4) -> k packed depth slabs of k x k taps: the w_packed of a dims = 3 descriptor.  */
+int ddpm_pack_conv3d_weight_f32(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize,
+                                ddpm_stream_t stream);
+
+/* ConvTranspose k4 s2 p1 weights, torch layout [Cin, Cout, 4, 4] (dims = 2) or [Cin, Cout, 4, 4, 4] (dims = 3), packed
+ * per output parity: out[2i + p] only sees kernel elements 3 - p - 2r (r = 0, 1) per axis, so every parity is a
+ * 2 x 2 (x 2)-tap convolution over the input.  16 (64) * Cout * Cin floats; 0 if Cout % 128 or Cin % 8.           */
+size_t ddpm_packed_convtr_weight_floats(int Cout, int Cin, int dims);
+int ddpm_pack_convtr_weight_f32(const float *w_raw, float *w_packed, int Cin, int Cout, int dims, ddpm_stream_t stream);
+
+/* VQ-VAE edge layers without an MFMA tiling (1 input / 1 output channel), NCDHW, stride 2, kernel 4, pad 1:
+ *   ddpm_conv3d_k4s2_cin1_f32:   out[B, Cout, D/2, H/2, W/2] = relu?(conv3d(in[B, 1, D, H, W], w[Cout, 1, 4, 4, 4]) + bias)
+ *   ddpm_convtr3d_k4s2_cout1_f32: out[B, 1, 2D, 2H, 2W] = conv_transpose3d(in[B, Cin, D, H, W], w[Cin, 1, 4, 4, 4]) + bias
+ * (first encoder / last decoder layer at src/trainers/reconstruct.py:124,166; torch weight layouts, no packing).   */
+int ddpm_conv3d_k4s2_cin1_f32(const float *in, const float *w, const float *bias, float *out, int B, int Cout, int D,
+                              int H, int W, int relu, ddpm_stream_t stream);
+int ddpm_convtr3d_k4s2_cout1_f32(const float *in, const float *w, const float *bias, float *out, int B, int Cin, int D,
+                                int H, int W, ddpm_stream_t stream);
 
 /* Pack `ksize*ksize` taps starting at `tap_off` out of the `src_taps` taps of a wider torch kernel, e.g. depth
  * tap kd of a conv3d weight [Cout, Cin, 3, 3, 3]: src_taps = 27, tap_off = 9 * kd.                       */

@@ -34,6 +34,9 @@ def _setup(tmp_path, channels, model_type="small", spatial_dims=2, **kw):
     from ddpm_ood_amd import synthetic
     from ddpm_ood_amd.trainer import MODEL_CONFIGS, Reconstruct
 
+    tiny = f"synthetic:{'blobs3d' if spatial_dims == 3 else 'blobs'}:n=1:channels={channels}:size=8"
+    kw.setdefault("validation_ids", tiny)  # Reconstruct.__init__ builds the val / in loaders (reconstruct.py:37-70)
+    kw.setdefault("in_ids", tiny)
     args = make_args(tmp_path, model_type=model_type, is_grayscale=int(channels == 1), spatial_dimension=spatial_dims,
                      **kw)
     sd = synthetic.random_state_dict(model_type, channels, spatial_dims=spatial_dims, seed=1)
@@ -112,15 +115,15 @@ def test_cfg2_all_25_chained_t_starts(device, tmp_path):
     One scheduler per batch, so each of the 25 trajectories starts with the PLMS history the previous one left
     behind (reconstruct.py:98-157).  val / in / out sets -> Z-scores <= 1e-4."""
     args, rec, ref = _setup(tmp_path, 1, inference_skip_factor=4, batch_size=3)
-    sets = {"val": "synthetic:blobs:n=3:seed=10", "in": "synthetic:blobs:n=2:seed=11",
-            "out": "synthetic:speckle:n=2:seed=12:mix=10"}
+    sets = {"val": "synthetic:blobs:n=2:seed=10", "in": "synthetic:blobs:n=2:seed=11",
+            "out": "synthetic:speckle:n=1:seed=12:mix=10"}  # 5 images x 1 250 forwards: ~1.5 min of CPU oracle
     rows_h, rows_o = {}, {}
     for name, ids in sets.items():
         rows_h[name] = hip_scores(args, rec, ids, name)
         rows_o[name] = oracle_scores(args, rec, ids, name, model=ref)
         assert sorted(set(rows_h[name]["t"])) == list(range(10, 1000, 40))
         assert_rows_close(rows_h[name], rows_o[name], 2e-4, name)
-    assert rec.last_stats["unet_forwards"] == 2 * 1250
+    assert rec.last_stats["unet_forwards"] == 1 * 1250
     assert_z_close(rows_h, rows_o)
 
 
@@ -185,12 +188,17 @@ VQ_README = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(25
                  upsample_parameters=((2, 4, 1, 1, 0),) * 4, num_embeddings=2048, embedding_dim=128)
 
 
-@pytest.mark.parametrize("volume", [(32, 128, 128), (128, 128, 128)])
+_SLOW = bool(int(__import__("os").environ.get("DDPM_SLOW_TESTS", "0")))
+
+
+@pytest.mark.parametrize("volume", [(64, 64, 64)] + ([(128, 128, 128)] if _SLOW else []))
 def test_cfg5_readme_vqvae_ldm_trajectory(device, tmp_path, volume):
-    """BASELINE configs[4] at the README VQ-VAE shape.  (32, 128, 128) -> latents [128, 2, 8, 8]: the 3-D UNet's
-    lower levels have depth 1 (centre depth tap only); (128, 128, 128) -> [128, 8, 8, 8] is the
-    reference's own geometry.  encode (VQ-VAE + nearest-code search) -> PLMS trajectories at t = 10 and 650 ->
-    re-quantise + decode -> clamp, MSE, 2.5-D LPIPS over 128 slices."""
+    """BASELINE configs[4] at the README VQ-VAE shape (4 x k4-s2 levels, 256 channels, 3 residual units per level,
+    2 048 codes x 128).  (64, 64, 64) -> latents [128, 4, 4, 4]: the 3-D UNet's lowest level is a 1x1x1 volume
+    (centre depth tap only; capped images per MFMA tile); (128, 128, 128) -> [128, 8, 8, 8] is the
+    reference's own geometry -- its CPU oracle run takes ~6 min on the GPU box's host, so it only runs with
+    DDPM_SLOW_TESTS=1 (log of such a run: profiles/r02_gpu_tests_slow.log).  encode (VQ-VAE + nearest-code search)
+    -> PLMS trajectories at t = 10 and 650 -> re-quantise + decode -> clamp, MSE, 2.5-D LPIPS over the slices."""
     import oracle
     from oracle.vqvae import VQVAE as OracleVQVAE
     from ddpm_ood_amd import synthetic
@@ -215,7 +223,7 @@ def test_cfg5_readme_vqvae_ldm_trajectory(device, tmp_path, volume):
     ref = oracle.DiffusionModelUNet(3, 128, 128, **MODEL_CONFIGS["small"]).eval()
     ref.load_state_dict(sd)
 
-    vol = synthetic_images("blobs3d", 1, 1, 128, seed=5)[:, :, : volume[0]].contiguous()
+    vol = synthetic_images("blobs3d", 1, 1, volume[0], seed=5)
     assert tuple(vol.shape[2:]) == volume
     mk = lambda: ListLoader(vol, ["vol_000000.npy"], 1)  # noqa: E731
     h = pd.DataFrame(rec.get_scores(mk(), "in", 64))
@@ -224,7 +232,7 @@ def test_cfg5_readme_vqvae_ldm_trajectory(device, tmp_path, volume):
     with torch.no_grad():
         z_h = rec.vqvae_model.encode_stage_2_inputs(vol.to(device)).cpu()
         z_o = vq.encode_stage_2_inputs(vol)
-    assert z_h.shape == z_o.shape == (1, 128, volume[0] // 16, 8, 8)
+    assert z_h.shape == z_o.shape == (1, 128) + tuple(v // 16 for v in volume)
     assert torch.equal(rec.vqvae_model.index_quantize(vol.to(device)).cpu(), vq.index_quantize(vol))
     assert (z_h - z_o).abs().max() < 1e-5
 
@@ -281,15 +289,15 @@ def test_option_branches_in_a_trajectory(device, tmp_path, case):
             beta_schedule=args.beta_schedule, beta_start=args.beta_start, beta_end=args.beta_end))
     else:
         o = oracle_scores(args, rec, ids, "in", model=ref)
-    n_t = 5 if case == "diffusers_list" else 4
-    assert len(h) == 3 * n_t, sorted(set(h["t"]))
+    assert sorted(set(h["t"])) == [10, 330, 650, 970]  # reversed(timesteps)[1::32], also for the 101-entry list
     assert_rows_close(h, o, 2e-4, case)
 
 
-@pytest.mark.parametrize("B,D,H", [(2, 4, 8), (1, 1, 8), (2, 2, 16)])
+@pytest.mark.parametrize("B,D,H", [(2, 4, 8), (1, 4, 4), (2, 8, 4)])
 def test_unet_forward_3d_shallow_depth(device, B, D, H):
-    """a 3-D UNet whose activations reach depth 1 (input depth <= 2^(levels-1)).  The outer depth
-    taps then only see padding; the engine used to run such a level as a 2-D conv with the kd = 0 weights."""
+    """a 3-D UNet whose activations reach depth 1 (input depth = 2^(levels-1); smaller or odd
+    depths do not survive the down / up path in the reference either).  The outer depth taps then only see padding;
+    the engine used to run such a level as a 2-D conv with the kd = 0 weights.  H = 4: the lowest level is 1x1."""
     import oracle
     from ddpm_ood_amd import DiffusionModelUNet
     from ddpm_ood_amd.synthetic import random_state_dict

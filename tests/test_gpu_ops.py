@@ -257,10 +257,13 @@ def test_no_cpu_fallback():
         ops.conv(torch.zeros(1, 8, 8, 8), torch.zeros(8, 8, 3, 3))
 
 
-@pytest.mark.parametrize("B,Cin,Cout,D,H", [(1, 128, 256, 8, 8), (2, 256, 256, 4, 16), (1, 256, 128, 6, 12)])
+@pytest.mark.parametrize("B,Cin,Cout,D,H", [(1, 128, 256, 8, 8), (2, 256, 256, 4, 16), (1, 256, 128, 6, 12),
+                                            (2, 128, 128, 1, 8), (1, 256, 256, 2, 2), (3, 128, 128, 1, 1),
+                                            (1, 256, 256, 32, 32)])
 def test_conv3d_depth_taps_with_relu_epilogues(device, B, Cin, Cout, D, H):
-    """F.conv3d (3x3x3, pad 1) as three depth-tap launches, with the input / output ReLU and residual fusions the
-    VQ-VAE residual units use."""
+    """F.conv3d (3x3x3, pad 1) as ONE launch whose chunk stream walks (depth tap, channel group), with the input /
+    output ReLU and residual fusions the VQ-VAE residual units use; depth-1 volumes (centre tap only) and 1x1 /
+    2x2 planes (capped images per tile) included."""
     from ddpm_ood_amd import ops
 
     g = torch.Generator().manual_seed(17)
@@ -272,6 +275,100 @@ def test_conv3d_depth_taps_with_relu_epilogues(device, B, Cin, Cout, D, H):
     _close(ops.conv3d(d(x), d(w), d(b)), F.conv3d(x, w, b, padding=1))
     _close(ops.conv3d(d(x), d(w), d(b), act=ops.ACT_RELU, out_act=ops.ACT_RELU, residual=d(res)),
            F.relu(F.conv3d(F.relu(x), w, b, padding=1) + res))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,D,H,W", [(1, 256, 256, 16, 16, 16), (1, 256, 256, 64, 64, 64), (2, 128, 256, 8, 32, 16),
+                                              (1, 256, 128, 4, 4, 4), (3, 8, 128, 2, 2, 2), (1, 128, 128, 6, 10, 12)])
+def test_conv3d_k4s2_matches_torch(device, B, Cin, Cout, D, H, W):
+    """VQ-VAE down-convolution: F.conv3d(kernel 4, stride 2, pad 1) (+ ReLU) on the MFMA kernel: 16 in-plane taps per
+    chunk, 4 depth taps in the chunk stream (reference: src/trainers/reconstruct.py:124 via the VQ-VAE encoder)."""
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(B, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 4, 4, 4, generator=g) / math.sqrt(Cin * 64)
+    b = torch.randn(Cout, generator=g)
+    d = lambda t: t.to(device)
+    y = ops.conv3d(d(x), d(w), d(b), stride=2, out_act=ops.ACT_RELU)
+    _close(y, F.relu(F.conv3d(x, w, b, stride=2, padding=1)))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,D,H,W", [(1, 256, 256, 8, 8, 8), (1, 256, 256, 32, 32, 32), (2, 128, 256, 4, 16, 8),
+                                              (1, 256, 128, 2, 2, 2), (3, 8, 128, 1, 1, 1), (1, 128, 128, 3, 5, 6)])
+def test_conv_transpose3d_k4s2_matches_torch(device, B, Cin, Cout, D, H, W):
+    """VQ-VAE up-convolution: F.conv_transpose3d(kernel 4, stride 2, pad 1) (+ ReLU) as one launch with grid.z = the
+    8 output parities, each a 2x2x2-tap convolution (reference: src/trainers/reconstruct.py:166 via the decoder)."""
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(B, Cin, D, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 4, 4, 4, generator=g) / math.sqrt(Cin * 8)
+    b = torch.randn(Cout, generator=g)
+    d = lambda t: t.to(device)
+    _close(ops.conv_transpose(d(x), d(w), d(b), out_act=ops.ACT_RELU), F.relu(F.conv_transpose3d(x, w, b, stride=2, padding=1)))
+    _close(ops.conv_transpose(d(x), d(w), None), F.conv_transpose3d(x, w, None, stride=2, padding=1))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 128, 128, 8, 8), (1, 64, 256, 16, 32), (3, 8, 128, 1, 3)])
+def test_conv_transpose2d_k4s2_matches_torch(device, B, Cin, Cout, H, W):
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 4, 4, generator=g) / math.sqrt(Cin * 4)
+    b = torch.randn(Cout, generator=g)
+    d = lambda t: t.to(device)
+    _close(ops.conv_transpose(d(x), d(w), d(b)), F.conv_transpose2d(x, w, b, stride=2, padding=1))
+
+
+@pytest.mark.parametrize("B,C,D,H,W", [(1, 256, 32, 32, 32), (2, 16, 4, 6, 10), (1, 32, 2, 2, 2)])
+def test_vqvae_edge_layers_match_torch(device, B, C, D, H, W):
+    """conv3d_edge.hip: Conv3d 1 -> C (k4 s2 p1, + ReLU) and ConvTranspose3d C -> 1 (k4 s2 p1) against torch."""
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(37)
+    d = lambda t: t.to(device)
+    x = torch.rand(B, 1, 2 * D, 2 * H, 2 * W, generator=g)
+    w = torch.randn(C, 1, 4, 4, 4, generator=g) / 8
+    b = torch.randn(C, generator=g)
+    _close(ops.conv3d_k4s2_cin1(d(x), d(w), d(b), relu=True), F.relu(F.conv3d(x, w, b, stride=2, padding=1)))
+    _close(ops.conv3d_k4s2_cin1(d(x), d(w), None), F.conv3d(x, w, None, stride=2, padding=1))
+    z = torch.randn(B, C, D, H, W, generator=g)
+    wt = torch.randn(C, 1, 4, 4, 4, generator=g) / math.sqrt(C * 8)
+    bt = torch.randn(1, generator=g)
+    _close(ops.convT3d_k4s2_cout1(d(z), d(wt), d(bt)), F.conv_transpose3d(z, wt, bt, stride=2, padding=1))
+
+
+def test_vqvae_readme_shape_all_layers_on_hip(device):
+    """README.md:153-158 VQ-VAE (4 x k4-s2 levels, 256 channels, 3 residual units per level, 2 048 codes x 128) on a
+    64^3 volume: every layer takes a HIP kernel (no PyTorch-ROCm fallback), encode / decode against the CPU oracle."""
+    from oracle.vqvae import VQVAE as OV
+    from ddpm_ood_amd import vqvae as pv
+
+    cfg = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(256,) * 4, num_res_layers=3,
+               num_res_channels=(256,) * 4, downsample_parameters=((2, 4, 1, 1),) * 4,
+               upsample_parameters=((2, 4, 1, 1, 0),) * 4, num_embeddings=2048, embedding_dim=128)
+    torch.manual_seed(1)
+    o = OV(**cfg).eval()
+    with torch.no_grad():
+        o.quantizer.quantizer.embedding.weight.mul_(3.0)
+    p = pv.VQVAE(**cfg)
+    p.load_state_dict(o.state_dict())
+    p = p.to(device).eval()
+    x = torch.rand(1, 1, 64, 64, 64, generator=torch.Generator().manual_seed(2))
+    kinds = []
+    orig = pv._Convolution._hip_kind
+    pv._Convolution._hip_kind = lambda self, t: (kinds.append(orig(self, t)), kinds[-1])[1]
+    try:
+        with torch.no_grad():
+            zo = o.encode_stage_2_inputs(x)
+            zp = p.encode_stage_2_inputs(x.to(device))
+            _close(zp, zo, tol=1e-5)
+            _close(p.decode_stage_2_outputs(zp), o.decode_stage_2_outputs(zo), tol=2e-5)
+    finally:
+        pv._Convolution._hip_kind = orig
+    assert None not in kinds and not pv._FALLBACK_WARNED, (kinds, pv._FALLBACK_WARNED)
+    assert kinds.count("conv_cin1") == 1 and kinds.count("convT_cout1") == 1 and kinds.count("convT") == 3
 
 
 def test_vqvae_residual_units_on_hip_match_torch(device):

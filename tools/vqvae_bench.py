@@ -29,3 +29,21 @@ with torch.no_grad():
         fl += 2 * (2 * s) ** 3 * 256 * (256 if lv < 3 else 1) * 8
     fl += 2 * 8 ** 3 * 128 * 256 * 27
     print(f"decode_stage_2_outputs: {dt * 1e3:.1f} ms for B={B}  ({fl * B / dt / 1e12:.1f} TFLOP/s, {fl / 1e12:.2f} TFLOP / volume)", flush=True)
+
+    # per-kernel-class breakdown of one decode through the library's hipEvent profiler
+    import ctypes, json
+    from ddpm_ood_amd import _lib
+    lib = _lib.load()
+    lib.ddpm_prof_enable(1)
+    m.decode_stage_2_outputs(z)
+    lib.ddpm_prof_enable(0)
+    torch.cuda.synchronize()
+    buf = ctypes.create_string_buffer(1 << 18)
+    lib.ddpm_prof_report(buf, len(buf))
+    prof = json.loads(buf.value.decode())
+    tot = sum(v["ms"] for v in prof.values())
+    print(f"{'kernel':60s} {'launch':>6s} {'ms':>9s} {'%':>6s} {'TFLOP/s':>8s} {'GB/s':>8s}")
+    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+        print(f"{k:60s} {v['launches']:6d} {v['ms']:9.3f} {100 * v['ms'] / tot:6.1f} "
+              f"{v['flops'] / v['ms'] / 1e9:8.2f} {v['bytes'] / v['ms'] / 1e6:8.1f}")
+    print(f"sum of kernel time: {tot:.2f} ms / decode", flush=True)
