@@ -72,7 +72,7 @@ struct ConvGeom {
   long long par_slab;  // floats between two parity slabs of w_packed
 };
 
-static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g) {
+static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g, int ps_cap = 0) {
   const int Cin = d.C1 + d.C2;
   g.Cin = Cin;
   g.MT = MT;
@@ -111,7 +111,7 @@ static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g) {
   if (g.TPI == 0) {
     // tiny images (1x1, 2x2: the halo outweighs the pixels): cap the images per tile so that the staged
     // plane still fits the instantiated variants (geom_ok); the tile then carries a few idle MFMA columns
-    const int max_ps = d.ksize == 1 ? 256 : (d.gscale ? 2 * 256 : 3 * 256);
+    const int max_ps = ps_cap ? ps_cap : d.ksize == 1 ? 256 : (d.gscale ? 2 * 256 : 3 * 256);
     if (g.TI * g.IRS > max_ps && max_ps / g.IRS >= 1) g.TI = max_ps / g.IRS;
     g.ntiles = (g.NI + g.TI - 1) / g.TI;
   }
@@ -142,10 +142,10 @@ static bool geom_ok(const ddpm_conv_desc &d, const ConvGeom &g) {
 }
 
 // Pick the pixel-tile size: 128 unless that grid cannot give every CU two workgroups.
-static bool pick_geom(const ddpm_conv_desc &d, ConvGeom &g) {
+static bool pick_geom(const ddpm_conv_desc &d, ConvGeom &g, int ps_cap = 0) {
   ConvGeom g128, g64;
-  const bool ok128 = make_geom(d, 128, g128) && geom_ok(d, g128);
-  const bool ok64 = make_geom(d, 64, g64) && geom_ok(d, g64);
+  const bool ok128 = make_geom(d, 128, g128, ps_cap) && geom_ok(d, g128);
+  const bool ok64 = make_geom(d, 64, g64, ps_cap) && geom_ok(d, g64);
   if (!ok128 && !ok64) return false;
   const long wg128 = ok128 ? (long)g128.ntiles * (d.Cout / kConvNT) : 0;
   static const long min_wg128 = getenv("DDPM_CONV_MIN_WG128") ? atol(getenv("DDPM_CONV_MIN_WG128")) : 512;
@@ -179,7 +179,7 @@ static bool transpose_geom(const ddpm_conv_desc &d, ConvGeom &g) {
   if (is3d && d.Do != 2 * (d.Di > 1 ? d.Di : 1)) return false;
   ddpm_conv_desc lr = lowres_view(d);
   lr.dims = 0;  // geometry of the in-plane tiling only; the depth walk is set below
-  if (!pick_geom(lr, g) || g.PS > 2 * 256) return false;
+  if (!pick_geom(lr, g, 2 * 256) || g.PS > 2 * 256) return false;  // parity variants: NPOS <= 2
   g.npar = is3d ? 8 : 4;
   g.nchunks_c = Cin / 8;               // KG = 2: eight channels per chunk
   g.par_slab = (long long)d.Cout * Cin * (is3d ? 8 : 4);
@@ -602,7 +602,7 @@ static int launch_upsample_folded(const ddpm_conv_desc &d, hipStream_t s, bool &
   ddpm_conv_desc lr = lowres_view(d);
   lr.w_packed = d.w_folded;
   ConvGeom g;
-  if (!pick_geom(lr, g) || g.PS > 2 * 256) return 0;
+  if (!pick_geom(lr, g, 2 * 256) || g.PS > 2 * 256) return 0;
   taken = true;
   g.npar = 4;
   g.par_slab = (long long)d.Cout * Cin * 4;

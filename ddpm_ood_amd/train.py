@@ -1,0 +1,210 @@
+"""``DDPMTrainer``: the epsilon-prediction training loop that produces the checkpoint the reconstruction path loads
+(SURVEY.md 8(f) row f-3).
+
+Mirrors /root/reference/src/trainers/ddpm_trainer.py:16-124 (epoch loop, best-loss / periodic checkpoints, the
+training step: random timesteps, Gaussian noise, ``scheduler.add_noise(images * b_scale)``, MSE between the UNet
+output and the noise) with Adam(lr = 2.5e-5) as at /root/reference/src/trainers/base.py:156 and the checkpoint
+dict of base.py:166-187.  Differences, on purpose:
+  * fp32 throughout (the reference trains under fp16 autocast + GradScaler; reduced precision would be the
+    deviation here, not the other way round);
+  * the backward pass is PyTorch-ROCm autograd: ``unet_forward_torch`` evaluates the SAME parameter holders the HIP
+    engine reads (``DiffusionModelUNet``) with differentiable ATen ops, so a checkpoint written here loads into the
+    HIP inference path unchanged.  Training is off the hot path (it runs once; reconstruction runs per image x
+    t_start x step) -- its kernels are rocBLAS / MIOpen via ATen, not hand-written;
+  * multi-GPU: one process per GPU, gradients averaged with ONE flat RCCL all_reduce per step (17.7 M parameters =
+    71 MB for `small`) instead of DistributedDataParallel's bucket hooks;
+  * no TensorBoard / matplotlib sample grids (not installed here; off the path).
+"""
+
+from __future__ import annotations
+
+import math
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .data import get_data_loader
+from .trainer import BaseTrainer
+
+
+# ---- differentiable forward over the parameter holders ------------------------------------
+
+def _conv(holder, x, stride=1):
+    c = holder.conv
+    f = F.conv2d if c.weight.ndim == 4 else F.conv3d
+    return f(x, c.weight, c.bias, stride=stride, padding=c.padding)
+
+
+def _resnet(blk, x, emb):
+    h = _conv(blk.conv1, F.silu(blk.norm1(x)))
+    t = F.linear(F.silu(emb), blk.time_emb_proj.weight, blk.time_emb_proj.bias)
+    h = h + t.reshape(t.shape + (1,) * (x.ndim - 2))
+    h = _conv(blk.conv2, F.silu(blk.norm2(h)))
+    skip = x if isinstance(blk.skip_connection, torch.nn.Identity) else _conv(blk.skip_connection, x)
+    return skip + h
+
+
+def _attention(blk, x, head_channels, use_proj_attn):
+    b, c = x.shape[:2]
+    heads = c // head_channels if head_channels else 1
+    seq = blk.norm(x).reshape(b, c, -1).transpose(1, 2)  # [b, n, c]
+
+    def split(t):
+        return t.reshape(b, -1, heads, c // heads).transpose(1, 2)  # [b, heads, n, d]
+
+    q, k, v = (split(F.linear(seq, m.weight, m.bias)) for m in (blk.to_q, blk.to_k, blk.to_v))
+    probs = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(c / heads), dim=-1)
+    o = (probs @ v).transpose(1, 2).reshape(b, -1, c)
+    if use_proj_attn:
+        o = F.linear(o, blk.proj_attn.weight, blk.proj_attn.bias)
+    return o.transpose(1, 2).reshape(x.shape) + x
+
+
+def unet_forward_torch(model, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+    """eps = DiffusionModelUNet(x, timesteps) with ATen ops and autograd (training only)."""
+    ch0 = model.block_out_channels[0]
+    freqs = model._freqs().to(x.device)
+    ang = timesteps[:, None].float() * freqs[None, :]
+    emb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+    if ch0 % 2:
+        emb = F.pad(emb, (0, 1))
+    emb = model.time_embed(emb)
+    h = _conv(model.conv_in, x)
+    skips = [h]
+    for blk, hc in zip(model.down_blocks, model.num_head_channels):
+        for j, r in enumerate(blk.resnets):
+            h = _resnet(r, h, emb)
+            if hasattr(blk, "attentions"):
+                h = _attention(blk.attentions[j], h, hc, model.use_proj_attn)
+            skips.append(h)
+        if blk.downsampler is not None:
+            h = _conv(blk.downsampler.op, h, stride=2)
+            skips.append(h)
+    mid = model.middle_block
+    h = _resnet(mid.resnet_1, h, emb)
+    h = _attention(mid.attention, h, model.num_head_channels[-1], model.use_proj_attn)
+    h = _resnet(mid.resnet_2, h, emb)
+    for blk, hc in zip(model.up_blocks, reversed(model.num_head_channels)):
+        for j, r in enumerate(blk.resnets):
+            h = _resnet(r, torch.cat([h, skips.pop()], dim=1), emb)
+            if hasattr(blk, "attentions"):
+                h = _attention(blk.attentions[j], h, hc, model.use_proj_attn)
+        if blk.upsampler is not None:
+            h = _conv(blk.upsampler.conv, F.interpolate(h, scale_factor=2.0, mode="nearest"))
+    return _conv(model.out[2], F.silu(model.out[0](h)))
+
+
+class DDPMTrainer(BaseTrainer):
+    def __init__(self, args):
+        super().__init__(args)
+        if getattr(args, "quick_test", 0):
+            print("Quick test enabled, only running on a single train and eval batch.")
+        self.quick_test = bool(getattr(args, "quick_test", 0))
+        self.num_epochs = args.n_epochs
+        self.seed = int(args.seed)
+        for p in self.model.parameters():
+            p.requires_grad_(True)
+        self.optimizer = torch.optim.Adam(params=self.model.parameters(), lr=2.5e-5)  # base.py:156
+        if self.found_checkpoint and self.optimizer_state:
+            self.optimizer.load_state_dict(self.optimizer_state)
+        kw = dict(batch_size=args.batch_size, is_grayscale=bool(args.is_grayscale), image_size=self.image_size,
+                  spatial_dimension=args.spatial_dimension, image_roi=args.image_roi)
+        self.train_loader = get_data_loader(args.training_ids, rank=self.rank, world=self.world, **kw)
+        self.val_loader = get_data_loader(args.validation_ids, rank=self.rank, world=self.world, **kw)
+        self.gen = torch.Generator(device=self.device).manual_seed(self.seed * 7919 + self.rank)
+        self.history = []  # (epoch, mean train loss)
+
+    # ---- one optimisation step (ddpm_trainer.py:77-101) --------------------------------------------------
+    def _loss(self, images: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            images = self.vqvae_model.encode_stage_2_inputs(images).float()
+            if self.do_latent_pad:
+                images = F.pad(input=images, pad=self.latent_pad, mode="constant", value=0)
+            b = images.shape[0]
+            timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (b,), device=self.device,
+                                      generator=self.gen).long()
+            noise = torch.randn(images.shape, device=self.device, generator=self.gen)
+            noisy = self.scheduler.add_noise(original_samples=images.contiguous(), noise=noise, timesteps=timesteps,
+                                             b_scale=self.b_scale)
+        pred = unet_forward_torch(self.model, noisy, timesteps)
+        if self.prediction_type == "v_prediction":
+            ac = self.scheduler.alphas_cumprod.to(self.device)[timesteps].reshape(-1, *([1] * (images.ndim - 1)))
+            target = ac.sqrt() * noise - (1 - ac).sqrt() * images * self.b_scale
+        else:
+            target = noise
+        return F.mse_loss(pred.float(), target.float())
+
+    def _sync_grads(self):
+        if not self.ddp:
+            return
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat)  # RCCL over xGMI: one collective per step
+        flat /= self.world
+        off = 0
+        for g in grads:
+            g.copy_(flat[off: off + g.numel()].view_as(g))
+            off += g.numel()
+
+    def train_epoch(self, epoch: int) -> float:
+        self.model.train()
+        order = torch.randperm(len(self.train_loader.names), generator=torch.Generator().manual_seed(self.seed + epoch))
+        bs = self.train_loader.batch_size
+        epoch_loss, epoch_step = 0.0, 0
+        t0 = time.time()
+        for s in range(0, len(order), bs):
+            idx = order[s: s + bs]
+            images = self.train_loader.images[idx].to(self.device, non_blocking=True)
+            self.optimizer.zero_grad(set_to_none=True)
+            loss = self._loss(images)
+            loss.backward()
+            self._sync_grads()
+            self.optimizer.step()
+            epoch_loss += loss.item()
+            self.global_step += images.shape[0]
+            epoch_step += images.shape[0]
+            if self.quick_test:
+                break
+        print(f"Epoch {epoch}: loss {epoch_loss / max(epoch_step, 1):.6f} ({time.time() - t0:.1f} s)")
+        return epoch_loss / max(epoch_step, 1)
+
+    @torch.no_grad()
+    def val_epoch(self, epoch: int) -> float:
+        self.model.eval()
+        tot, n = 0.0, 0
+        for batch in self.val_loader:
+            tot += self._loss(batch["image"].to(self.device)).item()
+            n += batch["image"].shape[0]
+            if self.quick_test:
+                break
+        print(f"Validation {epoch}: loss {tot / max(n, 1):.6f}")
+        return tot / max(n, 1)
+
+    def save_checkpoint(self, path, epoch, save_message=None):
+        if self.rank != 0:
+            return
+        checkpoint = {"epoch": epoch + 1,  # save epoch + 1, so we resume on the next epoch (base.py:170)
+                      "global_step": self.global_step, "model_state_dict": self.model.state_dict(),
+                      "optimizer_state_dict": self.optimizer.state_dict(), "best_loss": self.best_loss}
+        print(save_message)
+        torch.save(checkpoint, path)
+
+    def train(self, args):
+        self.run_dir.mkdir(parents=True, exist_ok=True)
+        for epoch in range(self.start_epoch, self.num_epochs):
+            epoch_loss = self.train_epoch(epoch)
+            self.history.append((epoch, epoch_loss))
+            if epoch_loss < self.best_loss:
+                self.best_loss = epoch_loss
+                self.save_checkpoint(self.run_dir / "checkpoint.pth", epoch,
+                                     save_message=f"Saving checkpoint for model with loss {self.best_loss}")
+            if args.checkpoint_every != 0 and (epoch + 1) % args.checkpoint_every == 0:
+                self.save_checkpoint(self.run_dir / f"checkpoint_{epoch + 1}.pth", epoch,
+                                     save_message=f"Saving checkpoint at epoch {epoch + 1}")
+            if (epoch + 1) % args.eval_freq == 0:
+                self.val_epoch(epoch)
+        print("Training completed.")
+        if self.ddp:
+            dist.destroy_process_group()

@@ -215,12 +215,14 @@ class BaseTrainer:
             self.global_step = checkpoint["global_step"]
             self.model.load_state_dict(checkpoint["model_state_dict"])
             self.best_loss = checkpoint["best_loss"]
+            self.optimizer_state = checkpoint.get("optimizer_state_dict")  # used by DDPMTrainer only
             print(f"Resuming training using checkpoint {checkpoint_path} at epoch {self.start_epoch}")
         else:
             self.start_epoch = 0
             self.best_loss = 1000
             self.global_step = 0
             self.found_checkpoint = False
+            self.optimizer_state = None
         # no optimizer, no GradScaler, no DDP wrap: inference only, every rank reads the same
         # checkpoint file instead of the reference's DDP parameter broadcast (Q15)
 

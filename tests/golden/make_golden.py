@@ -16,6 +16,7 @@ Files (all small):
   trajectory_rows.csv   get_scores on 3 x 4 synthetic images, k = 64 (t = 10, 650; stale PLMS history)
   ood_scores.json       Z-score / AUROC of those rows through the pandas / sklearn scorer
   cli_flags.json        flag names / defaults of the reference CLI (data parsed from its argparse calls)
+  train_cli_flags.json  the same for the reference's train_ddpm.py
 """
 
 import ast
@@ -131,9 +132,9 @@ def trajectory(sd, model):
               open(HERE / "ood_scores.json", "w"), indent=1)
 
 
-def cli_flags():
-    """Flag names / defaults of the reference CLI, as data (no source text is kept)."""
-    ref = Path("/root/reference/reconstruct.py")
+def cli_flags(ref_name="reconstruct.py", out_name="cli_flags.json"):
+    """Flag names / defaults of a reference CLI, as data (no source text is kept)."""
+    ref = Path("/root/reference") / ref_name
     if not ref.exists():
         return
     flags = {}
@@ -144,7 +145,7 @@ def cli_flags():
             default = ast.literal_eval(kw["default"]) if "default" in kw else None
             typ = getattr(kw.get("type"), "id", None) or getattr(kw.get("type"), "attr", None)
             flags[name] = {"default": default, "type": typ}
-    json.dump(flags, open(HERE / "cli_flags.json", "w"), indent=1, sort_keys=True)
+    json.dump(flags, open(HERE / out_name, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
@@ -152,6 +153,7 @@ if __name__ == "__main__":
     schedule()
     ops()
     cli_flags()
+    cli_flags("train_ddpm.py", "train_cli_flags.json")
     sd, model = unet_forward()
     trajectory(sd, model)
     print("golden fixtures written to", HERE)

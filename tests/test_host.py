@@ -338,6 +338,39 @@ def test_lpips_loads_a_state_dict_shaped_like_the_real_package():
         LPIPS().load_pretrained_state_dict({**real, "net.slice6.0.weight": torch.zeros(1)})
 
 
+def test_training_forward_and_cli(tmp_path):
+    """Row f-3: the differentiable ATen forward used for training evaluates the same parameter holders as the HIP
+    engine and equals the oracle UNet; train_ddpm.py keeps the reference's flags (/root/reference/train_ddpm.py:7-83,
+    names / defaults extracted as data into tests/golden/train_cli_flags.json)."""
+    import json
+
+    import train_ddpm
+    from ddpm_ood_amd import DiffusionModelUNet
+    from ddpm_ood_amd.synthetic import random_state_dict
+    from ddpm_ood_amd.train import unet_forward_torch
+
+    cfg = dict(num_channels=(32, 64), attention_levels=(False, True), num_res_blocks=2, num_head_channels=32)
+    sd = random_state_dict(config=cfg, channels=3, seed=3)
+    m = DiffusionModelUNet(2, 3, 3, use_proj_attn=True, **cfg)
+    m.load_state_dict(sd)
+    o = oracle.DiffusionModelUNet(2, 3, 3, use_proj_attn=True, **cfg).eval()
+    o.load_state_dict(sd)
+    x, t = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(1)), torch.tensor([10, 650])
+    for p in m.parameters():
+        p.requires_grad_(True)
+    y = unet_forward_torch(m, x, t)
+    with torch.no_grad():
+        assert (y - o(x, timesteps=t)).abs().max() < 1e-5
+    y.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in m.named_parameters()
+               if "proj_attn" in n or "conv" in n)
+    flags = json.load(open(G / "train_cli_flags.json"))
+    a = train_ddpm.parse_args(["--model_name", "m", "--output_dir", "o"])
+    assert set(flags) == set(vars(a)), set(flags) ^ set(vars(a))
+    for k, v in flags.items():
+        assert getattr(a, k) == v["default"] or k in ("model_name", "output_dir"), k
+
+
 def test_product_code_never_imports_the_oracle():
     """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use it."""
     import re
