@@ -97,6 +97,9 @@ SIGNATURES = {
     "ddpm_unet_workspace_bytes3d": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ddpm_unet_forward3d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddpm_unet_forward_graphed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddpm_unet_num_graphs": (C.c_int, [C.c_void_p]),
     "ddpm_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
 }

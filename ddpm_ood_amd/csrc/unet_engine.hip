@@ -15,6 +15,7 @@
 // torch.cat is virtual (two source pointers), nearest-x2 upsample and stride-2 are input
 // indexing, the 11 time_emb_proj Linears are ONE GEMM, to_q/to_k/to_v are ONE 1x1 conv.
 #include <map>
+#include <tuple>
 #include <vector>
 
 #include "common.h"
@@ -81,8 +82,37 @@ struct UpRef {
 
 using namespace ddpm;
 
+namespace ddpm {
+// One captured forward: the ~80 kernel launches of a UNet evaluation as a hipGraph, keyed by everything that is
+// baked into the kernel arguments (tensor addresses and extents).
+typedef std::tuple<const void *, const void *, void *, void *, int, int, int, int> GraphKey;
+struct GraphEntry {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int calls = 0;
+};
+}  // namespace ddpm
+
 struct ddpm_unet {
   ddpm_unet_config cfg;
+  // hipGraph replay (ddpm_unet_forward_graphed): private capture / replay stream + the events that order it
+  // against the caller's stream
+  std::map<ddpm::GraphKey, ddpm::GraphEntry> graphs;
+  hipStream_t gstream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  void drop_graphs() {
+    for (auto &kv : graphs) {
+      if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+      if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    graphs.clear();
+  }
+  ~ddpm_unet() {
+    drop_graphs();
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_out) (void)hipEventDestroy(ev_out);
+    if (gstream) (void)hipStreamDestroy(gstream);
+  }
   std::vector<ParamSlot> params;
   std::map<std::string, int> index;
   size_t blob_floats = 0;
@@ -325,6 +355,7 @@ extern "C" size_t ddpm_unet_param_blob_floats(const ddpm_unet *h) { return h ? h
 extern "C" int ddpm_unet_bind_param_blob(ddpm_unet *h, float *blob) {
   DDPM_CHECK_ARG(h && blob, "bind_param_blob: NULL");
   h->blob = blob;
+  h->drop_graphs();  // captured launches carry the old blob's addresses
   for (auto &p : h->params) p.set = false;
   return 0;
 }
@@ -374,6 +405,7 @@ extern "C" int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *
     if (rc) return rc;
   }
   p.set = true;
+  h->drop_graphs();  // (the packed copies live at fixed addresses, but keep replay and parameters in lock-step)
   return 0;
 }
 
@@ -625,4 +657,73 @@ extern "C" int ddpm_unet_forward3d(ddpm_unet *h, const float *x, const int64_t *
   char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
   Runner r{h, Bump{base, workspace_bytes, 0, 0, false}, as_stream(stream), B};
   return r.run(x, timesteps, out, H, W, D);
+}
+
+// ---- hipGraph replay --------------------------------------------------------------------------------------------
+// SURVEY.md section 7 step 6 / hard part 5: at small batch (BASELINE configs[0]: first_n = 16) a forward is ~80
+// launches of 5-30 us kernels and the host's launch path, not the GPU, sets the pace.  The first call with a given
+// (x, timesteps, out, workspace, B, D, H, W) runs eagerly (it also performs every one-time hipFuncSetAttribute); the
+// second captures the same launch sequence on a private stream into a hipGraph; later calls replay it with one
+// hipGraphLaunch.  The caller keeps the four addresses stable (the Python mirror owns static I/O tensors).  Ordering
+// against the caller's stream is by events, so the call remains asynchronous like ddpm_unet_forward3d.
+extern "C" int ddpm_unet_forward_graphed(ddpm_unet *h, const float *x, const int64_t *timesteps, float *out, int B,
+                                         int D, int H, int W, void *workspace, size_t workspace_bytes,
+                                         ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(h && x && timesteps && out && workspace, "unet_forward_graphed: NULL argument");
+  if (g_prof_on)  // per-kernel hipEvents are not graph nodes: profile the eager path
+    return ddpm_unet_forward3d(h, x, timesteps, out, B, D, H, W, workspace, workspace_bytes, stream);
+  const GraphKey key(x, timesteps, out, workspace, B, D, H, W);
+  GraphEntry &e = h->graphs[key];
+  e.calls += 1;
+  if (e.calls == 1)
+    return ddpm_unet_forward3d(h, x, timesteps, out, B, D, H, W, workspace, workspace_bytes, stream);
+  hipStream_t cs = as_stream(stream);
+  if (!h->gstream) {
+    if (hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess) {
+      set_error("unet_forward_graphed: cannot create the replay stream / events");
+      return DDPM_EINVAL;
+    }
+  }
+  if (!e.exec) {
+    hipError_t rc = hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal);
+    if (rc != hipSuccess) {
+      set_error("unet_forward_graphed: hipStreamBeginCapture: %s", hipGetErrorString(rc));
+      return (int)rc;
+    }
+    const int frc = ddpm_unet_forward3d(h, x, timesteps, out, B, D, H, W, workspace, workspace_bytes, h->gstream);
+    rc = hipStreamEndCapture(h->gstream, &e.graph);
+    if (frc != 0 || rc != hipSuccess || !e.graph) {
+      if (e.graph) (void)hipGraphDestroy(e.graph);
+      e.graph = nullptr;
+      h->graphs.erase(key);
+      if (frc == 0) set_error("unet_forward_graphed: hipStreamEndCapture: %s", hipGetErrorString(rc));
+      return frc ? frc : (int)rc;
+    }
+    rc = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
+    if (rc != hipSuccess) {
+      set_error("unet_forward_graphed: hipGraphInstantiate: %s", hipGetErrorString(rc));
+      (void)hipGraphDestroy(e.graph);
+      h->graphs.erase(key);
+      return (int)rc;
+    }
+  }
+  hipError_t rc = hipEventRecord(h->ev_in, cs);
+  if (rc == hipSuccess) rc = hipStreamWaitEvent(h->gstream, h->ev_in, 0);
+  if (rc == hipSuccess) rc = hipGraphLaunch(e.exec, h->gstream);
+  if (rc == hipSuccess) rc = hipEventRecord(h->ev_out, h->gstream);
+  if (rc == hipSuccess) rc = hipStreamWaitEvent(cs, h->ev_out, 0);
+  if (rc != hipSuccess) {
+    set_error("unet_forward_graphed: replay: %s", hipGetErrorString(rc));
+    return (int)rc;
+  }
+  return 0;
+}
+
+extern "C" int ddpm_unet_num_graphs(const ddpm_unet *h) {
+  int n = 0;
+  if (h)
+    for (auto &kv : h->graphs) n += kv.second.exec != nullptr;
+  return n;
 }

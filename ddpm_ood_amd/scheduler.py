@@ -91,6 +91,7 @@ class PNDMScheduler(Scheduler):
         self.skip_prk_steps = skip_prk_steps
         self.steps_offset = steps_offset
         self.timestep_list = timestep_list  # 100-entry (default) vs 101-entry list
+        self._coef_cache = {}
         self.cur_model_output = 0
         self.counter = 0
         self.cur_sample = None
@@ -123,14 +124,21 @@ class PNDMScheduler(Scheduler):
         return self.step_plms(model_output, int(timestep), sample), None
 
     def plms_coefficients(self, timestep: int, prev_timestep: int):
-        """fp32 scalars of _get_prev_sample, computed with the same 0-d torch CPU ops as the reference."""
+        """fp32 scalars of _get_prev_sample, computed with the same 0-d torch CPU ops as the reference (memoised per
+        (timestep, prev_timestep, table): ~70 us of 0-d tensor arithmetic otherwise, on every PLMS step)."""
+        key = (timestep, prev_timestep, id(self.alphas_cumprod))
+        hit = self._coef_cache.get(key)
+        if hit is not None:
+            return hit
         a_t = self.alphas_cumprod[timestep]
         a_p = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
         b_t = 1 - a_t
         b_p = 1 - a_p
         sample_coeff = (a_p / a_t) ** 0.5
         denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
-        return (float(sample_coeff), float(a_p - a_t), float(denom), float(a_t ** 0.5), float(b_t ** 0.5))
+        out = (float(sample_coeff), float(a_p - a_t), float(denom), float(a_t ** 0.5), float(b_t ** 0.5))
+        self._coef_cache[key] = out
+        return out
 
     def step_plms(self, model_output: torch.Tensor, timestep: int, sample: torch.Tensor) -> torch.Tensor:
         ratio = self._step_ratio

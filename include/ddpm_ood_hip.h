@@ -254,6 +254,15 @@ int ddpm_unet_forward3d(ddpm_unet *h, const float *x, const int64_t *timesteps, 
 int ddpm_unet_forward(ddpm_unet *h, const float *x, const int64_t *timesteps, float *out, int B, int H, int W,
                       void *workspace, size_t workspace_bytes, ddpm_stream_t stream);
 
+/* Same call, replayed from a captured hipGraph (the launch-bound small-batch regime,
+ * BASELINE configs[0]).  The 1st call with a given (x, timesteps, out, workspace, B, D, H, W) runs eagerly, the 2nd
+ * captures the launch sequence, later ones are ONE hipGraphLaunch on a private stream ordered against `stream` by
+ * events.  The caller must keep the four addresses stable and must not free them while the engine lives; rebinding
+ * or updating parameters drops every captured graph.  ddpm_unet_num_graphs: instantiated graphs (for tests).      */
+int ddpm_unet_forward_graphed(ddpm_unet *h, const float *x, const int64_t *timesteps, float *out, int B, int D, int H,
+                              int W, void *workspace, size_t workspace_bytes, ddpm_stream_t stream);
+int ddpm_unet_num_graphs(const ddpm_unet *h);
+
 /* ------------------------------------------------------------------------------------
  * In-situ kernel timing (bench.py's roofline leg).  While enabled, every kernel launch of
  * this library is bracketed by hipEvents on the launch stream; the report synchronises those

@@ -188,16 +188,12 @@ VQ_README = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(25
                  upsample_parameters=((2, 4, 1, 1, 0),) * 4, num_embeddings=2048, embedding_dim=128)
 
 
-_SLOW = bool(int(__import__("os").environ.get("DDPM_SLOW_TESTS", "0")))
-
-
-@pytest.mark.parametrize("volume", [(64, 64, 64)] + ([(128, 128, 128)] if _SLOW else []))
+@pytest.mark.parametrize("volume", [(64, 64, 64), (128, 128, 128)])
 def test_cfg5_readme_vqvae_ldm_trajectory(device, tmp_path, volume):
     """BASELINE configs[4] at the README VQ-VAE shape (4 x k4-s2 levels, 256 channels, 3 residual units per level,
     2 048 codes x 128).  (64, 64, 64) -> latents [128, 4, 4, 4]: the 3-D UNet's lowest level is a 1x1x1 volume
     (centre depth tap only; capped images per MFMA tile); (128, 128, 128) -> [128, 8, 8, 8] is the
-    reference's own geometry -- its CPU oracle run takes ~6 min on the GPU box's host, so it only runs with
-    DDPM_SLOW_TESTS=1 (log of such a run: profiles/r02_gpu_tests_slow.log).  encode (VQ-VAE + nearest-code search)
+    reference's own geometry (~25 s, most of it the CPU oracle's VQ-VAE).  encode (VQ-VAE + nearest-code search)
     -> PLMS trajectories at t = 10 and 650 -> re-quantise + decode -> clamp, MSE, 2.5-D LPIPS over the slices."""
     import oracle
     from oracle.vqvae import VQVAE as OracleVQVAE

@@ -87,6 +87,41 @@ def test_unet_forward_3d_cfg5(device, B, size):
     assert yr.abs().max() > 0.05
 
 
+def test_graph_replay_equals_eager(device, monkeypatch):
+    """the small-batch forward replayed from a captured hipGraph
+    (ddpm_unet_forward_graphed: eager, capture, then replay) returns bit-identical results to the eager launch
+    sequence, for changing inputs and timesteps, and survives a parameter update (graphs are dropped)."""
+    from ddpm_ood_amd import DiffusionModelUNet, _lib
+    from ddpm_ood_amd.synthetic import random_state_dict
+
+    sd = random_state_dict("small", 1, seed=1)
+    m = DiffusionModelUNet(2, 1, 1, **SMALL)
+    m.load_state_dict(sd)
+    m = m.to(device).eval()
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(4, 1, 32, 32, generator=g).to(device) for _ in range(4)]
+    ts = [torch.tensor(t, device=device) for t in ([10, 10, 10, 10], [650, 30, 0, 990], [5, 6, 7, 8], [640] * 4)]
+    monkeypatch.setenv("DDPM_UNET_GRAPH", "0")
+    eager = [m(x, timesteps=t).clone() for x, t in zip(xs, ts)]
+    monkeypatch.setenv("DDPM_UNET_GRAPH", "1")
+    graphed = [m(x, timesteps=t) for x, t in zip(xs, ts)]  # call 1 eager, call 2 captures, calls 3-4 replay
+    torch.cuda.synchronize()
+    assert _lib.load().ddpm_unet_num_graphs(m._engine) == 1
+    for a, b in zip(eager, graphed):
+        assert torch.equal(a, b)
+    assert len({y.data_ptr() for y in graphed}) == 4  # results are not views of the static output buffer
+    with torch.no_grad():  # parameter update -> blob re-sync -> graphs dropped, results follow the new weights
+        m.out[2].conv.weight.mul_(2.0)
+        m.out[2].conv.bias.zero_()
+    y2 = m(xs[0], timesteps=ts[0])
+    assert _lib.load().ddpm_unet_num_graphs(m._engine) == 0
+    monkeypatch.setenv("DDPM_UNET_GRAPH", "0")
+    assert torch.equal(y2, m(xs[0], timesteps=ts[0]))
+    assert not torch.equal(y2, eager[0])
+    monkeypatch.setenv("DDPM_UNET_GRAPH", "auto")
+    assert m._use_graph(16) and not m._use_graph(256)
+
+
 def test_unet_missing_key_and_bad_shape(device):
     from ddpm_ood_amd import DiffusionModelUNet
 

@@ -25,7 +25,10 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--model", default="small")
     ap.add_argument("--dims", type=int, default=2)
+    ap.add_argument("--graph", default="auto", help="DDPM_UNET_GRAPH: auto | 0 | 1")
     a = ap.parse_args()
+    import os
+    os.environ["DDPM_UNET_GRAPH"] = a.graph
 
     from ddpm_ood_amd import DiffusionModelUNet, _lib
     from ddpm_ood_amd.synthetic import random_state_dict
