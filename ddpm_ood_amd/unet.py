@@ -274,17 +274,13 @@ class DiffusionModelUNet(nn.Module):
         return out
 
     # ---- hipGraph replay for the launch-bound small-batch regime -------------------
-    GRAPH_MAX_BATCH = 32  # above this a forward is long enough for the host to stay ahead of the GPU
-
+    # Measured on MI355X (profiles/r02_small_batch.log): at B = 4 and B = 16 a `small` 32x32 forward is 3.3 ms of
+    # KERNEL time (the persistent convolutions are latency-bound: few items, each a serial stream of 16-64 chunks), so
+    # the host is not the limiter and replay gains nothing (3.41 vs 3.30 ms).  Replay therefore is opt-in.
     def _use_graph(self, B: int) -> bool:
         import os
 
-        mode = os.environ.get("DDPM_UNET_GRAPH", "auto")
-        if mode in ("0", "off"):
-            return False
-        if mode in ("1", "on"):
-            return True
-        return B <= self.GRAPH_MAX_BATCH and self.spatial_dims == 2
+        return os.environ.get("DDPM_UNET_GRAPH", "0") in ("1", "on")
 
     def _forward_graphed(self, x, timesteps, B, D, H, W):
         """Static input / timestep / output tensors per input shape keep the captured kernel arguments valid; the

@@ -118,8 +118,8 @@ def test_graph_replay_equals_eager(device, monkeypatch):
     monkeypatch.setenv("DDPM_UNET_GRAPH", "0")
     assert torch.equal(y2, m(xs[0], timesteps=ts[0]))
     assert not torch.equal(y2, eager[0])
-    monkeypatch.setenv("DDPM_UNET_GRAPH", "auto")
-    assert m._use_graph(16) and not m._use_graph(256)
+    monkeypatch.delenv("DDPM_UNET_GRAPH")
+    assert not m._use_graph(16)  # opt-in: measured no gain (kernel-time-bound even at B = 4)
 
 
 def test_unet_missing_key_and_bad_shape(device):

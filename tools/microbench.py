@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--model", default="small")
     ap.add_argument("--dims", type=int, default=2)
-    ap.add_argument("--graph", default="auto", help="DDPM_UNET_GRAPH: auto | 0 | 1")
+    ap.add_argument("--graph", default="0", help="DDPM_UNET_GRAPH: 0 | 1")
     a = ap.parse_args()
     import os
     os.environ["DDPM_UNET_GRAPH"] = a.graph
