@@ -776,6 +776,309 @@ __global__ __launch_bounds__(512, 2) void conv_wino_up_kernel(const ddpm_conv_de
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- four-wave variant: ONE wave per SIMD, all 16 transform positions of its 32 couts x 32 tiles in 256 AGPRs -----
+// tools/ubench/mfma_peak.hip: a register-only f32 MFMA loop reaches 154 TFLOP/s with one wave per SIMD but only 137
+// with two (arbitration between the two waves' MFMA streams), and the eight-wave kernel above additionally pays an
+// LDS exchange + two barriers per item because the transform rows of a tile are split over two waves.  Here a wave
+// owns whole tiles: the output transform A^T M A is register-only, items need no barrier of their own, and the 256
+// arch VGPRs left beside the accumulators hold every staging value without spills.  Staging work per lane doubles
+// (two channels of the chunk per wave) but so does the number of MFMA steps it is sliced into (64 per chunk).
+template <bool AFFINE, int NR, bool ONEIMG>
+__global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ddpm_conv_desc a, const WinoGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BUF = kWUF + kWVF;
+  constexpr int NGS = ONEIMG ? 1 : NR;
+  float *const P = smem + 2 * BUF;          // pixel tiles [2][8 channels][PCH] + 64 dump floats each
+  const int PB = kWC * g.PCH, PBS = PB + 64;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int cb = wave & 1, tb = wave >> 1;   // 4 waves = 2 (cout block) x 2 (tile block)
+  const bool silu = a.act == DDPM_ACT_SILU;
+
+  const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3;
+  const int kt = wj % g.KT, slot = (wj / g.KT) * 8 + xcd;
+  if (slot >= g.NS) return;
+  const int part = slot % g.parts, it0 = (slot / g.parts) * g.IPW;
+  const int nitems = min(g.IPW, g.NIT - it0);
+  const int r0 = part * g.TR;
+  const int n_first = it0 * g.TI, n_end = n_first + nitems * g.TI;
+  const int last = g.nchunks - 1;
+
+  // ---- staging roles: this wave stages channels `wave` and `wave + 4` of every chunk ------------------------
+  const int st = lane;
+  const int row_lo = max(0, 2 * r0 - 1), row_hi = min(a.Ho, 2 * (r0 + g.TR) + 1);
+  const int npx = (row_hi - row_lo) * a.Wo;
+  int pix[NR], pw[NR], tik[NR];  // pw: offset inside ONE channel tile of P (-> dump slot when out of range)
+  bool pvalid[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int ti = k / g.NRI, e = lane + 64 * (k - ti * g.NRI);
+    const bool valid = ti < g.TI && e < npx;
+    const int row = row_lo + e / a.Wo, col = e % a.Wo;
+    tik[k] = ti;
+    pvalid[k] = valid;
+    pix[k] = valid ? (row * a.Wo + col) * 4 : (int)0x80000000;
+    pw[k] = (ti * (2 * g.TR + 2) + row - (2 * r0 - 1)) * g.PW + col + 1;
+  }
+  int tbase;  // patch origin of tile st inside one channel tile of P
+  {
+    const int per = g.TR * g.TWc;
+    const int ti = st / per, rem = st - ti * per;
+    const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
+    tbase = (ti * (2 * g.TR + 2) + 2 * tr) * g.PW + 2 * tc;
+  }
+  const int bytes1 = a.B * a.C1 * g.HW * 4, bytes2 = a.B * a.C2 * g.HW * 4;
+  const __amdgpu_buffer_rsrc_t rs_sc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gscale), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_sh =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gshift), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+
+  // operand images [xi 16][kp 2][lhi 2][cout or tile 64][2]; pair p = (kp = p >> 4, xi = p & 15)
+  const int ub = (lhi * kWK + cb * 32 + l31) * 2;
+  const int vb = kWUF + (lhi * kWT + tb * 32 + l31) * 2;
+  const float *usrc = a.w_wino + (size_t)kt * g.nchunks * kWUF + wave * 8 * 256;  // 8 x 1 KB per wave and chunk
+
+  f32x16 acc[16];
+
+  float praw[2][NR], gs[2][NGS], gh[2][NGS], dreg[16], tt[16];
+  auto dma_u = [&](int i, int ch, int nb) {
+    const float *ubase = usrc + (size_t)ch * kWUF + i * 256;  // uniform
+    __builtin_amdgcn_global_load_lds(ubase + lane * 4, smem + nb + (wave * 8 + i) * 256, 16, 0, 0);
+  };
+  auto load_px = [&](int h, int k, int n, int ch) {  // h = 0 / 1: channel wave / wave + 4 of the chunk
+    const int cg = ch * kWC + wave + 4 * h, ni = min(n + tik[k], a.B - 1);
+    const bool first = cg < a.C1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
+    const int soff = first ? (ni * a.C1 + cg) * g.HW * 4 : (ni * a.C2 + cg - a.C1) * g.HW * 4;
+    praw[h][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pix[k], soff, 0));
+    if (AFFINE && (!ONEIMG || k == 0)) {
+      const int goff = (ni * g.Cin + cg) * 4;
+      gs[h][ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
+      gh[h][ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
+    }
+  };
+  auto activate_px = [&](int h, int k, int pb) {
+    const float x = praw[h][k];
+    float v;
+    if (AFFINE) {
+      const float sa = gs[h][ONEIMG ? 0 : k], sb = gh[h][ONEIMG ? 0 : k];
+      const float u = __builtin_fmaf(x, sa, sb);
+      const float t = __builtin_fmaf(x, -1.44269504088896341f * sa, -1.44269504088896341f * sb);
+      v = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+    } else {
+      const float sv = silu_fast(x);
+      v = silu ? sv : x;
+    }
+    P[pb + (pvalid[k] ? (wave + 4 * h) * g.PCH + pw[k] : PB + lane)] = v;
+  };
+  auto read_patch = [&](int h, int i, int pb) {
+    const float *p = P + pb + (wave + 4 * h) * g.PCH + tbase + i * g.PW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dreg[4 * i + j] = p[j];
+  };
+  auto row_transform = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tt[0 * 4 + j] = dreg[0 * 4 + j] - dreg[2 * 4 + j];
+      tt[1 * 4 + j] = dreg[1 * 4 + j] + dreg[2 * 4 + j];
+      tt[2 * 4 + j] = dreg[2 * 4 + j] - dreg[1 * 4 + j];
+      tt[3 * 4 + j] = dreg[1 * 4 + j] - dreg[3 * 4 + j];
+    }
+  };
+  auto col_commit = [&](int h, int i, int nb) {
+    const int sc = wave + 4 * h;  // channel sc = 4 kp + 2 e + lhi  ->  V [xi][kp][lhi][tile][e]
+    float *vl = smem + nb + kWUF + (((sc >> 2) * 2 + (sc & 1)) * kWT + st) * 2 + ((sc >> 1) & 1);
+    vl[(i * 4 + 0) * kWC * kWT] = tt[i * 4 + 0] - tt[i * 4 + 2];
+    vl[(i * 4 + 1) * kWC * kWT] = tt[i * 4 + 1] + tt[i * 4 + 2];
+    vl[(i * 4 + 2) * kWC * kWT] = tt[i * 4 + 2] - tt[i * 4 + 1];
+    vl[(i * 4 + 3) * kWC * kWT] = tt[i * 4 + 1] - tt[i * 4 + 3];
+  };
+  auto advance = [&](int &n, int &ch) {
+    if (ch < last) {
+      ++ch;
+    } else if (n + g.TI < n_end) {
+      n += g.TI;
+      ch = 0;
+    }
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------------------------
+  for (int i = tid; i < 2 * PBS; i += 256) P[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_u(i, 0, 0);
+  int nL = n_first, chL = 0;
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < NR; ++k) load_px(h, k, nL, chL);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < NR; ++k) activate_px(h, k, c * PBS);
+    advance(nL, chL);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) read_patch(h, i, 0);
+    row_transform();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) col_commit(h, i, 0);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int k = 0; k < NR; ++k) load_px(h, k, nL, chL);
+  advance(nL, chL);
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NR + (AFFINE ? 4 * NGS : 0)) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  // One chunk = 64 MFMA steps per wave (32 pairs); the staging of three later chunks is cut into slices, one per
+  // step, pinned with sched_barriers:
+  //   step 0..2NR-1    activation of pixel round s -> P (loaded a whole chunk ago)
+  //   step 14..        loads of pixel round s - 14 (three chunks ahead)      step 28..35  U eighth s - 28 by DMA
+  //   step 36..39 / 46..49  patch rows of channel wave / wave + 4;  40 / 50 row transform;  41..44 / 51..54 V writes
+  int c = 0;
+  auto chunk = [&](auto first_c, int ch_cur) {
+    constexpr bool FIRST = decltype(first_c)::value;
+    const int cbuf = (c & 1) * BUF;
+    const int nb = BUF - cbuf;
+    const int pb_t = ((c + 1) & 1) * PBS, pb_a = (c & 1) * PBS;
+    const int ch_u = ch_cur < last ? ch_cur + 1 : 0;
+    f2 av[4], bv[4];  // operand ring: four pairs
+    const int ua = (cbuf + ub) * 4, va = (cbuf + vb) * 4;  // bytes
+    auto load_pair = [&](int slot, int p) {
+      const int imm = (((p & 15) * 2 + (p >> 4)) * 2 * 64 * 2) * 4;
+      av[slot] = lds_read_b64(ua, imm);
+      bv[slot] = lds_read_b64(va, imm);
+    };
+    auto slice = [&](int s) {
+      if (s < 2 * NR) {
+        activate_px(s / NR, s % NR, pb_a);
+      } else if (s >= 14 && s < 14 + 2 * NR) {
+        load_px((s - 14) / NR, (s - 14) % NR, nL, chL);
+      } else if (s >= 28 && s < 36) {
+        dma_u(s - 28, ch_u, nb);
+      } else if (s >= 36 && s < 40) {
+        read_patch(0, s - 36, pb_t);
+      } else if (s == 40) {
+        row_transform();
+      } else if (s >= 41 && s < 45) {
+        col_commit(0, s - 41, nb);
+      } else if (s >= 46 && s < 50) {
+        read_patch(1, s - 46, pb_t);
+      } else if (s == 50) {
+        row_transform();
+      } else if (s >= 51 && s < 55) {
+        col_commit(1, s - 51, nb);
+      }
+    };
+    load_pair(0, 0);
+    load_pair(1, 1);
+    load_pair(2, 2);
+    load_pair(3, 3);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+      // operand reads issued after this pair's: three more pairs (6 reads), then 4, 2, 0 at the tail
+      if (FIRST && p < 16) {
+        if (p < 29) mfma_agpr_first_wait<6>(acc[p & 15], av[p & 3][0], bv[p & 3][0]);
+      } else if (p < 29) {
+        mfma_agpr_wait<6>(acc[p & 15], av[p & 3][0], bv[p & 3][0]);
+      } else if (p == 29) {
+        mfma_agpr_wait<4>(acc[p & 15], av[p & 3][0], bv[p & 3][0]);
+      } else if (p == 30) {
+        mfma_agpr_wait<2>(acc[p & 15], av[p & 3][0], bv[p & 3][0]);
+      } else {
+        mfma_agpr_wait<0>(acc[p & 15], av[p & 3][0], bv[p & 3][0]);
+      }
+      slice(2 * p);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_agpr(acc[p & 15], av[p & 3][1], bv[p & 3][1]);
+      if (p + 4 < 32) load_pair(p & 3, p + 4);
+      slice(2 * p + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    advance(nL, chL);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    ++c;
+  };
+
+  for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
+    chunk(std::true_type{}, 0);
+    for (int ch = 1; ch <= last; ++ch) chunk(std::false_type{}, ch);
+
+    // ---- end of an item: Y = A^T M A, register-only (this wave holds all 16 positions of its tiles) --------------
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' 16 passes
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int tq = tb * 32 + (elane & 31);
+    const int per = g.TR * g.TWc;
+    const int ti = tq / per, rem = tq - ti * per;
+    const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
+    const int n = n_cur + ti;
+    const int nn = min(n, a.B - 1);
+    const int co_base = kt * kWK + cb * 32 + 4 * (elane >> 5);
+    const size_t obase = ((size_t)nn * a.Cout + co_base) * g.HW + (size_t)(2 * (r0 + tr)) * a.Wo + 2 * tc;
+    // Y = A^T M A streamed over the 16 position tiles, one AGPR tuple at a time (a factored form that touches
+    // element r of all 16 tuples at once makes hipcc copy every accumulator into arch VGPRs first and spill the
+    // loop's registers): y_ab += A^T[a][i] * A^T[b][j] * M[i][j], all coefficients 0 / +1 / -1.
+    f32x16 y00, y01, y10, y11;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const int i = x >> 2, j = x & 3;
+      f32x16 m;  // one AGPR tuple -> arch VGPRs, right here (a plain copy is hoisted and batched by hipcc)
+      asm volatile("" : "=v"(m) : "0"(acc[x]));
+      const int c00 = kAT[0][i] * kAT[0][j], c01 = kAT[0][i] * kAT[1][j];
+      const int c10 = kAT[1][i] * kAT[0][j], c11 = kAT[1][i] * kAT[1][j];
+      if (c00) y00 = (x == 0) ? m : y00 + m;                               // +1 only
+      if (c01) y01 = (x == 1) ? m : (c01 > 0 ? y01 + m : y01 - m);
+      if (c10) y10 = (x == 4) ? m : (c10 > 0 ? y10 + m : y10 - m);
+      if (c11) y11 = (x == 5) ? m : (c11 > 0 ? y11 + m : y11 - m);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // 8 couts at a time: addends requested first, then added and stored
+      f2 ra[8], rb[8];
+      float addv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = half * 8 + q;
+        const int cof = (r & 3) + 8 * (r >> 2);
+        const size_t o = obase + (size_t)cof * g.HW;
+        ra[q] = rb[q] = f2{0.f, 0.f};
+        if (a.residual) {
+          ra[q] = *reinterpret_cast<const f2 *>(a.residual + o);
+          rb[q] = *reinterpret_cast<const f2 *>(a.residual + o + a.Wo);
+        }
+        addv[q] = (a.bias ? a.bias[co_base + cof] : 0.f) +
+                  (a.chan_add ? a.chan_add[(size_t)nn * a.chan_add_stride + co_base + cof] : 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = half * 8 + q;
+        if (n < a.B) {
+          const size_t o = obase + (size_t)((r & 3) + 8 * (r >> 2)) * g.HW;
+          *reinterpret_cast<f2 *>(a.out + o) = f2{y00[r] + addv[q] + ra[q][0], y01[r] + addv[q] + ra[q][1]};
+          *reinterpret_cast<f2 *>(a.out + o + a.Wo) = f2{y10[r] + addv[q] + rb[q][0], y11[r] + addv[q] + rb[q][1]};
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
 int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   WinoGeom g;
   if (!d.w_wino || !wino_geom(d, g)) {
@@ -798,6 +1101,27 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   }
   const int rounds = g.TI * g.NRI;
   kern_t kern = kerns[d.gscale ? 1 : 0][g.TI == 1 ? 1 : 0][rounds <= 4 ? 0 : rounds - 4];
+  // DDPM_WINO_WAVES=4: the one-wave-per-SIMD variant (A/B switch; see conv_wino4_kernel)
+  static const bool four = getenv("DDPM_WINO_WAVES") && atoi(getenv("DDPM_WINO_WAVES")) == 4;
+  int threads = 512;
+  size_t lds_bytes = lds;
+  if (four && !g.up) {
+    static const kern_t kerns4[2][2][3] = {
+        {{conv_wino4_kernel<false, 4, false>, conv_wino4_kernel<false, 5, false>, conv_wino4_kernel<false, 6, false>},
+         {conv_wino4_kernel<false, 4, true>, conv_wino4_kernel<false, 5, true>, conv_wino4_kernel<false, 6, true>}},
+        {{conv_wino4_kernel<true, 4, false>, conv_wino4_kernel<true, 5, false>, conv_wino4_kernel<true, 6, false>},
+         {conv_wino4_kernel<true, 4, true>, conv_wino4_kernel<true, 5, true>, conv_wino4_kernel<true, 6, true>}}};
+    static bool attr4_done = false;
+    if (!attr4_done) {
+      for (int i = 0; i < 12; ++i)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns4[i / 6][i / 3 % 2][i % 3]),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr4_done = true;
+    }
+    kern = kerns4[d.gscale ? 1 : 0][g.TI == 1 ? 1 : 0][rounds <= 4 ? 0 : rounds - 4];
+    threads = 256;
+    lds_bytes = ((size_t)2 * (kWUF + kWVF) + 2 * (kWC * g.PCH + 64)) * sizeof(float);
+  }
   if (g.up) {
     static const kern_t up_kerns[2] = {conv_wino_up_kernel<2>, conv_wino_up_kernel<6>};
     static bool up_attr_done = false;
@@ -820,7 +1144,7 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
     kname = kshape;
   }
   ProfScope prof(s, kname, flops, bytes);
-  hipLaunchKernelGGL(kern, dim3(g.grid), dim3(512), lds, s, d, g);
+  hipLaunchKernelGGL(kern, dim3(g.grid), dim3(threads), lds_bytes, s, d, g);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
