@@ -399,6 +399,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     }
     advance(nL, chL);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // DMAs landed; pixel loads are older
+    // (measured: issuing the DMAs before the pixel loads and waiting vmcnt(NVM) here -- pixel loads left in flight
+    //  across the barrier -- is 2 % slower: the wait just moves to the next chunk's first activation slice)
     __builtin_amdgcn_sched_barrier(0);
     ++c;
   };
@@ -783,6 +785,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_up_kernel(const ddpm_conv_de
 // owns whole tiles: the output transform A^T M A is register-only, items need no barrier of their own, and the 256
 // arch VGPRs left beside the accumulators hold every staging value without spills.  Staging work per lane doubles
 // (two channels of the chunk per wave) but so does the number of MFMA steps it is sliced into (64 per chunk).
+// MEASURED (tools/wino_ab.py, B = 256, five layer shapes of the `small` UNet): 2 986 us against 2 486 us for the
+// eight-wave kernel, i.e. 0.45-0.55 of the MFMA peak instead of 0.51-0.68; an ablation without any staging reached
+// 0.62-0.78.  With a single wave per SIMD nothing covers the wave's own LDS operand latency and its VALU slices, and
+// that costs more than the arbitration it avoids.  Kept as an opt-in A/B (DDPM_WINO_WAVES=4, parity-tested), NOT the
+// default; the single barrier placed after pair 28 with the next chunk's operands prefetched across it (no restart
+// bubble) made no measurable difference either.
 template <bool AFFINE, int NR, bool ONEIMG>
 __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ddpm_conv_desc a, const WinoGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -944,73 +952,68 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ddpm_conv_desc
 
   // One chunk = 64 MFMA steps per wave (32 pairs); the staging of three later chunks is cut into slices, one per
   // step, pinned with sched_barriers:
-  //   step 0..2NR-1    activation of pixel round s -> P (loaded a whole chunk ago)
-  //   step 14..        loads of pixel round s - 14 (three chunks ahead)      step 28..35  U eighth s - 28 by DMA
-  //   step 36..39 / 46..49  patch rows of channel wave / wave + 4;  40 / 50 row transform;  41..44 / 51..54 V writes
+  //   step 0..7    U eighth s by DMA           step 8..16 / 17..25  patch rows, row transform, V writes of channel
+  //   wave / wave + 4      step 28..  activation of pixel round s - 28 -> P      step 44..  loads of round s - 44
   int c = 0;
+  f2 av[4], bv[4];  // operand ring: four pairs, running ACROSS chunk (and item) boundaries
+  auto load_pair_at = [&](int slot, int buf, int p) {
+    const int imm = (((p & 15) * 2 + (p >> 4)) * 2 * 64 * 2) * 4;
+    av[slot] = lds_read_b64((buf + ub) * 4, imm);
+    bv[slot] = lds_read_b64((buf + vb) * 4, imm);
+  };
+#pragma unroll
+  for (int p = 0; p < 4; ++p) load_pair_at(p, 0, p);
+  __builtin_amdgcn_sched_barrier(0);
   auto chunk = [&](auto first_c, int ch_cur) {
     constexpr bool FIRST = decltype(first_c)::value;
     const int cbuf = (c & 1) * BUF;
     const int nb = BUF - cbuf;
     const int pb_t = ((c + 1) & 1) * PBS, pb_a = (c & 1) * PBS;
     const int ch_u = ch_cur < last ? ch_cur + 1 : 0;
-    f2 av[4], bv[4];  // operand ring: four pairs
-    const int ua = (cbuf + ub) * 4, va = (cbuf + vb) * 4;  // bytes
-    auto load_pair = [&](int slot, int p) {
-      const int imm = (((p & 15) * 2 + (p >> 4)) * 2 * 64 * 2) * 4;
-      av[slot] = lds_read_b64(ua, imm);
-      bv[slot] = lds_read_b64(va, imm);
-    };
     auto slice = [&](int s) {
-      if (s < 2 * NR) {
-        activate_px(s / NR, s % NR, pb_a);
-      } else if (s >= 14 && s < 14 + 2 * NR) {
-        load_px((s - 14) / NR, (s - 14) % NR, nL, chL);
-      } else if (s >= 28 && s < 36) {
-        dma_u(s - 28, ch_u, nb);
-      } else if (s >= 36 && s < 40) {
-        read_patch(0, s - 36, pb_t);
-      } else if (s == 40) {
+      if (s < 8) {
+        dma_u(s, ch_u, nb);                       // first: 48 steps to land, and OLDER than this chunk's pixel loads
+      } else if (s >= 8 && s < 12) {
+        read_patch(0, s - 8, pb_t);
+      } else if (s == 12) {
         row_transform();
-      } else if (s >= 41 && s < 45) {
-        col_commit(0, s - 41, nb);
-      } else if (s >= 46 && s < 50) {
-        read_patch(1, s - 46, pb_t);
-      } else if (s == 50) {
+      } else if (s >= 13 && s < 17) {
+        col_commit(0, s - 13, nb);
+      } else if (s >= 17 && s < 21) {
+        read_patch(1, s - 17, pb_t);
+      } else if (s == 21) {
         row_transform();
-      } else if (s >= 51 && s < 55) {
-        col_commit(1, s - 51, nb);
+      } else if (s >= 22 && s < 26) {
+        col_commit(1, s - 22, nb);
+      } else if (s >= 27 && s < 27 + 2 * NR) {
+        activate_px((s - 27) / NR, (s - 27) % NR, pb_a);   // pixels requested at steps 40.. of the PREVIOUS chunk
+      } else if (s >= 40 && s < 40 + 2 * NR) {
+        load_px((s - 40) / NR, (s - 40) % NR, nL, chL);
       }
     };
-    load_pair(0, 0);
-    load_pair(1, 1);
-    load_pair(2, 2);
-    load_pair(3, 3);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < 32; ++p) {
-      // operand reads issued after this pair's: three more pairs (6 reads), then 4, 2, 0 at the tail
-      if (FIRST && p < 16) {
-        if (p < 29) mfma_agpr_first_wait<6>(acc[p & 15], av[p & 3][0], bv[p & 3][0]);
-      } else if (p < 29) {
+      // six operand reads (three pairs) are always in flight behind this pair's
+      if (FIRST && p < 16)
+        mfma_agpr_first_wait<6>(acc[p & 15], av[p & 3][0], bv[p & 3][0]);
+      else
         mfma_agpr_wait<6>(acc[p & 15], av[p & 3][0], bv[p & 3][0]);
-      } else if (p == 29) {
-        mfma_agpr_wait<4>(acc[p & 15], av[p & 3][0], bv[p & 3][0]);
-      } else if (p == 30) {
-        mfma_agpr_wait<2>(acc[p & 15], av[p & 3][0], bv[p & 3][0]);
-      } else {
-        mfma_agpr_wait<0>(acc[p & 15], av[p & 3][0], bv[p & 3][0]);
-      }
       slice(2 * p);
       __builtin_amdgcn_sched_barrier(0);
       mfma_agpr(acc[p & 15], av[p & 3][1], bv[p & 3][1]);
-      if (p + 4 < 32) load_pair(p & 3, p + 4);
+      if (p == 28) {
+        // Every read of this chunk's operand buffer has been issued (pair 31 went out after pair 27) and every
+        // staging write of the next chunk's buffer is done: ONE barrier here covers both hazards, and the next
+        // chunk's first operands are fetched under this chunk's last MFMAs -- no restart bubble at the boundary.
+        // The U DMAs are older than this chunk's pixel loads: the counted wait leaves those loads in flight.
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NR + (AFFINE ? 4 * NGS : 0)) : "memory");
+      }
+      if (p + 4 < 32) load_pair_at(p & 3, cbuf, p + 4);
+      else load_pair_at(p & 3, nb, p + 4 - 32);
       slice(2 * p + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
     advance(nL, chL);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
     ++c;
   };
 
