@@ -66,6 +66,7 @@ SIGNATURES = {
     "ddpm_convtr3d_k4s2_cout1_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "ddpm_wino_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_wino_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_pack_wino3d_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_folded_upsample_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_fold_upsample_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_gn_scale_shift_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

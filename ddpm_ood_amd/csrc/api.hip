@@ -143,6 +143,11 @@ extern "C" int ddpm_pack_wino_weight_f32(const float *w_raw, float *w_wino, int 
   return launch_pack_wino_weight(w_raw, w_wino, Cout, Cin, as_stream(stream));
 }
 
+extern "C" int ddpm_pack_wino3d_weight_f32(const float *w_raw, float *w_wino, int Cout, int Cin, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(w_raw && w_wino, "wino3d pack: NULL pointer");
+  return launch_pack_wino_weight(w_raw, w_wino, Cout, Cin, as_stream(stream), 3);
+}
+
 extern "C" size_t ddpm_folded_upsample_weight_floats(int Cout, int Cin) {
   return folded_upsample_weight_floats(Cout, Cin);
 }

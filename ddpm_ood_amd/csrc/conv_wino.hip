@@ -85,6 +85,14 @@ struct WinoGeom {
   int IPW;          // items per workgroup
   int NS;           // (part, image range) slots = parts * ceil(NIT / IPW)
   int grid;         // KT * NS rounded up so that the cout tiles of one slot share an XCD
+  // 3-D (dims = 3, VQ-VAE residual units): an "image" is one (n, d) slice, the chunk stream of an item walks
+  // (depth tap, channel chunk) -- 2-D Winograd per depth tap, the taps accumulated in the transform domain
+  int D;            // slices per batch item (1: plain 2-D)
+  int NIMG;         // images the items walk: B * D
+  int nch_c;        // channel chunks per depth tap; nchunks = nkd * nch_c
+  int kd0, nkd;     // depth taps kd0 .. kd0 + nkd - 1 (a depth-1 volume only has its centre tap)
+  int CS;           // channel stride of the input / output tensors in floats: D * HW
+  int nkd_w;        // depth-tap slabs per cout tile in w_wino: 3 for a 3x3x3 weight, else 1
 };
 
 static int device_cus() {
@@ -101,8 +109,13 @@ static int device_cus() {
 
 static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   const int Cin = d.C1 + d.C2;
-  if (d.ksize != 3 || d.dims == 3 || d.Di > 1 || d.Do > 1 || d.out_act) return false;
+  const bool is3d = d.dims == 3;
+  if (d.ksize != 3 || (!is3d && (d.Di > 1 || d.Do > 1))) return false;
+  if (d.out_act != DDPM_ACT_NONE && d.out_act != DDPM_ACT_RELU) return false;
   if (d.mode != DDPM_CONV_NORMAL && d.mode != DDPM_CONV_UPSAMPLE2) return false;
+  // 3-D: stride 1, no GroupNorm / activation prologue (zero padding along the depth must stay zero), no concat
+  if (is3d && (d.mode != DDPM_CONV_NORMAL || d.gscale || d.act != DDPM_ACT_NONE || d.C2 || d.chan_add)) return false;
+  if (d.mode == DDPM_CONV_UPSAMPLE2 && d.out_act) return false;
   g.up = d.mode == DDPM_CONV_UPSAMPLE2;
   if (g.up && (d.gscale || d.act != DDPM_ACT_NONE || d.Ho != 2 * d.Hi || d.Wo != 2 * d.Wi)) return false;
   if (d.act == DDPM_ACT_RELU) return false;
@@ -110,7 +123,10 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   if (Cin % kWC || (d.C2 > 0 && d.C1 % kWC) || d.Cout % kWK) return false;
   if ((d.Ho & 1) || (d.Wo & 1)) return false;
   // pixels are fetched with 32-bit buffer offsets
-  if ((double)d.B * (d.C1 > d.C2 ? d.C1 : d.C2) * d.Ho * d.Wo * 4 >= 2147483648.0) return false;
+  const int Dd = is3d ? (d.Di > 1 ? d.Di : 1) : 1;
+  if (is3d && (d.Do > 1 ? d.Do : 1) != Dd) return false;
+  if ((double)d.B * (d.C1 > d.C2 ? d.C1 : d.C2) * Dd * d.Ho * d.Wo * 4 >= 2147483648.0) return false;
+  if ((double)d.B * d.Cout * Dd * d.Ho * d.Wo * 4 >= 2147483648.0 * 2) return false;
   g.TWc = d.Wo / 2;
   g.THr = d.Ho / 2;
   const int per_img = g.TWc * g.THr;
@@ -127,7 +143,14 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
     g.parts = 1;
   }
   g.Cin = Cin;
-  g.nchunks = Cin / kWC;
+  g.D = Dd;
+  g.NIMG = d.B * Dd;
+  g.nch_c = Cin / kWC;
+  g.kd0 = is3d && Dd == 1 ? 1 : 0;
+  g.nkd = is3d && Dd > 1 ? 3 : 1;
+  if (is3d && g.TI != 1) return false;  // slices smaller than 64 tiles stay on the direct kernel
+  g.nkd_w = is3d ? 3 : 1;
+  g.nchunks = g.nkd * g.nch_c;
   g.HW = d.Ho * d.Wo;
   g.HWin = d.Hi * d.Wi;
   const int prow = g.up ? g.TR + 2 : 2 * g.TR + 2;  // pixel-tile rows per image of an item
@@ -137,8 +160,9 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   g.NRI = (rows * d.Wi + 63) / 64;
   if (g.TI * g.NRI > 6) return false;
   if ((2 * (kWUF + kWVF) + 2 * kWC * g.PCH + 64) * sizeof(float) > 160 * 1024) return false;
+  g.CS = Dd * g.HW;
   g.KT = d.Cout / kWK;
-  g.NIT = (d.B + g.TI - 1) / g.TI;
+  g.NIT = (g.NIMG + g.TI - 1) / g.TI;
   const long items = (long)g.KT * g.parts * g.NIT;
   const int cus = device_cus();
   g.IPW = (int)((items + cus - 1) / cus);
@@ -212,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
     tbase = sc * g.PCH + (ti * (2 * g.TR + 2) + 2 * tr) * g.PW + 2 * tc;
   }
-  const int bytes1 = a.B * a.C1 * g.HW * 4, bytes2 = a.B * a.C2 * g.HW * 4;
+  const int bytes1 = a.B * a.C1 * g.CS * 4, bytes2 = a.B * a.C2 * g.CS * 4;
   const __amdgpu_buffer_rsrc_t rs_sc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gscale), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_sh =
@@ -230,7 +254,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   // The U tile of a chunk (32 KB, already in LDS order in global memory) is copied by LDS-DMA: 4 x 1 KB per wave,
   // no registers, no ds_write pass, and -- unlike loads into registers -- nothing in the loop has to wait for it
   // before the chunk's closing barrier, so the (in-order) vmcnt waits never drag the slow pixel loads along.
-  const float *usrc = a.w_wino + (size_t)kt * g.nchunks * kWUF + wave * 4 * 256;  // + lane * 4: per-lane offset
+  // U is stored [cout tile][depth tap][channel chunk][32 KB]: the chunk stream of an item reads it front to back
+  const float *usrc = a.w_wino + ((size_t)kt * g.nkd_w + g.kd0) * g.nch_c * kWUF + wave * 4 * 256;  // + lane * 4
 
   f32x16 acc[8];
 
@@ -243,12 +268,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   };
   // stage L: round k of chunk ch of the item at image n -> registers
   auto load_px = [&](int k, int n, int ch) {
-    const int cg = ch * kWC + sc, ni = min(n + tik[k], a.B - 1);
+    int cg = ch * kWC + sc, ni = min(n + tik[k], g.NIMG - 1);
+    int dsl = 0;  // input slice inside the volume (3-D)
+    bool dok = true;
+    if (g.CS != g.HW) {  // wave-uniform: stream chunk -> (depth tap, channel chunk), image -> (batch item, slice)
+      const int kdi = ch / g.nch_c;
+      cg = (ch - kdi * g.nch_c) * kWC + sc;
+      const int nb = ni / g.D;
+      dsl = ni - nb * g.D + g.kd0 + kdi - 1;
+      dok = dsl >= 0 && dsl < g.D;
+      ni = nb;
+    }
     const bool first = cg < a.C1;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
-    const int soff = first ? (ni * a.C1 + cg) * g.HW * 4 : (ni * a.C2 + cg - a.C1) * g.HW * 4;
-    praw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pix[k], soff, 0));
+    const int soff = first ? ((ni * a.C1 + cg) * g.D + (dok ? dsl : 0)) * g.HW * 4 : (ni * a.C2 + cg - a.C1) * g.HW * 4;
+    // a depth tap outside the volume reads zeros: the range check of a raw buffer load is on the VGPR offset, and
+    // 0x80000000 is past every resource (the same trick as for the halo pixels in pix[])
+    const int voff = dok ? pix[k] : (int)0x80000000;
+    praw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
     if (AFFINE && (!ONEIMG || k == 0)) {
       const int goff = (ni * g.Cin + cg) * 4;
       gs[ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
@@ -438,21 +476,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
     const int n = n_cur + ti;
     const int co_base = kt * kWK + cb * 32 + 4 * (elane >> 5) + 16 * hf;
-    const size_t obase = ((size_t)min(n, a.B - 1) * a.Cout + co_base) * g.HW + (size_t)(2 * (r0 + tr)) * a.Wo + 2 * tc;
+    const int ncl = min(n, g.NIMG - 1), nbat = ncl / g.D, dsl_o = ncl - nbat * g.D;  // (batch item, slice)
+    const size_t obase = (((size_t)nbat * a.Cout + co_base) * g.D + dsl_o) * g.HW + (size_t)(2 * (r0 + tr)) * a.Wo + 2 * tc;
     // the addends (residual, bias + temb) are requested first: their latency passes under the transform + exchange
     f2 ra[8], rb[8];
     float addv[8];
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int cof = (rr & 3) + 8 * (rr >> 2);
-      const size_t o = obase + (size_t)cof * g.HW;
+      const size_t o = obase + (size_t)cof * g.CS;
       ra[rr] = rb[rr] = f2{0.f, 0.f};
       if (a.residual) {
         ra[rr] = *reinterpret_cast<const f2 *>(a.residual + o);
         rb[rr] = *reinterpret_cast<const f2 *>(a.residual + o + a.Wo);
       }
       addv[rr] = (a.bias ? a.bias[co_base + cof] : 0.f) +
-                 (a.chan_add ? a.chan_add[(size_t)min(n, a.B - 1) * a.chan_add_stride + co_base + cof] : 0.f);
+                 (a.chan_add ? a.chan_add[(size_t)nbat * a.chan_add_stride + co_base + cof] : 0.f);
     }
     {
       float *xw = smem + cbuf + (((wave & 3) * 2 + hf) * 32) * 64 + elane;  // [pair][from hf][rr * 4 + x][lane]
@@ -476,8 +515,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
 #pragma unroll
         for (int x = 0; x < 4; ++x) yy[x] = (hf == 0 ? ya[x] : yb[x]) + xr[(rr * 4 + x) * 64] + addv[rr];
         yy[0] += ra[rr][0]; yy[1] += ra[rr][1]; yy[2] += rb[rr][0]; yy[3] += rb[rr][1];
-        if (n < a.B) {
-          const size_t o = obase + (size_t)((rr & 3) + 8 * (rr >> 2)) * g.HW;
+        if (a.out_act == DDPM_ACT_RELU) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x) yy[x] = fmaxf(yy[x], 0.f);
+        }
+        if (n < g.NIMG) {
+          const size_t o = obase + (size_t)((rr & 3) + 8 * (rr >> 2)) * g.CS;
           *reinterpret_cast<f2 *>(a.out + o) = f2{yy[0], yy[1]};
           *reinterpret_cast<f2 *>(a.out + o + a.Wo) = f2{yy[2], yy[3]};
         }
@@ -1108,7 +1151,7 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   static const bool four = getenv("DDPM_WINO_WAVES") && atoi(getenv("DDPM_WINO_WAVES")) == 4;
   int threads = 512;
   size_t lds_bytes = lds;
-  if (four && !g.up) {
+  if (four && !g.up && d.dims != 3) {
     static const kern_t kerns4[2][2][3] = {
         {{conv_wino4_kernel<false, 4, false>, conv_wino4_kernel<false, 5, false>, conv_wino4_kernel<false, 6, false>},
          {conv_wino4_kernel<false, 4, true>, conv_wino4_kernel<false, 5, true>, conv_wino4_kernel<false, 6, true>}},
@@ -1136,11 +1179,11 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
     }
     kern = up_kerns[rounds <= 2 ? 0 : 1];
   }
-  const double M = (double)d.B * g.HW;
-  // algorithmic work = the direct convolution's: 2*M*Cout*Cin*9; 16/36 of it is executed
-  const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9;
-  const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9);
-  const char *kname = g.up ? "conv3x3_wino_up" : d.gscale ? "conv3x3_wino_gn_silu" : "conv3x3_wino";
+  const double M = (double)g.NIMG * g.HW;
+  // algorithmic work = the direct convolution's: 2*M*Cout*Cin*9 (*3 depth taps); 16/36 of it is executed
+  const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9 * g.nkd;
+  const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9 * g.nkd);
+  const char *kname = d.dims == 3 ? "conv3d_wino" : g.up ? "conv3x3_wino_up" : d.gscale ? "conv3x3_wino_gn_silu" : "conv3x3_wino";
   char kshape[160];
   if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {
     snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);
@@ -1155,12 +1198,14 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
 // ---- weights: torch [Cout][Cin][3][3] -> U = G g G^T, packed as the LDS image the kernel's MFMAs read:
 //   [cout tile 64][chunk 8][xi 16][kp 2][lhi 2][cout 64][e 2],  channel of the chunk = 4 kp + 2 e + lhi
 // G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
-__global__ void wino_pack_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin) {
-  const int64_t total = (int64_t)Cout * Cin;
+// A 3x3x3 weight (nkd = 3) is transformed per depth tap kd: slab [cout tile][kd][chunk] holds G w[:, :, kd] G^T.
+__global__ void wino_pack_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin, int nkd) {
+  const int64_t total = (int64_t)Cout * Cin * nkd;
   const int nchunks = Cin / kWC;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % Cin), o = (int)(i / Cin);
-    const float *w = src + i * 9;
+    const int kd = (int)(i % nkd);
+    const int ci = (int)((i / nkd) % Cin), o = (int)(i / ((int64_t)nkd * Cin));
+    const float *w = src + ((size_t)o * Cin + ci) * 9 * nkd + kd * 9;
     float t[4][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {  // G g
@@ -1171,7 +1216,7 @@ __global__ void wino_pack_kernel(const float *__restrict__ src, float *__restric
     }
     const int tile = o / kWK, k64 = o % kWK, ch = ci / kWC, cl = ci % kWC;
     const int lhi = cl & 1, kp = cl >> 2, e = (cl >> 1) & 1;
-    float *d = dst + ((size_t)tile * nchunks + ch) * kWUF + ((kp * 2 + lhi) * kWK + k64) * 2 + e;
+    float *d = dst + (((size_t)tile * nkd + kd) * nchunks + ch) * kWUF + ((kp * 2 + lhi) * kWK + k64) * 2 + e;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {  // (G g) G^T
       d[(r * 4 + 0) * kWC * kWK] = t[r][0];
@@ -1187,11 +1232,11 @@ size_t wino_weight_floats(int Cout, int Cin) {
   return (size_t)16 * Cout * Cin;
 }
 
-int launch_pack_wino_weight(const float *w_raw, float *w_wino, int Cout, int Cin, hipStream_t s) {
-  DDPM_CHECK_ARG(wino_weight_floats(Cout, Cin) != 0, "wino pack: Cout %% 64 or Cin %% 8 != 0");
-  const int64_t total = (int64_t)Cout * Cin;
+int launch_pack_wino_weight(const float *w_raw, float *w_wino, int Cout, int Cin, hipStream_t s, int nkd) {
+  DDPM_CHECK_ARG(wino_weight_floats(Cout, Cin) != 0 && (nkd == 1 || nkd == 3), "wino pack: Cout %% 64 or Cin %% 8 != 0");
+  const int64_t total = (int64_t)Cout * Cin * nkd;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, s, w_raw, w_wino, Cout, Cin);
+  hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, s, w_raw, w_wino, Cout, Cin, nkd);
   DDPM_CHECK_LAUNCH();
   return 0;
 }

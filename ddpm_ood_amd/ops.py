@@ -144,6 +144,18 @@ def pack_conv3d_weight(weight: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_wino3d_weight(weight: torch.Tensor) -> torch.Tensor | None:
+    """torch [Cout, Cin, 3, 3, 3] -> per-depth-tap Winograd-domain weights U_kd = G w[:, :, kd] G^T (None if the
+    shape has no Winograd tiling: Cout % 64, Cin % 8)."""
+    lib = _lib.load()
+    w = require_device_f32(weight, "weight")
+    if w.ndim != 5 or tuple(w.shape[2:]) != (3, 3, 3) or lib.ddpm_wino_weight_floats(w.shape[0], w.shape[1]) == 0:
+        return None
+    out = torch.empty(3 * 16 * w.shape[0] * w.shape[1], dtype=torch.float32, device=w.device)
+    check(lib.ddpm_pack_wino3d_weight_f32(ptr(w), ptr(out), w.shape[0], w.shape[1], stream_ptr()), "pack_wino3d_weight")
+    return out
+
+
 def pack_convT_weight(weight: torch.Tensor) -> torch.Tensor:
     """torch ConvTranspose weight [Cin, Cout, 4, 4(, 4)] -> per-output-parity 2 x 2 (x 2)-tap packed weights."""
     lib = _lib.load()
@@ -157,10 +169,13 @@ def pack_convT_weight(weight: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=None, packed=None, stride: int = 1):
+def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=None, packed=None, stride: int = 1,
+           wino=None):
     """F.conv3d(act(x), weight, bias, stride, padding=1) (+ residual, + output activation) on NCDHW tensors:
     kernel 3 stride 1, or kernel 4 stride 2.  ONE launch of the MFMA kernel: the depth taps are part of its chunk
-    stream (chunk = (depth tap, channel group)), so the output is written once."""
+    stream (chunk = (depth tap, channel group)), so the output is written once.  ``wino`` (pack_wino3d_weight): a
+    stride-1 conv without input activation whose slices hold >= 64 2x2 tiles takes the Winograd kernel instead (2-D
+    F(2x2, 3x3) per depth tap, the taps accumulated in the transform domain: 2.25x fewer multiplies)."""
     lib = _lib.load()
     x = require_device_f32(x, "x")
     w = require_device_f32(weight, "weight")
@@ -187,6 +202,8 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
     d.B, d.Cout, d.Hi, d.Wi, d.Ho, d.Wo = B, cout, H, W, Ho, Wo
     d.ksize, d.mode, d.act, d.out_act = k, (CONV_NORMAL if stride == 1 else CONV_STRIDE2), act, out_act
     d.Di, d.Do, d.dims = D, Do, 3
+    if wino is not None and stride == 1:
+        d.w_wino = ptr(wino)
     check(lib.ddpm_conv_f32(C_byref(d), stream_ptr()), "conv3d")
     return out
 

@@ -143,6 +143,11 @@ int ddpm_pack_conv_weight_taps_f32(const float *w_raw, float *w_packed, int Cout
 size_t ddpm_wino_weight_floats(int Cout, int Cin);
 int ddpm_pack_wino_weight_f32(const float *w_raw, float *w_wino, int Cout, int Cin, ddpm_stream_t stream);
 
+/* Winograd-domain form of a [Cout, Cin, 3, 3, 3] conv3d weight: U_kd = G w[:, :, kd] G^T for each depth tap (3 * 16 * Cout *
+ * Cin floats).  A dims = 3, stride-1 descriptor without GroupNorm / activation prologue (the VQ-VAE residual units) that
+ * carries it in w_wino runs as 2-D Winograd F(2x2, 3x3) per depth tap, the taps accumulated in the transform domain.     */
+int ddpm_pack_wino3d_weight_f32(const float *w_raw, float *w_wino, int Cout, int Cin, ddpm_stream_t stream);
+
 /* Folded form of an Upsample conv weight (see ddpm_conv_desc.w_folded): 4 packed 2x2-tap weights.     */
 size_t ddpm_folded_upsample_weight_floats(int Cout, int Cin);
 int ddpm_fold_upsample_weight_f32(const float *w_raw, float *w_folded, int Cout, int Cin, ddpm_stream_t stream);

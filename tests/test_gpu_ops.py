@@ -277,6 +277,32 @@ def test_conv3d_depth_taps_with_relu_epilogues(device, B, Cin, Cout, D, H):
            F.relu(F.conv3d(F.relu(x), w, b, padding=1) + res))
 
 
+@pytest.mark.parametrize("B,Cin,Cout,D,H", [(1, 256, 256, 16, 16), (2, 128, 128, 3, 32), (1, 256, 256, 8, 64), (1, 64, 128, 1, 16),
+                                            (3, 8, 128, 5, 16)])
+def test_conv3d_winograd_per_depth_tap(device, B, Cin, Cout, D, H):
+    """The VQ-VAE residual-unit convolutions in the Winograd domain: 2-D F(2x2, 3x3) per depth tap, the three taps
+    accumulated in the transform domain by ONE persistent launch whose chunk stream walks (depth tap, channel chunk);
+    boundary slices read zeros for the tap that falls outside the volume; ReLU / residual epilogue.  Against
+    F.conv3d and against the direct MFMA kernel."""
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, Cin, D, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(Cin * 27)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, D, H, H, generator=g)
+    d = lambda t: t.to(device)
+    u = ops.pack_wino3d_weight(d(w))
+    assert u is not None
+    ref = F.relu(F.conv3d(x, w, b, padding=1) + res)
+    y = ops.conv3d(d(x), d(w), d(b), residual=d(res), out_act=ops.ACT_RELU, wino=u)
+    _close(y, ref)
+    _close(ops.conv3d(d(x), d(w), d(b), wino=u), F.conv3d(x, w, b, padding=1))
+    # it really is a different kernel from the direct one (rounding differs in the last bits), unless the shape fell back
+    yd = ops.conv3d(d(x), d(w), d(b), residual=d(res), out_act=ops.ACT_RELU)
+    assert (y - yd).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item())
+
+
 @pytest.mark.parametrize("B,Cin,Cout,D,H,W", [(1, 256, 256, 16, 16, 16), (1, 256, 256, 64, 64, 64), (2, 128, 256, 8, 32, 16),
                                               (1, 256, 128, 4, 4, 4), (3, 8, 128, 2, 2, 2), (1, 128, 128, 6, 10, 12)])
 def test_conv3d_k4s2_matches_torch(device, B, Cin, Cout, D, H, W):
