@@ -19,7 +19,7 @@ The only collective is the per-step all_gather of the dense score tensor (RCCL).
     cfg3  32x32x3 `small`                       (batch 256, k = 4)
     cfg4  64x64x3 `big` attention-heavy UNet    (batch 8,   k = 2: 50 t-starts, 2 550 forwards per image)
     cfg5  128^3 volumes, README VQ-VAE (4 x stride 2, 256 ch, 2 048 codes) -> [128, 8, 8, 8] latents -> 3-D
-          `small` UNet -> re-quantise + decode -> 2.5-D LPIPS  (batch 2, k = 4)
+          `small` UNet -> re-quantise + decode -> 2.5-D LPIPS  (batch 16, k = 4)
 
 One JSON line on rank 0.  `roofline` describes the kernel class with the most time in the sampled launches
 (first UNet step -- and, for the LDM, the decode -- of each t-start of the LAST timed step, hipEvent-bracketed on
@@ -67,7 +67,7 @@ CONFIGS = {
                  workload="BASELINE configs[3]: CelebA-shaped 64x64x3, big attention-heavy UNet (172.6M params, "
                           "attention over 4096/1024/256 tokens), 100 PLMS timesteps, inference_skip_factor=2 "
                           "(50 t-starts, 2550 UNet forwards per image)"),
-    "cfg5": dict(model_type="small", channels=1, size=128, spatial=3, skip=4, batch=2, vqvae=VQ_README,
+    "cfg5": dict(model_type="small", channels=1, size=128, spatial=3, skip=4, batch=16, vqvae=VQ_README,
                  metric_tag="Decathlon-shaped 128^3 LDM",
                  workload="BASELINE configs[4]: 128^3 volumes, README VQ-VAE (4 stride-2 levels, 256 ch, 2048 codes x "
                           "128) -> [128,8,8,8] latents, small 3-D UNet (47.5M params), 100 PLMS timesteps, "
@@ -149,6 +149,7 @@ MFMA_KERNELS = [
     ("conv3x3_wino_up", "conv_wino_up_kernel: nearest-x2 + 3x3 conv in the Winograd domain (9 of 16 positions), fp32 MFMA", 9.0 / 36.0),
     ("conv3x3_wino", "conv_wino_kernel: 3x3 conv as Winograd F(2x2,3x3), persistent, GN+SiLU prologue, fp32 MFMA", 16.0 / 36.0),
     ("conv3x3_mfma_up_folded", "conv_mfma_kernel<4>: nearest-x2 + 3x3 conv folded into four 2x2-tap convs, fp32 MFMA", 16.0 / 36.0),
+    ("conv3d_wino", "conv_wino_kernel, 3-D: Winograd F(2x2,3x3) per depth tap, taps accumulated in the transform domain, fp32 MFMA", 16.0 / 36.0),
     ("conv3d_", "conv_mfma_kernel: 3-D convolution (depth taps merged into one chunk stream), fp32 MFMA", 1.0),
     ("conv3x3_mfma", "conv_mfma_kernel<9>: direct 3x3 conv (stride 2, ragged extents, 3-D depth-tap launches), fp32 MFMA", 1.0),
     ("conv1x1_dma", "conv1x1_dma_kernel: LDS-DMA-fed 1x1 conv, fp32 MFMA", 1.0),

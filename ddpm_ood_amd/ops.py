@@ -119,6 +119,7 @@ def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NON
 
 
 CONV_TRANSPOSE2 = 3
+WINO_MAX_TENSOR_BYTES = 2 ** 31 - 1  # 32-bit buffer offsets of the Winograd kernels
 
 
 def conv3d_supported(weight: torch.Tensor, stride: int = 1, transposed: bool = False) -> bool:
@@ -170,7 +171,7 @@ def pack_convT_weight(weight: torch.Tensor) -> torch.Tensor:
 
 
 def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=None, packed=None, stride: int = 1,
-           wino=None):
+           wino=None, out=None):
     """F.conv3d(act(x), weight, bias, stride, padding=1) (+ residual, + output activation) on NCDHW tensors:
     kernel 3 stride 1, or kernel 4 stride 2.  ONE launch of the MFMA kernel: the depth taps are part of its chunk
     stream (chunk = (depth tap, channel group)), so the output is written once.  ``wino`` (pack_wino3d_weight): a
@@ -190,11 +191,22 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
     Do, Ho, Wo = (D, H, W) if stride == 1 else (D // 2, H // 2, W // 2)
     if packed is None:
         packed = pack_conv3d_weight(w)
-    out = torch.empty((B, cout, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((B, cout, Do, Ho, Wo), dtype=torch.float32, device=x.device)
     if bias is not None:
         bias = require_device_f32(bias, "bias")
     if residual is not None:
         residual = require_device_f32(residual, "residual")
+    if wino is not None and stride == 1 and B > 1:
+        # the Winograd kernel addresses pixels with 32-bit buffer offsets (tensors < 2 GiB): a larger batch is walked
+        # in sub-batches (views along dim 0, no copies) instead of dropping to the direct kernel
+        per = max(Cc, cout) * D * H * W * 4
+        nb = max(1, WINO_MAX_TENSOR_BYTES // per)
+        if B > nb:
+            for s0 in range(0, B, nb):
+                conv3d(x[s0:s0 + nb], w, bias, act=act, out_act=out_act, packed=packed, stride=stride, wino=wino,
+                       residual=None if residual is None else residual[s0:s0 + nb], out=out[s0:s0 + nb])
+            return out
     d = ConvDesc()
     d.in1, d.C1 = ptr(x), Cc
     d.w_packed = ptr(packed)

@@ -301,6 +301,13 @@ def test_conv3d_winograd_per_depth_tap(device, B, Cin, Cout, D, H):
     # it really is a different kernel from the direct one (rounding differs in the last bits), unless the shape fell back
     yd = ops.conv3d(d(x), d(w), d(b), residual=d(res), out_act=ops.ACT_RELU)
     assert (y - yd).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item())
+    if B > 1:  # batches past the kernel's 2 GiB addressing limit are walked in sub-batches: same result, bit for bit
+        old = ops.WINO_MAX_TENSOR_BYTES
+        try:
+            ops.WINO_MAX_TENSOR_BYTES = max(Cin, Cout) * D * H * H * 4  # one volume per launch
+            assert torch.equal(ops.conv3d(d(x), d(w), d(b), residual=d(res), out_act=ops.ACT_RELU, wino=u), y)
+        finally:
+            ops.WINO_MAX_TENSOR_BYTES = old
 
 
 @pytest.mark.parametrize("B,Cin,Cout,D,H,W", [(1, 256, 256, 16, 16, 16), (1, 256, 256, 64, 64, 64), (2, 128, 256, 8, 32, 16),
