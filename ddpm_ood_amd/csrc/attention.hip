@@ -119,28 +119,39 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 
     // ---- S quadrant: rows = queries qi*32.., cols = keys kj*32.. ----------------------------
     {
-      f32x16 sacc;
+      // two independent accumulator chains (even / odd k-steps) and an operand ring four k-steps deep: with one
+      // wave per SIMD nothing else hides the LDS latency of the operand reads
+      f32x16 sacc, sacc2;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      for (int r = 0; r < 16; ++r) sacc[r] = sacc2[r] = 0.f;
       const float *qa = Ql + lhi * kQB + qi * 32 + l31;
       const float *kb = KVl + lhi * kKB + kj * 32 + l31;
-      float av[2], bv[2];
-      av[0] = qa[0];
-      bv[0] = kb[0];
+      constexpr int kRing = 4;
+      float av[kRing], bv[kRing];
+#pragma unroll
+      for (int p = 0; p < kRing; ++p) {
+        av[p] = qa[2 * p * kQB];
+        bv[p] = kb[2 * p * kKB];
+      }
 #pragma unroll 16
       for (int d = 0; d < kDH; d += 2) {
-        const int cur = (d >> 1) & 1;
-        if (d + 2 < kDH) {
-          av[cur ^ 1] = qa[(d + 2) * kQB];
-          bv[cur ^ 1] = kb[(d + 2) * kKB];
+        const int cur = (d >> 1) % kRing;
+        const float a_ = av[cur], b_ = bv[cur];
+        if (d + 2 * kRing < kDH) {
+          av[cur] = qa[(d + 2 * kRing) * kQB];
+          bv[cur] = kb[(d + 2 * kRing) * kKB];
         }
-        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur], sacc, 0, 0, 0);
+        if ((d >> 1) & 1)
+          sacc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, sacc2, 0, 0, 0);
+        else
+          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, sacc, 0, 0, 0);
       }
       const bool colok = (j0 + kj * 32 + l31) < N;
+      // scores are kept in the log2 domain: s * scale * log2(e), so that the softmax below is one v_exp_f32 per key
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        Sl[row * kLd + kj * 32 + l31] = colok ? sacc[r] * scale : -INFINITY;
+        Sl[row * kLd + kj * 32 + l31] = colok ? (sacc[r] + sacc2[r]) * (scale * 1.44269504088896341f) : -INFINITY;
       }
     }
     __syncthreads();            // scores complete; every wave is done reading the K block
@@ -159,13 +170,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
       float sum = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        const float p = expf(sr[c] - mn);
+        const float p = __builtin_amdgcn_exp2f(sr[c] - mn);  // scores carry the log2(e) factor already
         sr[c] = p;
         sum += p;
       }
       sum += __shfl_xor(sum, 1, 64);
       sum += __shfl_xor(sum, 2, 64);
-      const float alpha = expf(mo - mn);  // exp(-inf) = 0 on the first block
+      const float alpha = __builtin_amdgcn_exp2f(mo - mn);  // exp2(-inf) = 0 on the first block
       store_block(KVl, kLd);              // V block over the K block, row stride 65
       __syncthreads();                    // all 4 readers of mrow[row] are done; V and P are visible
       if (part == 0) {
@@ -188,21 +199,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     }
     const float *va = KVl + ((wave * 2) * 32 + l31) * kLd + lhi;
     const float *pb = Sl + l31 * kLd + lhi;
-    float a0[2], a1[2], b0[2], b1[2];
-    a0[0] = va[0]; a1[0] = va[32 * kLd]; b0[0] = pb[0]; b1[0] = pb[32 * kLd];
-#pragma unroll 8
+    constexpr int kR = 3;  // operand ring: three k-steps (12 MFMAs) ahead
+    float a0[kR], a1[kR], b0[kR], b1[kR];
+#pragma unroll
+    for (int p = 0; p < kR; ++p) {
+      a0[p] = va[2 * p]; a1[p] = va[32 * kLd + 2 * p]; b0[p] = pb[2 * p]; b1[p] = pb[32 * kLd + 2 * p];
+    }
+#pragma unroll
     for (int jj = 0; jj < kKB; jj += 2) {
-      const int cur = (jj >> 1) & 1;
-      if (jj + 2 < kKB) {
-        a0[cur ^ 1] = va[jj + 2];
-        a1[cur ^ 1] = va[32 * kLd + jj + 2];
-        b0[cur ^ 1] = pb[jj + 2];
-        b1[cur ^ 1] = pb[32 * kLd + jj + 2];
+      const int cur = (jj >> 1) % kR;
+      const float x0 = a0[cur], x1 = a1[cur], y0 = b0[cur], y1 = b1[cur];
+      if (jj + 2 * kR < kKB) {
+        a0[cur] = va[jj + 2 * kR];
+        a1[cur] = va[32 * kLd + jj + 2 * kR];
+        b0[cur] = pb[jj + 2 * kR];
+        b1[cur] = pb[32 * kLd + jj + 2 * kR];
       }
-      o[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], b0[cur], o[0][0], 0, 0, 0);
-      o[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], b1[cur], o[0][1], 0, 0, 0);
-      o[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], b0[cur], o[1][0], 0, 0, 0);
-      o[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], b1[cur], o[1][1], 0, 0, 0);
+      o[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, o[0][0], 0, 0, 0);
+      o[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, o[0][1], 0, 0, 0);
+      o[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, o[1][0], 0, 0, 0);
+      o[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, o[1][1], 0, 0, 0);
     }
   }
 
