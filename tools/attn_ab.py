@@ -13,7 +13,7 @@ for B, heads, N in [(8, 1, 4096), (8, 2, 1024), (8, 3, 256), (256, 1, 64)]:
     qkv = torch.randn(B, 3 * C, N, device=dev, generator=g)
     res = torch.randn(B, C, N, device=dev, generator=g)
     y = ops.attention(qkv, res, heads, 1.0 / 16.0)
-    q, k, v = (t.reshape(B, heads, 256, N) for t in qkv[:1].split(C, dim=1))
+    q, k, v = (t.reshape(1, heads, 256, N) for t in qkv[:1].split(C, dim=1))
     ref = torch.einsum("bhij,bhdj->bhdi", (torch.einsum("bhdi,bhdj->bhij", q, k) / 16.0).softmax(-1), v).reshape(1, C, N) + res[:1]
     err = (y[:1] - ref).abs().max().item()
     for _ in range(3):
