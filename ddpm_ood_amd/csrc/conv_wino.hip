@@ -111,7 +111,7 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   const int Cin = d.C1 + d.C2;
   const bool is3d = d.dims == 3;
   if (d.ksize != 3 || (!is3d && (d.Di > 1 || d.Do > 1))) return false;
-  if (d.out_act != DDPM_ACT_NONE && d.out_act != DDPM_ACT_RELU) return false;
+  if (d.out_act != DDPM_ACT_NONE && !(is3d && d.out_act == DDPM_ACT_RELU)) return false;
   if (d.mode != DDPM_CONV_NORMAL && d.mode != DDPM_CONV_UPSAMPLE2) return false;
   // 3-D: stride 1, no GroupNorm / activation prologue (zero padding along the depth must stay zero), no concat
   if (is3d && (d.mode != DDPM_CONV_NORMAL || d.gscale || d.act != DDPM_ACT_NONE || d.C2 || d.chan_add)) return false;
@@ -177,7 +177,9 @@ bool conv_wino_supported(const ddpm_conv_desc &d) {
   return enabled && d.w_wino != nullptr && !d.force_direct && wino_geom(d, g);
 }
 
-template <bool AFFINE, int NR, bool ONEIMG>
+// D3: the 3-D form (images = (n, d) slices, chunk stream = (depth tap, channel chunk)); a template parameter so that
+// the 2-D instantiations carry none of its address arithmetic (as a run-time branch it cost them 9 %).
+template <bool AFFINE, int NR, bool ONEIMG, bool D3 = false>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc a, const WinoGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BUF = kWUF + kWVF;  // floats per operand buffer: U then V, both [xi 16][k-pair 2][k parity 2][64][2]
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
     tbase = sc * g.PCH + (ti * (2 * g.TR + 2) + 2 * tr) * g.PW + 2 * tc;
   }
-  const int bytes1 = a.B * a.C1 * g.CS * 4, bytes2 = a.B * a.C2 * g.CS * 4;
+  const int bytes1 = a.B * a.C1 * (D3 ? g.CS : g.HW) * 4, bytes2 = a.B * a.C2 * g.HW * 4;
   const __amdgpu_buffer_rsrc_t rs_sc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gscale), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_sh =
@@ -255,7 +257,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   // no registers, no ds_write pass, and -- unlike loads into registers -- nothing in the loop has to wait for it
   // before the chunk's closing barrier, so the (in-order) vmcnt waits never drag the slow pixel loads along.
   // U is stored [cout tile][depth tap][channel chunk][32 KB]: the chunk stream of an item reads it front to back
-  const float *usrc = a.w_wino + ((size_t)kt * g.nkd_w + g.kd0) * g.nch_c * kWUF + wave * 4 * 256;  // + lane * 4
+  const float *usrc = a.w_wino + (D3 ? ((size_t)kt * g.nkd_w + g.kd0) * g.nch_c : (size_t)kt * g.nchunks) * kWUF +
+                      wave * 4 * 256;  // + lane * 4: per-lane offset
 
   f32x16 acc[8];
 
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     int cg = ch * kWC + sc, ni = min(n + tik[k], g.NIMG - 1);
     int dsl = 0;  // input slice inside the volume (3-D)
     bool dok = true;
-    if (g.CS != g.HW) {  // wave-uniform: stream chunk -> (depth tap, channel chunk), image -> (batch item, slice)
+    if (D3) {  // wave-uniform: stream chunk -> (depth tap, channel chunk), image -> (batch item, slice)
       const int kdi = ch / g.nch_c;
       cg = (ch - kdi * g.nch_c) * kWC + sc;
       const int nb = ni / g.D;
@@ -282,10 +285,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     const bool first = cg < a.C1;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
-    const int soff = first ? ((ni * a.C1 + cg) * g.D + (dok ? dsl : 0)) * g.HW * 4 : (ni * a.C2 + cg - a.C1) * g.HW * 4;
+    const int soff = D3 ? ((ni * a.C1 + cg) * g.D + (dok ? dsl : 0)) * g.HW * 4
+                        : first ? (ni * a.C1 + cg) * g.HW * 4 : (ni * a.C2 + cg - a.C1) * g.HW * 4;
     // a depth tap outside the volume reads zeros: the range check of a raw buffer load is on the VGPR offset, and
     // 0x80000000 is past every resource (the same trick as for the halo pixels in pix[])
-    const int voff = dok ? pix[k] : (int)0x80000000;
+    const int voff = (!D3 || dok) ? pix[k] : (int)0x80000000;
     praw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
     if (AFFINE && (!ONEIMG || k == 0)) {
       const int goff = (ni * g.Cin + cg) * 4;
@@ -476,15 +480,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
     const int n = n_cur + ti;
     const int co_base = kt * kWK + cb * 32 + 4 * (elane >> 5) + 16 * hf;
-    const int ncl = min(n, g.NIMG - 1), nbat = ncl / g.D, dsl_o = ncl - nbat * g.D;  // (batch item, slice)
-    const size_t obase = (((size_t)nbat * a.Cout + co_base) * g.D + dsl_o) * g.HW + (size_t)(2 * (r0 + tr)) * a.Wo + 2 * tc;
+    const int ncl = min(n, g.NIMG - 1), nbat = D3 ? ncl / g.D : ncl, dsl_o = D3 ? ncl - nbat * g.D : 0;  // (item, slice)
+    const int cstr = D3 ? g.CS : g.HW;  // channel stride
+    const size_t obase = D3 ? (((size_t)nbat * a.Cout + co_base) * g.D + dsl_o) * g.HW + (size_t)(2 * (r0 + tr)) * a.Wo + 2 * tc
+                            : ((size_t)nbat * a.Cout + co_base) * g.HW + (size_t)(2 * (r0 + tr)) * a.Wo + 2 * tc;
     // the addends (residual, bias + temb) are requested first: their latency passes under the transform + exchange
     f2 ra[8], rb[8];
     float addv[8];
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int cof = (rr & 3) + 8 * (rr >> 2);
-      const size_t o = obase + (size_t)cof * g.CS;
+      const size_t o = obase + (size_t)cof * cstr;
       ra[rr] = rb[rr] = f2{0.f, 0.f};
       if (a.residual) {
         ra[rr] = *reinterpret_cast<const f2 *>(a.residual + o);
@@ -515,12 +521,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
 #pragma unroll
         for (int x = 0; x < 4; ++x) yy[x] = (hf == 0 ? ya[x] : yb[x]) + xr[(rr * 4 + x) * 64] + addv[rr];
         yy[0] += ra[rr][0]; yy[1] += ra[rr][1]; yy[2] += rb[rr][0]; yy[3] += rb[rr][1];
-        if (a.out_act == DDPM_ACT_RELU) {
+        if (D3 && a.out_act == DDPM_ACT_RELU) {
 #pragma unroll
           for (int x = 0; x < 4; ++x) yy[x] = fmaxf(yy[x], 0.f);
         }
         if (n < g.NIMG) {
-          const size_t o = obase + (size_t)((rr & 3) + 8 * (rr >> 2)) * g.CS;
+          const size_t o = obase + (size_t)((rr & 3) + 8 * (rr >> 2)) * cstr;
           *reinterpret_cast<f2 *>(a.out + o) = f2{yy[0], yy[1]};
           *reinterpret_cast<f2 *>(a.out + o + a.Wo) = f2{yy[2], yy[3]};
         }
@@ -1147,6 +1153,18 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   }
   const int rounds = g.TI * g.NRI;
   kern_t kern = kerns[d.gscale ? 1 : 0][g.TI == 1 ? 1 : 0][rounds <= 4 ? 0 : rounds - 4];
+  if (d.dims == 3) {  // only reached without GroupNorm prologue and with whole slices per item (wino_geom)
+    static const kern_t kerns3d[3] = {conv_wino_kernel<false, 4, true, true>, conv_wino_kernel<false, 5, true, true>,
+                                      conv_wino_kernel<false, 6, true, true>};
+    static bool attr3_done = false;
+    if (!attr3_done) {
+      for (int i = 0; i < 3; ++i)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns3d[i]),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr3_done = true;
+    }
+    kern = kerns3d[rounds <= 4 ? 0 : rounds - 4];
+  }
   // DDPM_WINO_WAVES=4: the one-wave-per-SIMD variant (A/B switch; see conv_wino4_kernel)
   static const bool four = getenv("DDPM_WINO_WAVES") && atoi(getenv("DDPM_WINO_WAVES")) == 4;
   int threads = 512;
