@@ -5,6 +5,8 @@
 // tiling does not cover -- conv_in (Cin = 1 / 3), conv_out (Cout = 1 / 3), odd extents such as
 // 28x28 -- and is the on-device cross-check for the MFMA kernel in tests.
 // Reference call site: /root/reference/src/trainers/reconstruct.py:151-153.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ddpm {
@@ -172,6 +174,126 @@ __global__ __launch_bounds__(256) void conv_smallco_kernel(const ddpm_conv_desc 
   }
 }
 
+// ---- conv_out, wave-parallel over channels ------------------------------------------------------------------------
+// conv_smallco_kernel above walks the channels 8 at a time with two block barriers per chunk: 16 dependent
+// load -> barrier -> LDS -> barrier rounds per workgroup, 1.2 TB/s.  Here every WAVE owns a quarter of the channels
+// and a private double-buffered LDS plane: it loads the haloed plane of its next channel (6 loads per lane in
+// flight) while the 3x3 windows of the current one are read back, with no block barrier until the final four-way
+// reduction of the per-wave partial sums.  Same tile (256 pixels = whole rows), one thread-quad of pixels per lane.
+constexpr int kSW_NJ = 6;   // plane elements per lane: PS <= 384
+constexpr int kSW_PPL = 4;  // output pixels per lane: 256 / 64
+
+__global__ __launch_bounds__(256) void conv_smallco_wave_kernel(const ddpm_conv_desc a, int TH, int RS, int PS) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][2][PS] planes, then [4][256][4] partials
+  const int HW = a.Ho * a.Wo;
+  const int Cin = a.C1 + a.C2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.y;
+  const int h0 = blockIdx.x * TH;
+  float *plane_lds = lds + wave * 2 * PS;
+
+  int soff[kSW_NJ];
+#pragma unroll
+  for (int j = 0; j < kSW_NJ; ++j) {
+    const int r = lane + 64 * j;
+    soff[j] = -1;
+    if (r < PS) {
+      const int ir = r / RS, ic = r - ir * RS;
+      const int hv = h0 + ir - 1, wv = ic - 1;
+      if (hv >= 0 && hv < a.Hi && wv >= 0 && wv < a.Wi) soff[j] = hv * a.Wi + wv;
+    }
+  }
+  int pix[kSW_PPL];  // top-left tap of each of this lane's pixels inside the haloed plane
+#pragma unroll
+  for (int k = 0; k < kSW_PPL; ++k) {
+    const int q = lane + 64 * k;
+    const int th = q / a.Wo, tw = q - th * a.Wo;
+    pix[k] = (q < TH * a.Wo) ? th * RS + tw : 0;
+  }
+  float acc[kSW_PPL][4];
+#pragma unroll
+  for (int k = 0; k < kSW_PPL; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[k][c] = 0.f;
+
+  // this wave's channels: wave, wave + 4, ... (the four waves read neighbouring planes at the same time)
+  float pre[kSW_NJ], psc = 1.f, psh = 0.f;
+  auto fetch = [&](int ci) {
+    const float *plane = (ci < a.C1) ? a.in1 + ((size_t)n * a.C1 + ci) * HW
+                                     : a.in2 + ((size_t)n * a.C2 + (ci - a.C1)) * HW;
+#pragma unroll
+    for (int j = 0; j < kSW_NJ; ++j) pre[j] = soff[j] >= 0 ? plane[soff[j]] : 0.f;
+    if (a.gscale) {
+      psc = a.gscale[(size_t)n * Cin + ci];
+      psh = a.gshift[(size_t)n * Cin + ci];
+    }
+  };
+  int buf = 0;
+  if (wave < Cin) fetch(wave);
+  for (int ci = wave; ci < Cin; ci += 4) {
+    float *pl = plane_lds + buf * PS;
+#pragma unroll
+    for (int j = 0; j < kSW_NJ; ++j) {
+      const int r = lane + 64 * j;
+      if (r < PS) {
+        float v = 0.f;
+        if (soff[j] >= 0) {
+          v = pre[j];
+          if (a.gscale) v = v * psc + psh;
+          if (a.act == DDPM_ACT_SILU) v = silu_fast(v);
+          if (a.act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
+        }
+        pl[r] = v;
+      }
+    }
+    if (ci + 4 < Cin) fetch(ci + 4);  // next plane flies while this one is consumed
+    // (LDS operations of one wave complete in order: the reads below see the writes above without a barrier)
+    float wreg[4][9];
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      const float *w = a.w_raw + ((size_t)min(co, a.Cout - 1) * Cin + ci) * 9;  // wave-uniform
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wreg[co][t] = w[t];
+    }
+#pragma unroll
+    for (int k = 0; k < kSW_PPL; ++k) {
+      float x[9];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) x[kh * 3 + kw] = pl[pix[k] + kh * RS + kw];
+#pragma unroll
+      for (int co = 0; co < 4; ++co)
+        if (co < a.Cout) {
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[k][co] = fmaf(x[t], wreg[co][t], acc[k][co]);
+        }
+    }
+    buf ^= 1;
+  }
+  // ---- four-way reduction of the per-wave partial sums (fixed order: wave 0 + 1 + 2 + 3), epilogue, store ------------
+  float *red = lds + 4 * 2 * PS;
+#pragma unroll
+  for (int k = 0; k < kSW_PPL; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[(wave * 256 + lane + 64 * k) * 4 + c] = acc[k][c];
+  __syncthreads();
+  if (tid < TH * a.Wo) {
+    const int th = tid / a.Wo, tw = tid - th * a.Wo;
+    const int p = (h0 + th) * a.Wo + tw;
+    for (int co = 0; co < a.Cout; ++co) {
+      float v = ((red[(0 * 256 + tid) * 4 + co] + red[(1 * 256 + tid) * 4 + co]) + red[(2 * 256 + tid) * 4 + co]) +
+                red[(3 * 256 + tid) * 4 + co];
+      const size_t idx = ((size_t)n * a.Cout + co) * HW + p;
+      if (a.bias) v += a.bias[co];
+      if (a.chan_add) v += a.chan_add[(size_t)n * a.chan_add_stride + co];
+      if (a.residual) v += a.residual[idx];
+      if (a.out_act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
+      a.out[idx] = v;
+    }
+  }
+}
+
 static bool smallco_supported(const ddpm_conv_desc &d, int &TH, int &RS, int &PS) {
   if (d.Cout > 4 || d.ksize != 3 || d.mode != DDPM_CONV_NORMAL || d.Wo > 256 || d.Di > 1 || d.Do > 1) return false;
   TH = 0;
@@ -189,12 +311,20 @@ int launch_conv_direct(const ddpm_conv_desc &d, hipStream_t s) {
   DDPM_CHECK_ARG(d.B <= 65535, "conv_direct: batch > 65535");
   const int HWo = d.Ho * d.Wo;
   const double cin = d.C1 + d.C2, taps = d.ksize * d.ksize;
+  const int Cin_i = d.C1 + d.C2;
   int TH, RS, PS;
   if (smallco_supported(d, TH, RS, PS)) {
     ProfScope prof(s, "conv3x3_small_cout", 2.0 * d.B * HWo * d.Cout * cin * 9,
                    4.0 * ((double)d.B * cin * HWo + (double)d.B * HWo * d.Cout + d.Cout * cin * 9));
-    const size_t lds = (size_t)kSC_CH * PS * sizeof(float);
     dim3 grid(d.Ho / TH, d.B);
+    static const bool wave_ok = !(getenv("DDPM_CONVOUT_WAVE") && atoi(getenv("DDPM_CONVOUT_WAVE")) == 0);
+    if (wave_ok && PS <= 64 * kSW_NJ && Cin_i >= 16) {
+      const size_t lds_w = ((size_t)4 * 2 * PS + 4 * 256 * 4) * sizeof(float);
+      hipLaunchKernelGGL(conv_smallco_wave_kernel, grid, dim3(256), lds_w, s, d, TH, RS, PS);
+      DDPM_CHECK_LAUNCH();
+      return 0;
+    }
+    const size_t lds = (size_t)kSC_CH * PS * sizeof(float);
     if (PS <= 256)
       hipLaunchKernelGGL(conv_smallco_kernel<1>, grid, dim3(256), lds, s, d, TH, RS, PS);
     else
