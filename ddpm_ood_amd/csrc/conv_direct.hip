@@ -216,21 +216,20 @@ __global__ __launch_bounds__(256) void conv_smallco_wave_kernel(const ddpm_conv_
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[k][c] = 0.f;
 
-  // this wave's channels: wave, wave + 4, ... (the four waves read neighbouring planes at the same time)
-  float pre[kSW_NJ], psc = 1.f, psh = 0.f;
-  auto fetch = [&](int ci) {
+  // this wave's channels: wave, wave + 4, ... (the four waves read neighbouring planes at the same time); two planes
+  // are always in flight per wave (register sets 0 / 1), a third is being consumed out of LDS
+  float pre[2][kSW_NJ], psc[2] = {1.f, 1.f}, psh[2] = {0.f, 0.f};
+  auto fetch = [&](int slot, int ci) {
     const float *plane = (ci < a.C1) ? a.in1 + ((size_t)n * a.C1 + ci) * HW
                                      : a.in2 + ((size_t)n * a.C2 + (ci - a.C1)) * HW;
 #pragma unroll
-    for (int j = 0; j < kSW_NJ; ++j) pre[j] = soff[j] >= 0 ? plane[soff[j]] : 0.f;
+    for (int j = 0; j < kSW_NJ; ++j) pre[slot][j] = soff[j] >= 0 ? plane[soff[j]] : 0.f;
     if (a.gscale) {
-      psc = a.gscale[(size_t)n * Cin + ci];
-      psh = a.gshift[(size_t)n * Cin + ci];
+      psc[slot] = a.gscale[(size_t)n * Cin + ci];
+      psh[slot] = a.gshift[(size_t)n * Cin + ci];
     }
   };
-  int buf = 0;
-  if (wave < Cin) fetch(wave);
-  for (int ci = wave; ci < Cin; ci += 4) {
+  auto consume = [&](int slot, int ci, int buf) {
     float *pl = plane_lds + buf * PS;
 #pragma unroll
     for (int j = 0; j < kSW_NJ; ++j) {
@@ -238,15 +237,15 @@ __global__ __launch_bounds__(256) void conv_smallco_wave_kernel(const ddpm_conv_
       if (r < PS) {
         float v = 0.f;
         if (soff[j] >= 0) {
-          v = pre[j];
-          if (a.gscale) v = v * psc + psh;
+          v = pre[slot][j];
+          if (a.gscale) v = v * psc[slot] + psh[slot];
           if (a.act == DDPM_ACT_SILU) v = silu_fast(v);
           if (a.act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
         }
         pl[r] = v;
       }
     }
-    if (ci + 4 < Cin) fetch(ci + 4);  // next plane flies while this one is consumed
+    if (ci + 8 < Cin) fetch(slot, ci + 8);  // refill this register set: the plane two channels ahead
     // (LDS operations of one wave complete in order: the reads below see the writes above without a barrier)
     float wreg[4][9];
 #pragma unroll
@@ -269,7 +268,12 @@ __global__ __launch_bounds__(256) void conv_smallco_wave_kernel(const ddpm_conv_
           for (int t = 0; t < 9; ++t) acc[k][co] = fmaf(x[t], wreg[co][t], acc[k][co]);
         }
     }
-    buf ^= 1;
+  };
+  if (wave < Cin) fetch(0, wave);
+  if (wave + 4 < Cin) fetch(1, wave + 4);
+  for (int ci = wave; ci < Cin; ci += 8) {
+    consume(0, ci, 0);
+    if (ci + 4 < Cin) consume(1, ci + 4, 1);
   }
   // ---- four-way reduction of the per-wave partial sums (fixed order: wave 0 + 1 + 2 + 3), epilogue, store ------------
   float *red = lds + 4 * 2 * PS;
@@ -292,6 +296,49 @@ __global__ __launch_bounds__(256) void conv_smallco_wave_kernel(const ddpm_conv_
       a.out[idx] = v;
     }
   }
+}
+
+// ---- conv_in: 3x3, 1..4 input channels, many output channels ------------------------------------------------------
+// HBM-bound on the OUTPUT (134 MB at B = 256, 128 channels, 32x32; the input is 1 MB).  conv_direct_kernel<8> spends a
+// workgroup per (256 pixels, 8 couts): 16 384 tiny workgroups, 1.5 TB/s.  Here a thread keeps its 9 x Cin input
+// values in registers and walks ALL output channels (weights wave-uniform -> scalar loads), issuing one coalesced
+// store per channel back to back.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_smallci_kernel(const ddpm_conv_desc a) {
+  const int HW = a.Ho * a.Wo;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (p >= HW) return;
+  const int ho = p / a.Wo, wo = p - ho * a.Wo;
+  float x[CIN * 9];
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci) {
+    const float *plane = a.in1 + ((size_t)n * CIN + ci) * HW;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int hv = ho + kh - 1, wv = wo + kw - 1;
+        x[ci * 9 + kh * 3 + kw] = (hv >= 0 && hv < a.Hi && wv >= 0 && wv < a.Wi) ? plane[hv * a.Wi + wv] : 0.f;
+      }
+  }
+  float *dst = a.out + (size_t)n * a.Cout * HW + p;
+#pragma unroll 4
+  for (int co = 0; co < a.Cout; ++co) {  // (unrolled: the scalar weight loads of four channels go out together)
+    const float *w = a.w_raw + (size_t)co * CIN * 9;  // wave-uniform
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < CIN * 9; ++k) acc = fmaf(x[k], w[k], acc);  // (ci, kh, kw) order, as conv_direct_kernel
+    if (a.bias) acc += a.bias[co];
+    dst[(size_t)co * HW] = acc;
+  }
+}
+
+static bool smallci_supported(const ddpm_conv_desc &d) {
+  static const bool on = !(getenv("DDPM_CONVIN_FAST") && atoi(getenv("DDPM_CONVIN_FAST")) == 0);
+  return on && d.C2 == 0 && d.C1 >= 1 && d.C1 <= 4 && d.ksize == 3 && d.mode == DDPM_CONV_NORMAL && !d.gscale &&
+         d.act == DDPM_ACT_NONE && !d.chan_add && !d.residual && d.out_act == DDPM_ACT_NONE && d.Cout >= 16 &&
+         d.Di <= 1 && d.Do <= 1 && d.dims != 3;
 }
 
 static bool smallco_supported(const ddpm_conv_desc &d, int &TH, int &RS, int &PS) {
@@ -329,6 +376,19 @@ int launch_conv_direct(const ddpm_conv_desc &d, hipStream_t s) {
       hipLaunchKernelGGL(conv_smallco_kernel<1>, grid, dim3(256), lds, s, d, TH, RS, PS);
     else
       hipLaunchKernelGGL(conv_smallco_kernel<2>, grid, dim3(256), lds, s, d, TH, RS, PS);
+    DDPM_CHECK_LAUNCH();
+    return 0;
+  }
+  if (smallci_supported(d)) {
+    ProfScope prof(s, "conv3x3_small_cin", 2.0 * d.B * HWo * d.Cout * cin * 9,
+                   4.0 * ((double)d.B * cin * HWo + (double)d.B * HWo * d.Cout + d.Cout * cin * 9));
+    dim3 grid((HWo + 255) / 256, d.B);
+    switch (d.C1) {
+      case 1: hipLaunchKernelGGL(conv_smallci_kernel<1>, grid, dim3(256), 0, s, d); break;
+      case 2: hipLaunchKernelGGL(conv_smallci_kernel<2>, grid, dim3(256), 0, s, d); break;
+      case 3: hipLaunchKernelGGL(conv_smallci_kernel<3>, grid, dim3(256), 0, s, d); break;
+      default: hipLaunchKernelGGL(conv_smallci_kernel<4>, grid, dim3(256), 0, s, d); break;
+    }
     DDPM_CHECK_LAUNCH();
     return 0;
   }
