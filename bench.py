@@ -17,7 +17,7 @@ The only collective is the per-step all_gather of the dense score tensor (RCCL).
 
 --config selects the other BASELINE configurations (same metric, their own `roofline`):
     cfg3  32x32x3 `small`                       (batch 256, k = 4)
-    cfg4  64x64x3 `big` attention-heavy UNet    (batch 8,   k = 2: 50 t-starts, 2 550 forwards per image)
+    cfg4  64x64x3 `big` attention-heavy UNet    (batch 16,  k = 2: 50 t-starts, 2 550 forwards per image)
     cfg5  128^3 volumes, README VQ-VAE (4 x stride 2, 256 ch, 2 048 codes) -> [128, 8, 8, 8] latents -> 3-D
           `small` UNet -> re-quantise + decode -> 2.5-D LPIPS  (batch 16, k = 4)
 
@@ -63,7 +63,7 @@ CONFIGS = {
     "cfg3": dict(model_type="small", channels=3, size=32, spatial=2, skip=4, batch=256, metric_tag="CIFAR10 32x32x3",
                  workload="BASELINE configs[2]: CIFAR10-shaped 32x32x3, small UNet, 100 PLMS timesteps, "
                           "inference_skip_factor=4 (25 t-starts, 1250 UNet forwards per image)"),
-    "cfg4": dict(model_type="big", channels=3, size=64, spatial=2, skip=2, batch=8, metric_tag="CelebA 64x64x3 big UNet",
+    "cfg4": dict(model_type="big", channels=3, size=64, spatial=2, skip=2, batch=16, metric_tag="CelebA 64x64x3 big UNet",
                  workload="BASELINE configs[3]: CelebA-shaped 64x64x3, big attention-heavy UNet (172.6M params, "
                           "attention over 4096/1024/256 tokens), 100 PLMS timesteps, inference_skip_factor=2 "
                           "(50 t-starts, 2550 UNet forwards per image)"),
