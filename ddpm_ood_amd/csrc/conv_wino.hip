@@ -155,7 +155,7 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   g.HWin = d.Hi * d.Wi;
   const int prow = g.up ? g.TR + 2 : 2 * g.TR + 2;  // pixel-tile rows per image of an item
   g.PW = d.Wi + 2;
-  g.PCH = g.TI * prow * g.PW;
+  g.PCH = (g.TI * prow * g.PW) | 1;  // odd: the two channel planes a patch-stage wave reads interleave over the LDS banks
   const int rows = prow < d.Hi ? prow : d.Hi;  // in-image rows an item reads, at most
   g.NRI = (rows * d.Wi + 63) / 64;
   if (g.TI * g.NRI > 6) return false;
@@ -218,7 +218,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   // is not free.
   // Patches (stage T): lane = tile `st`, wave = channel: 16 LDS reads of the 4x4 patch out of P (no masks: the
   // border is materialised), B^T d B, 16 LDS writes into the V image.
-  const int sc = wave, st = lane;
+  // LDS banks: a wave of stage T serves the two channels that share a V pair (e = 0 / 1 of [.. tile][e]) for half of the
+  // tiles -- lane = (tile, e) -- so that its 16 V writes are 64 consecutive floats, and the pair's two channel planes
+  // sit next to each other in P with an ODD plane size, so that its 16 patch reads (tile stride 2 floats) interleave
+  // even / odd banks.  With lane = tile, wave = channel both were two-way bank conflicts (PMC: 8-17 % of the CU's
+  // cycles with an LDS conflict stall).
+  const int sc = wave;
+  auto plane_of = [](int c) { return (((c >> 2) * 2 + (c & 1)) * 2) + ((c >> 1) & 1); };  // channel -> plane of P
+  const int tq = wave & 3, te = lane & 1;                 // stage T: V pair (kp, lhi') = (tq >> 1, tq & 1), e
+  const int st = (wave >> 2) * 32 + (lane >> 1);           //          tile
+  const int tch = 4 * (tq >> 1) + 2 * te + (tq & 1);       //          channel of the chunk this lane transforms
   const int row_lo = max(0, 2 * r0 - 1), row_hi = min(a.Ho, 2 * (r0 + g.TR) + 1);  // real rows an item reads
   const int npx = (row_hi - row_lo) * a.Wo;
   int pix[NR], pw[NR], tik[NR];
@@ -229,14 +238,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     const int row = row_lo + e / a.Wo, col = e % a.Wo;
     tik[k] = ti;
     pix[k] = valid ? (row * a.Wo + col) * 4 : (int)0x80000000;  // out of range: the buffer load returns 0
-    pw[k] = valid ? sc * g.PCH + (ti * (2 * g.TR + 2) + row - (2 * r0 - 1)) * g.PW + col + 1 : 2 * PB + lane;
+    pw[k] = valid ? plane_of(sc) * g.PCH + (ti * (2 * g.TR + 2) + row - (2 * r0 - 1)) * g.PW + col + 1 : 2 * PB + lane;
   }
-  int tbase;  // patch origin of tile st inside a channel tile of P
+  int tbase;  // patch origin of tile st inside the plane of channel tch
   {
     const int per = g.TR * g.TWc;
     const int ti = st / per, rem = st - ti * per;
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
-    tbase = sc * g.PCH + (ti * (2 * g.TR + 2) + 2 * tr) * g.PW + 2 * tc;
+    tbase = plane_of(tch) * g.PCH + (ti * (2 * g.TR + 2) + 2 * tr) * g.PW + 2 * tc;
   }
   const int bytes1 = a.B * a.C1 * (D3 ? g.CS : g.HW) * 4, bytes2 = a.B * a.C2 * g.HW * 4;
   const __amdgpu_buffer_rsrc_t rs_sc =
@@ -330,8 +339,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   };
   // ... then the columns of row i, written to the four positions (i, 0..3) of the V image
   auto col_commit = [&](int i, int nb) {
-    // channel sc = 4 kp + 2 e + lhi  ->  V [xi][kp][lhi][tile][e]
-    float *vl = smem + nb + kWUF + (((sc >> 2) * 2 + (sc & 1)) * kWT + st) * 2 + ((sc >> 1) & 1);
+    // channel tch = 4 kp + 2 e + lhi  ->  V [xi][kp][lhi][tile][e]: the wave's lanes write 64 consecutive floats
+    float *vl = smem + nb + kWUF + (tq * kWT + st) * 2 + te;
     vl[(i * 4 + 0) * kWC * kWT] = tt[i * 4 + 0] - tt[i * 4 + 2];
     vl[(i * 4 + 1) * kWC * kWT] = tt[i * 4 + 1] + tt[i * 4 + 2];
     vl[(i * 4 + 2) * kWC * kWT] = tt[i * 4 + 2] - tt[i * 4 + 1];
