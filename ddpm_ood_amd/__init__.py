@@ -8,6 +8,6 @@ surface (UNet, PNDM scheduler, perceptual loss, stage-1 passthrough, trainer, sc
 from .unet import DiffusionModelUNet  # noqa: F401
 from .scheduler import PNDMScheduler, DDPMScheduler  # noqa: F401
 from .perceptual import PerceptualLoss  # noqa: F401
-from .vqvae import PassthroughVQVAE  # noqa: F401
+from .vqvae import VQVAE, PassthroughVQVAE  # noqa: F401
 
-__all__ = ["DiffusionModelUNet", "PNDMScheduler", "DDPMScheduler", "PerceptualLoss", "PassthroughVQVAE"]
+__all__ = ["DiffusionModelUNet", "PNDMScheduler", "DDPMScheduler", "PerceptualLoss", "VQVAE", "PassthroughVQVAE"]
