@@ -312,3 +312,29 @@ def test_unet_forward_3d_shallow_depth(device, B, D, H):
     err = (yh - yr).abs().max().item()
     assert err <= 1e-4 * (1 + yr.abs().max().item()), err
     assert yr.abs().max() > 0.05
+
+
+def test_ragged_batches_first_n_drop_last_and_roi(device, tmp_path):
+    """Loader edge cases inside a trajectory: a ragged last batch (5 images, batch 2 -> 2 + 2 + 1; row order per batch,
+    per t_start, per image as reconstruct.py:128,192-204), --first_n truncation, --drop_last (the 1-image batch
+    disappears), --image_roi centre crop (40x40 source cropped to 32x32), and an empty id list."""
+    from parity_util import loader_for
+
+    args, rec, ref = _setup(tmp_path, 1, batch_size=2)
+    ids = "synthetic:blobs:n=5:seed=33"
+    h = hip_scores(args, rec, ids, "in")
+    o = oracle_scores(args, rec, ids, "in", model=ref)
+    assert len(h) == 10 and list(h["filename"])[:4] == ["blobs_33_000000", "blobs_33_000001"] * 2
+    assert_rows_close(h, o, 2e-4, "ragged")
+    h3 = hip_scores(args, rec, ids, "in", loader_kw=dict(first_n=3))
+    assert len(h3) == 6 and set(h3["filename"]) == {"blobs_33_000000", "blobs_33_000001", "blobs_33_000002"}
+    assert_rows_close(h3, oracle_scores(args, rec, ids, "in", model=ref, loader_kw=dict(first_n=3)), 2e-4, "first_n")
+    hd = hip_scores(args, rec, ids, "in", loader_kw=dict(drop_last=True))
+    assert len(hd) == 8 and "blobs_33_000004" not in set(hd["filename"])
+    args.image_roi = (32, 32)
+    big = "synthetic:blobs:n=2:size=40:seed=34"
+    assert next(iter(loader_for(args, big)))["image"].shape == (2, 1, 32, 32)
+    assert_rows_close(hip_scores(args, rec, big, "in"), oracle_scores(args, rec, big, "in", model=ref), 2e-4, "roi")
+    args.image_roi = None
+    assert rec.get_scores(loader_for(args, ids, first_n=None, rank=3, world=8), "in", 64) is not None  # shard of 1 image
+    assert rec.get_scores(loader_for(args, "synthetic:blobs:n=2:seed=1", rank=5, world=8), "in", 64) == []  # empty shard
