@@ -19,7 +19,7 @@ The only collective is the per-step all_gather of the dense score tensor (RCCL).
     cfg3  32x32x3 `small`                       (batch 256, k = 4)
     cfg4  64x64x3 `big` attention-heavy UNet    (batch 16,  k = 2: 50 t-starts, 2 550 forwards per image)
     cfg5  128^3 volumes, README VQ-VAE (4 x stride 2, 256 ch, 2 048 codes) -> [128, 8, 8, 8] latents -> 3-D
-          `small` UNet -> re-quantise + decode -> 2.5-D LPIPS  (batch 16, k = 4)
+          `small` UNet -> re-quantise + decode -> 2.5-D LPIPS  (batch 64, k = 4)
 
 One JSON line on rank 0.  `roofline` describes the kernel class with the most time in the sampled launches
 (first UNet step -- and, for the LDM, the decode -- of each t-start of the LAST timed step, hipEvent-bracketed on
@@ -67,7 +67,7 @@ CONFIGS = {
                  workload="BASELINE configs[3]: CelebA-shaped 64x64x3, big attention-heavy UNet (172.6M params, "
                           "attention over 4096/1024/256 tokens), 100 PLMS timesteps, inference_skip_factor=2 "
                           "(50 t-starts, 2550 UNet forwards per image)"),
-    "cfg5": dict(model_type="small", channels=1, size=128, spatial=3, skip=4, batch=16, vqvae=VQ_README,
+    "cfg5": dict(model_type="small", channels=1, size=128, spatial=3, skip=4, batch=64, vqvae=VQ_README,
                  metric_tag="Decathlon-shaped 128^3 LDM",
                  workload="BASELINE configs[4]: 128^3 volumes, README VQ-VAE (4 stride-2 levels, 256 ch, 2048 codes x "
                           "128) -> [128,8,8,8] latents, small 3-D UNet (47.5M params), 100 PLMS timesteps, "
