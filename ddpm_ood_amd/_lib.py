@@ -14,7 +14,7 @@ import torch
 
 _LIB = None
 LIB_NAME = "libddpm_ood_hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HipLibraryMissing(RuntimeError):
@@ -33,6 +33,7 @@ class ConvDesc(C.Structure):
         ("ksize", C.c_int), ("mode", C.c_int), ("act", C.c_int), ("force_direct", C.c_int),
         ("Di", C.c_int), ("Do", C.c_int), ("dims", C.c_int), ("reserved0", C.c_int),
         ("w_folded", C.c_void_p), ("out_act", C.c_int), ("reserved", C.c_int), ("w_wino", C.c_void_p),
+        ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t),
     ]
 
 
@@ -54,6 +55,7 @@ SIGNATURES = {
     "ddpm_abi_version": (C.c_int, []),
     "ddpm_last_error": (C.c_char_p, []),
     "ddpm_conv_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "ddpm_conv_scratch_floats": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "ddpm_packed_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ddpm_pack_conv_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p]),

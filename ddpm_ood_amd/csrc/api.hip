@@ -87,6 +87,11 @@ extern "C" int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream) {
   return conv_dispatch(*d, as_stream(stream));
 }
 
+extern "C" size_t ddpm_conv_scratch_floats(const ddpm_conv_desc *d) {
+  if (!d || d->dims == 3 || d->Di > 1 || d->Do > 1) return 0;
+  return conv_wino_scratch_floats(*d);
+}
+
 extern "C" size_t ddpm_packed_conv_weight_floats(int Cout, int Cin, int ksize) {
   return packed_conv_weight_floats(Cout, Cin, ksize);
 }

@@ -93,6 +93,11 @@ struct WinoGeom {
   int kd0, nkd;     // depth taps kd0 .. kd0 + nkd - 1 (a depth-1 volume only has its centre tap)
   int CS;           // channel stride of the input / output tensors in floats: D * HW
   int nkd_w;        // depth-tap slabs per cout tile in w_wino: 3 for a 3x3x3 weight, else 1
+  // small batches: fewer items than CUs, each a long serial chunk stream -> S workgroups share an item, each walks
+  // nchunks / S chunks and writes its partial output (after the output transform) into slab `split` of a scratch
+  // buffer; split_reduce_kernel adds the slabs in a fixed order together with bias / temb / residual.
+  int S;            // channel-stream splits per item (1: none)
+  long long pstride;  // floats between two partial-output slabs (0 when S == 1)
 };
 
 static int device_cus() {
@@ -167,7 +172,13 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   const int cus = device_cus();
   g.IPW = (int)((items + cus - 1) / cus);
   g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW);
-  g.grid = g.KT * ((g.NS + 7) / 8) * 8;
+  g.S = 1;
+  g.pstride = 0;
+  if (!is3d && !g.up && items * 2 <= cus) {  // launch would leave more than half of the chip idle
+    for (int sp = 4; sp >= 2; sp >>= 1)
+      if (items * sp <= cus && g.nchunks % sp == 0 && g.nchunks / sp >= 4) { g.S = sp; break; }
+  }
+  g.grid = g.KT * ((g.NS * g.S + 7) / 8) * 8;
   return true;
 }
 
@@ -200,14 +211,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   // Workgroup ids that differ by a multiple of 8 run on the same XCD (one L2): the cout tiles of one slot, which
   // read the same pixels, are placed there.
   const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3;
-  const int kt = wj % g.KT, slot = (wj / g.KT) * 8 + xcd;
-  if (slot >= g.NS) return;
+  const int kt = wj % g.KT, slot_s = (wj / g.KT) * 8 + xcd;
+  if (slot_s >= g.NS * g.S) return;
+  const int split = slot_s % g.S, slot = slot_s / g.S;  // the splits of an item sit on neighbouring XCD slots
   const int part = slot % g.parts, it0 = (slot / g.parts) * g.IPW;
   const int nitems = min(g.IPW, g.NIT - it0);
   const int r0 = part * g.TR;  // first tile row of the part
   const int n_first = it0 * g.TI, n_end = n_first + nitems * g.TI;
-  const int last = g.nchunks - 1;
-  const int ctot = nitems * g.nchunks;
+  const int ch_lo = split * (g.nchunks / g.S), last = ch_lo + g.nchunks / g.S - 1;  // this workgroup's chunk range
+  float *const outp = a.out + (size_t)split * g.pstride;  // S > 1: slab `split` of the scratch buffer
 
   // ---- staging roles ---------------------------------------------------------------------------------
   // Pixels (stage A): wave = channel `sc` of the chunk; its lanes walk the channel's in-image pixels of the item's
@@ -353,15 +365,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
       ++ch;
     } else if (n + g.TI < n_end) {
       n += g.TI;
-      ch = 0;
+      ch = ch_lo;
     }
   };
 
   // ---- prologue: zero borders; pixel tiles of stream chunks 0 and 1; U and V of chunk 0; registers for chunk 2
   for (int i = tid; i < 2 * PB + 64; i += 512) P[i] = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dma_u(i, 0, 0);
-  int nL = n_first, chL = 0;  // stream position of the pixel-load stage
+  for (int i = 0; i < 4; ++i) dma_u(i, ch_lo, 0);
+  int nL = n_first, chL = ch_lo;  // stream position of the pixel-load stage
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -403,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     const int cbuf = (c & 1) * BUF;
     const int nb = BUF - cbuf;
     const int pb_t = ((c + 1) & 1) * PB, pb_a = (c & 1) * PB;
-    const int ch_u = ch_cur < last ? ch_cur + 1 : 0;  // U depends on the chunk only, not on the image
+    const int ch_u = ch_cur < last ? ch_cur + 1 : ch_lo;  // U depends on the chunk only, not on the image
     f2 av[3], bv[3];  // operand ring: three pairs
     const int ua = (cbuf + ub + 8 * hf * 2 * 2 * 64 * 2) * 4, va = (cbuf + vb + 8 * hf * 2 * 2 * 64 * 2) * 4;  // bytes
     auto load_pair = [&](int slot, int p) {
@@ -457,8 +469,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   };
 
   for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
-    chunk(std::true_type{}, 0);
-    for (int ch = 1; ch <= last; ++ch) chunk(std::false_type{}, ch);
+    chunk(std::true_type{}, ch_lo);
+    for (int ch = ch_lo + 1; ch <= last; ++ch) chunk(std::false_type{}, ch);
     const int cbuf = ((c - 1) & 1) * BUF;  // the operand buffer the item's last chunk consumed
 
     // ---- end of an item: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  The transform is linear in M, so each wave
@@ -536,8 +548,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
         }
         if (n < g.NIMG) {
           const size_t o = obase + (size_t)((rr & 3) + 8 * (rr >> 2)) * cstr;
-          *reinterpret_cast<f2 *>(a.out + o) = f2{yy[0], yy[1]};
-          *reinterpret_cast<f2 *>(a.out + o + a.Wo) = f2{yy[2], yy[3]};
+          *reinterpret_cast<f2 *>(outp + o) = f2{yy[0], yy[1]};
+          *reinterpret_cast<f2 *>(outp + o + a.Wo) = f2{yy[2], yy[3]};
         }
       }
     }
@@ -1140,6 +1152,31 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ddpm_conv_desc
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
+// out = sum of the S partial slabs (fixed order 0, 1, ..) + bias + temb + residual: the epilogue of a split launch
+__global__ __launch_bounds__(256) void wino_split_reduce_kernel(const float *__restrict__ part, long long pstride, int S,
+                                                                const float *__restrict__ bias,
+                                                                const float *__restrict__ chan_add, int chan_stride,
+                                                                const float *__restrict__ residual,
+                                                                float *__restrict__ out, int Cout, int HW4,
+                                                                long long total4) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= total4) return;
+  const int c = (int)((i / HW4) % Cout), n = (int)(i / ((long long)HW4 * Cout));
+  v4f v = reinterpret_cast<const v4f *>(part)[i];
+  for (int sp = 1; sp < S; ++sp) v += reinterpret_cast<const v4f *>(part + sp * pstride)[i];
+  float add = bias ? bias[c] : 0.f;
+  if (chan_add) add += chan_add[(size_t)n * chan_stride + c];
+  v += add;
+  if (residual) v += reinterpret_cast<const v4f *>(residual)[i];
+  reinterpret_cast<v4f *>(out)[i] = v;
+}
+
+size_t conv_wino_scratch_floats(const ddpm_conv_desc &d) {
+  WinoGeom g;
+  if (!conv_wino_supported(d) || !wino_geom(d, g) || g.S == 1) return 0;
+  return (size_t)g.S * d.B * d.Cout * g.HW;
+}
+
 int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   WinoGeom g;
   if (!d.w_wino || !wino_geom(d, g)) {
@@ -1160,6 +1197,19 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  const size_t out_floats = (size_t)d.B * d.Cout * g.HW;
+  if (g.S > 1 && (!d.scratch || d.scratch_floats < g.S * out_floats)) {  // no scratch buffer: run unsplit
+    g.S = 1;
+    g.grid = g.KT * ((g.NS + 7) / 8) * 8;
+  }
+  ddpm_conv_desc dk = d;  // the descriptor the kernel sees
+  if (g.S > 1) {  // partial sums go to the scratch slabs, the addends to the reduce pass
+    g.pstride = (long long)out_floats;
+    dk.out = d.scratch;
+    dk.bias = nullptr;
+    dk.chan_add = nullptr;
+    dk.residual = nullptr;
+  }
   const int rounds = g.TI * g.NRI;
   kern_t kern = kerns[d.gscale ? 1 : 0][g.TI == 1 ? 1 : 0][rounds <= 4 ? 0 : rounds - 4];
   if (d.dims == 3) {  // only reached without GroupNorm prologue and with whole slices per item (wino_geom)
@@ -1178,7 +1228,7 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   static const bool four = getenv("DDPM_WINO_WAVES") && atoi(getenv("DDPM_WINO_WAVES")) == 4;
   int threads = 512;
   size_t lds_bytes = lds;
-  if (four && !g.up && d.dims != 3) {
+  if (four && !g.up && d.dims != 3 && g.S == 1) {
     static const kern_t kerns4[2][2][3] = {
         {{conv_wino4_kernel<false, 4, false>, conv_wino4_kernel<false, 5, false>, conv_wino4_kernel<false, 6, false>},
          {conv_wino4_kernel<false, 4, true>, conv_wino4_kernel<false, 5, true>, conv_wino4_kernel<false, 6, true>}},
@@ -1217,8 +1267,14 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
     kname = kshape;
   }
   ProfScope prof(s, kname, flops, bytes);
-  hipLaunchKernelGGL(kern, dim3(g.grid), dim3(threads), lds_bytes, s, d, g);
+  hipLaunchKernelGGL(kern, dim3(g.grid), dim3(threads), lds_bytes, s, dk, g);
   DDPM_CHECK_LAUNCH();
+  if (g.S > 1) {
+    const long long total4 = (long long)out_floats / 4;  // H, W even: HW % 4 == 0
+    hipLaunchKernelGGL(wino_split_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, d.scratch,
+                       g.pstride, g.S, d.bias, d.chan_add, d.chan_add_stride, d.residual, d.out, d.Cout, g.HW / 4, total4);
+    DDPM_CHECK_LAUNCH();
+  }
   return 0;
 }
 

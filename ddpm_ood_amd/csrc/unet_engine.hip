@@ -444,7 +444,7 @@ struct Runner {
 
   void conv(const ConvRef &c, const Act &in1, const Act *in2, const float *gsc, const float *gsh, int act, int mode,
             const float *chan_add, int chan_stride, const float *residual, float *out, int Ho, int Wo, int Do = 1) {
-    if (ws.dry || rc) return;
+    if (rc) return;
     ddpm_conv_desc d{};
     d.in1 = in1.p; d.C1 = in1.C;
     d.in2 = in2 ? in2->p : nullptr; d.C2 = in2 ? in2->C : 0;
@@ -471,6 +471,13 @@ struct Runner {
       // pointwise over a volume: the NCDHW tensor is an NCHW tensor of extent (D*H) x W
       d.Hi = in1.D * in1.H; d.Ho = Do * Ho;
     }
+    // small batches: scratch slabs for the Winograd kernel's channel-stream split (released with the enclosing block's
+    // temporaries; the dry run that sizes the workspace takes the same decisions)
+    if (const size_t need = (d.dims == 3 || in1.D > 1 || Do > 1) ? 0 : conv_wino_scratch_floats(d)) {
+      d.scratch = ws.get(need);
+      d.scratch_floats = need;
+    }
+    if (ws.dry) return;
     rc = conv_dispatch(d, s);
   }
 

@@ -114,6 +114,11 @@ def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NON
     d.w_folded = ptr(folded)
     d.w_wino = ptr(wino)
     d.out_act = out_act
+    need = lib.ddpm_conv_scratch_floats(C.byref(d))  # small batches: split-K partial slabs (0 otherwise)
+    if need:
+        scratch = torch.empty(need, dtype=torch.float32, device=x.device)
+        keep.append(scratch)
+        d.scratch, d.scratch_floats = ptr(scratch), need
     check(lib.ddpm_conv_f32(C.byref(d), stream_ptr()), "conv")
     return out[:, :, 0, 0] if was_linear else out
 

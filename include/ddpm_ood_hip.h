@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDPM_ABI_VERSION 2
+#define DDPM_ABI_VERSION 3
 
 #define DDPM_EINVAL (-1)      /* bad argument / unsupported shape      */
 #define DDPM_ENOPARAM (-2)    /* unknown or missing parameter name     */
@@ -104,9 +104,16 @@ typedef struct ddpm_conv_desc {
    * multiplies (4x fewer for UPSAMPLE2, where 9 of the 16 transform positions are non-zero on a nearest-x2
    * image); fp32 rounding differs from the direct form by ~1e-6 relative.                  */
   const float *w_wino;
+  /* Optional scratch (ddpm_conv_scratch_floats): a launch with fewer work items than CUs (small batches) splits the
+   * channel stream of each item over 2 or 4 workgroups, whose partial outputs go to slabs of this buffer and are added in
+   * a fixed order by a second pass.  NULL / too small: the convolution runs unsplit (same result up to fp32 rounding). */
+  float *scratch;
+  size_t scratch_floats;
 } ddpm_conv_desc;
 
 int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream);
+/* Floats of scratch this descriptor can use (0: none); device- and shape-dependent, constant for a given process.  */
+size_t ddpm_conv_scratch_floats(const ddpm_conv_desc *d);
 
 /* Number of floats of the packed form of a [Cout, Cin, k, k] weight (0 if unpackable). */
 size_t ddpm_packed_conv_weight_floats(int Cout, int Cin, int ksize);
