@@ -371,6 +371,29 @@ def test_training_forward_and_cli(tmp_path):
         assert getattr(a, k) == v["default"] or k in ("model_name", "output_dir"), k
 
 
+def test_bench_roofline_object_is_the_executed_mfma_fraction():
+    """`roofline.frac` must be EXECUTED MFMA work over the 157.3 TFLOP/s peak (never > 1); the
+    direct-conv-equivalent rate of a Winograd kernel lives in its own key; `traffic` is labelled as a builder-side pass."""
+    import bench
+
+    prof = {"conv3x3_wino_gn_silu": {"launches": 10, "ms": 3.0, "flops": 10 * 66.8e9, "bytes": 10 * 159e6},
+            "conv3x3_wino_up": {"launches": 2, "ms": 1.0, "flops": 2 * 154.6e9, "bytes": 1e9},
+            "attention": {"launches": 4, "ms": 0.1, "flops": 4 * 0.1e9, "bytes": 1e8},
+            "conv3d_wino": {"launches": 1, "ms": 2.0, "flops": 3.4e11, "bytes": 1e9},
+            "conv3d_k3": {"launches": 1, "ms": 1.0, "flops": 1e11, "bytes": 1e9},
+            "gn_scale_shift": {"launches": 27, "ms": 0.5, "flops": 1e9, "bytes": 2e9}}
+    r = bench.rooflines_of(prof)
+    assert set(r) == {"conv3x3_wino", "conv3x3_wino_up", "attention", "conv3d_wino", "conv3d_"}  # MFMA classes only
+    w = r["conv3x3_wino"]
+    alg = 10 * 66.8e9 / 3.0e-3 / 1e12
+    assert abs(w["algorithmic_equiv_tflops"] - alg) < 0.01 and abs(w["achieved"] - alg * 16 / 36) < 0.01
+    assert abs(w["frac"] - alg * 16 / 36 / 157.3) < 1e-3 and w["frac"] < 1 and w["bound"] == "mfma"
+    assert abs(r["conv3x3_wino_up"]["achieved"] - 2 * 154.6e9 / 1e-3 / 1e12 * 9 / 36) < 0.01
+    assert r["conv3d_wino"]["executed_over_algorithmic_flops"] == round(16 / 36, 4) and r["conv3d_"]["executed_over_algorithmic_flops"] == 1.0
+    assert w["traffic"] is None or "builder-side" in w["traffic_source"]
+    assert all(v["frac"] <= 1.0 for v in r.values())
+
+
 def test_product_code_never_imports_the_oracle():
     """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use it."""
     import re
