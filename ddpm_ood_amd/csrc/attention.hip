@@ -18,6 +18,11 @@
 // ds_reads are software-pipelined one k-step ahead of the MFMAs.
 // Head dim is fixed at 256 (num_head_channels = 256 in both reference configs,
 // /root/reference/src/trainers/base.py:73,84).
+#include <stdint.h>
+
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 namespace ddpm {
@@ -25,11 +30,54 @@ namespace ddpm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 constexpr int kDH = 256;   // head dim
 constexpr int kQB = 64;    // queries per workgroup
 constexpr int kKB = 64;    // keys per block
 constexpr int kLd = 65;    // padded leading dimension (V tile, score tile)
 constexpr int kPF = kDH * kKB / 256;  // prefetch floats per thread for one K or V block (64)
+
+// The two MFMA loops are issued by hand: operand reads as inline-asm ds_read2 with immediate offsets, a ring of
+// operand registers several MFMAs ahead, and counted lgkmcnt waits fused with the consuming MFMA.  Left to hipcc the
+// ring collapses to "read, wait, use" (an exposed LDS latency every 8 MFMAs) and the unrolled QK^T loop gets
+// branches; with one wave per SIMD nothing else covers those stalls.
+typedef float f2a __attribute__((ext_vector_type(2)));
+template <int O0, int O1>
+__device__ __forceinline__ f2a lds_read2st64(int addr) {  // floats at addr + 256 O0, addr + 256 O1 bytes
+  f2a v;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+  return v;
+}
+template <int O0, int O1>
+__device__ __forceinline__ f2a lds_read2(int addr) {  // floats at addr + 4 O0, addr + 4 O1 bytes
+  f2a v;
+  asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+  return v;
+}
+template <int WAIT>
+__device__ __forceinline__ void mfma_w(f32x16 &c, float a, float b) {
+  asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b), "n"(WAIT));
+}
+template <int WAIT>
+__device__ __forceinline__ void mfma_first_w(f32x16 &c, float a, float b) {  // C = 0
+  asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b), "n"(WAIT));
+}
+__device__ __forceinline__ void mfma_n(f32x16 &c, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_first_n(f32x16 &c, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+}
+// the hazard recogniser does not see inside inline asm: a VALU read of an MFMA result needs the 16 passes to retire
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
 
 // VEC: N % 4 == 0 -> 16-byte global loads of K / V / Q rows
 template <bool VEC>
@@ -110,6 +158,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
       for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
 
   const int qi = wave >> 1, kj = wave & 1;
+  const int lds0 = static_cast<int>(reinterpret_cast<uintptr_t>(smem));  // LDS byte address of the dynamic block
 
   for (int j0 = 0; j0 < N; j0 += kKB) {
     __syncthreads();            // previous PV finished with KVl / Sl; orders the Q tile and m / l init
@@ -119,33 +168,35 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 
     // ---- S quadrant: rows = queries qi*32.., cols = keys kj*32.. ----------------------------
     {
-      // two independent accumulator chains (even / odd k-steps) and an operand ring four k-steps deep: with one
-      // wave per SIMD nothing else hides the LDS latency of the operand reads
+      // two independent accumulator chains (even / odd k-steps); pair p = k-steps 2 p, 2 p + 1 = one ds_read2st64
+      // per operand; ring of four pairs (8 MFMAs ahead of their use)
       f32x16 sacc, sacc2;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = sacc2[r] = 0.f;
-      const float *qa = Ql + lhi * kQB + qi * 32 + l31;
-      const float *kb = KVl + lhi * kKB + kj * 32 + l31;
-      constexpr int kRing = 4;
-      float av[kRing], bv[kRing];
-#pragma unroll
-      for (int p = 0; p < kRing; ++p) {
-        av[p] = qa[2 * p * kQB];
-        bv[p] = kb[2 * p * kKB];
-      }
-#pragma unroll 16
-      for (int d = 0; d < kDH; d += 2) {
-        const int cur = (d >> 1) % kRing;
-        const float a_ = av[cur], b_ = bv[cur];
-        if (d + 2 * kRing < kDH) {
-          av[cur] = qa[(d + 2 * kRing) * kQB];
-          bv[cur] = kb[(d + 2 * kRing) * kKB];
+      const int qa = lds0 + (lhi * kQB + qi * 32 + l31) * 4;
+      const int kb = lds0 + (kDH * kQB + lhi * kKB + kj * 32 + l31) * 4;
+      f2a av[4], bv[4];
+      auto ld = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        av[p & 3] = lds_read2st64<4 * p, 4 * p + 2>(qa);
+        bv[p & 3] = lds_read2st64<4 * p, 4 * p + 2>(kb);
+      };
+      auto step = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int w = p <= 60 ? 6 : 2 * (63 - p);  // operand reads issued after this pair's
+        if constexpr (p == 0) {
+          mfma_first_w<w>(sacc, av[p & 3][0], bv[p & 3][0]);
+          mfma_first_n(sacc2, av[p & 3][1], bv[p & 3][1]);
+        } else {
+          mfma_w<w>(sacc, av[p & 3][0], bv[p & 3][0]);
+          mfma_n(sacc2, av[p & 3][1], bv[p & 3][1]);
         }
-        if ((d >> 1) & 1)
-          sacc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, sacc2, 0, 0, 0);
-        else
-          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, sacc, 0, 0, 0);
-      }
+        if constexpr (p + 4 < 64) ld(std::integral_constant<int, p + 4>{});
+      };
+      ld(std::integral_constant<int, 0>{});
+      ld(std::integral_constant<int, 1>{});
+      ld(std::integral_constant<int, 2>{});
+      ld(std::integral_constant<int, 3>{});
+      static_for<64>(step);
+      mfma_drain();
       const bool colok = (j0 + kj * 32 + l31) < N;
       // scores are kept in the log2 domain: s * scale * log2(e), so that the softmax below is one v_exp_f32 per key
 #pragma unroll
@@ -197,30 +248,38 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[a][b][r] *= al;
     }
-    const float *va = KVl + ((wave * 2) * 32 + l31) * kLd + lhi;
-    const float *pb = Sl + l31 * kLd + lhi;
-    constexpr int kR = 3;  // operand ring: three k-steps (12 MFMAs) ahead
-    float a0[kR], a1[kR], b0[kR], b1[kR];
-#pragma unroll
-    for (int p = 0; p < kR; ++p) {
-      a0[p] = va[2 * p]; a1[p] = va[32 * kLd + 2 * p]; b0[p] = pb[2 * p]; b1[p] = pb[32 * kLd + 2 * p];
-    }
-#pragma unroll
-    for (int jj = 0; jj < kKB; jj += 2) {
-      const int cur = (jj >> 1) % kR;
-      const float x0 = a0[cur], x1 = a1[cur], y0 = b0[cur], y1 = b1[cur];
-      if (jj + 2 * kR < kKB) {
-        a0[cur] = va[jj + 2 * kR];
-        a1[cur] = va[32 * kLd + jj + 2 * kR];
-        b0[cur] = pb[jj + 2 * kR];
-        b1[cur] = pb[32 * kLd + jj + 2 * kR];
-      }
-      o[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, o[0][0], 0, 0, 0);
-      o[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, o[0][1], 0, 0, 0);
-      o[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, o[1][0], 0, 0, 0);
-      o[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, o[1][1], 0, 0, 0);
-    }
+    // group g = k-steps 2 g, 2 g + 1 (keys 4 g + lhi, 4 g + 2 + lhi): one ds_read2 per operand row block, 8 MFMAs;
+    // ring of three groups
+    const int va0 = lds0 + (kDH * kQB + ((wave * 2) * 32 + l31) * kLd + lhi) * 4, va1 = va0 + 32 * kLd * 4;
+    const int pb0 = lds0 + (kDH * kQB + kDH * kLd + l31 * kLd + lhi) * 4, pb1 = pb0 + 32 * kLd * 4;
+    f2a a0[3], a1[3], b0[3], b1[3];
+    auto ldg = [&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      a0[g % 3] = lds_read2<4 * g, 4 * g + 2>(va0);
+      b0[g % 3] = lds_read2<4 * g, 4 * g + 2>(pb0);
+      a1[g % 3] = lds_read2<4 * g, 4 * g + 2>(va1);
+      b1[g % 3] = lds_read2<4 * g, 4 * g + 2>(pb1);
+    };
+    auto pv = [&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int w = g <= 13 ? 8 : 4 * (15 - g);
+      constexpr int c = g % 3;
+      mfma_w<w + 2>(o[0][0], a0[c][0], b0[c][0]);
+      mfma_w<w>(o[0][1], a0[c][0], b1[c][0]);
+      mfma_n(o[1][0], a1[c][0], b0[c][0]);
+      mfma_n(o[1][1], a1[c][0], b1[c][0]);
+      mfma_n(o[0][0], a0[c][1], b0[c][1]);
+      mfma_n(o[0][1], a0[c][1], b1[c][1]);
+      mfma_n(o[1][0], a1[c][1], b0[c][1]);
+      mfma_n(o[1][1], a1[c][1], b1[c][1]);
+      if constexpr (g + 3 < 16) ldg(std::integral_constant<int, g + 3>{});
+    };
+    ldg(std::integral_constant<int, 0>{});
+    ldg(std::integral_constant<int, 1>{});
+    ldg(std::integral_constant<int, 2>{});
+    static_for<16>(pv);
   }
+  mfma_drain();
 
   // ---- normalise, add residual, store [B, C, N] ------------------------------------------------
 #pragma unroll

@@ -1,11 +1,29 @@
 #!/usr/bin/env bash
 # Build libddpm_ood_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+# One object per source (compiled in parallel, JOBS at a time), then one link; extra arguments go to every compile.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="${here}/../libddpm_ood_hip.so"
+obj="${here}/../../build/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-"${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value \
-  "${here}/api.hip" "${here}/conv_mfma.hip" "${here}/conv_wino.hip" "${here}/conv1x1_dma.hip" "${here}/conv_direct.hip" "${here}/conv3d_edge.hip" "${here}/groupnorm.hip" \
-  "${here}/attention.hip" "${here}/elementwise.hip" "${here}/lpips.hip" "${here}/vq.hip" "${here}/unet_engine.hip" \
-  -o "${out}" "$@"
+JOBS="${JOBS:-4}"
+mkdir -p "${obj}"
+srcs=(api conv_mfma conv_wino conv1x1_dma conv_direct conv3d_edge linear_skinny groupnorm attention elementwise lpips vq
+      unet_engine)
+common=(--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value)
+# per-file flags: declare an array flags_<source> to add options to one translation unit, e.g.
+#   flags_attention=(-mllvm -amdgpu-mfma-vgpr-form=1)   # measured: 80 vs 86 TFLOP/s at n = 4096, not used
+pids=()
+for f in "${srcs[@]}"; do
+  extra_name="flags_${f}[@]"
+  extra=()
+  if declare -p "flags_${f}" >/dev/null 2>&1; then extra=("${!extra_name}"); fi
+  "${HIPCC}" "${common[@]}" "${extra[@]}" "$@" -c "${here}/${f}.hip" -o "${obj}/${f}.o" &
+  pids+=($!)
+  if (( ${#pids[@]} >= JOBS )); then wait "${pids[0]}"; pids=("${pids[@]:1}"); fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+objs=()
+for f in "${srcs[@]}"; do objs+=("${obj}/${f}.o"); done
+"${HIPCC}" --offload-arch=gfx950 -fPIC -shared "${objs[@]}" -o "${out}"
 echo "built ${out}"

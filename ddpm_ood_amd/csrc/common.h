@@ -84,6 +84,8 @@ size_t packed_conv_weight_floats(int Cout, int Cin, int ksize);
 size_t folded_upsample_weight_floats(int Cout, int Cin);
 bool conv1x1_dma_supported(const ddpm_conv_desc &d);
 int launch_conv1x1_dma(const ddpm_conv_desc &d, hipStream_t s);
+bool linear_skinny_supported(const ddpm_conv_desc &d);
+int launch_linear_skinny(const ddpm_conv_desc &d, hipStream_t s);
 bool conv_wino_supported(const ddpm_conv_desc &d);
 int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s);
 size_t wino_weight_floats(int Cout, int Cin);

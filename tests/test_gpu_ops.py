@@ -144,8 +144,11 @@ def test_conv_direct_shapes(device, shape):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,act", [(16, 128, 512, 0), (256, 512, 512, 1), (3, 512, 2432, 1),
-                                            (130, 512, 256, 0), (4, 32, 96, 1)])
+                                            (130, 512, 256, 0), (4, 32, 96, 1), (1, 128, 512, 1), (1024, 64, 32, 0),
+                                            (1025, 512, 128, 1), (33, 160, 64, 1)])
 def test_linear(device, B, Cin, Cout, act):
+    """<= 1024 rows: linear_skinny_kernel (32 x 32 tiles, K split over four waves, ragged last row tile); more rows or
+    channel counts it cannot split: the tiled MFMA kernel."""
     from ddpm_ood_amd import ops
 
     g = torch.Generator().manual_seed(3)
