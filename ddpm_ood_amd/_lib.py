@@ -14,7 +14,7 @@ import torch
 
 _LIB = None
 LIB_NAME = "libddpm_ood_hip.so"
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HipLibraryMissing(RuntimeError):
@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
         ("ksize", C.c_int), ("mode", C.c_int), ("act", C.c_int), ("force_direct", C.c_int),
         ("Di", C.c_int), ("Do", C.c_int), ("dims", C.c_int), ("reserved0", C.c_int),
         ("w_folded", C.c_void_p), ("out_act", C.c_int), ("reserved", C.c_int), ("w_wino", C.c_void_p),
-        ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t),
+        ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t), ("w_wino44", C.c_void_p),
     ]
 
 
@@ -68,6 +68,8 @@ SIGNATURES = {
     "ddpm_convtr3d_k4s2_cout1_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "ddpm_wino_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_wino_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_wino44_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "ddpm_pack_wino44_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_pack_wino3d_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_folded_upsample_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_fold_upsample_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

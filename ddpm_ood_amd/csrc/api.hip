@@ -148,6 +148,13 @@ extern "C" int ddpm_pack_wino_weight_f32(const float *w_raw, float *w_wino, int 
   return launch_pack_wino_weight(w_raw, w_wino, Cout, Cin, as_stream(stream));
 }
 
+extern "C" size_t ddpm_wino44_weight_floats(int Cout, int Cin) { return wino44_weight_floats(Cout, Cin); }
+
+extern "C" int ddpm_pack_wino44_weight_f32(const float *w_raw, float *w_wino44, int Cout, int Cin, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(w_raw && w_wino44, "wino44 pack: NULL pointer");
+  return launch_pack_wino44_weight(w_raw, w_wino44, Cout, Cin, as_stream(stream));
+}
+
 extern "C" int ddpm_pack_wino3d_weight_f32(const float *w_raw, float *w_wino, int Cout, int Cin, ddpm_stream_t stream) {
   DDPM_CHECK_ARG(w_raw && w_wino, "wino3d pack: NULL pointer");
   return launch_pack_wino_weight(w_raw, w_wino, Cout, Cin, as_stream(stream), 3);

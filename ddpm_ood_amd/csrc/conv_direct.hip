@@ -434,6 +434,7 @@ int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
   }
   DDPM_CHECK_ARG(d.Di <= 1 && d.Do <= 1, "conv: Di / Do > 1 needs dims == 3");
   if (linear_skinny_supported(d)) return launch_linear_skinny(d, s);  // Linear over <= 1024 rows: latency, not FLOPs
+  if (conv_wino44_supported(d)) return launch_conv_wino44(d, s);
   if (conv_wino_supported(d)) return launch_conv_wino(d, s);
   if (conv1x1_dma_supported(d) && conv_mfma_supported(d)) return launch_conv1x1_dma(d, s);
   if (conv_mfma_supported(d)) return launch_conv_mfma(d, s);

@@ -32,6 +32,8 @@ struct ParamSlot {
   size_t folded_base = 0;
   bool has_wino = false;        // 3x3 stride-1 conv: also keep the Winograd-domain form
   size_t wino_base = 0;
+  bool has_wino44 = false;      // ... and the F(4x4, 3x3) form
+  size_t wino44_base = 0;
   int Cout = 0, Cin = 0, ksize = 1, cout_offset = 0, Cout_total = 0;
   int dims = 2;                 // 3: [Cout, Cin, k, k, k] packed as k slabs of 2-D taps (one per depth tap)
   bool optional = false;
@@ -39,8 +41,8 @@ struct ParamSlot {
 };
 
 struct ConvRef {  // a conv-like op: weight (raw + packed) and bias locations in the blob
-  size_t w_raw = 0, w_packed = 0, bias = 0, w_folded = 0, w_wino = 0;
-  bool has_packed = false, has_folded = false, has_wino = false;
+  size_t w_raw = 0, w_packed = 0, bias = 0, w_folded = 0, w_wino = 0, w_wino44 = 0;
+  bool has_packed = false, has_folded = false, has_wino = false, has_wino44 = false;
   int Cin = 0, Cout = 0, ksize = 1;
   int dims = 2;
 };
@@ -214,6 +216,12 @@ static ResRef build_res(ddpm_unet *u, const std::string &prefix, int Cin, int Co
       ParamSlot &ps = u->params[u->index[prefix + nm[i]]];
       ps.has_wino = true;
       ps.wino_base = cr[i]->w_wino;
+      if (const size_t n44 = wino44_weight_floats(cr[i]->Cout, cr[i]->Cin)) {
+        cr[i]->has_wino44 = true;
+        cr[i]->w_wino44 = u->alloc(n44);
+        ps.has_wino44 = true;
+        ps.wino44_base = cr[i]->w_wino44;
+      }
     }
   }
   r.has_skip = Cin != Cout;
@@ -400,6 +408,10 @@ extern "C" int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *
     rc = launch_pack_wino_weight(src, h->blob + p.wino_base, p.Cout, p.Cin, s);
     if (rc) return rc;
   }
+  if (p.has_wino44) {
+    rc = launch_pack_wino44_weight(src, h->blob + p.wino44_base, p.Cout, p.Cin, s);
+    if (rc) return rc;
+  }
   if (p.has_folded) {
     rc = launch_fold_upsample_weight(src, h->blob + p.folded_base, p.Cout, p.Cin, s);
     if (rc) return rc;
@@ -461,6 +473,7 @@ struct Runner {
     if (mode == DDPM_CONV_UPSAMPLE2 && c.has_folded) d.w_folded = P(c.w_folded);
     if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino && c.dims == 2)
       d.w_wino = P(c.w_wino);
+    if (mode == DDPM_CONV_NORMAL && c.has_wino44 && c.dims == 2) d.w_wino44 = P(c.w_wino44);
     if (c.dims == 3 && c.ksize == 3) {
       // F.conv3d: ONE launch walks the (depth tap, channel group) chunks (w_packed = three depth slabs); a
       // volume of depth 1 (input depth <= 2^(levels-1)) only has its centre tap

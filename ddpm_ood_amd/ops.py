@@ -34,6 +34,20 @@ def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor | None:
     return out
 
 
+def pack_wino44_weight(weight: torch.Tensor) -> torch.Tensor | None:
+    """torch [Cout, Cin, 3, 3] -> F(4x4, 3x3) Winograd-domain weights (6 x 6 positions) in the MFMA layout."""
+    lib = _lib.load()
+    w = require_device_f32(weight, "weight")
+    if w.ndim != 4 or tuple(w.shape[2:]) != (3, 3):
+        return None
+    n = lib.ddpm_wino44_weight_floats(w.shape[0], w.shape[1])
+    if n == 0:
+        return None
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib.ddpm_pack_wino44_weight_f32(ptr(w), ptr(out), w.shape[0], w.shape[1], stream_ptr()), "pack_wino44_weight")
+    return out
+
+
 def pack_wino_weight(weight: torch.Tensor) -> torch.Tensor | None:
     """torch [Cout, Cin, 3, 3] -> Winograd-domain weights U = G g G^T in the MFMA layout (None if unsupported)."""
     lib = _lib.load()
@@ -62,7 +76,7 @@ def fold_upsample_weight(weight: torch.Tensor) -> torch.Tensor | None:
 
 def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NONE, mode=CONV_NORMAL,
          chan_add=None, chan_add_offset=0, residual=None, packed=None, force_direct=False, folded=None,
-         wino=None, out_act=ACT_NONE):
+         wino=None, out_act=ACT_NONE, wino44=None):
     """Fused conv / linear.  x: [B, C1, H, W]; x2: optional second source of a virtual concat."""
     lib = _lib.load()
     x = require_device_f32(x, "x")
@@ -113,6 +127,7 @@ def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NON
     d.ksize, d.mode, d.act, d.force_direct = k, mode, act, int(force_direct)
     d.w_folded = ptr(folded)
     d.w_wino = ptr(wino)
+    d.w_wino44 = ptr(wino44)
     d.out_act = out_act
     need = lib.ddpm_conv_scratch_floats(C.byref(d))  # small batches: split-K partial slabs (0 otherwise)
     if need:

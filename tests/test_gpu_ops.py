@@ -479,6 +479,57 @@ def test_conv_winograd(device, case):
         assert (y - y_direct).abs().max().item() < 4e-5 * (1 + ref.abs().max().item())
 
 
+WINO44_CASES = [
+    # B, C1, C2, Cout, H, gn, chan_add, residual
+    (2, 64, 0, 64, 32, False, False, False),      # plain: 2 parts per image, one cout tile
+    (3, 128, 0, 128, 32, True, True, True),
+    (2, 256, 128, 128, 32, True, True, False),    # virtual concat
+    (5, 256, 0, 256, 16, True, False, True),      # two images per item, ragged last item
+    (19, 128, 128, 64, 8, True, True, True),      # eight images per item, ragged
+    (1, 64, 0, 64, 64, True, False, False),       # W = 64: two tile rows per item, 8 parts
+    (300, 128, 0, 128, 16, True, True, True),     # 2 x 150 items: several items per persistent workgroup
+    (70, 64, 64, 128, 32, True, True, True),      # 2 x 2 x 70 = 280 items
+]
+
+
+@pytest.mark.parametrize("case", WINO44_CASES)
+def test_conv_winograd_f4x4(device, case, monkeypatch):
+    """3x3 stride-1 conv as Winograd F(4x4, 3x3) (conv_wino44.hip) vs F.conv2d.  The 6x6 transforms (constants up to 8,
+    weights down to 1/24) cost about 10x the direct kernel's rounding error: tolerance 2e-4 * (1 + max|ref|) on
+    single values, 1e-5 on the rms (the trajectory-level effect on Z-scores is 5e-6)."""
+    monkeypatch.setenv("DDPM_CONV_WINO44", "2")  # also for launches smaller than the chip (read once per process)
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, Cout, H, gn, chan, res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    Cin = C1 + C2
+    x = torch.randn(B, C1, H, H, generator=g)
+    x2 = torch.randn(B, C2, H, H, generator=g) * 1.5 + 0.3 if C2 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    gamma = torch.randn(Cin, generator=g) * 0.2 + 1
+    beta = torch.randn(Cin, generator=g) * 0.2
+    chan_add = torch.randn(B, Cout + 64, generator=g) if chan else None
+    residual = torch.randn(B, Cout, H, H, generator=g) if res else None
+    ref = _ref_conv(x, x2, w, b, (gamma, beta, 32, 1e-6) if gn else None, gn, 0,
+                    chan_add[:, 32:32 + Cout] if chan else None, residual)
+    d = lambda t: None if t is None else t.to(device)
+    gs = gh = None
+    if gn:
+        gs, gh = ops.gn_scale_shift(d(x), d(gamma), d(beta), 32, 1e-6, x2=d(x2))
+    w44 = ops.pack_wino44_weight(d(w))
+    assert w44 is not None and w44.numel() == 36 * Cout * Cin
+    kw = dict(x2=d(x2), gscale=gs, gshift=gh, act=int(gn), chan_add=d(chan_add), chan_add_offset=32, residual=d(residual))
+    y = ops.conv(d(x), d(w), d(b), wino44=w44, **kw)
+    y_f2 = ops.conv(d(x), d(w), d(b), wino=ops.pack_wino_weight(d(w)), **kw)
+    torch.cuda.synchronize()
+    assert not torch.equal(y, y_f2)  # the F(4x4) kernel really ran
+    err = (y.cpu() - ref)
+    assert err.abs().max().item() < 2e-4 * (1 + ref.abs().max().item()), err.abs().max().item()
+    assert err.pow(2).mean().sqrt().item() < 1e-5 * (1 + ref.pow(2).mean().sqrt().item())
+    assert torch.equal(y, ops.conv(d(x), d(w), d(b), wino44=w44, **kw))  # no dependence on leftover LDS state
+
+
 WINO_STREAM_CASES = [
     # B, C1, C2, Cout, H: more work items than the chip has CUs, so every persistent workgroup streams several
     # items back to back (the B <= 5 cases above run one item per workgroup)
