@@ -146,6 +146,7 @@ def cpu_baseline():
 # MFMA kernel classes by profiler-key prefix -> (description, executed / algorithmic MFMA FLOPs).
 # Longest prefix wins.  The library counts `flops` as the ALGORITHMIC (direct-form) work of the op.
 MFMA_KERNELS = [
+    ("conv3x3_wino44", "conv_wino44_kernel: 3x3 conv as Winograd F(4x4,3x3) (36 of 144 multiplies), persistent, GN+SiLU prologue, fp32 MFMA", 36.0 / 144.0),
     ("conv3x3_wino_up", "conv_wino_up_kernel: nearest-x2 + 3x3 conv in the Winograd domain (9 of 16 positions), fp32 MFMA", 9.0 / 36.0),
     ("conv3x3_wino", "conv_wino_kernel: 3x3 conv as Winograd F(2x2,3x3), persistent, GN+SiLU prologue, fp32 MFMA", 16.0 / 36.0),
     ("conv3x3_mfma_up_folded", "conv_mfma_kernel<4>: nearest-x2 + 3x3 conv folded into four 2x2-tap convs, fp32 MFMA", 16.0 / 36.0),

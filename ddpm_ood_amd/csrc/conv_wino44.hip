@@ -17,8 +17,9 @@
 //
 // Persistent workgroups and the staging pipeline follow conv_wino.hip: pixel loads three chunks ahead (two register sets,
 // a load has more than a whole chunk to land), activation two ahead into a zero-bordered pixel tile, patch transform one
-// ahead, the U tile by LDS-DMA one ahead.  The 6x6 transform of a (tile, channel) pair is split over three lanes by output
-// row pair -- rows (0, 5), (1, 2), (3, 4) share their inputs -- so that six of the eight waves carry 48 VALU ops each.
+// ahead, the U tile by LDS-DMA (buffer form) one ahead.  The 6x6 transform of a (tile, channel) pair is split over three
+// lanes by output row pair -- rows (0, 5), (1, 2), (3, 4) share their inputs; lane = (tile of 16, channel of 4) over a pixel
+// tile padded so that the 64 patch reads of a wave hit 64 banks.
 // At the end of an item the 36 positions of every (cout, tile) meet through LDS (four passes of four accumulator
 // registers; the last operand buffer + one extra slab) and each lane finishes one cout x one 4x4 tile: float4 rows.
 #include <stdint.h>
@@ -40,8 +41,8 @@ constexpr int kT = 32;               // tiles per item
 constexpr int kK = 64;               // output channels per item
 constexpr int kC = 4;                // input channels per chunk
 constexpr int kX = 36;               // transform positions
-constexpr int kUF = kX * kC * kK;    // U floats per chunk and cout tile (9216): [xi][lhi][cout 64][e], channel = 2 e + lhi
-constexpr int kVF = kX * kC * kT;    // V floats per chunk (4608):              [xi][lhi][tile 32][e]
+constexpr int kUF = kX * kC * kK;    // U floats per chunk and cout tile (9216): [xi][cout 64][lhi][e], channel = 2 e + lhi
+constexpr int kVF = kX * kC * kT;    // V floats per chunk (4608):              [xi][tile 32][lhi][e]
 constexpr int kBUF = kUF + kVF;      // one operand buffer (13824 floats = 3 exchange slabs)
 constexpr int kXS = kX * 2 * 64;     // exchange slab: [xi][cout block][lane] of one accumulator register (4608)
 constexpr int kNDMA = kUF / 256;     // 1 KB LDS-DMA transfers per U tile (36)
@@ -72,6 +73,11 @@ template <int N>
 __device__ __forceinline__ void mfma_v_first_wait(f32x16 &c, float a, float b) {  // C = 0
   asm volatile("s_setprio 1\n\ts_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0\n\ts_setprio 0"
                : "=v"(c) : "v"(a), "v"(b), "n"(N));
+}
+// two floats 16 bytes apart through the scalar cache (lgkmcnt, not vmcnt); the pointer must be wave-uniform
+__device__ __forceinline__ void sload2(const float *p, float &x0, float &x1) {
+  asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(x0), "=&s"(x1) : "s"(p) : "memory");
 }
 __device__ __forceinline__ f2 lds_b64(int byte_addr, int imm) {
   f2 v;
@@ -107,7 +113,8 @@ struct W44Geom {
   int parts;        // items per image along the rows
   int Cin, nchunks, HW;
   int prow;         // pixel-tile rows per image of an item: 4 TR + 2
-  int PW, PCH;      // pixel tile in LDS: padded row length (W + 2), floats per channel plane
+  int PW, IS, PCH;  // pixel tile in LDS: row length (>= W + 2), image stride (>= prow PW), floats per channel plane; padded so
+                    // that the 16 tiles x 4 channels a patch-stage wave reads land on 64 different banks
   int UI;           // staging units of 64 pixels per image of an item; a wave pair stages units hv, hv + 2, ...
   int NR;           // staging rounds per wave: ceil(TI * UI / 2), at most 5
   int KT, NIT, IPW, NS, grid;  // as conv_wino.hip: cout tiles, items per (cout tile, part), items per workgroup, slots
@@ -155,13 +162,29 @@ static bool w44_geom(const ddpm_conv_desc &d, W44Geom &g) {
   g.nchunks = Cin / kC;
   g.HW = d.Ho * d.Wo;
   g.prow = 4 * g.TR + 2;
-  g.PW = d.Wi + 2;
-  g.PCH = (g.TI * g.prow * g.PW) | 1;
+  // bank of a patch element = (ch PCH + ti IS + 4 tr PW + 4 tc + const) % 64 for the wave's 16 tiles x 4 channels:
+  // 4 tc covers 4 TWc banks, so the next tile row must start 4 TWc banks further (PW = TWc mod 16), the next image
+  // 4 TWc THr further, and the channel planes fill the residues mod 4 (PCH = 1 mod 4).  Without room: plain W + 2.
+  auto layout = [&](bool pad) {
+    g.PW = d.Wi + 2;
+    if (pad && g.TWc < 16) g.PW += ((g.TWc - g.PW) % 16 + 16) % 16;
+    g.IS = g.prow * g.PW;
+    if (pad && g.TI > 1 && per_img < 16) g.IS += ((4 * per_img - g.IS) % 64 + 64) % 64;
+    g.PCH = g.TI * g.IS;
+    g.PCH += ((1 - g.PCH) % 4 + 4) % 4;
+    return ((size_t)2 * kBUF + kXS + 2 * kC * g.PCH + 64) * sizeof(float) <= 160 * 1024;
+  };
+  if (!layout(true) && !layout(false)) return false;
   const int rows = g.prow < d.Hi ? g.prow : d.Hi;
   g.UI = (rows * d.Wi + 63) / 64;
   g.NR = (g.TI * g.UI + 1) / 2;
-  if (g.NR > 5) return false;
-  if (((size_t)2 * kBUF + kXS + 2 * kC * g.PCH + 64) * sizeof(float) > 160 * 1024) return false;
+  if (g.NR > (g.TI == 1 ? 5 : 4)) return false;
+  // closed-form round addressing of the kernel: rounds of one image are 128 pixels = whole rows apart; all rounds but the
+  // last of a one-image item are fully inside the item's rows even for the parts at the image's top / bottom (one row less);
+  // images of several units are exactly four, images of one unit are whole
+  if (128 % d.Wi) return false;
+  if (g.TI == 1 && (rows - 1) * d.Wi < 128 * (g.NR - 1)) return false;
+  if (g.TI > 1 && !((g.UI == 4 && rows * d.Wi == 256) || (g.UI == 1 && rows * d.Wi <= 64 && g.TI <= 8))) return false;
   g.KT = d.Cout / kK;
   g.NIT = (d.B + g.TI - 1) / g.TI;
   const long items = (long)g.KT * g.parts * g.NIT;
@@ -186,10 +209,13 @@ bool conv_wino44_supported(const ddpm_conv_desc &d) {
   return enabled && d.w_wino44 != nullptr && !d.force_direct && w44_geom(d, g);
 }
 
-template <bool AFFINE, int NR, bool ONEIMG>
+// GD = consecutive staging rounds of a wave that belong to one image (they share a GroupNorm scale / shift pair):
+// NR for one-image items, UI / 2 when an image is an even number of 64-pixel units, else 1
+template <bool AFFINE, int NR, int GD, bool RES>
 __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_desc a, const W44Geom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NGS = ONEIMG ? 1 : NR;              // GroupNorm scale / shift pairs per chunk: one per round's image
+  constexpr bool ONEIMG = GD >= NR;
+  constexpr int NGS = (NR + GD - 1) / GD;           // GroupNorm scale / shift pairs per chunk
   constexpr int NVM = NR + (AFFINE ? 2 * NGS : 0);  // vector-memory loads of one pixel stage
   float *const P = smem + 2 * kBUF + kXS;           // pixel tiles [2][4 channels][PCH] (zero borders) + 64 dump floats
   const int PB = kC * g.PCH;
@@ -219,31 +245,57 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
   const int sc = wave & 3, hv = wave >> 2;
   const int row_lo = max(0, 4 * r0 - 1), row_hi = min(a.Ho, 4 * (r0 + g.TR) + 1);
   const int npx = (row_hi - row_lo) * a.Wo;
-  int pix[NR], pw[NR], tik[NR];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    const int u = hv + 2 * k, ti = u / g.UI, e = (u - ti * g.UI) * 64 + lane;
-    const bool valid = ti < g.TI && e < npx;
-    const int row = row_lo + e / a.Wo, col = e % a.Wo;
-    tik[k] = min(ti, g.TI - 1);
-    pix[k] = valid ? (row * a.Wo + col) * 4 : (int)0x80000000;  // out of range: the buffer load returns 0
-    pw[k] = valid ? sc * g.PCH + (ti * g.prow + row - (4 * r0 - 1)) * g.PW + col + 1 : 2 * PB + lane;
+  // Round k of this wave = unit u = hv + 2 k.  Its pixel offset and pixel-tile slot follow from round 0 in closed form
+  // (five address pairs per lane were the first thing hipcc spilled):
+  //   one image (GD >= NR):  64 u pixels further: + 512 k bytes, + k (128 / W) rows of the tile; only the last round can hold
+  //                          pixels past the item's rows, it keeps its own (masked) pair
+  //   GD == 2 (four units per image):  k & 1 as above, k >> 1 = next image;     GD == 1 (one unit per image): image u
+  int pix0, pw0, pixL = 0, pwL = 0;
+  {
+    const int e = hv * 64 + lane;
+    const bool valid = e < npx;
+    pix0 = valid ? ((row_lo + e / a.Wo) * a.Wo + e % a.Wo) * 4 : (int)0x80000000;  // out of range: the load returns 0
+    pw0 = valid ? sc * g.PCH + (hv >= g.UI ? hv * g.IS : 0) + (row_lo + e / a.Wo - (4 * r0 - 1)) * g.PW + e % a.Wo + 1
+                : 2 * PB + lane;
+    if (GD == 1 && hv >= g.UI) {  // one unit per image: wave half hv starts at image hv
+      pix0 = lane < npx ? ((row_lo + lane / a.Wo) * a.Wo + lane % a.Wo) * 4 : (int)0x80000000;
+      pw0 = lane < npx ? sc * g.PCH + hv * g.IS + (row_lo + lane / a.Wo - (4 * r0 - 1)) * g.PW + lane % a.Wo + 1
+                       : 2 * PB + lane;
+    }
+    if (ONEIMG) {
+      const int eL = e + 128 * (NR - 1);
+      const bool vL = eL < npx;
+      pixL = vL ? ((row_lo + eL / a.Wo) * a.Wo + eL % a.Wo) * 4 : (int)0x80000000;
+      pwL = vL ? sc * g.PCH + (row_lo + eL / a.Wo - (4 * r0 - 1)) * g.PW + eL % a.Wo + 1 : 2 * PB + lane;
+    }
   }
-  // patches: waves 0..5; (tile, channel) pair = 64 (wave / 3) + lane, output-row pair = wave % 3: rows (0, 5), (1, 2), (3, 4)
-  const bool tact = wave < 6;
-  const int trio = wave / 3, third = wave - 3 * trio;
-  const int st = lane & 31, tch = 2 * trio + (lane >> 5);
+  const int prs = (128 / a.Wo) * g.PW;  // pixel-tile floats between a lane's pixels of consecutive rounds of one image
+  auto pix_of = [&](int k) { return ONEIMG ? (k == NR - 1 ? pixL : pix0 + 512 * k) : GD == 2 ? pix0 + 512 * (k & 1) : pix0; };
+  auto pw_of = [&](int k) {
+    return ONEIMG ? (k == NR - 1 ? pwL : pw0 + k * prs) : GD == 2 ? pw0 + (k & 1) * prs + (k >> 1) * g.IS : pw0 + 2 * k * g.IS;
+  };
+  auto img_of = [&](int k) { return ONEIMG ? 0 : GD == 2 ? (k >> 1) : min(hv + 2 * k, g.TI - 1); };  // wave-uniform
+  // patches: lane = (tile of 16, channel of 4), wave = (tile half, output-row pair): rows (0, 5), (1, 2), (3, 4).  Waves 6 and
+  // 7 repeat the work of waves 0 and 1 (same values to the same addresses): they share SIMDs 2 and 3 with waves 2 and 3, so
+  // the copies are off the critical path and the stage needs no wave-dependent branch.
+  const int trio = (wave / 3) & 1, third = wave % 3;
+  const int st = trio * 16 + (lane & 15), tch = lane >> 4;
   int tbase;
   {
     const int per = g.TR * g.TWc;
     const int ti = st / per, rem = st - ti * per;
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
-    tbase = tch * g.PCH + (ti * g.prow + 4 * tr) * g.PW + 4 * tc;
+    tbase = tch * g.PCH + ti * g.IS + 4 * tr * g.PW + 4 * tc;
   }
-  const int vofs = kUF + ((tch & 1) * kT + st) * 2 + (tch >> 1);  // + xi * 2 * kT * 2
-  const int rowA = third == 0 ? 0 : third == 1 ? 1 : 3, rowB = third == 0 ? 5 : third == 1 ? 2 : 4;  // output rows
-  const int rB0 = third == 0 ? 5 : 3, rB1 = third == 0 ? 3 : 1;                                        // input rows
-  const float c1 = third == 0 ? -5.f : third == 1 ? -4.f : -1.f, beta = third == 1 ? 1.f : 2.f;
+  int vofs = kUF + st * 4 + (tch & 1) * 2 + (tch >> 1);  // + xi * 128
+  // Output rows (rowA, rowB) of B^T d, each a combination of three input rows -- the same instruction stream for all:
+  //   rows (0, 5): A = d4 - 5 d2 + 4 d0,  B = d5 - 5 d3 + 4 d1
+  //   rows (1, 2): p = d4 - 2 d2 - 2 d2,  q = d3 - 2 d1 - 2 d1,  A = p + q, B = p - q     (the halves are exact)
+  //   rows (3, 4): p = d4 - d2/2 - d2/2,  q = d3 - d1/2 - d1/2,  A = p + 2 q, B = p - 2 q
+  const bool t0 = third == 0;
+  const int rowA = t0 ? 0 : third == 1 ? 1 : 3, rowB = t0 ? 5 : third == 1 ? 2 : 4;
+  const int rA2 = t0 ? 0 : 2, rB0 = t0 ? 5 : 3, rB1 = t0 ? 3 : 1;
+  const float c1 = t0 ? -5.f : third == 1 ? -2.f : -0.5f, c2 = t0 ? 4.f : c1, bm = t0 ? 0.f : third == 1 ? 1.f : 2.f;
 
   const int bytes1 = a.B * a.C1 * g.HW * 4, bytes2 = a.B * a.C2 * g.HW * 4;
   const __amdgpu_buffer_rsrc_t rs_sc =
@@ -253,9 +305,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
   int vzero;  // keeps the uniform scale / shift loads on the vector memory path (see conv_wino.hip)
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
 
-  // ---- MFMA operands: A = U [xi][lhi][cout][e], B = V [xi][lhi][tile][e]; one ds_read_b64 = both k-steps of a position
-  const int ub = (lhi * kK + cb * 32 + l31) * 2 + 9 * pg * kC * kK;
-  const int vb = kUF + (lhi * kT + l31) * 2 + 9 * pg * kC * kT;
+  // ---- MFMA operands: A = U [xi][cout][lhi][e], B = V [xi][tile][lhi][e]; one ds_read_b64 = both k-steps of a position
+  // (a wave's 64 lanes read 512 consecutive bytes; the patch stage writes 64 consecutive floats)
+  const int ub = (cb * 32 + l31) * 4 + lhi * 2 + 9 * pg * kC * kK;
+  const int vb = kUF + l31 * 4 + lhi * 2 + 9 * pg * kC * kT;
 
   f32x16 acc[8], acc8;  // positions 0..7 of the group in AGPRs, position 8 in arch VGPRs
   float praw[2][NR], gs[2][NGS], gh[2][NGS], drow[6], wA[6], wB[6];
@@ -268,44 +321,49 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
       const_cast<float *>(a.w_wino44), 0, (int)((size_t)kX * a.Cout * g.Cin * 4), 0x00020000);
   const int ulane = lane * 16;
   const int ukt = kt * g.nchunks;
-  auto dma_u = [&](int j, int ch, int nb) {
-    const int i = wave + 8 * j;
-    if (i < kNDMA) {
-      const int soff = ((ukt + ch) * kUF + i * 256) * 4;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (__attribute__((address_space(3))) void *)(smem + nb + i * 256), 16,
-                                               ulane, soff, 0, 0);
-    }
+  int u_soff = 0;  // byte offset of this wave's first transfer of the chunk being fetched
+  auto dma_u = [&](int j, int nb) {
+    if (j < 4 || wave < 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_u, (__attribute__((address_space(3))) void *)(smem + nb + (wave + 8 * j) * 256), 16, ulane,
+          u_soff + j * 8192, 0, 0);
   };
-  auto load_px = [&](auto setc, int k, int n, int ch) {
+  // pixel stage addressing of the chunk being loaded: resource / channel offsets once per chunk, image offset per round
+  __amdgpu_buffer_rsrc_t l_rs;
+  int l_cx, l_cgl, l_cg;
+  auto load_setup = [&](int ch) {
+    l_cg = ch * kC + sc;
+    const bool first = l_cg < a.C1;
+    l_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2,
+                                             0x00020000);
+    l_cx = first ? a.C1 : a.C2;
+    l_cgl = first ? l_cg : l_cg - a.C1;
+  };
+  auto load_px = [&](auto setc, int k, int n) {
     constexpr int S = decltype(setc)::value;
-    const int cg = ch * kC + sc, ni = min(n + tik[k], a.B - 1);
-    const bool first = cg < a.C1;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
-    const int soff = first ? (ni * a.C1 + cg) * g.HW * 4 : (ni * a.C2 + cg - a.C1) * g.HW * 4;
-    praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pix[k], soff, 0));
-    if (AFFINE && (!ONEIMG || k == 0)) {
-      const int goff = (ni * g.Cin + cg) * 4;
-      gs[S][ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
-      gh[S][ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
+    const int ni = min(n + img_of(k), a.B - 1);
+    const int soff = (ni * l_cx + l_cgl) * g.HW * 4;
+    praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(l_rs, pix_of(k), soff, 0));
+    if (AFFINE && k % GD == 0) {
+      const int goff = (ni * g.Cin + l_cg) * 4;
+      gs[S][k / GD] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
+      gh[S][k / GD] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
     }
   };
   auto activate_px = [&](auto setc, int k, int pb) {
     constexpr int S = decltype(setc)::value;
     const float x = praw[S][k];
     if (AFFINE) {
-      const float sa = gs[S][ONEIMG ? 0 : k], sb = gh[S][ONEIMG ? 0 : k];
+      const float sa = gs[S][k / GD], sb = gh[S][k / GD];
       const float v = __builtin_fmaf(x, sa, sb);
       const float t = __builtin_fmaf(x, -1.44269504088896341f * sa, -1.44269504088896341f * sb);
-      P[pb + pw[k]] = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+      P[pb + pw_of(k)] = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
     } else {
       const float sv = silu_fast(x);
-      P[pb + pw[k]] = silu ? sv : x;
+      P[pb + pw_of(k)] = silu ? sv : x;
     }
   };
-  // patch transform of chunk c + 1, nine steps: V rows (rowA, rowB) = B^T d B restricted to this lane's output rows.
-  //   rows (0, 5): A = d4 - 5 d2 + 4 d0, B = d5 - 5 d3 + 4 d1;   rows (1, 2): p = d4 - 4 d2, q = d3 - 4 d1, p +- q;
-  //   rows (3, 4): p = d4 - d2, q = d3 - d1, p +- 2 q
+  // patch transform of chunk c + 1 in nine steps (one per even MFMA step)
   auto rd = [&](int r, int pb) {
     const float *p = P + pb + tbase + r * g.PW;
 #pragma unroll
@@ -314,12 +372,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
   auto commit = [&](const float (&w)[6], int row, int nb) {
     float t[6];
     bt6(w, t);
-    float *vl = smem + nb + vofs + row * 6 * (2 * kT * 2);
+    float *vl = smem + nb + vofs + row * 6 * (kC * kT);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) vl[j * (2 * kT * 2)] = t[j];
+    for (int j = 0; j < 6; ++j) vl[j * (kC * kT)] = t[j];
   };
   auto tstep = [&](int s, int pb, int nb) {
-    if (!tact) return;
     if (s == 0) {
       rd(4, pb);
     } else if (s == 1) {
@@ -329,12 +386,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
     } else if (s == 2) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) wA[j] = __builtin_fmaf(c1, drow[j], wA[j]);
-      if (third == 0) rd(0, pb);
+      rd(rA2, pb);
     } else if (s == 3) {
-      if (third == 0) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) wA[j] = __builtin_fmaf(4.f, drow[j], wA[j]);
-      }
+      for (int j = 0; j < 6; ++j) wA[j] = __builtin_fmaf(c2, drow[j], wA[j]);
       rd(rB0, pb);
     } else if (s == 4) {
 #pragma unroll
@@ -343,18 +398,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
     } else if (s == 5) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) wB[j] = __builtin_fmaf(c1, drow[j], wB[j]);
-      if (third == 0) rd(1, pb);
+      rd(1, pb);
     } else if (s == 6) {
-      if (third == 0) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) wB[j] = __builtin_fmaf(4.f, drow[j], wB[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          const float p = wA[j], q = wB[j];
-          wA[j] = __builtin_fmaf(beta, q, p);
-          wB[j] = __builtin_fmaf(-beta, q, p);
-        }
+      for (int j = 0; j < 6; ++j) {
+        const float q = __builtin_fmaf(c2, drow[j], wB[j]), p = wA[j];
+        wA[j] = __builtin_fmaf(bm, q, p);
+        wB[j] = t0 ? q : __builtin_fmaf(-bm, q, p);
       }
     } else if (s == 7) {
       commit(wA, rowA, nb);
@@ -375,32 +425,36 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
 
   // ---- prologue: zero borders; pixel tiles of stream chunks 0 and 1; U and V of chunk 0; registers for chunk 2
   for (int i = tid; i < 2 * PB + 64; i += 512) P[i] = 0.f;
+  u_soff = (ukt * kUF + wave * 256) * 4;
 #pragma unroll
-  for (int j = 0; j < 5; ++j) dma_u(j, 0, 0);
+  for (int j = 0; j < 5; ++j) dma_u(j, 0);
   int nL = n_first, chL = 0;  // stream position of the pixel-load stage
   __syncthreads();
+  load_setup(chL);
 #pragma unroll
-  for (int k = 0; k < NR; ++k) load_px(S0{}, k, nL, chL);
+  for (int k = 0; k < NR; ++k) load_px(S0{}, k, nL);
 #pragma unroll
   for (int k = 0; k < NR; ++k) activate_px(S0{}, k, 0);
   advance(nL, chL);
+  load_setup(chL);
 #pragma unroll
-  for (int k = 0; k < NR; ++k) load_px(S1{}, k, nL, chL);
+  for (int k = 0; k < NR; ++k) load_px(S1{}, k, nL);
 #pragma unroll
   for (int k = 0; k < NR; ++k) activate_px(S1{}, k, PB);
   advance(nL, chL);
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 9; ++s) tstep(s, 0, 0);
+  load_setup(chL);
 #pragma unroll
-  for (int k = 0; k < NR; ++k) load_px(S0{}, k, nL, chL);
+  for (int k = 0; k < NR; ++k) load_px(S0{}, k, nL);
   advance(nL, chL);
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NVM) : "memory");
   __builtin_amdgcn_sched_barrier(0);
 
   // One chunk = 9 positions x 2 k-steps = 18 MFMA steps per wave.  Staging slices pinned to the steps:
-  //   step 0..4   LDS-DMA of the U tile of chunk c + 1          step 5..9    loads of pixel round s - 5 of chunk c + 3
-  //   step 10..14 activation of round s - 10 of chunk c + 2 (loaded during chunk c - 1)
+  //   step 0..2   LDS-DMA of the U tile of chunk c + 1          step 3..7    loads of pixel round s - 3 of chunk c + 3
+  //   step 13..17 activation of the rounds of chunk c + 2 (loaded during chunk c - 1: 1.5 chunks to land)
   //   step 0, 2, .., 16  patch-transform step s / 2 of chunk c + 1
   // The chunk closes with vmcnt(NVM): the DMAs (issued first) have landed, this chunk's pixel loads stay in flight.
   auto chunk = [&](auto parc, auto firstc, int ch_cur) {
@@ -409,6 +463,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
     constexpr int cbuf = PAR * kBUF, nb = (1 - PAR) * kBUF;
     const int pb_t = (1 - PAR) * PB, pb_a = PAR * PB;
     const int ch_u = ch_cur < last ? ch_cur + 1 : 0;
+    // the staging addresses are derived from a handful of per-lane bases inside the chunk; hidden from the optimiser here,
+    // else it hoists every base + offset combination out of the loop (twenty-odd registers) and spills them -- and a
+    // spill reload is a scratch load: vmcnt(0), all pixel loads drained
+    asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL), "+v"(tbase), "+v"(vofs));
+    u_soff = ((ukt + ch_u) * kUF + wave * 256) * 4;
+    load_setup(chL);
     f2 av[3], bv[3];
     const int ua = (cbuf + ub) * 4, va = (cbuf + vb) * 4;  // bytes
     auto load_pair = [&](int slot, int x) {
@@ -416,9 +476,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
       bv[slot] = lds_b64(va, x * (kC * kT * 4));
     };
     auto slice = [&](int s) {
-      if (s < 5) dma_u(s, ch_u, nb);
-      if (s >= 5 && s < 5 + NR) load_px(std::integral_constant<int, 1 - PAR>{}, s - 5, nL, chL);
-      if (s >= 10 && s < 10 + NR) activate_px(std::integral_constant<int, PAR>{}, s - 10, pb_a);
+      if (s < 3) {
+        dma_u(2 * s, nb);
+        if (s < 2) dma_u(2 * s + 1, nb);
+      }
+      if (s >= 3 && s < 3 + NR) load_px(std::integral_constant<int, 1 - PAR>{}, s - 3, nL);
+      if (s >= 18 - NR) activate_px(std::integral_constant<int, PAR>{}, s - (18 - NR), pb_a);
       if ((s & 1) == 0) tstep(s >> 1, pb_t, nb);
     };
     load_pair(0, 0);
@@ -471,52 +534,104 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
     const int n = n_cur + ti, ncl = min(n, a.B - 1);
     float *const XS = smem + kBUF;
+    // Stores and loads share vmcnt and it retires in order: a load issued after a store cannot be waited for without
+    // waiting for the store's acknowledgement.  So everything the epilogue reads is requested BEFORE the stores it could
+    // queue behind: the per-channel addends of all four passes up front (scalar loads when the item is one image: they
+    // count in lgkmcnt), the residual rows of pass q + 1 in the middle of pass q.
+    float addv[4];
+    if (ONEIMG) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co0 = kt * kK + cb * 32 + 8 * q + pg;  // lanes 0..31; lanes 32..63 hold co0 + 4
+        float b0 = 0.f, b1 = 0.f, t0v = 0.f, t1v = 0.f;
+        if (a.bias) sload2(a.bias + co0, b0, b1);
+        if (a.chan_add) sload2(a.chan_add + (size_t)min(n_cur, a.B - 1) * a.chan_add_stride + co0, t0v, t1v);
+        addv[q] = elhi ? b1 + t1v : b0 + t0v;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = kt * kK + cb * 32 + 8 * q + 4 * elhi + pg;
+        addv[q] = (a.bias ? a.bias[co] : 0.f) + (a.chan_add ? a.chan_add[(size_t)ncl * a.chan_add_stride + co] : 0.f);
+      }
+    }
+    const size_t obase0 = ((size_t)ncl * a.Cout + kt * kK + cb * 32 + 4 * elhi + pg) * g.HW + (size_t)(4 * (r0 + tr)) * a.Wo +
+                          4 * tc;  // pass q: + 8 q HW
+    v4f res[4];
+    auto load_res = [&](int q) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        res[k] = *reinterpret_cast<const v4f *>(a.residual + obase0 + (size_t)(8 * q) * g.HW + (size_t)k * a.Wo);
+    };
+    if (RES) load_res(0);
     auto pass = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      const int co = kt * kK + cb * 32 + 8 * q + 4 * elhi + pg;
-      const size_t obase = ((size_t)ncl * a.Cout + co) * g.HW + (size_t)(4 * (r0 + tr)) * a.Wo + 4 * tc;
-      // addends first: their latency passes under the exchange
-      const float addv = (a.bias ? a.bias[co] : 0.f) +
-                         (a.chan_add ? a.chan_add[(size_t)ncl * a.chan_add_stride + co] : 0.f);
+      const size_t obase = obase0 + (size_t)(8 * q) * g.HW;
       {
         float *xw = XS + ((9 * pg) * 2 + cb) * 64 + elane;
 #pragma unroll
         for (int x = 0; x < 9; ++x) {
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            xw[rr * kXS + x * 128] = x == 8 ? acc8[4 * q + rr] : acc[x & 7][4 * q + rr];
-          }
+          for (int rr = 0; rr < 4; ++rr) xw[rr * kXS + x * 128] = x == 8 ? acc8[4 * q + rr] : acc[x & 7][4 * q + rr];
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      {
-        const float *xr = XS + pg * kXS + cb * 64 + elane;  // + xi * 128
-        float w[4][6];
+      const float *xr = XS + pg * kXS + cb * 64 + elane;  // + xi * 128
+      const float ad = addv[q];
+      // output rows (0, 1), then (2, 3): twelve live column sums instead of twenty-four, M is read twice
+      auto half = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        float w[2][6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {  // columns of M through A^T
-          float y[4];
-          at4(xr[(0 * 6 + j) * 128], xr[(1 * 6 + j) * 128], xr[(2 * 6 + j) * 128], xr[(3 * 6 + j) * 128],
-              xr[(4 * 6 + j) * 128], xr[(5 * 6 + j) * 128], y);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) w[k][j] = y[k];
+        for (int j = 0; j < 6; ++j) {  // columns of M through two rows of A^T
+          const float m1 = xr[(1 * 6 + j) * 128], m2 = xr[(2 * 6 + j) * 128], m3 = xr[(3 * 6 + j) * 128],
+                      m4 = xr[(4 * 6 + j) * 128];
+          if (h == 0) {
+            const float m0 = xr[(0 * 6 + j) * 128];
+            w[0][j] = (m0 + (m1 + m2)) + (m3 + m4);
+            w[1][j] = __builtin_fmaf(2.f, m3 - m4, m1 - m2);
+          } else {
+            const float m5 = xr[(5 * 6 + j) * 128];
+            w[0][j] = __builtin_fmaf(4.f, m3 + m4, m1 + m2);
+            w[1][j] = __builtin_fmaf(8.f, m3 - m4, m1 - m2) + m5;
+          }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int kk = 0; kk < 2; ++kk) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int k = 2 * h + kk;
           float y[4];
-          at4(w[k][0], w[k][1], w[k][2], w[k][3], w[k][4], w[k][5], y);
-          const v4f res = a.residual ? *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)k * a.Wo) : v4f{0.f, 0.f, 0.f, 0.f};
-          if (n < a.B)
-            *reinterpret_cast<v4f *>(a.out + obase + (size_t)k * a.Wo) =
-                v4f{y[0] + addv + res[0], y[1] + addv + res[1], y[2] + addv + res[2], y[3] + addv + res[3]};
+          at4(w[kk][0], w[kk][1], w[kk][2], w[kk][3], w[kk][4], w[kk][5], y);
+          v4f o = v4f{y[0] + ad, y[1] + ad, y[2] + ad, y[3] + ad};
+          if (RES) o += res[k];
+          if (n < a.B) *reinterpret_cast<v4f *>(a.out + obase + (size_t)k * a.Wo) = o;
         }
+      };
+      half(std::integral_constant<int, 0>{});
+      v4f r01[2];  // next pass's rows 0, 1 go to fresh registers (this pass's rows 2, 3 are still needed)
+      if (RES && q < 3) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          r01[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * g.HW + (size_t)k * a.Wo);
+      }
+      half(std::integral_constant<int, 1>{});
+      if (RES && q < 3) {
+        res[0] = r01[0];
+        res[1] = r01[1];
+#pragma unroll
+        for (int k = 2; k < 4; ++k)
+          res[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * g.HW + (size_t)k * a.Wo);
       }
       // nobody may overwrite the slabs (next pass, or the next chunk's staging) while a neighbour still reads them
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
+#ifndef W44_SKIP_EPILOGUE  // timing experiment only
     pass(std::integral_constant<int, 0>{});
     pass(std::integral_constant<int, 1>{});
     pass(std::integral_constant<int, 2>{});
     pass(std::integral_constant<int, 3>{});
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
@@ -530,19 +645,20 @@ int launch_conv_wino44(const ddpm_conv_desc &d, hipStream_t s) {
   }
   const size_t lds = ((size_t)2 * kBUF + kXS + 2 * kC * g.PCH + 64) * sizeof(float);
   typedef void (*kern_t)(const ddpm_conv_desc, const W44Geom);
-  static const kern_t kerns[2][2][2] = {
-      {{conv_wino44_kernel<false, 4, false>, conv_wino44_kernel<false, 5, false>},
-       {conv_wino44_kernel<false, 4, true>, conv_wino44_kernel<false, 5, true>}},
-      {{conv_wino44_kernel<true, 4, false>, conv_wino44_kernel<true, 5, false>},
-       {conv_wino44_kernel<true, 4, true>, conv_wino44_kernel<true, 5, true>}}};
+  // shapes: one-image items (five rounds), two rounds per image (16x16 images), one round per image
+#define W44_K(A, N, G) {conv_wino44_kernel<A, N, G, false>, conv_wino44_kernel<A, N, G, true>}
+  static const kern_t kerns[2][3][2] = {{W44_K(false, 5, 5), W44_K(false, 4, 2), W44_K(false, 4, 1)},
+                                        {W44_K(true, 5, 5), W44_K(true, 4, 2), W44_K(true, 4, 1)}};
+#undef W44_K
   static bool attr_done = false;
   if (!attr_done) {
-    for (int i = 0; i < 8; ++i)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[i / 4][i / 2 % 2][i % 2]),
+    for (int i = 0; i < 12; ++i)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[i / 6][i / 2 % 3][i % 2]),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  kern_t kern = kerns[d.gscale ? 1 : 0][g.TI == 1 ? 1 : 0][g.NR <= 4 ? 0 : 1];
+  const int shape = g.TI == 1 ? 0 : g.UI == 4 ? 1 : 2;
+  kern_t kern = kerns[d.gscale ? 1 : 0][shape][d.residual ? 1 : 0];
   const double M = (double)d.B * g.HW;
   // algorithmic work = the direct convolution's: 2 M Cout Cin 9; 36 / 144 of it is executed
   const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9;
@@ -560,7 +676,7 @@ int launch_conv_wino44(const ddpm_conv_desc &d, hipStream_t s) {
 }
 
 // ---- weights: torch [Cout][Cin][3][3] -> U = G g G^T (6 x 6), packed as the LDS image the kernel's MFMAs read:
-//   [cout tile 64][chunk 4][xi 36][lhi 2][cout 64][e 2],  channel of the chunk = 2 e + lhi
+//   [cout tile 64][chunk 4][xi 36][cout 64][lhi 2][e 2],  channel of the chunk = 2 e + lhi
 // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], evaluated in double
 __global__ void wino44_pack_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin) {
   const int64_t total = (int64_t)Cout * Cin;
@@ -575,7 +691,7 @@ __global__ void wino44_pack_kernel(const float *__restrict__ src, float *__restr
       for (int j = 0; j < 3; ++j) t[r][j] = G[r][0] * w[0 * 3 + j] + G[r][1] * w[1 * 3 + j] + G[r][2] * w[2 * 3 + j];
     const int tile = o / kK, k64 = o % kK, ch = ci / kC, cl = ci % kC;
     const int lhi = cl & 1, e = cl >> 1;
-    float *d = dst + ((size_t)tile * nchunks + ch) * kUF + (lhi * kK + k64) * 2 + e;
+    float *d = dst + ((size_t)tile * nchunks + ch) * kUF + k64 * 4 + lhi * 2 + e;
     for (int r = 0; r < 6; ++r)
       for (int c = 0; c < 6; ++c)
         d[(r * 6 + c) * (kC * kK)] = (float)(t[r][0] * G[c][0] + t[r][1] * G[c][1] + t[r][2] * G[c][2]);
