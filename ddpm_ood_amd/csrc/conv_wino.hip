@@ -278,42 +278,56 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   // no registers, no ds_write pass, and -- unlike loads into registers -- nothing in the loop has to wait for it
   // before the chunk's closing barrier, so the (in-order) vmcnt waits never drag the slow pixel loads along.
   // U is stored [cout tile][depth tap][channel chunk][32 KB]: the chunk stream of an item reads it front to back
-  const float *usrc = a.w_wino + (D3 ? ((size_t)kt * g.nkd_w + g.kd0) * g.nch_c : (size_t)kt * g.nchunks) * kWUF +
-                      wave * 4 * 256;  // + lane * 4: per-lane offset
 
   f32x16 acc[8];
 
   // ---- staging registers, and the slices of staging work the chunk loop places between its MFMAs -----------
   float praw[NR], gs[NGS], gh[NGS], dreg[16], tt[16];
-  // quarter i of this wave's share of the U tile of chunk ch -> operand buffer at float offset nb
+  // quarter i of this wave's share of the U tile of chunk ch -> operand buffer at float offset nb.  Buffer form of the
+  // LDS-DMA: resource + scalar offset + one loop-invariant lane offset (with global_load_lds hipcc keeps 64-bit per-lane
+  // addresses, spills them, and every reload -- a scratch load -- waits vmcnt(0))
+  const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(a.w_wino), 0, (int)((size_t)16 * a.Cout * g.Cin * g.nkd_w * 4), 0x00020000);
+  const int ulane = lane * 16;
+  const int ubase_f = (D3 ? (kt * g.nkd_w + g.kd0) * g.nch_c : kt * g.nchunks) * kWUF + wave * 4 * 256;  // floats
   auto dma_u = [&](int i, int ch, int nb) {
-    const float *ubase = usrc + (size_t)ch * kWUF + i * 256;  // uniform
-    __builtin_amdgcn_global_load_lds(ubase + lane * 4, smem + nb + (wave * 4 + i) * 256, 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (__attribute__((address_space(3))) void *)(smem + nb + (wave * 4 + i) * 256),
+                                             16, ulane, (ubase_f + ch * kWUF + i * 256) * 4, 0, 0);
   };
-  // stage L: round k of chunk ch of the item at image n -> registers
-  auto load_px = [&](int k, int n, int ch) {
-    int cg = ch * kWC + sc, ni = min(n + tik[k], g.NIMG - 1);
-    int dsl = 0;  // input slice inside the volume (3-D)
-    bool dok = true;
-    if (D3) {  // wave-uniform: stream chunk -> (depth tap, channel chunk), image -> (batch item, slice)
+  // stage L: round k of chunk ch of the item at image n -> registers.  What depends on the chunk only (source tensor,
+  // channel, depth tap) is set up once per chunk, the image offset per round
+  __amdgpu_buffer_rsrc_t l_rs;
+  int l_cx, l_cgl, l_cg, l_kd;
+  auto load_setup = [&](int ch) {
+    l_cg = ch * kWC + sc;
+    l_kd = 0;
+    if (D3) {  // stream chunk -> (depth tap, channel chunk)
       const int kdi = ch / g.nch_c;
-      cg = (ch - kdi * g.nch_c) * kWC + sc;
-      const int nb = ni / g.D;
-      dsl = ni - nb * g.D + g.kd0 + kdi - 1;
-      dok = dsl >= 0 && dsl < g.D;
-      ni = nb;
+      l_cg = (ch - kdi * g.nch_c) * kWC + sc;
+      l_kd = g.kd0 + kdi - 1;
     }
-    const bool first = cg < a.C1;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
-    const int soff = D3 ? ((ni * a.C1 + cg) * g.D + (dok ? dsl : 0)) * g.HW * 4
-                        : first ? (ni * a.C1 + cg) * g.HW * 4 : (ni * a.C2 + cg - a.C1) * g.HW * 4;
-    // a depth tap outside the volume reads zeros: the range check of a raw buffer load is on the VGPR offset, and
-    // 0x80000000 is past every resource (the same trick as for the halo pixels in pix[])
-    const int voff = (!D3 || dok) ? pix[k] : (int)0x80000000;
-    praw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    const bool first = l_cg < a.C1;
+    l_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2,
+                                             0x00020000);
+    l_cx = first ? a.C1 : a.C2;
+    l_cgl = first ? l_cg : l_cg - a.C1;
+  };
+  auto load_px = [&](int k, int n) {
+    int ni = min(n + tik[k], g.NIMG - 1);
+    int soff, voff = pix[k];
+    if (D3) {  // image -> (batch item, slice); a depth tap outside the volume reads zeros: the range check of a raw buffer
+               // load is on the VGPR offset, and 0x80000000 is past every resource (as for the halo pixels in pix[])
+      const int nb = ni / g.D, dsl = ni - nb * g.D + l_kd;
+      const bool dok = dsl >= 0 && dsl < g.D;
+      soff = ((nb * a.C1 + l_cg) * g.D + (dok ? dsl : 0)) * g.HW * 4;
+      if (!dok) voff = (int)0x80000000;
+      ni = nb;
+    } else {
+      soff = (ni * l_cx + l_cgl) * g.HW * 4;
+    }
+    praw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(l_rs, voff, soff, 0));
     if (AFFINE && (!ONEIMG || k == 0)) {
-      const int goff = (ni * g.Cin + cg) * 4;
+      const int goff = (ni * g.Cin + l_cg) * 4;
       gs[ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
       gh[ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
     }
@@ -377,8 +391,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
+    load_setup(chL);
 #pragma unroll
-    for (int k = 0; k < NR; ++k) load_px(k, nL, chL);
+    for (int k = 0; k < NR; ++k) load_px(k, nL);
 #pragma unroll
     for (int k = 0; k < NR; ++k) activate_px(k, c * PB);
     advance(nL, chL);
@@ -389,8 +404,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   row_transform();
 #pragma unroll
   for (int i = 0; i < 4; ++i) col_commit(i, 0);
+  load_setup(chL);
 #pragma unroll
-  for (int k = 0; k < NR; ++k) load_px(k, nL, chL);
+  for (int k = 0; k < NR; ++k) load_px(k, nL);
   advance(nL, chL);
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NVM) : "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -416,6 +432,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     const int nb = BUF - cbuf;
     const int pb_t = ((c + 1) & 1) * PB, pb_a = (c & 1) * PB;
     const int ch_u = ch_cur < last ? ch_cur + 1 : ch_lo;  // U depends on the chunk only, not on the image
+    load_setup(chL);
     f2 av[3], bv[3];  // operand ring: three pairs
     const int ua = (cbuf + ub + 8 * hf * 2 * 2 * 64 * 2) * 4, va = (cbuf + vb + 8 * hf * 2 * 2 * 64 * 2) * 4;  // bytes
     auto load_pair = [&](int slot, int p) {
@@ -427,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
       if (s < NR) {
         activate_px(s, pb_a);
       } else if (s >= 6 && s < 6 + NR) {
-        load_px(s - 6, nL, chL);
+        load_px(s - 6, nL);
       } else if (s >= 12 && s < 16) {
         dma_u(s - 12, ch_u, nb);
       } else if (s >= 16 && s < 20) {

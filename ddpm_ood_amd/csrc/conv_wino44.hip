@@ -33,6 +33,16 @@ namespace ddpm {
 
 namespace {
 
+// s_setprio 1 around every MFMA issue paid 3 % in conv_wino.hip; here (18 MFMAs per chunk, longer staging streams) the 36
+// extra scalar instructions cost 1.7 %: off unless built with -DW44_SETPRIO
+#ifndef W44_SETPRIO
+#define W44_PRIO1 ""
+#define W44_PRIO0 ""
+#else
+#define W44_PRIO1 "s_setprio 1\n\t"
+#define W44_PRIO0 "\n\ts_setprio 0"
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -48,30 +58,30 @@ constexpr int kXS = kX * 2 * 64;     // exchange slab: [xi][cout block][lane] of
 constexpr int kNDMA = kUF / 256;     // 1 KB LDS-DMA transfers per U tile (36)
 
 __device__ __forceinline__ void mfma_a(f32x16 &c, float a, float b) {
-  asm volatile("s_setprio 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_setprio 0" : "+a"(c) : "v"(a), "v"(b));
+  asm volatile(W44_PRIO1 "v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" W44_PRIO0 : "+a"(c) : "v"(a), "v"(b));
 }
 template <int N>
 __device__ __forceinline__ void mfma_a_wait(f32x16 &c, float a, float b) {
-  asm volatile("s_setprio 1\n\ts_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_setprio 0"
+  asm volatile(W44_PRIO1 "s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" W44_PRIO0
                : "+a"(c) : "v"(a), "v"(b), "n"(N));
 }
 template <int N>
 __device__ __forceinline__ void mfma_a_first_wait(f32x16 &c, float a, float b) {  // C = 0
-  asm volatile("s_setprio 1\n\ts_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0\n\ts_setprio 0"
+  asm volatile(W44_PRIO1 "s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" W44_PRIO0
                : "=a"(c) : "v"(a), "v"(b), "n"(N));
 }
 // the ninth accumulator tile of a wave lives in arch VGPRs: hipcc gives a 512-thread kernel 128 + 128 registers
 __device__ __forceinline__ void mfma_v(f32x16 &c, float a, float b) {
-  asm volatile("s_setprio 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_setprio 0" : "+v"(c) : "v"(a), "v"(b));
+  asm volatile(W44_PRIO1 "v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" W44_PRIO0 : "+v"(c) : "v"(a), "v"(b));
 }
 template <int N>
 __device__ __forceinline__ void mfma_v_wait(f32x16 &c, float a, float b) {
-  asm volatile("s_setprio 1\n\ts_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_setprio 0"
+  asm volatile(W44_PRIO1 "s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" W44_PRIO0
                : "+v"(c) : "v"(a), "v"(b), "n"(N));
 }
 template <int N>
 __device__ __forceinline__ void mfma_v_first_wait(f32x16 &c, float a, float b) {  // C = 0
-  asm volatile("s_setprio 1\n\ts_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0\n\ts_setprio 0"
+  asm volatile(W44_PRIO1 "s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" W44_PRIO0
                : "=v"(c) : "v"(a), "v"(b), "n"(N));
 }
 // two floats 16 bytes apart through the scalar cache (lgkmcnt, not vmcnt); the pointer must be wave-uniform
@@ -118,6 +128,7 @@ struct W44Geom {
   int UI;           // staging units of 64 pixels per image of an item; a wave pair stages units hv, hv + 2, ...
   int NR;           // staging rounds per wave: ceil(TI * UI / 2), at most 5
   int KT, NIT, IPW, NS, grid;  // as conv_wino.hip: cout tiles, items per (cout tile, part), items per workgroup, slots
+  int abl;          // ablation mask (DDPM_W44_ABL, experiments): 1 no patch transform, 2 no pixel stage, 4 no U DMA
   int xmap;         // 1: an XCD serves ONE cout tile (its L2 keeps that tile's U stream); 0: the cout tiles of a slot share an XCD
 };
 
@@ -196,6 +207,7 @@ static bool w44_geom(const ddpm_conv_desc &d, W44Geom &g) {
   g.IPW = (int)((items + cus - 1) / cus);
   g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW);
   g.grid = g.KT * ((g.NS + 7) / 8) * 8;
+  g.abl = getenv("DDPM_W44_ABL") ? atoi(getenv("DDPM_W44_ABL")) : 0;
   const char *xm = getenv("DDPM_WINO44_XMAP");
   g.xmap = (xm ? atoi(xm) != 0 : 1) && (8 % g.KT == 0);
   if (g.xmap) g.grid = 8 * ((g.NS + 8 / g.KT - 1) / (8 / g.KT));
@@ -476,6 +488,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
       bv[slot] = lds_b64(va, x * (kC * kT * 4));
     };
     auto slice = [&](int s) {
+#ifdef W44_ABLATION  // timing experiments only
+      if (s < 3 && !(g.abl & 4)) {
+        dma_u(2 * s, nb);
+        if (s < 2) dma_u(2 * s + 1, nb);
+      }
+      if (!(g.abl & 2)) {
+        if (s >= 3 && s < 3 + NR) load_px(std::integral_constant<int, 1 - PAR>{}, s - 3, nL);
+        if (s >= 18 - NR) activate_px(std::integral_constant<int, PAR>{}, s - (18 - NR), pb_a);
+      }
+      if ((s & 1) == 0 && !(g.abl & 1)) tstep(s >> 1, pb_t, nb);
+#else
       if (s < 3) {
         dma_u(2 * s, nb);
         if (s < 2) dma_u(2 * s + 1, nb);
@@ -483,6 +506,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
       if (s >= 3 && s < 3 + NR) load_px(std::integral_constant<int, 1 - PAR>{}, s - 3, nL);
       if (s >= 18 - NR) activate_px(std::integral_constant<int, PAR>{}, s - (18 - NR), pb_a);
       if ((s & 1) == 0) tstep(s >> 1, pb_t, nb);
+#endif
     };
     load_pair(0, 0);
     load_pair(1, 1);

@@ -50,7 +50,8 @@ def main(root, out_csv, out_json):
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/microbench.py, B=256; "
                      "reads = 2 x FETCH_SIZE KB (gfx950 correction), launch-weighted mean over the kernel's launches"}
     # profiler key of bench.py's roofline object -> the kernel instantiations behind it
-    for key, prefix in (("conv3x3_wino_gn_silu", "conv_wino_kernel<true"), ("conv3x3_mfma_gn_silu", "conv_mfma_kernel<9, 1, true, 128")):
+    for key, prefix in (("conv3x3_wino44_gn_silu", "conv_wino44_kernel<true"), ("conv3x3_wino_gn_silu", "conv_wino_kernel<true"),
+                        ("conv3x3_mfma_gn_silu", "conv_mfma_kernel<9, 1, true, 128")):
         sel = m[m.kernel.str.startswith(prefix)]
         if len(sel):
             wgt = sel.launches / sel.launches.sum()
