@@ -537,14 +537,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
     __builtin_amdgcn_sched_barrier(0);
   };
 
+#ifdef W44_PROBE  // timing experiment: cycle stamps of workgroup 0, wave 0 -> desc.scratch[item][4]
+  int probe_item = 0;
+#define W44_STAMP(i)                                                                              \
+  if (blockIdx.x == 0 && tid == 0 && a.scratch)                                                   \
+    reinterpret_cast<unsigned long long *>(a.scratch)[probe_item * 4 + (i)] = __builtin_readcyclecounter();
+#else
+#define W44_STAMP(i)
+#endif
   for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
+    W44_STAMP(0)
     chunk(S0{}, std::true_type{}, 0);
     chunk(S1{}, std::false_type{}, 1);
+    W44_STAMP(1)
     for (int ch = 2; ch <= last; ch += 2) {
       chunk(S0{}, std::false_type{}, ch);
       chunk(S1{}, std::false_type{}, ch + 1);
     }
 
+    W44_STAMP(2)
     // ---- end of an item: Y = A^T M A.  The item's last chunk (odd) consumed operand buffer 1; buffer 1 + the extra slab
     // are four exchange slabs [xi][cout block][lane], one per accumulator register of a pass.  Pass q moves registers
     // 4 q .. 4 q + 3 of all 36 positions through them; wave (cb, pg) then finishes register 4 q + pg of cout block cb:
@@ -655,6 +666,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
     pass(std::integral_constant<int, 1>{});
     pass(std::integral_constant<int, 2>{});
     pass(std::integral_constant<int, 3>{});
+#endif
+    W44_STAMP(3)
+#ifdef W44_PROBE
+    ++probe_item;
 #endif
     __builtin_amdgcn_sched_barrier(0);
   }
