@@ -14,7 +14,7 @@ import torch
 
 _LIB = None
 LIB_NAME = "libddpm_ood_hip.so"
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HipLibraryMissing(RuntimeError):
@@ -71,6 +71,7 @@ SIGNATURES = {
     "ddpm_wino44_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_wino44_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_pack_wino3d_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_pack_wino44_weight3d_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_folded_upsample_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_fold_upsample_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_gn_scale_shift_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

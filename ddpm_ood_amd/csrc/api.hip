@@ -88,8 +88,8 @@ extern "C" int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream) {
 }
 
 extern "C" size_t ddpm_conv_scratch_floats(const ddpm_conv_desc *d) {
-  if (!d || d->dims == 3 || d->Di > 1 || d->Do > 1) return 0;
-  return conv_wino_scratch_floats(*d);
+  if (!d) return 0;
+  return conv_scratch_floats(*d);
 }
 
 extern "C" size_t ddpm_packed_conv_weight_floats(int Cout, int Cin, int ksize) {
@@ -153,6 +153,11 @@ extern "C" size_t ddpm_wino44_weight_floats(int Cout, int Cin) { return wino44_w
 extern "C" int ddpm_pack_wino44_weight_f32(const float *w_raw, float *w_wino44, int Cout, int Cin, ddpm_stream_t stream) {
   DDPM_CHECK_ARG(w_raw && w_wino44, "wino44 pack: NULL pointer");
   return launch_pack_wino44_weight(w_raw, w_wino44, Cout, Cin, as_stream(stream));
+}
+
+extern "C" int ddpm_pack_wino44_weight3d_f32(const float *w_raw, float *w_wino44, int Cout, int Cin, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(w_raw && w_wino44, "wino44 3d pack: NULL pointer");
+  return launch_pack_wino44_weight(w_raw, w_wino44, Cout, Cin, as_stream(stream), 3);
 }
 
 extern "C" int ddpm_pack_wino3d_weight_f32(const float *w_raw, float *w_wino, int Cout, int Cin, ddpm_stream_t stream) {

@@ -90,10 +90,13 @@ bool conv_wino_supported(const ddpm_conv_desc &d);
 int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s);
 size_t wino_weight_floats(int Cout, int Cin);
 size_t conv_wino_scratch_floats(const ddpm_conv_desc &d);
+int launch_wino_split_reduce(const ddpm_conv_desc &d, int S, long long pstride, int HW, hipStream_t s);
+size_t conv_wino44_scratch_floats(const ddpm_conv_desc &d);
+size_t conv_scratch_floats(const ddpm_conv_desc &d);  // what conv_dispatch can use: the larger of the two Winograd kernels' needs
 bool conv_wino44_supported(const ddpm_conv_desc &d);
 int launch_conv_wino44(const ddpm_conv_desc &d, hipStream_t s);
 size_t wino44_weight_floats(int Cout, int Cin);
-int launch_pack_wino44_weight(const float *w_raw, float *w_wino44, int Cout, int Cin, hipStream_t s);
+int launch_pack_wino44_weight(const float *w_raw, float *w_wino44, int Cout, int Cin, hipStream_t s, int nkd = 1);
 int launch_pack_wino_weight(const float *w_raw, float *w_wino, int Cout, int Cin, hipStream_t s, int nkd = 1);
 int launch_fold_upsample_weight(const float *w_raw, float *w_folded, int Cout, int Cin, hipStream_t s);
 int launch_pack_conv_weight(const float *w_raw, float *w_packed, int Cout, int Cin, int ksize, int cout_offset,

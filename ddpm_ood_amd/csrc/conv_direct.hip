@@ -406,6 +406,12 @@ int launch_conv_direct(const ddpm_conv_desc &d, hipStream_t s) {
   return 0;
 }
 
+size_t conv_scratch_floats(const ddpm_conv_desc &d) {
+  if (d.dims == 3 || d.Di > 1 || d.Do > 1) return 0;
+  const size_t a = conv_wino44_scratch_floats(d), b = conv_wino_scratch_floats(d);
+  return a > b ? a : b;
+}
+
 int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
   DDPM_CHECK_ARG(d.in1 && d.out && d.B > 0 && d.Cout > 0 && d.C1 > 0, "conv: null tensor or empty shape");
   DDPM_CHECK_ARG(d.C2 == 0 || d.in2, "conv: C2 > 0 but in2 is NULL");
@@ -427,7 +433,8 @@ int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
     if (is3d && d.mode == DDPM_CONV_UPSAMPLE2) DDPM_CHECK_ARG(Do == 2 * Di, "conv3d: upsample needs Do == 2 Di");
     if (is3d && d.mode == DDPM_CONV_STRIDE2)
       DDPM_CHECK_ARG(Do == (d.ksize == 3 ? (Di + 1) / 2 : Di / 2) && Do > 0, "conv3d: stride-2 output depth");
-    if (is3d && d.w_wino && conv_wino_supported(d)) return launch_conv_wino(d, s);  // VQ-VAE residual units
+    if (is3d && conv_wino44_supported(d)) return launch_conv_wino44(d, s);           // VQ-VAE residual units
+    if (is3d && d.w_wino && conv_wino_supported(d)) return launch_conv_wino(d, s);
     DDPM_CHECK_ARG(conv_mfma_supported(d),
                    "conv: 3-D / k4 / transposed convolutions need an MFMA tiling (Cin %% 4 (8), Cout %% 128, packed weights)");
     return launch_conv_mfma(d, s);

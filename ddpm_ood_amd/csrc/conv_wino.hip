@@ -1188,6 +1188,15 @@ __global__ __launch_bounds__(256) void wino_split_reduce_kernel(const float *__r
   reinterpret_cast<v4f *>(out)[i] = v;
 }
 
+// d.out = sum of the S slabs of d.scratch + d.bias + d.chan_add + d.residual (shared with conv_wino44.hip)
+int launch_wino_split_reduce(const ddpm_conv_desc &d, int S, long long pstride, int HW, hipStream_t s) {
+  const long long total4 = (long long)d.B * d.Cout * HW / 4;  // H, W even: HW % 4 == 0
+  hipLaunchKernelGGL(wino_split_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, d.scratch, pstride,
+                     S, d.bias, d.chan_add, d.chan_add_stride, d.residual, d.out, d.Cout, HW / 4, total4);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
 size_t conv_wino_scratch_floats(const ddpm_conv_desc &d) {
   WinoGeom g;
   if (!conv_wino_supported(d) || !wino_geom(d, g) || g.S == 1) return 0;
@@ -1286,12 +1295,7 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   ProfScope prof(s, kname, flops, bytes);
   hipLaunchKernelGGL(kern, dim3(g.grid), dim3(threads), lds_bytes, s, dk, g);
   DDPM_CHECK_LAUNCH();
-  if (g.S > 1) {
-    const long long total4 = (long long)out_floats / 4;  // H, W even: HW % 4 == 0
-    hipLaunchKernelGGL(wino_split_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, d.scratch,
-                       g.pstride, g.S, d.bias, d.chan_add, d.chan_add_stride, d.residual, d.out, d.Cout, g.HW / 4, total4);
-    DDPM_CHECK_LAUNCH();
-  }
+  if (g.S > 1) return launch_wino_split_reduce(d, g.S, g.pstride, g.HW, s);
   return 0;
 }
 

@@ -130,6 +130,19 @@ struct W44Geom {
   int KT, NIT, IPW, NS, grid;  // as conv_wino.hip: cout tiles, items per (cout tile, part), items per workgroup, slots
   int abl;          // ablation mask (DDPM_W44_ABL, experiments): 1 no patch transform, 2 no pixel stage, 4 no U DMA
   int xmap;         // 1: an XCD serves ONE cout tile (its L2 keeps that tile's U stream); 0: the cout tiles of a slot share an XCD
+  // launches with fewer items than CUs (the 8x8 level at B = 256; small batches): S workgroups share an item, each walks
+  // nchunks / S chunks of the channel stream and writes its partial output (after the output transform) into slab
+  // `split` of a scratch buffer; conv_wino.hip's reduce pass adds the slabs in a fixed order with bias / temb / residual
+  int S;            // channel-stream splits per item (1: none)
+  long long pstride;  // floats between two partial-output slabs (0 when S == 1)
+  // 3-D (dims = 3, VQ-VAE residual units; as conv_wino.hip): an "image" is one (n, d) slice, the chunk stream of an item
+  // walks (depth tap, channel chunk) -- 2-D F(4x4) per depth tap, the taps accumulated in the transform domain
+  int D;            // slices per batch item (1: plain 2-D)
+  int NIMG;         // images the items walk: B * D
+  int nch_c;        // channel chunks per depth tap; nchunks = nkd * nch_c
+  int kd0, nkd;     // depth taps kd0 .. kd0 + nkd - 1 (a depth-1 volume only has its centre tap)
+  int CS;           // channel stride of the input / output tensors in floats: D * HW
+  int nkd_w;        // depth-tap slabs per cout tile in w_wino44: 3 for a 3x3x3 weight, else 1
 };
 
 static int w44_cus() {
@@ -144,16 +157,22 @@ static int w44_cus() {
   return cus;
 }
 
-static bool w44_geom(const ddpm_conv_desc &d, W44Geom &g) {
+// sizing: only decide the split (the scratch-size query); else a split launch needs its scratch slabs in the descriptor
+static bool w44_geom(const ddpm_conv_desc &d, W44Geom &g, bool sizing = false) {
   const int Cin = d.C1 + d.C2;
-  if (d.ksize != 3 || d.dims == 3 || d.Di > 1 || d.Do > 1 || d.mode != DDPM_CONV_NORMAL) return false;
-  if (d.out_act != DDPM_ACT_NONE || d.act == DDPM_ACT_RELU) return false;
+  const bool is3d = d.dims == 3;
+  if (d.ksize != 3 || (!is3d && (d.Di > 1 || d.Do > 1)) || d.mode != DDPM_CONV_NORMAL) return false;
+  if ((d.out_act != DDPM_ACT_NONE && !(is3d && d.out_act == DDPM_ACT_RELU)) || d.act == DDPM_ACT_RELU) return false;
   if (d.gscale && d.act != DDPM_ACT_SILU) return false;  // the affine variant has SiLU built in
+  // 3-D: no GroupNorm / activation prologue (zero padding along the depth must stay zero), no concat, no temb
+  if (is3d && (d.gscale || d.act != DDPM_ACT_NONE || d.C2 || d.chan_add)) return false;
+  const int Dd = is3d ? (d.Di > 1 ? d.Di : 1) : 1;
+  if (is3d && (d.Do > 1 ? d.Do : 1) != Dd) return false;
   if (Cin % 8 || (d.C2 > 0 && d.C1 % kC) || d.Cout % kK) return false;  // an even number of 4-channel chunks
   if ((d.Ho & 3) || (d.Wo & 3) || d.Hi != d.Ho || d.Wi != d.Wo) return false;
   if ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.residual)) & 15) return false;  // float4 rows
-  if ((double)d.B * (d.C1 > d.C2 ? d.C1 : d.C2) * d.Ho * d.Wo * 4 >= 2147483648.0) return false;  // 32-bit buffer offsets
-  if ((double)d.B * d.Cout * d.Ho * d.Wo * 4 >= 2147483648.0 * 2) return false;
+  if ((double)d.B * (d.C1 > d.C2 ? d.C1 : d.C2) * Dd * d.Ho * d.Wo * 4 >= 2147483648.0) return false;  // 32-bit buffer offsets
+  if ((double)d.B * d.Cout * Dd * d.Ho * d.Wo * 4 >= 2147483648.0 * 2) return false;
   g.TWc = d.Wo / 4;
   g.THr = d.Ho / 4;
   const int per_img = g.TWc * g.THr;
@@ -169,9 +188,17 @@ static bool w44_geom(const ddpm_conv_desc &d, W44Geom &g) {
     g.TR = g.THr;
     g.parts = 1;
   }
+  if (is3d && g.TI != 1) return false;  // slices smaller than 32 tiles stay on conv_wino.hip / the direct kernel
   g.Cin = Cin;
-  g.nchunks = Cin / kC;
+  g.D = Dd;
+  g.NIMG = d.B * Dd;
+  g.nch_c = Cin / kC;
+  g.kd0 = is3d && Dd == 1 ? 1 : 0;
+  g.nkd = is3d && Dd > 1 ? 3 : 1;
+  g.nkd_w = is3d ? 3 : 1;
+  g.nchunks = g.nkd * g.nch_c;
   g.HW = d.Ho * d.Wo;
+  g.CS = Dd * g.HW;
   g.prow = 4 * g.TR + 2;
   // bank of a patch element = (ch PCH + ti IS + 4 tr PW + 4 tc + const) % 64 for the wave's 16 tiles x 4 channels:
   // 4 tc covers 4 TWc banks, so the next tile row must start 4 TWc banks further (PW = TWc mod 16), the next image
@@ -197,15 +224,29 @@ static bool w44_geom(const ddpm_conv_desc &d, W44Geom &g) {
   if (g.TI == 1 && (rows - 1) * d.Wi < 128 * (g.NR - 1)) return false;
   if (g.TI > 1 && !((g.UI == 4 && rows * d.Wi == 256) || (g.UI == 1 && rows * d.Wi <= 64 && g.TI <= 8))) return false;
   g.KT = d.Cout / kK;
-  g.NIT = (d.B + g.TI - 1) / g.TI;
+  g.NIT = (g.NIMG + g.TI - 1) / g.TI;
   const long items = (long)g.KT * g.parts * g.NIT;
   const int cus = w44_cus();
   // small launches: conv_wino.hip (half-size items) and its channel-stream split.  DDPM_CONV_WINO44=2 lifts the rule (tests)
   const char *sw = getenv("DDPM_CONV_WINO44");  // read per call: tests flip it
   const bool any_size = sw && atoi(sw) == 2;
-  if (items < cus && !any_size) return false;
+  g.S = 1;
+  g.pstride = 0;
+  if (items < cus && !any_size) {
+    if (is3d) return false;
+    // every workgroup of a split walks an even number (>= 4) of chunks; DDPM_WINO44_SPLIT caps S (0 / 1: no split)
+    const char *sp_env = getenv("DDPM_WINO44_SPLIT");
+    const int sp_max = sp_env ? atoi(sp_env) : 4;
+    for (int sp = 4; sp >= 2; sp >>= 1)
+      if (sp <= sp_max && items * sp <= cus && g.nchunks % (2 * sp) == 0 && g.nchunks / sp >= 4) { g.S = sp; break; }
+    if (g.S == 1 || items * g.S < cus) return false;  // still not the whole chip: conv_wino.hip's half-size items and its split
+                                                       // (measured at B = 16: 16x16 layers 43 / 63 us there vs 48 / 74 us here)
+    const size_t out_floats = (size_t)d.B * d.Cout * g.HW;
+    if (!sizing && (!d.scratch || d.scratch_floats < g.S * out_floats)) return false;
+    g.pstride = (long long)out_floats;
+  }
   g.IPW = (int)((items + cus - 1) / cus);
-  g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW);
+  g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW) * g.S;
   g.grid = g.KT * ((g.NS + 7) / 8) * 8;
   g.abl = getenv("DDPM_W44_ABL") ? atoi(getenv("DDPM_W44_ABL")) : 0;
   const char *xm = getenv("DDPM_WINO44_XMAP");
@@ -221,9 +262,19 @@ bool conv_wino44_supported(const ddpm_conv_desc &d) {
   return enabled && d.w_wino44 != nullptr && !d.force_direct && w44_geom(d, g);
 }
 
+// floats of scratch with which this descriptor runs as a split F(4x4) launch (0: unsplit, or not an F(4x4) shape)
+size_t conv_wino44_scratch_floats(const ddpm_conv_desc &d) {
+  const char *sw = getenv("DDPM_CONV_WINO44");
+  W44Geom g;
+  if ((sw && atoi(sw) == 0) || !d.w_wino44 || d.force_direct || !w44_geom(d, g, true) || g.S == 1) return 0;
+  return (size_t)g.S * d.B * d.Cout * g.HW;
+}
+
 // GD = consecutive staging rounds of a wave that belong to one image (they share a GroupNorm scale / shift pair):
 // NR for one-image items, UI / 2 when an image is an even number of 64-pixel units, else 1
-template <bool AFFINE, int NR, int GD, bool RES>
+// D3: the 3-D form (images = (n, d) slices, chunk stream = (depth tap, channel chunk)); a template parameter so that the
+// 2-D instantiations carry none of its address arithmetic
+template <bool AFFINE, int NR, int GD, bool RES, bool D3 = false>
 __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_desc a, const W44Geom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool ONEIMG = GD >= NR;
@@ -246,11 +297,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
     slot = wj * (8 / g.KT) + xcd / g.KT;
   }
   if (slot >= g.NS) return;
+  const int split = slot % g.S;  // the splits of an item sit on neighbouring slots
+  slot /= g.S;
   const int part = slot % g.parts, it0 = (slot / g.parts) * g.IPW;
   const int nitems = min(g.IPW, g.NIT - it0);
   const int r0 = part * g.TR;
   const int n_first = it0 * g.TI, n_end = n_first + nitems * g.TI;
-  const int last = g.nchunks - 1;
+  const int ch_lo = split * (g.nchunks / g.S), last = ch_lo + g.nchunks / g.S - 1;  // this workgroup's chunk range
+  float *const outp = a.out + (size_t)split * g.pstride;  // S > 1: slab `split` of the scratch buffer
 
   // ---- staging roles
   // pixels: channel sc of the chunk, units hv, hv + 2, ... of 64 pixels (unit u = image u / UI, pixels 64 (u % UI) ..)
@@ -309,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
   const int rA2 = t0 ? 0 : 2, rB0 = t0 ? 5 : 3, rB1 = t0 ? 3 : 1;
   const float c1 = t0 ? -5.f : third == 1 ? -2.f : -0.5f, c2 = t0 ? 4.f : c1, bm = t0 ? 0.f : third == 1 ? 1.f : 2.f;
 
-  const int bytes1 = a.B * a.C1 * g.HW * 4, bytes2 = a.B * a.C2 * g.HW * 4;
+  const int bytes1 = a.B * a.C1 * (D3 ? g.CS : g.HW) * 4, bytes2 = a.B * a.C2 * g.HW * 4;
   const __amdgpu_buffer_rsrc_t rs_sc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gscale), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_sh =
@@ -330,9 +384,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
   // per-lane addresses, spilled them, and every reload -- a scratch load -- waited vmcnt(0): all pixel loads drained
   // five times per chunk.)
   const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(a.w_wino44), 0, (int)((size_t)kX * a.Cout * g.Cin * 4), 0x00020000);
+      const_cast<float *>(a.w_wino44), 0, (int)((size_t)kX * a.Cout * g.Cin * g.nkd_w * 4), 0x00020000);
   const int ulane = lane * 16;
-  const int ukt = kt * g.nchunks;
+  const int ukt = D3 ? (kt * g.nkd_w + g.kd0) * g.nch_c : kt * g.nchunks;
   int u_soff = 0;  // byte offset of this wave's first transfer of the chunk being fetched
   auto dma_u = [&](int j, int nb) {
     if (j < 4 || wave < 4)
@@ -343,8 +397,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
   // pixel stage addressing of the chunk being loaded: resource / channel offsets once per chunk, image offset per round
   __amdgpu_buffer_rsrc_t l_rs;
   int l_cx, l_cgl, l_cg;
+  int l_soff3 = 0, l_dok = 1;  // D3: byte offset of the (batch item, channel, slice) plane; depth tap inside the volume
+  int nL = n_first, chL = ch_lo;  // stream position of the pixel-load stage
   auto load_setup = [&](int ch) {
     l_cg = ch * kC + sc;
+    if (D3) {  // stream chunk -> (depth tap, channel chunk); image -> (batch item, slice).  One image per item: once per chunk
+      const int kdi = ch / g.nch_c;
+      l_cg = (ch - kdi * g.nch_c) * kC + sc;
+      const int ni = min(nL, g.NIMG - 1);
+      const int nb = ni / g.D, dsl = ni - nb * g.D + g.kd0 + kdi - 1;
+      l_dok = dsl >= 0 && dsl < g.D;
+      l_soff3 = ((nb * a.C1 + l_cg) * g.D + (l_dok ? dsl : 0)) * g.HW * 4;
+    }
     const bool first = l_cg < a.C1;
     l_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2,
                                              0x00020000);
@@ -353,9 +417,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
   };
   auto load_px = [&](auto setc, int k, int n) {
     constexpr int S = decltype(setc)::value;
-    const int ni = min(n + img_of(k), a.B - 1);
-    const int soff = (ni * l_cx + l_cgl) * g.HW * 4;
-    praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(l_rs, pix_of(k), soff, 0));
+    const int ni = min(n + img_of(k), g.NIMG - 1);
+    // D3: a depth tap outside the volume reads zeros -- the range check of a raw buffer load is on the VGPR offset, and
+    // 0x80000000 is past every resource (as for the halo pixels in pix0)
+    const int soff = D3 ? l_soff3 : (ni * l_cx + l_cgl) * g.HW * 4;
+    const int voff = D3 && !l_dok ? (int)0x80000000 : pix_of(k);
+    praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(l_rs, voff, soff, 0));
     if (AFFINE && k % GD == 0) {
       const int goff = (ni * g.Cin + l_cg) * 4;
       gs[S][k / GD] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
@@ -429,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
       ++ch;
     } else if (n + g.TI < n_end) {
       n += g.TI;
-      ch = 0;
+      ch = ch_lo;
     }
   };
   using S0 = std::integral_constant<int, 0>;
@@ -437,10 +504,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
 
   // ---- prologue: zero borders; pixel tiles of stream chunks 0 and 1; U and V of chunk 0; registers for chunk 2
   for (int i = tid; i < 2 * PB + 64; i += 512) P[i] = 0.f;
-  u_soff = (ukt * kUF + wave * 256) * 4;
+  u_soff = ((ukt + ch_lo) * kUF + wave * 256) * 4;
 #pragma unroll
   for (int j = 0; j < 5; ++j) dma_u(j, 0);
-  int nL = n_first, chL = 0;  // stream position of the pixel-load stage
   __syncthreads();
   load_setup(chL);
 #pragma unroll
@@ -474,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
     constexpr bool FIRST = decltype(firstc)::value;
     constexpr int cbuf = PAR * kBUF, nb = (1 - PAR) * kBUF;
     const int pb_t = (1 - PAR) * PB, pb_a = PAR * PB;
-    const int ch_u = ch_cur < last ? ch_cur + 1 : 0;
+    const int ch_u = ch_cur < last ? ch_cur + 1 : ch_lo;
     // the staging addresses are derived from a handful of per-lane bases inside the chunk; hidden from the optimiser here,
     // else it hoists every base + offset combination out of the loop (twenty-odd registers) and spills them -- and a
     // spill reload is a scratch load: vmcnt(0), all pixel loads drained
@@ -547,10 +613,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
 #endif
   for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
     W44_STAMP(0)
-    chunk(S0{}, std::true_type{}, 0);
-    chunk(S1{}, std::false_type{}, 1);
+    chunk(S0{}, std::true_type{}, ch_lo);
+    chunk(S1{}, std::false_type{}, ch_lo + 1);
     W44_STAMP(1)
-    for (int ch = 2; ch <= last; ch += 2) {
+    for (int ch = ch_lo + 2; ch <= last; ch += 2) {
       chunk(S0{}, std::false_type{}, ch);
       chunk(S1{}, std::false_type{}, ch + 1);
     }
@@ -567,7 +633,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
     const int per = g.TR * g.TWc;
     const int ti = el31 / per, rem = el31 - ti * per;
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
-    const int n = n_cur + ti, ncl = min(n, a.B - 1);
+    const int n = n_cur + ti, ncl = min(n, g.NIMG - 1);
+    const int nbat = D3 ? ncl / g.D : ncl, dsl_o = D3 ? ncl - nbat * g.D : 0;  // (batch item, slice)
+    const int cstr = D3 ? g.CS : g.HW;                                        // channel stride
     float *const XS = smem + kBUF;
     // Stores and loads share vmcnt and it retires in order: a load issued after a store cannot be waited for without
     // waiting for the store's acknowledgement.  So everything the epilogue reads is requested BEFORE the stores it could
@@ -580,7 +648,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
         const int co0 = kt * kK + cb * 32 + 8 * q + pg;  // lanes 0..31; lanes 32..63 hold co0 + 4
         float b0 = 0.f, b1 = 0.f, t0v = 0.f, t1v = 0.f;
         if (a.bias) sload2(a.bias + co0, b0, b1);
-        if (a.chan_add) sload2(a.chan_add + (size_t)min(n_cur, a.B - 1) * a.chan_add_stride + co0, t0v, t1v);
+        if (a.chan_add) sload2(a.chan_add + (size_t)min(n_cur, g.NIMG - 1) * a.chan_add_stride + co0, t0v, t1v);
         addv[q] = elhi ? b1 + t1v : b0 + t0v;
       }
     } else {
@@ -590,18 +658,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
         addv[q] = (a.bias ? a.bias[co] : 0.f) + (a.chan_add ? a.chan_add[(size_t)ncl * a.chan_add_stride + co] : 0.f);
       }
     }
-    const size_t obase0 = ((size_t)ncl * a.Cout + kt * kK + cb * 32 + 4 * elhi + pg) * g.HW + (size_t)(4 * (r0 + tr)) * a.Wo +
-                          4 * tc;  // pass q: + 8 q HW
+    const size_t co_e = (size_t)kt * kK + cb * 32 + 4 * elhi + pg;
+    const size_t obase0 = (D3 ? (((size_t)nbat * a.Cout + co_e) * g.D + dsl_o) * g.HW : ((size_t)ncl * a.Cout + co_e) * g.HW) +
+                          (size_t)(4 * (r0 + tr)) * a.Wo + 4 * tc;  // pass q: + 8 q cstr
     v4f res[4];
     auto load_res = [&](int q) {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        res[k] = *reinterpret_cast<const v4f *>(a.residual + obase0 + (size_t)(8 * q) * g.HW + (size_t)k * a.Wo);
+        res[k] = *reinterpret_cast<const v4f *>(a.residual + obase0 + (size_t)(8 * q) * cstr + (size_t)k * a.Wo);
     };
     if (RES) load_res(0);
     auto pass = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      const size_t obase = obase0 + (size_t)(8 * q) * g.HW;
+      const size_t obase = obase0 + (size_t)(8 * q) * cstr;
       {
         float *xw = XS + ((9 * pg) * 2 + cb) * 64 + elane;
 #pragma unroll
@@ -640,7 +709,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
           at4(w[kk][0], w[kk][1], w[kk][2], w[kk][3], w[kk][4], w[kk][5], y);
           v4f o = v4f{y[0] + ad, y[1] + ad, y[2] + ad, y[3] + ad};
           if (RES) o += res[k];
-          if (n < a.B) *reinterpret_cast<v4f *>(a.out + obase + (size_t)k * a.Wo) = o;
+          if (D3 && a.out_act == DDPM_ACT_RELU) o = v4f{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)};
+          if (n < g.NIMG) *reinterpret_cast<v4f *>(outp + obase + (size_t)k * a.Wo) = o;
         }
       };
       half(std::integral_constant<int, 0>{});
@@ -648,7 +718,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
       if (RES && q < 3) {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-          r01[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * g.HW + (size_t)k * a.Wo);
+          r01[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * cstr + (size_t)k * a.Wo);
       }
       half(std::integral_constant<int, 1>{});
       if (RES && q < 3) {
@@ -656,7 +726,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
         res[1] = r01[1];
 #pragma unroll
         for (int k = 2; k < 4; ++k)
-          res[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * g.HW + (size_t)k * a.Wo);
+          res[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * cstr + (size_t)k * a.Wo);
       }
       // nobody may overwrite the slabs (next pass, or the next chunk's staging) while a neighbour still reads them
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -696,41 +766,62 @@ int launch_conv_wino44(const ddpm_conv_desc &d, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  ddpm_conv_desc dk = d;  // the descriptor the kernel sees
+  if (g.S > 1) {          // partial sums go to the scratch slabs, the addends to the reduce pass
+    dk.out = d.scratch;
+    dk.bias = nullptr;
+    dk.chan_add = nullptr;
+    dk.residual = nullptr;
+  }
   const int shape = g.TI == 1 ? 0 : g.UI == 4 ? 1 : 2;
-  kern_t kern = kerns[d.gscale ? 1 : 0][shape][d.residual ? 1 : 0];
-  const double M = (double)d.B * g.HW;
-  // algorithmic work = the direct convolution's: 2 M Cout Cin 9; 36 / 144 of it is executed
-  const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9;
-  const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9);
-  const char *kname = d.gscale ? "conv3x3_wino44_gn_silu" : "conv3x3_wino44";
+  kern_t kern = kerns[d.gscale ? 1 : 0][shape][dk.residual ? 1 : 0];
+  if (d.dims == 3) {  // only reached without prologue and with whole slices per item (w44_geom)
+    static const kern_t kerns3d[2] = {conv_wino44_kernel<false, 5, 5, false, true>, conv_wino44_kernel<false, 5, 5, true, true>};
+    static bool attr3_done = false;
+    if (!attr3_done) {
+      for (int i = 0; i < 2; ++i)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns3d[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+      attr3_done = true;
+    }
+    kern = kerns3d[d.residual ? 1 : 0];
+  }
+  const double M = (double)g.NIMG * g.HW;
+  // algorithmic work = the direct convolution's: 2 M Cout Cin 9 (x 3 depth taps); 36 / 144 of it is executed
+  const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9 * g.nkd;
+  const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9 * g.nkd);
+  const char *kname = d.dims == 3 ? "conv3d_wino44" : d.gscale ? "conv3x3_wino44_gn_silu" : "conv3x3_wino44";
   char kshape[160];
   if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {
     snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);
     kname = kshape;
   }
   ProfScope prof(s, kname, flops, bytes);
-  hipLaunchKernelGGL(kern, dim3(g.grid), dim3(512), lds, s, d, g);
+  hipLaunchKernelGGL(kern, dim3(g.grid), dim3(512), lds, s, dk, g);
   DDPM_CHECK_LAUNCH();
+  if (g.S > 1) return launch_wino_split_reduce(d, g.S, g.pstride, g.HW, s);
   return 0;
 }
 
 // ---- weights: torch [Cout][Cin][3][3] -> U = G g G^T (6 x 6), packed as the LDS image the kernel's MFMAs read:
 //   [cout tile 64][chunk 4][xi 36][cout 64][lhi 2][e 2],  channel of the chunk = 2 e + lhi
 // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], evaluated in double
-__global__ void wino44_pack_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin) {
-  const int64_t total = (int64_t)Cout * Cin;
+// A 3x3x3 weight (nkd = 3) is transformed per depth tap kd: slab [cout tile][kd][chunk] holds G w[:, :, kd] G^T.
+__global__ void wino44_pack_kernel(const float *__restrict__ src, float *__restrict__ dst, int Cout, int Cin, int nkd) {
+  const int64_t total = (int64_t)Cout * Cin * nkd;
   const int nchunks = Cin / kC;
   const double G[6][3] = {{0.25, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},   {0, 0, 1}};
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % Cin), o = (int)(i / Cin);
-    const float *w = src + ((size_t)o * Cin + ci) * 9;
+    const int kd = (int)(i % nkd);
+    const int ci = (int)((i / nkd) % Cin), o = (int)(i / ((int64_t)nkd * Cin));
+    const float *w = src + ((size_t)o * Cin + ci) * 9 * nkd + kd * 9;
     double t[6][3];
     for (int r = 0; r < 6; ++r)
       for (int j = 0; j < 3; ++j) t[r][j] = G[r][0] * w[0 * 3 + j] + G[r][1] * w[1 * 3 + j] + G[r][2] * w[2 * 3 + j];
     const int tile = o / kK, k64 = o % kK, ch = ci / kC, cl = ci % kC;
     const int lhi = cl & 1, e = cl >> 1;
-    float *d = dst + ((size_t)tile * nchunks + ch) * kUF + k64 * 4 + lhi * 2 + e;
+    float *d = dst + (((size_t)tile * nkd + kd) * nchunks + ch) * kUF + k64 * 4 + lhi * 2 + e;
     for (int r = 0; r < 6; ++r)
       for (int c = 0; c < 6; ++c)
         d[(r * 6 + c) * (kC * kK)] = (float)(t[r][0] * G[c][0] + t[r][1] * G[c][1] + t[r][2] * G[c][2]);
@@ -742,11 +833,11 @@ size_t wino44_weight_floats(int Cout, int Cin) {
   return (size_t)kX * Cout * Cin;
 }
 
-int launch_pack_wino44_weight(const float *w_raw, float *w_wino44, int Cout, int Cin, hipStream_t s) {
-  DDPM_CHECK_ARG(wino44_weight_floats(Cout, Cin) != 0, "wino44 pack: Cout %% 64 or Cin %% 8 != 0");
-  const int64_t total = (int64_t)Cout * Cin;
+int launch_pack_wino44_weight(const float *w_raw, float *w_wino44, int Cout, int Cin, hipStream_t s, int nkd) {
+  DDPM_CHECK_ARG(wino44_weight_floats(Cout, Cin) != 0 && (nkd == 1 || nkd == 3), "wino44 pack: Cout %% 64 or Cin %% 8 != 0");
+  const int64_t total = (int64_t)Cout * Cin * nkd;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(wino44_pack_kernel, dim3(blocks), dim3(256), 0, s, w_raw, w_wino44, Cout, Cin);
+  hipLaunchKernelGGL(wino44_pack_kernel, dim3(blocks), dim3(256), 0, s, w_raw, w_wino44, Cout, Cin, nkd);
   DDPM_CHECK_LAUNCH();
   return 0;
 }

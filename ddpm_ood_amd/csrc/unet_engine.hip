@@ -486,7 +486,7 @@ struct Runner {
     }
     // small batches: scratch slabs for the Winograd kernel's channel-stream split (released with the enclosing block's
     // temporaries; the dry run that sizes the workspace takes the same decisions)
-    if (const size_t need = (d.dims == 3 || in1.D > 1 || Do > 1) ? 0 : conv_wino_scratch_floats(d)) {
+    if (const size_t need = (d.dims == 3 || in1.D > 1 || Do > 1) ? 0 : conv_scratch_floats(d)) {
       d.scratch = ws.get(need);
       d.scratch_floats = need;
     }

@@ -177,6 +177,18 @@ def pack_wino3d_weight(weight: torch.Tensor) -> torch.Tensor | None:
     return out
 
 
+def pack_wino44_3d_weight(weight: torch.Tensor) -> torch.Tensor | None:
+    """torch [Cout, Cin, 3, 3, 3] -> per-depth-tap F(4x4, 3x3) weights U_kd = G w[:, :, kd] G^T, 6 x 6 (None if the shape
+    has no tiling: Cout % 64, Cin % 8)."""
+    lib = _lib.load()
+    w = require_device_f32(weight, "weight")
+    if w.ndim != 5 or tuple(w.shape[2:]) != (3, 3, 3) or lib.ddpm_wino44_weight_floats(w.shape[0], w.shape[1]) == 0:
+        return None
+    out = torch.empty(3 * 36 * w.shape[0] * w.shape[1], dtype=torch.float32, device=w.device)
+    check(lib.ddpm_pack_wino44_weight3d_f32(ptr(w), ptr(out), w.shape[0], w.shape[1], stream_ptr()), "pack_wino44_3d_weight")
+    return out
+
+
 def pack_convT_weight(weight: torch.Tensor) -> torch.Tensor:
     """torch ConvTranspose weight [Cin, Cout, 4, 4(, 4)] -> per-output-parity 2 x 2 (x 2)-tap packed weights."""
     lib = _lib.load()
@@ -191,12 +203,13 @@ def pack_convT_weight(weight: torch.Tensor) -> torch.Tensor:
 
 
 def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=None, packed=None, stride: int = 1,
-           wino=None, out=None):
+           wino=None, out=None, wino44=None):
     """F.conv3d(act(x), weight, bias, stride, padding=1) (+ residual, + output activation) on NCDHW tensors:
     kernel 3 stride 1, or kernel 4 stride 2.  ONE launch of the MFMA kernel: the depth taps are part of its chunk
     stream (chunk = (depth tap, channel group)), so the output is written once.  ``wino`` (pack_wino3d_weight): a
     stride-1 conv without input activation whose slices hold >= 64 2x2 tiles takes the Winograd kernel instead (2-D
-    F(2x2, 3x3) per depth tap, the taps accumulated in the transform domain: 2.25x fewer multiplies)."""
+    F(2x2, 3x3) per depth tap, the taps accumulated in the transform domain: 2.25x fewer multiplies); ``wino44``
+    (pack_wino44_3d_weight): F(4x4, 3x3) per depth tap where a slice holds >= 32 4x4 tiles and the launch fills the chip."""
     lib = _lib.load()
     x = require_device_f32(x, "x")
     w = require_device_f32(weight, "weight")
@@ -217,7 +230,7 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
         bias = require_device_f32(bias, "bias")
     if residual is not None:
         residual = require_device_f32(residual, "residual")
-    if wino is not None and stride == 1 and B > 1:
+    if (wino is not None or wino44 is not None) and stride == 1 and B > 1:
         # the Winograd kernel addresses pixels with 32-bit buffer offsets (tensors < 2 GiB): a larger batch is walked
         # in sub-batches (views along dim 0, no copies) instead of dropping to the direct kernel
         per = max(Cc, cout) * D * H * W * 4
@@ -225,7 +238,7 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
         if B > nb:
             for s0 in range(0, B, nb):
                 conv3d(x[s0:s0 + nb], w, bias, act=act, out_act=out_act, packed=packed, stride=stride, wino=wino,
-                       residual=None if residual is None else residual[s0:s0 + nb], out=out[s0:s0 + nb])
+                       wino44=wino44, residual=None if residual is None else residual[s0:s0 + nb], out=out[s0:s0 + nb])
             return out
     d = ConvDesc()
     d.in1, d.C1 = ptr(x), Cc
@@ -236,6 +249,8 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
     d.Di, d.Do, d.dims = D, Do, 3
     if wino is not None and stride == 1:
         d.w_wino = ptr(wino)
+    if wino44 is not None and stride == 1:
+        d.w_wino44 = ptr(wino44)
     check(lib.ddpm_conv_f32(C_byref(d), stream_ptr()), "conv3d")
     return out
 

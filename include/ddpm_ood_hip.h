@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDPM_ABI_VERSION 4
+#define DDPM_ABI_VERSION 5
 
 #define DDPM_EINVAL (-1)      /* bad argument / unsupported shape      */
 #define DDPM_ENOPARAM (-2)    /* unknown or missing parameter name     */
@@ -104,14 +104,14 @@ typedef struct ddpm_conv_desc {
    * multiplies (4x fewer for UPSAMPLE2, where 9 of the 16 transform positions are non-zero on a nearest-x2
    * image); fp32 rounding differs from the direct form by ~1e-6 relative.                  */
   const float *w_wino;
-  /* Optional scratch (ddpm_conv_scratch_floats): a launch with fewer work items than CUs (small batches) splits the
-   * channel stream of each item over 2 or 4 workgroups, whose partial outputs go to slabs of this buffer and are added in
+  /* Optional scratch (ddpm_conv_scratch_floats): a launch with fewer work items than CUs (small batches; the F(4x4) kernel
+   * at the 8x8 level) splits the channel stream of each item over 2 or 4 workgroups, whose partial outputs go to slabs of this buffer and are added in
    * a fixed order by a second pass.  NULL / too small: the convolution runs unsplit (same result up to fp32 rounding). */
   float *scratch;
   size_t scratch_floats;
   /* Optional, 2-D 3x3 DDPM_CONV_NORMAL only: weights pre-transformed by ddpm_pack_wino44_weight_f32 (U = G g G^T, 6 x 6).
-   * When present, the shape has a 4x4 tiling (H, W % 4 == 0; Cin % 8 == 0; Cout % 64 == 0) and the launch fills the
-   * chip, the conv runs as Winograd F(4x4, 3x3): 4x fewer multiplies than the direct form (F(2x2): 2.25x); fp32
+   * When present, the shape has a 4x4 tiling (H, W % 4 == 0; Cin % 8 == 0; Cout % 64 == 0) and the launch fills at least
+   * half of the chip (with `scratch`: after a 2- / 4-way channel split), the conv runs as Winograd F(4x4, 3x3): 4x fewer multiplies than the direct form (F(2x2): 2.25x); fp32
    * rounding differs from the direct form by ~3e-6 rms relative.  Takes precedence over w_wino.  */
   const float *w_wino44;
 } ddpm_conv_desc;
@@ -164,6 +164,10 @@ int ddpm_pack_wino44_weight_f32(const float *w_raw, float *w_wino44, int Cout, i
  * Cin floats).  A dims = 3, stride-1 descriptor without GroupNorm / activation prologue (the VQ-VAE residual units) that
  * carries it in w_wino runs as 2-D Winograd F(2x2, 3x3) per depth tap, the taps accumulated in the transform domain.     */
 int ddpm_pack_wino3d_weight_f32(const float *w_raw, float *w_wino, int Cout, int Cin, ddpm_stream_t stream);
+/* The same for F(4x4, 3x3) (3 * 36 * Cout * Cin floats), carried in w_wino44: slices of at least 32 4x4 tiles (32 x 16 pixels
+ * and up: the 32^3 and 64^3 levels of the README VQ-VAE, reference call site src/trainers/reconstruct.py:166) run as 2-D
+ * F(4x4, 3x3) per depth tap -- 4x fewer multiplies than the direct form.  Takes precedence over w_wino.                      */
+int ddpm_pack_wino44_weight3d_f32(const float *w_raw, float *w_wino44, int Cout, int Cin, ddpm_stream_t stream);
 
 /* Folded form of an Upsample conv weight (see ddpm_conv_desc.w_folded): 4 packed 2x2-tap weights.     */
 size_t ddpm_folded_upsample_weight_floats(int Cout, int Cin);

@@ -46,7 +46,7 @@ def test_struct_layouts_match_header(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.ddpm_abi_version() == 4
+    assert lib.ddpm_abi_version() == 5
     assert lib.ddpm_packed_conv_weight_floats(128, 128, 3) == 128 * 128 * 9
     assert lib.ddpm_packed_conv_weight_floats(96, 128, 3) == 0      # Cout % 128
     assert lib.ddpm_packed_conv_weight_floats(128, 3, 3) == 0       # Cin % 8

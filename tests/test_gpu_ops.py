@@ -479,6 +479,41 @@ def test_conv_winograd(device, case):
         assert (y - y_direct).abs().max().item() < 4e-5 * (1 + ref.abs().max().item())
 
 
+@pytest.mark.parametrize("B,Cin,Cout,D,H", [(1, 256, 256, 8, 64), (2, 128, 128, 3, 32), (1, 64, 128, 1, 32), (3, 8, 128, 5, 32)])
+def test_conv3d_winograd_f4x4_per_depth_tap(device, B, Cin, Cout, D, H, monkeypatch):
+    """The VQ-VAE residual-unit convolutions as 2-D F(4x4, 3x3) per depth tap (conv_wino44.hip, 3-D form): slices of >= 32
+    tiles, chunk stream = (depth tap, channel chunk), zeros for the taps outside the volume (D = 1: centre tap only), ReLU /
+    residual epilogue.  Against F.conv3d at the F(4x4) tolerance, and really a different kernel from the F(2x2) one."""
+    monkeypatch.setenv("DDPM_CONV_WINO44", "2")  # also for launches smaller than the chip
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(B, Cin, D, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(Cin * 27)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, D, H, H, generator=g)
+    d = lambda t: t.to(device)
+    u, v = ops.pack_wino3d_weight(d(w)), ops.pack_wino44_3d_weight(d(w))
+    assert v is not None and v.numel() == 3 * 36 * Cout * Cin
+    ref = F.relu(F.conv3d(x, w, b, padding=1) + res)
+    y = ops.conv3d(d(x), d(w), d(b), residual=d(res), out_act=ops.ACT_RELU, wino=u, wino44=v)
+    y2 = ops.conv3d(d(x), d(w), d(b), residual=d(res), out_act=ops.ACT_RELU, wino=u)
+    torch.cuda.synchronize()
+    assert not torch.equal(y, y2)  # the F(4x4) kernel really ran
+    for got, want in ((y, ref), (ops.conv3d(d(x), d(w), d(b), wino=u, wino44=v), F.conv3d(x, w, b, padding=1))):
+        err = got.cpu() - want
+        assert err.abs().max().item() < 2e-4 * (1 + want.abs().max().item()), err.abs().max().item()
+        assert err.pow(2).mean().sqrt().item() < 1e-5 * (1 + want.pow(2).mean().sqrt().item())
+    assert torch.equal(y, ops.conv3d(d(x), d(w), d(b), residual=d(res), out_act=ops.ACT_RELU, wino=u, wino44=v))
+    if B > 1:  # sub-batch walk past the 2 GiB addressing limit: same result, bit for bit
+        old = ops.WINO_MAX_TENSOR_BYTES
+        try:
+            ops.WINO_MAX_TENSOR_BYTES = max(Cin, Cout) * D * H * H * 4  # one volume per launch
+            assert torch.equal(ops.conv3d(d(x), d(w), d(b), residual=d(res), out_act=ops.ACT_RELU, wino=u, wino44=v), y)
+        finally:
+            ops.WINO_MAX_TENSOR_BYTES = old
+
+
 WINO44_CASES = [
     # B, C1, C2, Cout, H, gn, chan_add, residual
     (2, 64, 0, 64, 32, False, False, False),      # plain: 2 parts per image, one cout tile
@@ -528,6 +563,54 @@ def test_conv_winograd_f4x4(device, case, monkeypatch):
     assert err.abs().max().item() < 2e-4 * (1 + ref.abs().max().item()), err.abs().max().item()
     assert err.pow(2).mean().sqrt().item() < 1e-5 * (1 + ref.pow(2).mean().sqrt().item())
     assert torch.equal(y, ops.conv(d(x), d(w), d(b), wino44=w44, **kw))  # no dependence on leftover LDS state
+
+
+WINO44_SPLIT_CASES = [
+    # B, C1, C2, Cout, H, residual: fewer F(4x4) items than the 256 CUs -> the channel stream of an item is split over 2 / 4
+    # workgroups (partial slabs in scratch + the reduce pass)
+    (256, 256, 0, 256, 8, True),      # the 8x8 level of cfg2 at B = 256: 128 items, S = 2
+    (251, 256, 256, 256, 8, False),   # virtual concat, ragged last item
+    (128, 128, 0, 256, 8, True),      # 64 items, S = 4
+    (255, 128, 128, 128, 16, True),   # 2 x 128 items (ragged) = 256: not split; 127 images: 2 x 64 items, S = 2
+    (127, 128, 128, 128, 16, True),
+]
+
+
+@pytest.mark.parametrize("case", WINO44_SPLIT_CASES)
+def test_conv_winograd_f4x4_channel_split(device, case, monkeypatch):
+    """F(4x4) launches with fewer items than CUs: S workgroups share an item's channel stream; slabs added in a fixed
+    order by the reduce pass together with bias / temb / residual.  Same tolerance as the unsplit kernel."""
+    monkeypatch.delenv("DDPM_CONV_WINO44", raising=False)
+    monkeypatch.delenv("DDPM_WINO44_SPLIT", raising=False)
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, Cout, H, res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    Cin = C1 + C2
+    x = torch.randn(B, C1, H, H, generator=g)
+    x2 = torch.randn(B, C2, H, H, generator=g) * 1.5 + 0.3 if C2 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    gamma = torch.randn(Cin, generator=g) * 0.2 + 1
+    beta = torch.randn(Cin, generator=g) * 0.2
+    chan_add = torch.randn(B, Cout + 64, generator=g)
+    residual = torch.randn(B, Cout, H, H, generator=g) if res else None
+    ref = _ref_conv(x, x2, w, b, (gamma, beta, 32, 1e-6), True, 0, chan_add[:, 32:32 + Cout], residual)
+    d = lambda t: None if t is None else t.to(device)
+    gs, gh = ops.gn_scale_shift(d(x), d(gamma), d(beta), 32, 1e-6, x2=d(x2))
+    w44, w22 = ops.pack_wino44_weight(d(w)), ops.pack_wino_weight(d(w))
+    kw = dict(x2=d(x2), gscale=gs, gshift=gh, act=1, chan_add=d(chan_add), chan_add_offset=32, residual=d(residual))
+    y = ops.conv(d(x), d(w), d(b), wino44=w44, wino=w22, **kw)
+    monkeypatch.setenv("DDPM_WINO44_SPLIT", "0")  # no split: the launch falls to the F(2x2) kernel
+    y_f2 = ops.conv(d(x), d(w), d(b), wino44=w44, wino=w22, **kw)
+    monkeypatch.delenv("DDPM_WINO44_SPLIT")
+    torch.cuda.synchronize()
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert not torch.equal(y, y_f2)  # the split F(4x4) launch really ran
+    err = (y.cpu() - ref)
+    assert err.abs().max().item() < 2e-4 * (1 + ref.abs().max().item()), err.abs().max().item()
+    assert err.pow(2).mean().sqrt().item() < 1e-5 * (1 + ref.pow(2).mean().sqrt().item())
+    assert torch.equal(y, ops.conv(d(x), d(w), d(b), wino44=w44, wino=w22, **kw))  # fixed slab order: bit-reproducible
 
 
 WINO_STREAM_CASES = [

@@ -12,7 +12,9 @@ from ddpm_ood_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 SHAPES = [(256, 128, 0, 128, 32), (256, 256, 128, 128, 32), (256, 256, 0, 256, 16), (256, 256, 256, 256, 16),
-          (256, 256, 0, 256, 8)]
+          (256, 256, 0, 256, 8), (256, 256, 256, 256, 8)]
+if len(sys.argv) > 1:  # batch size of every shape, e.g. 16 for the small-batch regime
+    SHAPES = [(int(sys.argv[1]),) + s[1:] for s in SHAPES]
 tot = 0.0
 for B, C1, C2, Cout, H in SHAPES:
     Cin = C1 + C2
@@ -43,4 +45,4 @@ for B, C1, C2, Cout, H in SHAPES:
     fl = 2.0 * B * H * H * Cout * Cin * 9
     print(f"{C1}+{C2}->{Cout}@{H}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.2f} alg TFLOP/s  ({fl / ms / 1e9 * 16 / 36 / 157.3:.3f} of MFMA peak)  "
           f"err vs direct {err:.1e}", flush=True)
-print(f"WAVES={os.environ.get('DDPM_WINO_WAVES', '8')} WINO44={os.environ.get('DDPM_CONV_WINO44', '1')} total {tot * 1e3:.1f} us", flush=True)
+print(f"WAVES={os.environ.get('DDPM_WINO_WAVES', '8')} WINO44={os.environ.get('DDPM_CONV_WINO44', '1')} SPLIT44={os.environ.get('DDPM_WINO44_SPLIT', '4')} total {tot * 1e3:.1f} us", flush=True)
