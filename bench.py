@@ -150,11 +150,13 @@ MFMA_KERNELS = [
     ("conv3x3_wino_up", "conv_wino_up_kernel: nearest-x2 + 3x3 conv in the Winograd domain (9 of 16 positions), fp32 MFMA", 9.0 / 36.0),
     ("conv3x3_wino", "conv_wino_kernel: 3x3 conv as Winograd F(2x2,3x3), persistent, GN+SiLU prologue, fp32 MFMA", 16.0 / 36.0),
     ("conv3x3_mfma_up_folded", "conv_mfma_kernel<4>: nearest-x2 + 3x3 conv folded into four 2x2-tap convs, fp32 MFMA", 16.0 / 36.0),
+    ("conv3d_wino44", "conv_wino44_kernel, 3-D: Winograd F(4x4,3x3) per depth tap (36 of 144 multiplies), taps accumulated in the transform domain, fp32 MFMA", 36.0 / 144.0),
     ("conv3d_wino", "conv_wino_kernel, 3-D: Winograd F(2x2,3x3) per depth tap, taps accumulated in the transform domain, fp32 MFMA", 16.0 / 36.0),
     ("conv3d_", "conv_mfma_kernel: 3-D convolution (depth taps merged into one chunk stream), fp32 MFMA", 1.0),
     ("conv3x3_mfma", "conv_mfma_kernel<9>: direct 3x3 conv (stride 2, ragged extents, 3-D depth-tap launches), fp32 MFMA", 1.0),
     ("conv1x1_dma", "conv1x1_dma_kernel: LDS-DMA-fed 1x1 conv, fp32 MFMA", 1.0),
     ("conv1x1_mfma", "conv_mfma_kernel<1>: 1x1 conv / Linear (fused QKV, time MLP), fp32 MFMA", 1.0),
+    ("lpips_conv_mfma", "lpips_conv_mfma_kernel: AlexNet 5x5 layer of the 2.5-D LPIPS as an implicit GEMM, fp32 MFMA", 1.0),
     ("attention", "attention_kernel: QK^T, online softmax, AV (+ residual), fp32 MFMA", 1.0),
 ]
 

@@ -88,6 +88,10 @@ SIGNATURES = {
     "ddpm_vq_nearest_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "ddpm_lpips_conv_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 10 + [C.c_void_p]),
     "ddpm_maxpool3s2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_lpips_conv_biasmap_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 9 + [C.c_void_p]),
+    "ddpm_lpips_conv_mfma_supported": (C.c_int, [C.c_int] * 5),
+    "ddpm_lpips_pack_conv_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_lpips_conv_mfma_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
     "ddpm_lpips_layer_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "ddpm_prof_enable": (C.c_int, [C.c_int]),
     "ddpm_prof_report": (C.c_int, [C.c_char_p, C.c_size_t]),

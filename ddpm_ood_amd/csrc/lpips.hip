@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void lpips_conv_kernel(const float *__restrict
                                                          const float *__restrict__ in_scale,
                                                          const float *__restrict__ in_shift, float *__restrict__ out,
                                                          int N, int Cx, int Cin, int H, int W, int Cout, int Ho, int Wo,
-                                                         int k, int stride, int pad, int relu) {
+                                                         int k, int stride, int pad, int relu,
+                                                         const float *__restrict__ bias_map) {
   const int64_t pos = blockIdx.x * (int64_t)256 + threadIdx.x;  // (n, ho, wo)
   const int co0 = blockIdx.y * kLpCob;
   const int HWo = Ho * Wo;
@@ -34,7 +35,8 @@ __global__ __launch_bounds__(256) void lpips_conv_kernel(const float *__restrict
   const int h0 = ho * stride - pad, w0 = wo * stride - pad;
   float acc[kLpCob];
 #pragma unroll
-  for (int j = 0; j < kLpCob; ++j) acc[j] = (co0 + j < Cout && bias) ? bias[co0 + j] : 0.f;
+  for (int j = 0; j < kLpCob; ++j)  // bias_map: a per-position bias [Cout][Ho * Wo] (the folded grey first layer)
+    acc[j] = co0 + j >= Cout ? 0.f : bias_map ? bias_map[(size_t)(co0 + j) * HWo + p] : bias ? bias[co0 + j] : 0.f;
   for (int ci = 0; ci < Cin; ++ci) {
     const float *plane = in + ((size_t)n * Cx + (Cx == Cin ? ci : 0)) * H * W;  // 1-channel input feeds all three
     const float a = in_scale ? in_scale[ci] : 1.f, b = in_shift ? in_shift[ci] : 0.f;
@@ -98,9 +100,147 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float *__restric
   if (tid == 0) out[n] = accumulate ? out[n] + tot : tot;
 }
 
+// ---- the 5x5 layer on the fp32 MFMA pipe -------------------------------------------------------------------------------
+// For 2.5-D LPIPS over 128^3 volumes (cfg5: 128 slices x 3 views x 2 inputs per volume and t-start) the 5x5 layer
+// (64 -> 192 over 15 x 15) is 35 GFLOP per call and the scalar kernel above ran it at 9 TFLOP/s -- a quarter of a
+// cfg5 step.  Same-padded k x k stride-1 convolution as an implicit GEMM on v_mfma_f32_32x32x2_f32:
+//   one workgroup = one image, its whole input (all Cin planes with a zero halo) staged once in LDS (Cin * PS floats,
+//   PS = 32 mod 64 so that the two channel planes a wave reads at once sit on disjoint banks);
+//   A = weights, packed [cout block of 32][channel pair][tap][lhi][cout]: one coalesced 256-byte load per (pair, tap),
+//       held in registers for a whole channel pair and prefetched one pair ahead;
+//   B = pixels straight from the LDS planes (lane = pixel of a 32-pixel tile, lhi = channel of the pair);
+//   a wave owns one cout block x 4 pixel tiles (4 accumulator tiles); 12 waves = 192 couts x 8 tiles for AlexNet at 128^2.
+// Channels are accumulated in ascending order, taps in row-major order inside a channel pair (fp32 MFMA = fmaf chain).
+constexpr int kL5Tiles = 4;   // pixel tiles (of 32) per wave
+constexpr int kL5Threads = 768;
+
+typedef float l5_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KS>
+__global__ __launch_bounds__(kL5Threads) void lpips_conv_mfma_kernel(const float *__restrict__ in,
+                                                                     const float *__restrict__ wp,
+                                                                     const float *__restrict__ bias,
+                                                                     float *__restrict__ out, int Cin, int H, int W,
+                                                                     int Cout, int PS, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float l5_smem[];
+  constexpr int KK = KS * KS, PAD = KS / 2;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int HW = H * W, WP = W + 2 * PAD;
+  for (int i = tid; i < Cin * PS; i += kL5Threads) l5_smem[i] = 0.f;
+  __syncthreads();
+  const float *src = in + (size_t)n * Cin * HW;
+  for (int i = tid; i < Cin * HW; i += kL5Threads) {
+    const int c = i / HW, p = i - c * HW;
+    const int y = p / W, x = p - y * W;
+    l5_smem[c * PS + (y + PAD) * WP + x + PAD] = src[i];
+  }
+  __syncthreads();
+  const int ncb = Cout / 32, nt = (HW + 31) / 32, ngrp = (nt + kL5Tiles - 1) / kL5Tiles, nkk = Cin / 2;
+  for (int u = wave; u < ncb * ngrp; u += kL5Threads / 64) {
+    const int cb = u % ncb, grp = u / ncb;
+    int pb[kL5Tiles];  // LDS float index of this lane's pixel (tap 0, 0) in channel plane lhi
+#pragma unroll
+    for (int t = 0; t < kL5Tiles; ++t) {
+      const int p = min((grp * kL5Tiles + t) * 32 + l31, HW - 1);
+      const int y = p / W, x = p - y * W;
+      pb[t] = lhi * PS + y * WP + x;
+    }
+    l5_f32x16 acc[kL5Tiles];
+#pragma unroll
+    for (int t = 0; t < kL5Tiles; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const float *wq = wp + (size_t)cb * nkk * KK * 64 + lane;
+    float a_cur[KK], a_nxt[KK];
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) a_cur[tap] = wq[tap * 64];
+    for (int kk = 0; kk < nkk; ++kk) {
+      const float *wn = wq + (size_t)min(kk + 1, nkk - 1) * KK * 64;
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap) a_nxt[tap] = wn[tap * 64];
+      const float *plane = l5_smem + 2 * kk * PS;
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap) {
+        const int toff = (tap / KS) * WP + tap % KS;
+#pragma unroll
+        for (int t = 0; t < kL5Tiles; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[tap], plane[pb[t] + toff], acc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap) a_cur[tap] = a_nxt[tap];
+    }
+    // D: lane = pixel l31, register r = cout 8 (r / 4) + 4 lhi + r % 4 of the block
+#pragma unroll
+    for (int t = 0; t < kL5Tiles; ++t) {
+      const int p = (grp * kL5Tiles + t) * 32 + l31;
+      if (p < HW) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cb * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+          const float v = acc[t][r] + (bias ? bias[co] : 0.f);
+          out[((size_t)n * Cout + co) * HW + p] = relu ? fmaxf(v, 0.f) : v;
+        }
+      }
+    }
+  }
+}
+
+// torch [Cout][Cin][k][k] -> [cout block][channel pair][tap][lhi][cout of 32]
+__global__ void lpips_pack_conv_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int KK) {
+  const int64_t total = (int64_t)Cout * Cin * KK;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % KK), ci = (int)((i / KK) % Cin), co = (int)(i / ((int64_t)KK * Cin));
+    wp[((((size_t)(co / 32) * (Cin / 2) + ci / 2) * KK + tap) * 2 + (ci & 1)) * 32 + co % 32] = w[i];
+  }
+}
+
+static int l5_plane(int H, int W, int k) {  // floats per padded channel plane, = 32 mod 64
+  const int ps = (H + k - 1) * (W + k - 1);
+  return ps + ((32 - ps) % 64 + 64) % 64;
+}
+
+bool lpips_conv_mfma_supported(int Cin, int H, int W, int Cout, int k) {
+  if (k != 5 && k != 3) return false;
+  if (Cin < 2 || Cin % 2 || Cout % 32 || H < 1 || W < 1 || H * W < 64) return false;  // tiny images: the scalar kernel
+  return (size_t)Cin * l5_plane(H, W, k) * sizeof(float) <= 160 * 1024;
+}
+
+int launch_lpips_pack_conv(const float *w, float *wp, int Cout, int Cin, int k, hipStream_t s) {
+  DDPM_CHECK_ARG(w && wp && Cout > 0 && Cout % 32 == 0 && Cin > 0 && Cin % 2 == 0 && k > 0, "lpips pack: bad arguments");
+  const int64_t total = (int64_t)Cout * Cin * k * k;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(lpips_pack_conv_kernel, dim3(blocks), dim3(256), 0, s, w, wp, Cout, Cin, k * k);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_lpips_conv_mfma(const float *in, const float *wp, const float *bias, float *out, int N, int Cin, int H, int W,
+                           int Cout, int k, int relu, hipStream_t s) {
+  DDPM_CHECK_ARG(in && wp && out && N > 0, "lpips_conv_mfma: null pointer");
+  DDPM_CHECK_ARG(lpips_conv_mfma_supported(Cin, H, W, Cout, k), "lpips_conv_mfma: unsupported shape");
+  const int PS = l5_plane(H, W, k);
+  const size_t lds = (size_t)Cin * PS * sizeof(float);
+  typedef void (*kern_t)(const float *, const float *, const float *, float *, int, int, int, int, int, int);
+  kern_t kern = k == 5 ? lpips_conv_mfma_kernel<5> : lpips_conv_mfma_kernel<3>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lpips_conv_mfma_kernel<5>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lpips_conv_mfma_kernel<3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const double npos = (double)N * H * W;
+  ProfScope prof(s, "lpips_conv_mfma", 2.0 * npos * Cout * Cin * k * k, 4.0 * (npos * Cin + npos * Cout + (double)Cout * Cin * k * k));
+  hipLaunchKernelGGL(kern, dim3(N), dim3(kL5Threads), lds, s, in, wp, bias, out, Cin, H, W, Cout, PS, relu);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
 int launch_lpips_conv(const float *in, const float *w, const float *bias, const float *in_scale, const float *in_shift,
                       float *out, int N, int Cx, int Cin, int H, int W, int Cout, int k, int stride, int pad, int relu,
-                      hipStream_t s) {
+                      hipStream_t s, const float *bias_map = nullptr) {
   DDPM_CHECK_ARG(in && w && out, "lpips_conv: null pointer");
   DDPM_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && k > 0 && stride > 0 && pad >= 0, "lpips_conv: bad shape");
   DDPM_CHECK_ARG(Cx == Cin || Cx == 1, "lpips_conv: the input has %d channels, the layer wants %d (or 1, broadcast)", Cx, Cin);
@@ -109,7 +249,7 @@ int launch_lpips_conv(const float *in, const float *w, const float *bias, const 
   const int64_t npos = (int64_t)N * Ho * Wo;
   ProfScope prof(s, "lpips_conv", 2.0 * npos * Cout * Cin * k * k, 4.0 * ((double)N * Cx * H * W + (double)npos * Cout));
   hipLaunchKernelGGL(lpips_conv_kernel, dim3((unsigned)((npos + 255) / 256), (Cout + kLpCob - 1) / kLpCob), dim3(256), 0, s,
-                     in, w, bias, in_scale, in_shift, out, N, Cx, Cin, H, W, Cout, Ho, Wo, k, stride, pad, relu);
+                     in, w, bias, in_scale, in_shift, out, N, Cx, Cin, H, W, Cout, Ho, Wo, k, stride, pad, relu, bias_map);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
@@ -142,6 +282,26 @@ extern "C" int ddpm_lpips_conv_f32(const float *in, const float *w, const float 
                                    int k, int stride, int pad, int relu, ddpm_stream_t stream) {
   return launch_lpips_conv(in, w, bias, in_scale, in_shift, out, N, Cx, Cin, H, W, Cout, k, stride, pad, relu,
                            as_stream(stream));
+}
+
+extern "C" int ddpm_lpips_conv_biasmap_f32(const float *in, const float *w, const float *bias_map, float *out, int N, int Cin,
+                                           int H, int W, int Cout, int k, int stride, int pad, int relu, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(bias_map != nullptr, "lpips_conv_biasmap: bias_map is NULL");
+  return launch_lpips_conv(in, w, nullptr, nullptr, nullptr, out, N, Cin, Cin, H, W, Cout, k, stride, pad, relu,
+                           as_stream(stream), bias_map);
+}
+
+extern "C" int ddpm_lpips_conv_mfma_supported(int Cin, int H, int W, int Cout, int k) {
+  return lpips_conv_mfma_supported(Cin, H, W, Cout, k) ? 1 : 0;
+}
+
+extern "C" int ddpm_lpips_pack_conv_weight_f32(const float *w, float *w_packed, int Cout, int Cin, int k, ddpm_stream_t stream) {
+  return launch_lpips_pack_conv(w, w_packed, Cout, Cin, k, as_stream(stream));
+}
+
+extern "C" int ddpm_lpips_conv_mfma_f32(const float *in, const float *w_packed, const float *bias, float *out, int N, int Cin,
+                                        int H, int W, int Cout, int k, int relu, ddpm_stream_t stream) {
+  return launch_lpips_conv_mfma(in, w_packed, bias, out, N, Cin, H, W, Cout, k, relu, as_stream(stream));
 }
 
 extern "C" int ddpm_maxpool3s2_f32(const float *in, float *out, int64_t planes, int H, int W, ddpm_stream_t stream) {

@@ -420,6 +420,49 @@ def lpips_conv(x, weight, bias, stride: int, pad: int, relu: bool = True, in_sca
     return out
 
 
+def lpips_conv_biasmap(x, weight, bias_map, stride: int, pad: int, relu: bool = True):
+    """relu(conv2d(x, weight, None, stride, pad) + bias_map[None]); bias_map: [Cout, Ho, Wo]."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    w = require_device_f32(weight, "weight")
+    bias_map = require_device_f32(bias_map, "bias_map")
+    N, cin, H, W = x.shape
+    cout, _, k, _ = w.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if tuple(bias_map.shape[-3:]) != (cout, Ho, Wo) or w.shape[1] != cin:
+        raise ValueError(f"lpips_conv_biasmap: bias_map {tuple(bias_map.shape)} / weight {tuple(w.shape)} do not fit the input")
+    out = torch.empty((N, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(lib.ddpm_lpips_conv_biasmap_f32(ptr(x), ptr(w), ptr(bias_map), ptr(out), N, cin, H, W, cout, k, stride, pad,
+                                          int(relu), stream_ptr()), "lpips_conv_biasmap")
+    return out
+
+
+def lpips_pack_conv_weight(weight):
+    """torch [Cout, Cin, k, k] -> the MFMA operand layout of lpips_conv_mfma (Cout % 32 == 0, Cin % 2 == 0)."""
+    lib = _lib.load()
+    w = require_device_f32(weight, "weight")
+    cout, cin, k, _ = w.shape
+    out = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    check(lib.ddpm_lpips_pack_conv_weight_f32(ptr(w), ptr(out), cout, cin, k, stream_ptr()), "lpips_pack_conv_weight")
+    return out
+
+
+def lpips_conv_mfma_supported(cin: int, h: int, w: int, cout: int, k: int) -> bool:
+    return bool(_lib.load().ddpm_lpips_conv_mfma_supported(cin, h, w, cout, k))
+
+
+def lpips_conv_mfma(x, packed, bias, cout: int, k: int, relu: bool = True):
+    """relu(conv2d(x, w, bias, stride 1, padding k // 2)) on the fp32 MFMA pipe; packed = lpips_pack_conv_weight(w)."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    N, cin, H, W = x.shape
+    out = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device)
+    bias = None if bias is None else require_device_f32(bias, "bias")
+    check(lib.ddpm_lpips_conv_mfma_f32(ptr(x), ptr(packed), ptr(bias), ptr(out), N, cin, H, W, cout, k, int(relu),
+                                       stream_ptr()), "lpips_conv_mfma")
+    return out
+
+
 def maxpool3s2(x):
     """MaxPool2d(3, 2)."""
     lib = _lib.load()

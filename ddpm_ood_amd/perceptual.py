@@ -17,6 +17,7 @@ the ``perceptual_difference`` column is then NOT an LPIPS value, only ``mse`` is
 
 from __future__ import annotations
 
+import os
 from typing import Dict, Tuple
 
 import torch
@@ -127,9 +128,34 @@ class LPIPS(nn.Module):
         b = ((-1.0 if normalize else 0.0) - shift) / scale
         convs = [self.net.slice1[0], self.net.slice2[1], self.net.slice3[1], self.net.slice4[0], self.net.slice5[0]]
         outs = []
-        h = ops.lpips_conv(x, convs[0].weight, convs[0].bias, 4, 2, True, a.contiguous(), b.contiguous())
+        c0 = convs[0]
+        if x.shape[1] == 1 and x.shape[0] >= 64:
+            # grey slices in bulk (2.5-D LPIPS): the 1 -> 3 broadcast and the per-channel affine fold into one input
+            # channel, conv(a_c x + b_c) = (sum_c a_c w_c) * x + [(sum_c b_c w_c) * inside + bias] -- a third of the
+            # multiplies; the bracket does not depend on the image (a per-position bias map, computed once per shape
+            # by the general kernel on a zero image)
+            key = ("c0", c0.weight.data_ptr(), c0.weight._version, bool(normalize), tuple(x.shape[2:]), str(x.device))
+            fold = self._packed.get("c0")
+            if fold is None or fold[0] != key:
+                wa = (c0.weight.detach() * a[None, :, None, None]).sum(1, keepdim=True).contiguous()
+                zero = torch.zeros((1, 1) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+                bmap = ops.lpips_conv(zero, c0.weight, c0.bias, 4, 2, False, a.contiguous(), b.contiguous())[0]
+                fold = self._packed["c0"] = (key, wa, bmap.contiguous())
+            h = ops.lpips_conv_biasmap(x, fold[1], fold[2], 4, 2, True)
+        else:
+            h = ops.lpips_conv(x, c0.weight, c0.bias, 4, 2, True, a.contiguous(), b.contiguous())
         outs.append(h)
-        h = ops.lpips_conv(ops.maxpool3s2(h), convs[1].weight, convs[1].bias, 1, 2, True)
+        h = ops.maxpool3s2(h)
+        c1 = convs[1]
+        if ops.lpips_conv_mfma_supported(c1.weight.shape[1], h.shape[2], h.shape[3], c1.weight.shape[0], 5):
+            # maps of >= 64 pixels (2.5-D LPIPS over volumes): the 5x5 layer on the fp32 MFMA pipe
+            key = ("l5", id(c1), c1.weight.data_ptr(), c1.weight._version)
+            packed = self._packed.get("l5")
+            if packed is None or packed[0] != key or packed[1].device != h.device:
+                packed = self._packed["l5"] = (key, ops.lpips_pack_conv_weight(c1.weight.detach()))
+            h = ops.lpips_conv_mfma(h, packed[1], c1.bias, c1.weight.shape[0], 5, True)
+        else:
+            h = ops.lpips_conv(h, c1.weight, c1.bias, 1, 2, True)
         outs.append(h)
         h = ops.maxpool3s2(h)
         for c in convs[2:]:
@@ -198,8 +224,12 @@ class PerceptualLoss(nn.Module):
         y = y.float()
         y_pred = y_pred.float()
         if self.dimensions == 3 and self.fake_3D_views:
+            # Reference quirk Q7 (perceptual_loss.py:112-122): the loop ASSIGNS `loss` per view, so only the last view
+            # reaches the caller.  The earlier views are dead stores -- same returned value with or without them -- and
+            # are not computed here; DDPM_LPIPS_ALL_VIEWS=1 computes them anyway (the reference's literal work).
+            views = self.fake_3D_views if os.environ.get("DDPM_LPIPS_ALL_VIEWS", "0") == "1" else self.fake_3D_views[-1:]
             loss = torch.zeros(())
-            for permute_dims, view_dims in self.fake_3D_views:  # reference quirk Q7: the last view wins
+            for permute_dims, view_dims in views:
                 loss = self._calculate_fake_3d_loss(y, y_pred, permute_dims, view_dims) * self.perceptual_factor
             return loss
         return self.perceptual_function.forward(y, y_pred, normalize=self.lpips_normalize) * self.perceptual_factor

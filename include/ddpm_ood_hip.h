@@ -229,6 +229,23 @@ int ddpm_lpips_conv_f32(const float *in, const float *w, const float *bias, cons
                         const float *in_shift, float *out, int N, int Cx, int Cin, int H, int W, int Cout, int k,
                         int stride, int pad, int relu, ddpm_stream_t stream);
 
+/* The same convolution with a per-position bias: out = relu?(conv2d(in, w, stride, pad) + bias_map[Cout, Ho, Wo]).  Used for
+ * the first AlexNet layer over GREY images: the ScalingLayer's 1 -> 3 broadcast and per-channel affine fold into ONE input
+ * channel, conv(a_c x + b_c) = (sum_c a_c w_c) * x + (sum_c b_c w_c) * [inside the image] -- a third of the multiplies; the
+ * second term (+ bias) does not depend on the image and is the bias map (it differs from a constant only at the border).  */
+int ddpm_lpips_conv_biasmap_f32(const float *in, const float *w, const float *bias_map, float *out, int N, int Cin, int H,
+                                int W, int Cout, int k, int stride, int pad, int relu, ddpm_stream_t stream);
+
+/* The same-padded stride-1 k x k layers (k = 5: AlexNet's second layer, 64 -> 192; k = 3) on the fp32 MFMA pipe, for images
+ * of at least 64 pixels whose Cin zero-haloed planes fit the 160 KB LDS (2.5-D LPIPS over 128^3 volumes runs the 5 x 5
+ * layer over 15 x 15 maps 2 x 128 x 3 times per volume and t-start).  w_packed: Cout * Cin * k * k floats written by
+ * ddpm_lpips_pack_conv_weight_f32 from the torch [Cout, Cin, k, k] layout (Cout % 32 == 0, Cin % 2 == 0).
+ * out[N,Cout,H,W] = relu?(conv2d(in[N,Cin,H,W], w, padding = k / 2) + bias).                                             */
+int ddpm_lpips_conv_mfma_supported(int Cin, int H, int W, int Cout, int k);
+int ddpm_lpips_pack_conv_weight_f32(const float *w, float *w_packed, int Cout, int Cin, int k, ddpm_stream_t stream);
+int ddpm_lpips_conv_mfma_f32(const float *in, const float *w_packed, const float *bias, float *out, int N, int Cin, int H,
+                             int W, int Cout, int k, int relu, ddpm_stream_t stream);
+
 /* MaxPool2d(kernel 3, stride 2, no padding) over `planes` = N * C planes of H x W. */
 int ddpm_maxpool3s2_f32(const float *in, float *out, int64_t planes, int H, int W, ddpm_stream_t stream);
 

@@ -571,8 +571,7 @@ WINO44_SPLIT_CASES = [
     (256, 256, 0, 256, 8, True),      # the 8x8 level of cfg2 at B = 256: 128 items, S = 2
     (251, 256, 256, 256, 8, False),   # virtual concat, ragged last item
     (128, 128, 0, 256, 8, True),      # 64 items, S = 4
-    (255, 128, 128, 128, 16, True),   # 2 x 128 items (ragged) = 256: not split; 127 images: 2 x 64 items, S = 2
-    (127, 128, 128, 128, 16, True),
+    (127, 128, 128, 128, 16, True),   # 2 x 64 items (ragged), S = 2
 ]
 
 
@@ -731,6 +730,35 @@ def test_lpips_conv(device, case):
     _close(y, ref, tol=2e-5)
 
 
+@pytest.mark.parametrize("case", [
+    # N, Cin, H, W, Cout, k
+    (6, 64, 15, 15, 192, 5),      # AlexNet layer 2 over a 128 x 128 slice: 8 pixel tiles, 6 cout blocks = 12 waves
+    (3, 64, 15, 11, 192, 5),      # non-square, ragged last pixel-tile group
+    (2, 64, 23, 23, 64, 5),       # 529 pixels: several units per wave
+    (2, 8, 9, 9, 32, 3),          # the 3 x 3 instantiation
+])
+def test_lpips_conv_mfma(device, case):
+    """The same-padded stride-1 LPIPS layers on the fp32 MFMA pipe (lpips.hip) vs F.conv2d."""
+    from ddpm_ood_amd import ops
+
+    N, Cin, H, W, Cout, k = case
+    assert ops.lpips_conv_mfma_supported(Cin, H, W, Cout, k)
+    assert not ops.lpips_conv_mfma_supported(64, 7, 7, 192, 5)  # tiny maps stay on the scalar kernel
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.rand(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, padding=k // 2)
+    d = lambda t: t.to(device)
+    packed = ops.lpips_pack_conv_weight(d(w))
+    y = ops.lpips_conv_mfma(d(x), packed, d(b), Cout, k, relu=False)
+    yr = ops.lpips_conv_mfma(d(x), packed, d(b), Cout, k, relu=True)
+    torch.cuda.synchronize()
+    _close(y, ref, tol=2e-5)
+    _close(yr, F.relu(ref), tol=2e-5)
+    _close(y, ops.lpips_conv(d(x), d(w), d(b), 1, k // 2, False).cpu(), tol=2e-5)  # and vs the scalar kernel
+
+
 def test_maxpool3s2(device):
     from ddpm_ood_amd import ops
 
@@ -759,9 +787,10 @@ def test_lpips_layer(device):
     _close(val, ref, tol=1e-5)
 
 
-@pytest.mark.parametrize("shape", [(7, 1, 32, 32), (3, 3, 64, 64), (2, 1, 128, 96)])
+@pytest.mark.parametrize("shape", [(7, 1, 32, 32), (3, 3, 64, 64), (2, 1, 128, 96), (70, 1, 128, 128), (66, 1, 32, 32)])
 def test_lpips_score_vs_oracle(device, shape):
-    """Whole LPIPS(normalize=True) on the HIP kernels vs the CPU oracle with the same weights."""
+    """Whole LPIPS(normalize=True) on the HIP kernels vs the CPU oracle with the same weights.  128-pixel maps take the MFMA
+    form of the 5x5 layer; grey batches of >= 64 images (2.5-D LPIPS over volumes) the folded one-channel first layer."""
     import oracle
     from ddpm_ood_amd.perceptual import LPIPS
 
@@ -775,6 +804,29 @@ def test_lpips_score_vs_oracle(device, shape):
     torch.cuda.synchronize()
     assert got.shape == want.shape
     _close(got, want, tol=2e-5)
+
+
+def test_perceptual_loss_3d_last_view_only(device, monkeypatch):
+    """2.5-D LPIPS over a volume: the reference's loop overwrites `loss` per view (quirk Q7), so only the last view is
+    returned.  The default path computes that view alone; DDPM_LPIPS_ALL_VIEWS=1 (all three, as the reference literally
+    does) returns the same bits; both match the oracle, which runs all three."""
+    import oracle
+    from ddpm_ood_amd.perceptual import PerceptualLoss
+
+    g = torch.Generator().manual_seed(8)
+    y, p = torch.rand(1, 1, 64, 48, 40, generator=g), torch.rand(1, 1, 64, 48, 40, generator=g)
+    hip = PerceptualLoss(dimensions=3, lpips_kwargs={"seed": 5})
+    ref = oracle.PerceptualLoss(dimensions=3)
+    ref.perceptual_function.load_state_dict(hip.perceptual_function.state_dict())
+    want = ref(y, p)
+    hip = hip.to(device)
+    monkeypatch.delenv("DDPM_LPIPS_ALL_VIEWS", raising=False)
+    got = hip(y.to(device), p.to(device))
+    monkeypatch.setenv("DDPM_LPIPS_ALL_VIEWS", "1")
+    got_all = hip(y.to(device), p.to(device))
+    torch.cuda.synchronize()
+    assert torch.equal(got, got_all)
+    _close(got.reshape(()), want.reshape(()), tol=2e-5)
 
 
 CONV1X1_DMA_CASES = [

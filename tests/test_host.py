@@ -382,9 +382,12 @@ def test_bench_roofline_object_is_the_executed_mfma_fraction():
             "attention": {"launches": 4, "ms": 0.1, "flops": 4 * 0.1e9, "bytes": 1e8},
             "conv3d_wino": {"launches": 1, "ms": 2.0, "flops": 3.4e11, "bytes": 1e9},
             "conv3d_k3": {"launches": 1, "ms": 1.0, "flops": 1e11, "bytes": 1e9},
+            "conv3d_wino44": {"launches": 1, "ms": 2.0, "flops": 3.4e11, "bytes": 1e9},
             "gn_scale_shift": {"launches": 27, "ms": 0.5, "flops": 1e9, "bytes": 2e9}}
     r = bench.rooflines_of(prof)
-    assert set(r) == {"conv3x3_wino", "conv3x3_wino44", "conv3x3_wino_up", "attention", "conv3d_wino", "conv3d_"}  # MFMA classes only
+    assert set(r) == {"conv3x3_wino", "conv3x3_wino44", "conv3x3_wino_up", "attention", "conv3d_wino", "conv3d_wino44",
+                      "conv3d_"}  # MFMA classes only
+    assert r["conv3d_wino44"]["executed_over_algorithmic_flops"] == 0.25
     assert abs(r["conv3x3_wino44"]["achieved"] - 12 * 100e9 / 4e-3 / 1e12 * 36 / 144) < 0.01  # F(4x4): a quarter of the multiplies
     w = r["conv3x3_wino"]
     alg = 10 * 66.8e9 / 3.0e-3 / 1e12
