@@ -118,8 +118,9 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   if (d.ksize != 3 || (!is3d && (d.Di > 1 || d.Do > 1))) return false;
   if (d.out_act != DDPM_ACT_NONE && !(is3d && d.out_act == DDPM_ACT_RELU)) return false;
   if (d.mode != DDPM_CONV_NORMAL && d.mode != DDPM_CONV_UPSAMPLE2) return false;
-  // 3-D: stride 1, no GroupNorm / activation prologue (zero padding along the depth must stay zero), no concat
-  if (is3d && (d.mode != DDPM_CONV_NORMAL || d.gscale || d.act != DDPM_ACT_NONE || d.C2 || d.chan_add)) return false;
+  // 3-D: stride 1.  A depth tap outside the volume reads zero pixels AND zero GroupNorm scale / shift (out-of-range buffer
+  // offsets), so the padding stays zero through the SiLU prologue
+  if (is3d && d.mode != DDPM_CONV_NORMAL) return false;
   if (d.mode == DDPM_CONV_UPSAMPLE2 && d.out_act) return false;
   g.up = d.mode == DDPM_CONV_UPSAMPLE2;
   if (g.up && (d.gscale || d.act != DDPM_ACT_NONE || d.Ho != 2 * d.Hi || d.Wo != 2 * d.Wi)) return false;
@@ -153,7 +154,6 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   g.nch_c = Cin / kWC;
   g.kd0 = is3d && Dd == 1 ? 1 : 0;
   g.nkd = is3d && Dd > 1 ? 3 : 1;
-  if (is3d && g.TI != 1) return false;  // slices smaller than 64 tiles stay on the direct kernel
   g.nkd_w = is3d ? 3 : 1;
   g.nchunks = g.nkd * g.nch_c;
   g.HW = d.Ho * d.Wo;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
     tbase = plane_of(tch) * g.PCH + (ti * (2 * g.TR + 2) + 2 * tr) * g.PW + 2 * tc;
   }
-  const int bytes1 = a.B * a.C1 * (D3 ? g.CS : g.HW) * 4, bytes2 = a.B * a.C2 * g.HW * 4;
+  const int bytes1 = a.B * a.C1 * (D3 ? g.CS : g.HW) * 4, bytes2 = a.B * a.C2 * (D3 ? g.CS : g.HW) * 4;
   const __amdgpu_buffer_rsrc_t rs_sc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gscale), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_sh =
@@ -315,12 +315,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
   auto load_px = [&](int k, int n) {
     int ni = min(n + tik[k], g.NIMG - 1);
     int soff, voff = pix[k];
+    bool dok3 = true;
     if (D3) {  // image -> (batch item, slice); a depth tap outside the volume reads zeros: the range check of a raw buffer
                // load is on the VGPR offset, and 0x80000000 is past every resource (as for the halo pixels in pix[])
       const int nb = ni / g.D, dsl = ni - nb * g.D + l_kd;
       const bool dok = dsl >= 0 && dsl < g.D;
-      soff = ((nb * a.C1 + l_cg) * g.D + (dok ? dsl : 0)) * g.HW * 4;
+      soff = ((nb * l_cx + l_cgl) * g.D + (dok ? dsl : 0)) * g.HW * 4;
       if (!dok) voff = (int)0x80000000;
+      dok3 = dok;
       ni = nb;
     } else {
       soff = (ni * l_cx + l_cgl) * g.HW * 4;
@@ -328,8 +330,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ddpm_conv_desc 
     praw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(l_rs, voff, soff, 0));
     if (AFFINE && (!ONEIMG || k == 0)) {
       const int goff = (ni * g.Cin + l_cg) * 4;
-      gs[ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
-      gh[ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
+      const int gv = D3 && !dok3 ? (int)0x80000000 : vzero;  // tap outside the volume: scale = shift = 0 -> SiLU(0) = 0
+      gs[ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, gv, goff, 0));
+      gh[ONEIMG ? 0 : k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, gv, goff, 0));
     }
   };
   // stage A: round k -> pixel tile `pb` (float offset of the P buffer).  With the GroupNorm affine the SiLU argument
@@ -1238,17 +1241,21 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   }
   const int rounds = g.TI * g.NRI;
   kern_t kern = kerns[d.gscale ? 1 : 0][g.TI == 1 ? 1 : 0][rounds <= 4 ? 0 : rounds - 4];
-  if (d.dims == 3) {  // only reached without GroupNorm prologue and with whole slices per item (wino_geom)
-    static const kern_t kerns3d[3] = {conv_wino_kernel<false, 4, true, true>, conv_wino_kernel<false, 5, true, true>,
-                                      conv_wino_kernel<false, 6, true, true>};
+  if (d.dims == 3) {  // the same variants with the 3-D stream (VQ-VAE residual units: no prologue, whole slices per item;
+                      // 3-D UNet: GroupNorm + SiLU prologue, concat, four 8x8 slices per item)
+    static const kern_t kerns3d[2][2][3] = {
+        {{conv_wino_kernel<false, 4, false, true>, conv_wino_kernel<false, 5, false, true>, conv_wino_kernel<false, 6, false, true>},
+         {conv_wino_kernel<false, 4, true, true>, conv_wino_kernel<false, 5, true, true>, conv_wino_kernel<false, 6, true, true>}},
+        {{conv_wino_kernel<true, 4, false, true>, conv_wino_kernel<true, 5, false, true>, conv_wino_kernel<true, 6, false, true>},
+         {conv_wino_kernel<true, 4, true, true>, conv_wino_kernel<true, 5, true, true>, conv_wino_kernel<true, 6, true, true>}}};
     static bool attr3_done = false;
     if (!attr3_done) {
-      for (int i = 0; i < 3; ++i)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns3d[i]),
+      for (int i = 0; i < 12; ++i)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns3d[i / 6][i / 3 % 2][i % 3]),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr3_done = true;
     }
-    kern = kerns3d[rounds <= 4 ? 0 : rounds - 4];
+    kern = kerns3d[d.gscale ? 1 : 0][g.TI == 1 ? 1 : 0][rounds <= 4 ? 0 : rounds - 4];
   }
   // DDPM_WINO_WAVES=4: the one-wave-per-SIMD variant (A/B switch; see conv_wino4_kernel)
   static const bool four = getenv("DDPM_WINO_WAVES") && atoi(getenv("DDPM_WINO_WAVES")) == 4;
@@ -1286,7 +1293,7 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   // algorithmic work = the direct convolution's: 2*M*Cout*Cin*9 (*3 depth taps); 16/36 of it is executed
   const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9 * g.nkd;
   const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9 * g.nkd);
-  const char *kname = d.dims == 3 ? "conv3d_wino" : g.up ? "conv3x3_wino_up" : d.gscale ? "conv3x3_wino_gn_silu" : "conv3x3_wino";
+  const char *kname = d.dims == 3 ? (d.gscale ? "conv3d_wino_gn_silu" : "conv3d_wino") : g.up ? "conv3x3_wino_up" : d.gscale ? "conv3x3_wino_gn_silu" : "conv3x3_wino";
   char kshape[160];
   if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {
     snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);

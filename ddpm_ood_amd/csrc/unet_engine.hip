@@ -205,17 +205,19 @@ static ResRef build_res(ddpm_unet *u, const std::string &prefix, int Cin, int Co
   temb_cursor += Cout;
   r.n2 = u->add_gn(prefix + ".norm2", Cout);
   r.c2 = u->add_conv(prefix + ".conv2.conv", Cout, Cout, 3, false, u->cfg.spatial_dims);
-  if (u->cfg.spatial_dims == 2) {  // both 3x3 convs of a ResnetBlock are stride 1: Winograd-domain weights too
+  {  // both 3x3 convs of a ResnetBlock are stride 1: Winograd-domain weights too (3-D: one F(2x2) slab per depth tap)
+    const bool d3 = u->cfg.spatial_dims == 3;
     ConvRef *cr[2] = {&r.c1, &r.c2};
     const char *nm[2] = {".conv1.conv.weight", ".conv2.conv.weight"};
     for (int i = 0; i < 2; ++i) {
-      const size_t nw = wino_weight_floats(cr[i]->Cout, cr[i]->Cin);
+      const size_t nw = wino_weight_floats(cr[i]->Cout, cr[i]->Cin) * (d3 ? 3 : 1);
       if (!nw) continue;
       cr[i]->has_wino = true;
       cr[i]->w_wino = u->alloc(nw);
       ParamSlot &ps = u->params[u->index[prefix + nm[i]]];
       ps.has_wino = true;
       ps.wino_base = cr[i]->w_wino;
+      if (d3) continue;  // latent volumes (8^3) have no F(4x4) tiling
       if (const size_t n44 = wino44_weight_floats(cr[i]->Cout, cr[i]->Cin)) {
         cr[i]->has_wino44 = true;
         cr[i]->w_wino44 = u->alloc(n44);
@@ -405,7 +407,7 @@ extern "C" int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *
     if (rc) return rc;
   }
   if (p.has_wino) {
-    rc = launch_pack_wino_weight(src, h->blob + p.wino_base, p.Cout, p.Cin, s);
+    rc = launch_pack_wino_weight(src, h->blob + p.wino_base, p.Cout, p.Cin, s, p.dims == 3 ? 3 : 1);
     if (rc) return rc;
   }
   if (p.has_wino44) {
@@ -474,6 +476,7 @@ struct Runner {
     if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino && c.dims == 2)
       d.w_wino = P(c.w_wino);
     if (mode == DDPM_CONV_NORMAL && c.has_wino44 && c.dims == 2) d.w_wino44 = P(c.w_wino44);
+    if (c.dims == 3 && c.ksize == 3 && mode == DDPM_CONV_NORMAL && c.has_wino) d.w_wino = P(c.w_wino);  // F(2x2) per depth tap
     if (c.dims == 3 && c.ksize == 3) {
       // F.conv3d: ONE launch walks the (depth tap, channel group) chunks (w_packed = three depth slabs); a
       // volume of depth 1 (input depth <= 2^(levels-1)) only has its centre tap

@@ -734,7 +734,7 @@ def test_lpips_conv(device, case):
     # N, Cin, H, W, Cout, k
     (6, 64, 15, 15, 192, 5),      # AlexNet layer 2 over a 128 x 128 slice: 8 pixel tiles, 6 cout blocks = 12 waves
     (3, 64, 15, 11, 192, 5),      # non-square, ragged last pixel-tile group
-    (2, 64, 23, 23, 64, 5),       # 529 pixels: several units per wave
+    (2, 32, 23, 23, 64, 5),       # 529 pixels: 17 pixel tiles, 2 x 5 units over 12 waves
     (2, 8, 9, 9, 32, 3),          # the 3 x 3 instantiation
 ])
 def test_lpips_conv_mfma(device, case):

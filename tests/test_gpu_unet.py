@@ -75,7 +75,7 @@ def test_unet_forward_big_cfg4(device):
 @pytest.mark.parametrize("B,size", [(2, 8), (1, 16)])
 def test_unet_forward_3d_cfg5(device, B, size):
     """BASELINE configs[4]: the `small` UNet over 3-D VQ-VAE latents [B, 128, 8, 8, 8] (47.5 M params).
-    conv3d runs as three depth-tap launches of the 2-D MFMA kernel; attention sees 2^3 = 8 tokens."""
+    conv3d: one launch per conv, the depth taps part of the chunk stream; attention sees 2^3 = 8 tokens."""
     ref, hip = _pair(device, 128, SMALL, spatial_dims=3)
     x = torch.randn(B, 128, size, size, size, generator=torch.Generator().manual_seed(12))
     t = torch.tensor([650, 30][:B])
@@ -85,6 +85,21 @@ def test_unet_forward_3d_cfg5(device, B, size):
     err = (yh - yr).abs().max().item()
     assert math.isfinite(err) and err <= 1e-4 * (1 + yr.abs().max().item()), err
     assert yr.abs().max() > 0.05
+    if size == 8:
+        # the 8^3 level runs in the Winograd domain (2-D F(2x2, 3x3) per depth tap with the GroupNorm + SiLU prologue,
+        # concat and temb: four 8x8 slices per work item); out-of-volume depth taps must stay zero through the prologue
+        import ctypes
+        import json
+
+        from ddpm_ood_amd import _lib
+        lib = _lib.load()
+        lib.ddpm_prof_enable(1)
+        hip(x.to(device), timesteps=t.to(device))
+        lib.ddpm_prof_enable(0)
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 18)
+        lib.ddpm_prof_report(buf, len(buf))
+        assert "conv3d_wino_gn_silu" in json.loads(buf.value.decode())
 
 
 def test_graph_replay_equals_eager(device, monkeypatch):
