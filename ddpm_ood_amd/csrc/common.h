@@ -92,7 +92,8 @@ size_t wino_weight_floats(int Cout, int Cin);
 size_t conv_wino_scratch_floats(const ddpm_conv_desc &d);
 int launch_wino_split_reduce(const ddpm_conv_desc &d, int S, long long pstride, int HW, hipStream_t s);
 size_t conv_wino44_scratch_floats(const ddpm_conv_desc &d);
-size_t conv_scratch_floats(const ddpm_conv_desc &d);  // what conv_dispatch can use: the larger of the two Winograd kernels' needs
+size_t conv_mfma_scratch_floats(const ddpm_conv_desc &d);
+size_t conv_scratch_floats(const ddpm_conv_desc &d);  // what conv_dispatch can use: the largest of the kernels' needs
 bool conv_wino44_supported(const ddpm_conv_desc &d);
 int launch_conv_wino44(const ddpm_conv_desc &d, hipStream_t s);
 size_t wino44_weight_floats(int Cout, int Cin);

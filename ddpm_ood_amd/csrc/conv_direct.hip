@@ -407,9 +407,11 @@ int launch_conv_direct(const ddpm_conv_desc &d, hipStream_t s) {
 }
 
 size_t conv_scratch_floats(const ddpm_conv_desc &d) {
-  if (d.dims == 3 || d.Di > 1 || d.Do > 1) return 0;
-  const size_t a = conv_wino44_scratch_floats(d), b = conv_wino_scratch_floats(d);
-  return a > b ? a : b;
+  const bool vol = d.dims == 3 || d.Di > 1 || d.Do > 1;  // the Winograd splits are 2-D only
+  const size_t a = vol ? 0 : conv_wino44_scratch_floats(d), b = vol ? 0 : conv_wino_scratch_floats(d);
+  const size_t c = linear_skinny_supported(d) ? 0 : conv_mfma_scratch_floats(d);
+  const size_t ab = a > b ? a : b;
+  return ab > c ? ab : c;
 }
 
 int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {

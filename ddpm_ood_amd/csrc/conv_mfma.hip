@@ -70,6 +70,11 @@ struct ConvGeom {
   // the tile walks LOW-RES pixels, tap (r, c) reads LDS at (py + r, px + c), the output pixel is (2h + py, 2w + px)
   int npar;
   long long par_slab;  // floats between two parity slabs of w_packed
+  // ---- split-K (blockIdx.z of the non-parity launches): a launch with fewer workgroups than half the CUs -- the 4^3 / 2^3
+  // levels of the latent UNet, small batches -- gives every tile to `ksplit` workgroups, each walking nchunks / ksplit
+  // chunks; partial outputs go to slabs of d.scratch, conv_wino.hip's reduce pass adds them in a fixed order
+  int ksplit;
+  long long pstride;   // floats between two partial-output slabs
 };
 
 static bool make_geom(const ddpm_conv_desc &d, int MT, ConvGeom &g, int ps_cap = 0) {
@@ -243,6 +248,9 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   const int nt = blockIdx.y;
   // output parity of this workgroup (PARITY launches): out pixel (2 d + pz, 2 h + py, 2 w + px)
   const int par = PARITY ? blockIdx.z : 0;
+  const int ks = PARITY ? 0 : blockIdx.z;                       // split-K share of this workgroup
+  const int nch_s = g.nchunks / g.ksplit, q_lo = ks * nch_s, q_hi = q_lo + nch_s;
+  float *const outp = a.out + (size_t)ks * g.pstride;
   const int px = par & 1, py = (par >> 1) & 1, pz = par >> 2;
 
   // ---- tile origin -------------------------------------------------------------------------
@@ -394,12 +402,12 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
 
   // ---- prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers ----------------------------------
 #pragma unroll
-  for (int p = 0; p < NP; ++p) prefetch_piece(p, 0);
+  for (int p = 0; p < NP; ++p) prefetch_piece(p, q_lo);
 #pragma unroll
   for (int p = 0; p < NP; ++p) commit_piece(p, 0);
-  if (g.nchunks > 1) {
+  if (nch_s > 1) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) prefetch_piece(p, 1);
+    for (int p = 0; p < NP; ++p) prefetch_piece(p, q_lo + 1);
   }
   __syncthreads();
 
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
   auto chunk = [&](auto commit_c, auto pref_c, int q) {
     constexpr bool DO_COMMIT = decltype(commit_c)::value;
     constexpr bool DO_PREF = decltype(pref_c)::value;
-    const int cb = (q & 1) * bufsz;
+    const int cb = ((q - q_lo) & 1) * bufsz;
     const int nb = bufsz - cb;
     float av[2][NAB], bv[2][2];
     auto fetch = [&](int st, int slot) {
@@ -446,9 +454,9 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
     __syncthreads();
   };
 
-  int q = 0;
-  for (; q + 2 < g.nchunks; ++q) chunk(std::true_type{}, std::true_type{}, q);
-  if (q + 1 < g.nchunks) {
+  int q = q_lo;
+  for (; q + 2 < q_hi; ++q) chunk(std::true_type{}, std::true_type{}, q);
+  if (q + 1 < q_hi) {
     chunk(std::true_type{}, std::false_type{}, q);
     ++q;
   }
@@ -498,11 +506,22 @@ __global__ __launch_bounds__(256, (NPOS == 1 ? 3 : 2)) void conv_mfma_kernel(con
           if (chan_p) v += cv[r];
           if (res_p) v += rv[r];
           if (a.out_act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
-          a.out[obase + (size_t)dco * cstride] = v;
+          outp[obase + (size_t)dco * cstride] = v;
         }
       }
     }
   }
+}
+
+static int mfma_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
 }
 
 template <int NTAPS, int NPOS, bool AFFINE, int MT, int KG = 1>
@@ -526,7 +545,30 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g_in, hipStre
               (int)AFFINE, MT, lds, fa.numRegs, nb);
     }
   }
-  dim3 grid(g.ntiles, d.Cout / kConvNT, g.npar);
+  // split-K: see ConvGeom::ksplit.  Only plain layouts (no output parities, no output activation), whole float4 rows
+  g.ksplit = 1;
+  g.pstride = 0;
+  ddpm_conv_desc dk = d;
+  const size_t out_floats = (size_t)d.B * d.Cout * g.Do * g.HWo;
+  const char *sk_env = getenv("DDPM_CONV_SPLITK");  // 0: off (A/B, tests); read per call
+  const bool sk_on = !(sk_env && atoi(sk_env) == 0);
+  if (sk_on && NTAPS != 4 && g.npar == 1 && d.scratch && d.out_act == DDPM_ACT_NONE && (g.Do * g.HWo) % 4 == 0) {
+    const long wgs = (long)g.ntiles * (d.Cout / kConvNT);
+    const int cus = mfma_cus();
+    for (int sp = 8; sp >= 2; sp >>= 1)
+      if (wgs * sp <= cus && g.nchunks % sp == 0 && g.nchunks / sp >= 8 && d.scratch_floats >= sp * out_floats) {
+        g.ksplit = sp;
+        break;
+      }
+    if (g.ksplit > 1) {
+      g.pstride = (long long)out_floats;
+      dk.out = d.scratch;
+      dk.bias = nullptr;
+      dk.chan_add = nullptr;
+      dk.residual = nullptr;
+    }
+  }
+  dim3 grid(g.ntiles, d.Cout / kConvNT, g.npar > 1 ? g.npar : g.ksplit);
   // algorithmic work of this launch: 2 * (output pixels) * Cout * Cin * taps FLOP, counted as the
   // op the launch replaces (a folded nearest-x2 upsample counts the 9 taps of the unfolded 3x3; a ConvTranspose
   // k4 s2 has 2 x 2 (x 2) live taps per output); bytes = input + output (+ residual) + weights, once each
@@ -556,8 +598,9 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g_in, hipStre
     kname = kshape;
   }
   ProfScope prof(s, kname, flops, bytes);
-  hipLaunchKernelGGL((conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT, KG>), grid, dim3(256), lds, s, d, g);
+  hipLaunchKernelGGL((conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT, KG>), grid, dim3(256), lds, s, dk, g);
   DDPM_CHECK_LAUNCH();
+  if (g.ksplit > 1) return launch_wino_split_reduce(d, g.ksplit, g.pstride, g.Do * g.HWo, s);
   return 0;
 }
 
@@ -620,6 +663,19 @@ static int launch_transpose(const ddpm_conv_desc &d, hipStream_t s) {
   ddpm_conv_desc lr = lowres_view(d);
   lr.mode = DDPM_CONV_TRANSPOSE2;
   return launch_parity(lr, g, s);
+}
+
+// floats of scratch with which this descriptor's launch can be split over K (0: none): an upper bound of what
+// launch_variant uses (the largest split that still fits the chip; the chunk count may force a smaller one)
+size_t conv_mfma_scratch_floats(const ddpm_conv_desc &d) {
+  if (d.mode == DDPM_CONV_TRANSPOSE2 || d.out_act != DDPM_ACT_NONE || !conv_mfma_supported(d)) return 0;
+  ConvGeom g;
+  if (!pick_geom(d, g) || (g.Do * g.HWo) % 4) return 0;
+  const long wgs = (long)g.ntiles * (d.Cout / kConvNT);
+  int sp = 8;
+  while (sp >= 2 && wgs * sp > mfma_cus()) sp >>= 1;
+  if (sp < 2) return 0;
+  return (size_t)sp * d.B * d.Cout * g.Do * g.HWo;
 }
 
 int launch_conv_mfma(const ddpm_conv_desc &d, hipStream_t s) {

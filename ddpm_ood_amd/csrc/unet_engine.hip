@@ -487,9 +487,9 @@ struct Runner {
       // pointwise over a volume: the NCDHW tensor is an NCHW tensor of extent (D*H) x W
       d.Hi = in1.D * in1.H; d.Ho = Do * Ho;
     }
-    // small batches: scratch slabs for the Winograd kernel's channel-stream split (released with the enclosing block's
+    // launches smaller than the chip: scratch slabs for the Winograd kernels' channel-stream split / the MFMA kernel's split-K (released with the enclosing block's
     // temporaries; the dry run that sizes the workspace takes the same decisions)
-    if (const size_t need = (d.dims == 3 || in1.D > 1 || Do > 1) ? 0 : conv_scratch_floats(d)) {
+    if (const size_t need = conv_scratch_floats(d)) {
       d.scratch = ws.get(need);
       d.scratch_floats = need;
     }

@@ -251,6 +251,10 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
         d.w_wino = ptr(wino)
     if wino44 is not None and stride == 1:
         d.w_wino44 = ptr(wino44)
+    need = lib.ddpm_conv_scratch_floats(C_byref(d))  # launches smaller than the chip: split-K partial slabs
+    if need:
+        scratch = torch.empty(need, dtype=torch.float32, device=x.device)
+        d.scratch, d.scratch_floats = ptr(scratch), need
     check(lib.ddpm_conv_f32(C_byref(d), stream_ptr()), "conv3d")
     return out
 
