@@ -47,12 +47,19 @@ def main(root, out_csv, out_json):
     m = m.sort_values("dur_us", ascending=False)[cols]
     m.to_csv(out_csv, index=False, float_format="%.4g")
     print(m.head(12).to_string())
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/microbench.py, B=256; "
-                     "reads = 2 x FETCH_SIZE KB (gfx950 correction), launch-weighted mean over the kernel's launches"}
+    out = json.load(open(out_json)) if len(sys.argv) > 4 and sys.argv[4] == "--merge" else {}
+    out["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/microbench.py, B=256 (2-D kernels) and "
+                     "tools/vqvae_bench.py (3-D kernels); reads = 2 x FETCH_SIZE KB (gfx950 correction), launch-weighted mean "
+                     "over the kernel's launches")
     # profiler key of bench.py's roofline object -> the kernel instantiations behind it
-    for key, prefix in (("conv3x3_wino44_gn_silu", "conv_wino44_kernel<true"), ("conv3x3_wino_gn_silu", "conv_wino_kernel<true"),
-                        ("conv3x3_mfma_gn_silu", "conv_mfma_kernel<9, 1, true, 128")):
-        sel = m[m.kernel.str.startswith(prefix)]
+    # (a regular expression on the instantiation name; the last template argument of the Winograd kernels is the 3-D form)
+    for key, pattern in (("conv3x3_wino44_gn_silu", r"conv_wino44_kernel<true, \d, \d, (true|false), false>"),
+                         ("conv3x3_wino_gn_silu", r"conv_wino_kernel<true, \d, (true|false), false>"),
+                         ("conv3x3_mfma_gn_silu", r"conv_mfma_kernel<9, 1, true, 128"),
+                         ("conv3d_wino44", r"conv_wino44_kernel<false, \d, \d, (true|false), true>"),
+                         ("conv3d_wino", r"conv_wino_kernel<false, \d, (true|false), true>"),
+                         ("lpips_conv_mfma", r"lpips_conv_mfma_kernel")):
+        sel = m[m.kernel.str.contains(pattern)]
         if len(sel):
             wgt = sel.launches / sel.launches.sum()
             out[key + "_bytes_per_launch"] = float((sel.hbm_MB_per_launch * wgt).sum() * 1e6)
