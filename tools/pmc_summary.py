@@ -53,11 +53,11 @@ def main(root, out_csv, out_json):
                      "over the kernel's launches")
     # profiler key of bench.py's roofline object -> the kernel instantiations behind it
     # (a regular expression on the instantiation name; the last template argument of the Winograd kernels is the 3-D form)
-    for key, pattern in (("conv3x3_wino44_gn_silu", r"conv_wino44_kernel<true, \d, \d, (true|false), false>"),
-                         ("conv3x3_wino_gn_silu", r"conv_wino_kernel<true, \d, (true|false), false>"),
+    for key, pattern in (("conv3x3_wino44_gn_silu", r"conv_wino44_kernel<true, \d, \d, (?:true|false), false>"),
+                         ("conv3x3_wino_gn_silu", r"conv_wino_kernel<true, \d, (?:true|false), false>"),
                          ("conv3x3_mfma_gn_silu", r"conv_mfma_kernel<9, 1, true, 128"),
-                         ("conv3d_wino44", r"conv_wino44_kernel<false, \d, \d, (true|false), true>"),
-                         ("conv3d_wino", r"conv_wino_kernel<false, \d, (true|false), true>"),
+                         ("conv3d_wino44", r"conv_wino44_kernel<false, \d, \d, (?:true|false), true>"),
+                         ("conv3d_wino", r"conv_wino_kernel<false, \d, (?:true|false), true>"),
                          ("lpips_conv_mfma", r"lpips_conv_mfma_kernel")):
         sel = m[m.kernel.str.contains(pattern)]
         if len(sel):
