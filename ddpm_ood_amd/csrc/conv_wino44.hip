@@ -402,6 +402,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
   auto load_setup = [&](int ch) {
     l_cg = ch * kC + sc;
     if (D3) {  // stream chunk -> (depth tap, channel chunk); image -> (batch item, slice).  One image per item: once per chunk
+      // (kept as two scalar divisions: tracking the position incrementally cost four more live SGPRs and hipcc spilled
+      // vector registers inside the chunk loop instead -- see activate_px)
       const int kdi = ch / g.nch_c;
       l_cg = (ch - kdi * g.nch_c) * kC + sc;
       const int ni = min(nL, g.NIMG - 1);
@@ -438,6 +440,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44_kernel(const ddpm_conv_des
       const float t = __builtin_fmaf(x, -1.44269504088896341f * sa, -1.44269504088896341f * sb);
       P[pb + pw_of(k)] = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
     } else {
+      // (the 3-D form never has an input activation, but skipping the SiLU there -- tried together with an incremental
+      // stream position -- made hipcc spill inside the chunk loop: scratch reloads next to the MFMAs, each a vmcnt(0)
+      // drain, 37.8 -> 47.9 ms of F(4x4) time per two-volume decode; left as is)
       const float sv = silu_fast(x);
       P[pb + pw_of(k)] = silu ? sv : x;
     }
