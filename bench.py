@@ -332,7 +332,11 @@ def main():
                    "images_per_step": n_images, "reconstructions_per_step": recon_per_step,
                    "unet_forwards_per_image": rec.last_stats["unet_forwards"] // max(per_rank[rank], 1),
                    "sharding": f"images x{world} ({a.scaling})",
-                   "lpips_weights": "pretrained" if rec.last_stats.get("lpips_pretrained") else "seeded random"},
+                   "lpips_weights": "pretrained" if rec.last_stats.get("lpips_pretrained") else "seeded random",
+                   **({"lpips_2p5d_views_computed": "all 3 (DDPM_LPIPS_ALL_VIEWS=1)"
+                       if os.environ.get("DDPM_LPIPS_ALL_VIEWS", "0") == "1" else
+                       "last of 3 (the reference's loop overwrites the other two: same scores)"}
+                      if cfg.get("spatial") == 3 else {})},
         "roofline": dominant,
         "rooflines": {k: {kk: r[kk] for kk in ("achieved", "frac", "algorithmic_equiv_tflops", "avg_launch_ms",
                                                 "launches_timed", "ms_in_sample", "algorithmic_GBps")}
