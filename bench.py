@@ -6,17 +6,20 @@
 
 Default workload (BASELINE.json configs[1], the configuration the metric is quoted on): FashionMNIST-shaped
 32x32x1 synthetic images, `small` UNet with seeded random weights, 100 PLMS timesteps, inference_skip_factor=4
--> 25 t-starts, 1 250 UNet forwards per image, batch 256 per GPU.  One "step" = one batch of 256 images per
-rank through the whole hot path (noise, add_noise, every PLMS trajectory, clamp + MSE, LPIPS, score gather)
-= 6 400 reconstructions per rank, inputs resident in HBM when timing starts.
+-> 25 t-starts, 1 250 UNet forwards per image, batch 1 024 per GPU (sized for the 288 GB of HBM: the persistent
+convolution kernels amortise their per-launch and per-item costs over more items -- measured 617 / 645 / 663
+reconstructions/s at batch 256 / 512 / 1 024; --batch 256 is the reference's default batch size).  One "step" = one
+batch of 1 024 images per rank through the whole hot path (noise, add_noise, every PLMS trajectory, clamp + MSE,
+LPIPS, score gather) = 25 600 reconstructions per rank, inputs resident in HBM when timing starts.
 
---scaling weak   (default) every rank gets its own 256-image shard of a 256*N-image set per step.
---scaling strong a fixed --images set (default 2048 = 8 batches of 256) is split round-robin over the N
-                 ranks; a step is one pass over the whole set, so the work per step does not grow with N.
+--scaling weak   (default) every rank gets its own 1 024-image shard of a 1 024*N-image set per step.
+--scaling strong a fixed --images set (default 2 048 for cfg2 / cfg3, 8 batches for cfg4 / cfg5) is split round-robin
+                 over the N ranks (each rank's batch is its share, at most --batch); a step is one pass over the
+                 whole set, so the work per step does not grow with N.
 The only collective is the per-step all_gather of the dense score tensor (RCCL).
 
 --config selects the other BASELINE configurations (same metric, their own `roofline`):
-    cfg3  32x32x3 `small`                       (batch 256, k = 4)
+    cfg3  32x32x3 `small`                       (batch 1 024, k = 4)
     cfg4  64x64x3 `big` attention-heavy UNet    (batch 16,  k = 2: 50 t-starts, 2 550 forwards per image)
     cfg5  128^3 volumes, README VQ-VAE (4 x stride 2, 256 ch, 2 048 codes) -> [128, 8, 8, 8] latents -> 3-D
           `small` UNet -> re-quantise + decode -> 2.5-D LPIPS  (batch 64, k = 4)
@@ -57,10 +60,10 @@ VQ_README = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(25
                  upsample_parameters=((2, 4, 1, 1, 0),) * 4, num_embeddings=2048, embedding_dim=128)
 
 CONFIGS = {
-    "cfg2": dict(model_type="small", channels=1, size=32, spatial=2, skip=4, batch=256, metric_tag="FashionMNIST 32x32",
+    "cfg2": dict(model_type="small", channels=1, size=32, spatial=2, skip=4, batch=1024, metric_tag="FashionMNIST 32x32",
                  workload="BASELINE configs[1]: FashionMNIST-shaped 32x32x1, small UNet (17.7M params, random init), "
                           "100 PLMS timesteps, inference_skip_factor=4 (25 t-starts, 1250 UNet forwards per image)"),
-    "cfg3": dict(model_type="small", channels=3, size=32, spatial=2, skip=4, batch=256, metric_tag="CIFAR10 32x32x3",
+    "cfg3": dict(model_type="small", channels=3, size=32, spatial=2, skip=4, batch=1024, metric_tag="CIFAR10 32x32x3",
                  workload="BASELINE configs[2]: CIFAR10-shaped 32x32x3, small UNet, 100 PLMS timesteps, "
                           "inference_skip_factor=4 (25 t-starts, 1250 UNet forwards per image)"),
     "cfg4": dict(model_type="big", channels=3, size=64, spatial=2, skip=2, batch=16, metric_tag="CelebA 64x64x3 big UNet",
@@ -263,7 +266,7 @@ def main():
     from ddpm_ood_amd.trainer import Reconstruct
 
     lib = _lib.load()
-    n_images, per_rank = shard_sizes(a.scaling, world, batch, a.images or 8 * batch)
+    n_images, per_rank = shard_sizes(a.scaling, world, batch, a.images or (2048 if cfg["size"] == 32 else 8 * batch))
     run_root = Path(tempfile.mkdtemp(prefix=f"ddpm_bench_r{rank}_"))
     args = make_args(run_root, cfg, n_images, batch)
     ddpm_channels = cfg["vqvae"]["embedding_dim"] if cfg.get("vqvae") else cfg["channels"]

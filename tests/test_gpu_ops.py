@@ -160,7 +160,7 @@ def test_linear(device, B, Cin, Cout, act):
 
 
 @pytest.mark.parametrize("B,C1,C2,HW", [(2, 128, 0, 1024), (3, 256, 128, 256), (2, 256, 256, 64), (1, 64, 0, 49),
-                                        (2, 768, 0, 4096)])
+                                        (2, 768, 0, 4096), (2, 256, 512, 1024), (1, 96, 0, 1026)])
 def test_gn_scale_shift(device, B, C1, C2, HW):
     from ddpm_ood_amd import ops
 
