@@ -239,8 +239,10 @@ static bool w44_geom(const ddpm_conv_desc &d, W44Geom &g, bool sizing = false) {
     const int sp_max = sp_env ? atoi(sp_env) : 4;
     for (int sp = 4; sp >= 2; sp >>= 1)
       if (sp <= sp_max && items * sp <= cus && g.nchunks % (2 * sp) == 0 && g.nchunks / sp >= 4) { g.S = sp; break; }
-    if (g.S == 1 || items * g.S < cus) return false;  // still not the whole chip: conv_wino.hip's half-size items and its split
-                                                       // (measured at B = 16: 16x16 layers 43 / 63 us there vs 48 / 74 us here)
+    // below three quarters of the chip conv_wino.hip's half-size items (and its own split) are faster -- measured at B = 16:
+    // `small` 16x16 layers (32 items x 4) 48 / 74 us here vs 43 / 63 us there, but the 768-channel 16x16 layers of `big`
+    // (96 items x 2 = 192 workgroups) 3.07 here vs 3.85 ms there per forward
+    if (g.S == 1 || items * g.S * 4 < (long)cus * 3) return false;
     const size_t out_floats = (size_t)d.B * d.Cout * g.HW;
     if (!sizing && (!d.scratch || d.scratch_floats < g.S * out_floats)) return false;
     g.pstride = (long long)out_floats;
