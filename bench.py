@@ -53,6 +53,7 @@ import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
 HBM_PEAK_GBPS = 8000.0
+F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA (same guide)
 SCHED = dict(beta_schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195)
 
 VQ_README = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(256, 256, 256, 256), num_res_layers=3,
@@ -157,7 +158,9 @@ MFMA_KERNELS = [
     ("conv3d_wino", "conv_wino_kernel, 3-D: Winograd F(2x2,3x3) per depth tap, taps accumulated in the transform domain, fp32 MFMA", 16.0 / 36.0),
     ("conv3d_", "conv_mfma_kernel: 3-D convolution (depth taps merged into one chunk stream), fp32 MFMA", 1.0),
     ("conv3x3_mfma", "conv_mfma_kernel<9>: direct 3x3 conv (stride 2, ragged extents, 3-D depth-tap launches), fp32 MFMA", 1.0),
-    ("conv1x1_dma", "conv1x1_dma_kernel: LDS-DMA-fed 1x1 conv, fp32 MFMA", 1.0),
+    # split-f16: three v_mfma_f32_32x32x16_f16 per fp32 product, 16x the f32 MFMA rate -> the layer is HBM-bound
+    ("conv1x1_dma", "conv1x1_dma_kernel: LDS-DMA-fed 1x1 conv (skip connections; with GroupNorm prologue: q / k / v), "
+                    "fp32 products from three f16 MFMAs (hi / lo split, fp32 accumulate)", "hbm"),
     ("conv1x1_mfma", "conv_mfma_kernel<1>: 1x1 conv / Linear (fused QKV, time MLP), fp32 MFMA", 1.0),
     ("lpips_conv_mfma", "lpips_conv_mfma_kernel: AlexNet 5x5 layer of the 2.5-D LPIPS as an implicit GEMM, fp32 MFMA", 1.0),
     ("attention", "attention_kernel: QK^T, online softmax, AV (+ residual), fp32 MFMA", 1.0),
@@ -188,6 +191,16 @@ def rooflines_of(prof):
     pmc = json.load(open(pmc_path)) if pmc_path.exists() else {}
     for prefix, a in agg.items():
         alg = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        if a["ratio"] == "hbm":  # priced against HBM: algorithmic bytes (in + residual + out + weights) per second
+            gbps = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+            out[prefix] = {"bound": "hbm", "kernel": a["label"], "profile_key": prefix, "achieved": round(gbps, 1),
+                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                           "algorithmic_equiv_tflops": round(alg, 2), "algorithmic_GBps": round(gbps, 1),
+                           "f16_mfma_tflops_executed": round(3 * alg, 2), "f16_mfma_peak_tflops": F16_MFMA_PEAK_TFLOPS,
+                           "launches_timed": a["launches"], "avg_launch_ms": round(a["ms"] / a["launches"], 4),
+                           "ms_in_sample": round(a["ms"], 3), "bytes_per_launch": a["bytes"] / a["launches"],
+                           "traffic": None}
+            continue
         ex = alg * a["ratio"]
         r = {"bound": "mfma", "kernel": a["label"], "profile_key": prefix, "achieved": round(ex, 2),
              "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ex / F32_MFMA_PEAK_TFLOPS, 4),
@@ -341,8 +354,8 @@ def main():
                        "last of 3 (the reference's loop overwrites the other two: same scores)"}
                       if cfg.get("spatial") == 3 else {})},
         "roofline": dominant,
-        "rooflines": {k: {kk: r[kk] for kk in ("achieved", "frac", "algorithmic_equiv_tflops", "avg_launch_ms",
-                                                "launches_timed", "ms_in_sample", "algorithmic_GBps")}
+        "rooflines": {k: {kk: r[kk] for kk in ("bound", "achieved", "unit", "frac", "algorithmic_equiv_tflops",
+                                                "avg_launch_ms", "launches_timed", "ms_in_sample", "algorithmic_GBps")}
                       for k, r in rooflines.items()},
         "kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                         "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,

@@ -17,33 +17,88 @@
 // Two workgroups fit a CU, so one's epilogue (these layers move as many bytes in the epilogue -- residual in, result
 // out -- as in the main loop) overlaps the other's main loop; a 512-pixel / 8-wave version, one workgroup per CU,
 // measured the same 100 TFLOP/s with and without deeper operand prefetch: the layers are HBM-side bound.
+//
+// Split-f16 form (conv1x1_dma_kernel<true>, the default; DDPM_CONV1X1_F16X3=0 restores the f32 MFMA loop).  The
+// f32 loop above is MFMA-side limited for these layers (64 v_mfma_f32_32x32x2_f32 = 4 096 SIMD cycles per chunk
+// against ~0.25 of that in HBM time).  v_mfma_f32_32x32x16_f16 multiplies a whole 16-channel chunk in one
+// instruction at 16x the f32 rate, so an fp32 product is rebuilt from three of them:
+//   x = xh + xl, w = wh + wl  (xh = f16(x) round-to-nearest, xl = f16(x - xh); x - xh is exact in fp32)
+//   x w ~= xh wh + xh wl + xl wh     (fp32 accumulate in the MFMA; the dropped xl wl is <= 2^-22 |x w|)
+// which keeps 22 mantissa bits per product -- the accumulation itself stays fp32 and channels are still added in
+// ascending order.  The operands are split in registers right after the ds_read (3 VALU per value:
+// v_cvt_pk_f16_f32, v_cvt_f32_f16, v_sub_f32, v_cvt_pk_f16_f32 per pair); the DMA pipeline, LDS image and epilogue
+// are the f32 kernel's.  Per chunk and wave: 24 MFMAs (768 cycles) + ~160 VALU instead of 64 MFMAs (4 096 cycles).
+// f16 range (5 exponent bits): the low halves would fall into f16 subnormals and lose their bits, so they are
+// scaled up before the conversion and the factor is taken back on the HIGH half of the other operand (a power of
+// two: exact while that half stays normal):   x w 2^6 = wh xh + (wh 2^-5)(xl 2^5) + (wl 2^5)(xh 2^-5)
+// with w' = 2^6 w = wh + wl split in place of w and the accumulators multiplied by 2^-6 after the loop.  Every
+// product keeps 22 bits for |x| in [4e-3, 6.5e4] and |w| in [6e-5, 1e3]; below those ranges an operand carries an
+// ABSOLUTE error <= 2^-30 (x) / 2^-36 (w) -- it degrades gracefully, like fp32 flush-to-zero does much further
+// down -- and above them the high half overflows to inf (loud; nothing a GroupNorm-ed UNet produces).
+//
+// GroupNorm prologue (split-f16 form only): the operands pass through registers for the split anyway, so the
+// per-(image, channel) affine of a GroupNorm-ed input (the attention blocks' q / k / v projections) is applied
+// there; its scale / shift pairs for the chunk ride the DMA ring (one global_load_lds_dword per wave and chunk:
+// [4 groups of 64 pixels][16 scale | 16 shift]).  v = x * scale + shift as in conv_mfma.hip.
 #include "common.h"
 
 namespace ddpm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float kF16WScale = 64.f;  // 2^6 on the weights before the hi / lo split, 2^-6 on the accumulators after
+constexpr float kF16LoScale = 32.f;  // 2^5 on a low half, 2^-5 on the high half it is multiplied with
+
+// One MFMA operand (eight fp32 values: the 32x32x16 f16 instruction's k = 8 (lane / 32) .. + 7) as three f16
+// vectors: hi = f16(v), lo = f16((v - hi) 2^5) (v - hi is exact in fp32), hs = hi 2^-5
+__device__ __forceinline__ void split_f16x8(const float (&v)[8], f16x8 &hi, f16x8 &lo, f16x8 &hs) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const _Float16 h = (_Float16)v[t];
+    hi[t] = h;
+    lo[t] = (_Float16)((v[t] - (float)h) * kF16LoScale);
+  }
+  hs = hi * (_Float16)(1.f / kF16LoScale);
+}
 
 constexpr int kDC = 16;          // input channels per chunk
 constexpr int kDM = 128;         // output channels per workgroup
 constexpr int kDP = 256;         // pixels per workgroup
 constexpr int kDBuf = kDC * (kDM + kDP);  // floats per LDS buffer (6 144)
+constexpr int kDAff = 4 * 64;             // + the chunk's GroupNorm scale / shift pairs (AFFINE)
+
+static bool conv1x1_f16x3_enabled() {
+  static const bool on = !(getenv("DDPM_CONV1X1_F16X3") && atoi(getenv("DDPM_CONV1X1_F16X3")) == 0);
+  return on;
+}
 
 bool conv1x1_dma_supported(const ddpm_conv_desc &d) {
   static const bool enabled = !(getenv("DDPM_CONV1X1_DMA") && atoi(getenv("DDPM_CONV1X1_DMA")) == 0);
   const int Cin = d.C1 + d.C2;
   const long HW = (long)d.Ho * d.Wo;
   if (!enabled || d.force_direct || !d.w_packed) return false;
-  if (d.ksize != 1 || d.mode != DDPM_CONV_NORMAL || d.gscale || d.act != DDPM_ACT_NONE) return false;
+  if (d.ksize != 1 || d.mode != DDPM_CONV_NORMAL || d.act != DDPM_ACT_NONE) return false;
+  // GroupNorm prologue: split-f16 form only; a 64-pixel group of a tile belongs to one image
+  if (d.gscale && (!conv1x1_f16x3_enabled() || !d.gshift || HW % 64)) return false;
   if (d.Di > 1 || d.Do > 1) return false;
   if (Cin % kDC || (d.C2 > 0 && d.C1 % kDC) || d.Cout % kDM) return false;
   // a tile is 256 consecutive pixels of one image or a whole number of images; rows of 4 pixels never straddle
   if (HW % 4 || !((HW % kDP == 0) || (kDP % HW == 0))) return false;
   const long tiles = ((long)d.B * HW + kDP - 1) / kDP;
-  return tiles * (d.Cout / kDM) >= 384;  // smaller launches stay with conv_mfma's 64 / 128-pixel tiles
+  // smaller launches stay with conv_mfma's 64 / 128-pixel tiles and its split-K (DDPM_CONV1X1_DMA_MIN_WG: A/B of the
+  // threshold).  Split-f16: half a chip of workgroups already wins (8x8 skip at B = 256, 128 workgroups: 83 -> 55 us;
+  // the `big` UNet's q / k / v at B = 16, 192 workgroups: 115 -> 70 us); the f32 loop needed 1.5 waves of the chip
+  static const long min_wg = getenv("DDPM_CONV1X1_DMA_MIN_WG") ? atol(getenv("DDPM_CONV1X1_DMA_MIN_WG"))
+                             : conv1x1_f16x3_enabled()         ? 128
+                                                               : 384;
+  return tiles * (d.Cout / kDM) >= min_wg;
 }
 
+template <bool F16X3, bool AFFINE>
 __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_desc a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][ A [16][128] | B [16][256] ]
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][ A [16][128] | B [16][256] | affine [4][64] ]
+  constexpr int kBuf = kDBuf + (AFFINE ? kDAff : 0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -65,8 +120,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_des
     boff1 = ((size_t)n * a.C1) * HW + p;
     boff2 = ((size_t)n * a.C2) * HW + p;
   }
+  // AFFINE: wave w fetches the pairs of the tile's pixel group w (64 pixels, one image): lanes 0-15 the chunk's 16
+  // scales, 16-31 its shifts (lanes 32-63 repeat them into the unused half of the slot)
+  const float *gsrc = nullptr;
+  if constexpr (AFFINE) {
+    long n = (t0 + 64 * wave) / HW;
+    if (n >= a.B) n = a.B - 1;
+    gsrc = ((lane & 16) ? a.gshift : a.gscale) + (size_t)n * Cin + (lane & 15);
+  }
   auto dma_chunk = [&](int q, int buf) {
-    float *dstA = smem + buf * kDBuf;
+    float *dstA = smem + buf * kBuf;
     float *dstB = dstA + kDC * kDM;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -78,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_des
       const float *src = first ? a.in1 + boff1 + (size_t)cg * HW : a.in2 + boff2 + (size_t)(cg - a.C1) * HW;
       __builtin_amdgcn_global_load_lds(src, dstB + c * kDP, 16, 0, 0);
     }
+    if constexpr (AFFINE) __builtin_amdgcn_global_load_lds(gsrc + q * kDC, dstA + kDBuf + wave * 64, 4, 0, 0);
   };
 
   f32x16 acc[2][4];
@@ -92,34 +156,83 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_des
   if (nchunks > 1) dma_chunk(1, 1);
   for (int q = 0; q < nchunks; ++q) {
     // chunk q's six pieces per wave are older than chunk q + 1's: a counted wait leaves the younger ones in flight
-    if (q + 1 < nchunks)
-      asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-    else
+    if (q + 1 < nchunks) {
+      if constexpr (AFFINE)
+        asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    } else
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     // everyone has left chunk q - 1: its buffer takes chunk q + 2
     if (q + 2 < nchunks) dma_chunk(q + 2, (q + 2) % 3);
-    const float *A = smem + (q % 3) * kDBuf + lhi * kDM + wco + l31;
-    const float *Bm = A - (lhi * kDM + wco + l31) + kDC * kDM + lhi * kDP + wpx + l31;
-    // operands of k-step ks + 1 are requested before the 8 MFMAs of k-step ks (pinned: left alone, hipcc re-uses one
-    // register set and issues the reads one MFMA ahead of their use)
-    float av[2][2], bv[2][4];
-    auto fetch = [&](int ks, int slot) {
+    if constexpr (F16X3) {
+      // operand images: A[k][cout] / B[k][pixel]; this lane's eight k are 8 lhi .. 8 lhi + 7 (the 32x32x16 layout)
+      const float *A = smem + (q % 3) * kBuf + 8 * lhi * kDM + wco + l31;
+      const float *Bm = smem + (q % 3) * kBuf + kDC * kDM + 8 * lhi * kDP + wpx + l31;
+      const float *G = smem + (q % 3) * kBuf + kDBuf + (wpx >> 6) * 64 + 8 * lhi;
+      f16x8 ah[2], al[2], as[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) av[slot][i] = A[2 * ks * kDM + 32 * i];
+      for (int i = 0; i < 2; ++i) {
+        float v[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[slot][j] = Bm[2 * ks * kDP + 32 * j];
-    };
-    fetch(0, 0);
+        for (int t = 0; t < 8; ++t) v[t] = A[t * kDM + 32 * i] * kF16WScale;
+        split_f16x8(v, ah[i], al[i], as[i]);
+      }
+      float bq[2][8];
 #pragma unroll
-    for (int ks = 0; ks < kDC / 2; ++ks) {
-      if (ks + 1 < kDC / 2) fetch(ks + 1, (ks + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < 8; ++t) bq[0][t] = Bm[t * kDP];
+      float sc[8], sh[8];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 4; ++j) {
+        if (j + 1 < 4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][i], bv[ks & 1][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+          for (int t = 0; t < 8; ++t) bq[(j + 1) & 1][t] = Bm[t * kDP + 32 * (j + 1)];
+        }
+        if constexpr (AFFINE) {
+          if ((j & 1) == 0) {  // pixel tiles 2 g, 2 g + 1 are the wave's 64-pixel group g
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              sc[t] = G[(j >> 1) * 64 + t];
+              sh[t] = G[(j >> 1) * 64 + 16 + t];
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < 8; ++t) bq[j & 1][t] = bq[j & 1][t] * sc[t] + sh[t];
+        }
+        f16x8 bh, bl, bs;
+        split_f16x8(bq[j & 1], bh, bl, bs);
+        // the two cross terms first, the two cout tiles interleaved (no MFMA waits on the one before it)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[i], bl, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bs, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+      }
+    } else {
+      const float *A = smem + (q % 3) * kBuf + lhi * kDM + wco + l31;
+      const float *Bm = A - (lhi * kDM + wco + l31) + kDC * kDM + lhi * kDP + wpx + l31;
+      // operands of k-step ks + 1 are requested before the 8 MFMAs of k-step ks (pinned: left alone, hipcc re-uses one
+      // register set and issues the reads one MFMA ahead of their use)
+      float av[2][2], bv[2][4];
+      auto fetch = [&](int ks, int slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[slot][i] = A[2 * ks * kDM + 32 * i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[slot][j] = Bm[2 * ks * kDP + 32 * j];
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < kDC / 2; ++ks) {
+        if (ks + 1 < kDC / 2) fetch(ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][i], bv[ks & 1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
@@ -145,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_des
         for (int r = 0; r < 16; ++r) {
           const int dco = 32 * i + (r & 3) + 8 * (r >> 2);
           float v = acc[i][j][r];
+          if constexpr (F16X3) v *= 1.f / kF16WScale;
           if (a.bias || a.chan_add) v += add[r];
           if (a.residual) v += rv[r];
           if (a.out_act == DDPM_ACT_RELU) v = fmaxf(v, 0.f);
@@ -160,18 +274,27 @@ int launch_conv1x1_dma(const ddpm_conv_desc &d, hipStream_t s) {
     set_error("conv1x1_dma: unsupported shape");
     return DDPM_EINVAL;
   }
-  const size_t lds = (size_t)3 * kDBuf * sizeof(float);
+  const bool f16x3 = conv1x1_f16x3_enabled(), aff = d.gscale != nullptr;
+  const size_t lds = (size_t)3 * (kDBuf + (aff ? kDAff : 0)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_dma_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (const void *f : {reinterpret_cast<const void *>(&conv1x1_dma_kernel<false, false>),
+                          reinterpret_cast<const void *>(&conv1x1_dma_kernel<true, false>),
+                          reinterpret_cast<const void *>(&conv1x1_dma_kernel<true, true>)})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const long HW = (long)d.Ho * d.Wo, npix = (long)d.B * HW;
   const int Cin = d.C1 + d.C2;
-  ProfScope prof(s, "conv1x1_dma", 2.0 * npix * d.Cout * Cin,
+  ProfScope prof(s, aff ? "conv1x1_dma_gn" : "conv1x1_dma", 2.0 * npix * d.Cout * Cin,
                  4.0 * ((double)npix * Cin + (double)npix * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * Cin));
-  hipLaunchKernelGGL(conv1x1_dma_kernel, dim3((unsigned)((npix + kDP - 1) / kDP), d.Cout / kDM), dim3(256), lds, s, d);
+  const dim3 grid((unsigned)((npix + kDP - 1) / kDP), d.Cout / kDM);
+  if (aff)
+    hipLaunchKernelGGL((conv1x1_dma_kernel<true, true>), grid, dim3(256), lds, s, d);
+  else if (f16x3)
+    hipLaunchKernelGGL((conv1x1_dma_kernel<true, false>), grid, dim3(256), lds, s, d);
+  else
+    hipLaunchKernelGGL((conv1x1_dma_kernel<false, false>), grid, dim3(256), lds, s, d);
   DDPM_CHECK_LAUNCH();
   return 0;
 }

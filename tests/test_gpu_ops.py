@@ -885,6 +885,13 @@ CONV1X1_DMA_CASES = [
     (256, 256, 256, 256, 16, True, True, False),    # one image per 256-pixel tile, two cout tiles
     (1537, 128, 0, 128, 8, False, False, True),     # four images per tile, ragged last tile (384.25 tiles)
 ]
+CONV1X1_DMA_GN_CASES = [
+    # B, C, Cout, H -- fused q / k / v projection behind the attention block's GroupNorm (split-f16 kernel's prologue)
+    (512, 256, 768, 8),      # small UNet, 8x8 level: four images per 256-pixel tile
+    (67, 128, 384, 16),      # one image per tile, odd batch
+    (31, 128, 128, 32),      # four tiles per image; 124 workgroups: below the threshold, stays on conv_mfma (same answer)
+    (100, 256, 256, 32),     # 400 x 2 workgroups
+]
 
 
 @pytest.mark.parametrize("case", CONV1X1_DMA_CASES)
@@ -907,6 +914,51 @@ def test_conv1x1_dma(device, case):
     y = ops.conv(d(x), d(w), d(b), x2=d(x2), chan_add=d(chan_add), residual=d(residual))
     torch.cuda.synchronize()
     _close(y, ref, tol=2e-5)
+
+
+@pytest.mark.parametrize("case", CONV1X1_DMA_GN_CASES)
+def test_conv1x1_dma_groupnorm_prologue(device, case):
+    """1x1 convolution of a GroupNorm-ed input (no activation): the scale / shift pairs ride the DMA ring and are
+    applied where the split-f16 kernel splits its operands; vs F.group_norm + F.conv2d."""
+    from ddpm_ood_amd import ops
+
+    B, C, Cout, H = case
+    g = torch.Generator().manual_seed(B + C + H)
+    x = torch.randn(B, C, H, H, generator=g) * 1.7 + 0.3
+    w = torch.randn(Cout, C, 1, 1, generator=g) / math.sqrt(C)
+    b = torch.randn(Cout, generator=g)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = _ref_conv(x, None, w, b, (gamma, beta, 32, 1e-6), False, 0, None, None)
+    d = lambda t: t.to(device)
+    gs, gh = ops.gn_scale_shift(d(x), d(gamma), d(beta), 32, 1e-6)
+    y = ops.conv(d(x), d(w), d(b), gscale=gs, gshift=gh)
+    torch.cuda.synchronize()
+    _close(y, ref, tol=2e-5)
+
+
+@pytest.mark.parametrize("xs,ws,floor", [(1.0, 1.0, 1e-6), (1e-2, 30.0, 1e-6), (50.0, 1e-2, 1e-6), (1e-3, 1.0, 4e-6),
+                                         (300.0, 3e-4, 4e-6)])
+def test_conv1x1_dma_split_f16_error(device, xs, ws, floor):
+    """The split-f16 MFMA loop of the DMA-fed 1x1 (x w ~ xh wh + xh wl + xl wh, fp32 accumulate, low halves scaled
+    into the f16 normal range) against a float64 convolution over several decades of operand scale: inside the
+    documented range its error stays within a few fp32 roundings of the output (2^-22 per product), the same order
+    as an fp32 convolution's own error; one decade below it (last two cases) it degrades gracefully."""
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, Cout, H = 96, 256, 128, 128, 32
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, C1, H, H, generator=g) * xs
+    x2 = torch.randn(B, C2, H, H, generator=g) * xs
+    w = torch.randn(Cout, C1 + C2, 1, 1, generator=g) / math.sqrt(C1 + C2) * ws
+    n = 8  # float64 reference on a slice of the batch
+    ref64 = F.conv2d(torch.cat([x[:n], x2[:n]], 1).double(), w.double())
+    ref32 = F.conv2d(torch.cat([x[:n], x2[:n]], 1), w)
+    y = ops.conv(x.to(device), w.to(device), None, x2=x2.to(device))
+    torch.cuda.synchronize()
+    scale = ref64.abs().max().item()
+    err = (y[:n].cpu().double() - ref64).abs().max().item() / scale
+    err32 = (ref32.double() - ref64).abs().max().item() / scale
+    assert math.isfinite(err) and err <= max(4 * err32, floor), (err, err32)
 
 
 UP_WINO_CASES = [

@@ -384,6 +384,14 @@ def test_bench_roofline_object_is_the_executed_mfma_fraction():
             "conv3d_k3": {"launches": 1, "ms": 1.0, "flops": 1e11, "bytes": 1e9},
             "conv3d_wino44": {"launches": 1, "ms": 2.0, "flops": 3.4e11, "bytes": 1e9},
             "gn_scale_shift": {"launches": 27, "ms": 0.5, "flops": 1e9, "bytes": 2e9}}
+    hbm = bench.rooflines_of({"conv1x1_dma": {"launches": 7, "ms": 1.0, "flops": 7 * 26e9, "bytes": 7 * 600e6},
+                              "conv1x1_dma_gn": {"launches": 1, "ms": 0.5, "flops": 1e10, "bytes": 3e8}})["conv1x1_dma"]
+    # the split-f16 1x1 is priced against HBM: algorithmic bytes per second over 8 TB/s
+    assert hbm["bound"] == "hbm" and hbm["unit"] == "GB/s" and hbm["launches_timed"] == 8
+    for kk in ("bound", "achieved", "unit", "frac", "algorithmic_equiv_tflops", "avg_launch_ms", "launches_timed",
+               "ms_in_sample", "algorithmic_GBps"):  # the keys the bench line copies from every class
+        assert kk in hbm and kk in bench.rooflines_of({"attention": {"launches": 1, "ms": 1.0, "flops": 1e9, "bytes": 1e6}})["attention"]
+    assert abs(hbm["achieved"] - (7 * 600e6 + 3e8) / 1.5e-3 / 1e9) < 0.1 and abs(hbm["frac"] - hbm["achieved"] / 8000.0) < 1e-3
     r = bench.rooflines_of(prof)
     assert set(r) == {"conv3x3_wino", "conv3x3_wino44", "conv3x3_wino_up", "attention", "conv3d_wino", "conv3d_wino44",
                       "conv3d_"}  # MFMA classes only
