@@ -19,6 +19,7 @@
 // Head dim is fixed at 256 (num_head_channels = 256 in both reference configs,
 // /root/reference/src/trainers/base.py:73,84).
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 #include <utility>
@@ -80,7 +81,11 @@ __device__ __forceinline__ void mfma_first_n(f32x16 &c, float a, float b) {
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
 
 // VEC: N % 4 == 0 -> 16-byte global loads of K / V / Q rows
-template <bool VEC>
+// F16X3: both contractions on the f16 MFMA, every fp32 product rebuilt from three v_mfma_f32_32x32x16_f16 (common.h
+// split_f16x8; 22 mantissa bits per product, fp32 accumulate -- conv1x1_dma.hip has the error budget).  The operands
+// are split in registers on their way from the fp32 LDS tiles to the MFMA; staging, softmax and epilogue are shared
+// with the f32 MFMA form.  DDPM_ATTN_F16X3=0 selects the f32 loops.
+template <bool VEC, bool F16X3>
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ qkv,
                                                         const float *__restrict__ residual,
                                                         float *__restrict__ out, int C, int N, int heads,
@@ -167,7 +172,40 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     load_block(vp, j0);         // V of this block flies while QK^T runs
 
     // ---- S quadrant: rows = queries qi*32.., cols = keys kj*32.. ----------------------------
-    {
+    if constexpr (F16X3) {
+      // k-step ks = head-dim channels 16 ks .. 16 ks + 15; this lane's eight are 16 ks + 8 lhi + t
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      const float *qa = Ql + 8 * lhi * kQB + qi * 32 + l31;
+      const float *kb = KVl + 8 * lhi * kKB + kj * 32 + l31;
+      float av[2][8], bv[2][8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        av[0][t] = qa[t * kQB];
+        bv[0][t] = kb[t * kKB];
+      }
+#pragma unroll
+      for (int ks = 0; ks < kDH / 16; ++ks) {
+        if (ks + 1 < kDH / 16) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            av[(ks + 1) & 1][t] = qa[(16 * (ks + 1) + t) * kQB];
+            bv[(ks + 1) & 1][t] = kb[(16 * (ks + 1) + t) * kKB];
+          }
+        }
+        f16x8 ah, al, as, bh, bl, bs;
+        split_f16x8(av[ks & 1], ah, al, as);
+        split_f16x8(bv[ks & 1], bh, bl, bs);
+        DDPM_MFMA_F16X3(sacc, ah, al, as, bh, bl, bs);
+      }
+      const bool colok = (j0 + kj * 32 + l31) < N;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        Sl[row * kLd + kj * 32 + l31] = colok ? sacc[r] * (scale * 1.44269504088896341f) : -INFINITY;
+      }
+    } else {
       // two independent accumulator chains (even / odd k-steps); pair p = k-steps 2 p, 2 p + 1 = one ds_read2st64
       // per operand; ring of four pairs (8 MFMAs ahead of their use)
       f32x16 sacc, sacc2;
@@ -248,6 +286,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[a][b][r] *= al;
     }
+    if constexpr (F16X3) {
+      // k-step ks = keys 16 ks .. 16 ks + 15 of the block; A = V rows d (row stride 65), B = P rows i (row stride 65)
+      const float *va = KVl + ((wave * 2) * 32 + l31) * kLd + 8 * lhi;
+      const float *pb = Sl + l31 * kLd + 8 * lhi;
+#pragma unroll
+      for (int ks = 0; ks < kKB / 16; ++ks) {
+        f16x8 ah[2], al[2], as[2], bh[2], bl[2], bs[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          float v[8], p[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            v[t] = va[a * 32 * kLd + 16 * ks + t];
+            p[t] = pb[a * 32 * kLd + 16 * ks + t];
+          }
+          split_f16x8(v, ah[a], al[a], as[a]);
+          split_f16x8(p, bh[a], bl[a], bs[a]);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) DDPM_MFMA_F16X3(o[a][b], ah[a], al[a], as[a], bh[b], bl[b], bs[b]);
+      }
+    } else {
     // group g = k-steps 2 g, 2 g + 1 (keys 4 g + lhi, 4 g + 2 + lhi): one ds_read2 per operand row block, 8 MFMAs;
     // ring of three groups
     const int va0 = lds0 + (kDH * kQB + ((wave * 2) * 32 + l31) * kLd + lhi) * 4, va1 = va0 + 32 * kLd * 4;
@@ -278,6 +340,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     ldg(std::integral_constant<int, 1>{});
     ldg(std::integral_constant<int, 2>{});
     static_for<16>(pv);
+    }
   }
   mfma_drain();
 
@@ -313,18 +376,20 @@ int launch_attention(const float *qkv, const float *residual, float *out, int B,
   const size_t lds = (size_t)(kDH * kQB + kDH * kLd + kQB * kLd + 3 * kQB) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (const void *f : {reinterpret_cast<const void *>(&attention_kernel<true, false>),
+                          reinterpret_cast<const void *>(&attention_kernel<false, false>),
+                          reinterpret_cast<const void *>(&attention_kernel<true, true>),
+                          reinterpret_cast<const void *>(&attention_kernel<false, true>)})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   dim3 grid((N + kQB - 1) / kQB, heads, B);
   ProfScope prof(s, "attention", 4.0 * B * (double)N * N * C, 4.0 * B * C * (double)N * (residual ? 5 : 4));
-  if ((N & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv) & 15) == 0))
-    hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), lds, s, qkv, residual, out, C, N, heads, scale);
-  else
-    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), lds, s, qkv, residual, out, C, N, heads, scale);
+  static const bool f16x3 = !(getenv("DDPM_ATTN_F16X3") && atoi(getenv("DDPM_ATTN_F16X3")) == 0);
+  const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv) & 15) == 0);
+  auto kern = f16x3 ? (vec ? attention_kernel<true, true> : attention_kernel<false, true>)
+                    : (vec ? attention_kernel<true, false> : attention_kernel<false, false>);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, qkv, residual, out, C, N, heads, scale);
   DDPM_CHECK_LAUNCH();
   return 0;
 }

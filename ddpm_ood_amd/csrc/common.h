@@ -64,6 +64,33 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- split-f16 MFMA operands (conv1x1_dma.hip has the derivation and the error / range budget) --------------
+// An fp32 product is rebuilt from three v_mfma_f32_32x32x16_f16: a b ~= ah bh + (ah 2^-5)(bl 2^5) + (al 2^5)(bh 2^-5),
+// fp32 accumulate; the low halves are scaled into the f16 normal range, the factor goes back on a high half.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr float kF16LoScale = 32.f;  // 2^5 on a low half, 2^-5 on the high half it is multiplied with
+
+// One MFMA operand (eight fp32 values: the 32x32x16 f16 instruction's k = 8 (lane / 32) .. + 7) as three f16
+// vectors: hi = f16(v), lo = f16((v - hi) 2^5) (v - hi is exact in fp32), hs = hi 2^-5
+__device__ __forceinline__ void split_f16x8(const float (&v)[8], f16x8 &hi, f16x8 &lo, f16x8 &hs) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const _Float16 h = (_Float16)v[t];
+    hi[t] = h;
+    lo[t] = (_Float16)((v[t] - (float)h) * kF16LoScale);
+  }
+  hs = hi * (_Float16)(1.f / kF16LoScale);
+}
+
+// acc += a b for one 32x32x16 operand pair, cross terms first
+#define DDPM_MFMA_F16X3(acc, ah, al, as, bh, bl, bs)                              \
+  do {                                                                            \
+    (acc) = __builtin_amdgcn_mfma_f32_32x32x16_f16((as), (bl), (acc), 0, 0, 0);   \
+    (acc) = __builtin_amdgcn_mfma_f32_32x32x16_f16((al), (bs), (acc), 0, 0, 0);   \
+    (acc) = __builtin_amdgcn_mfma_f32_32x32x16_f16((ah), (bh), (acc), 0, 0, 0);   \
+  } while (0)
+
 // Block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 floats of LDS.
 // Deterministic: fixed butterfly inside the wave, fixed order across waves.
 __device__ __forceinline__ float block_sum_256(float v, float *red) {

@@ -45,22 +45,7 @@
 namespace ddpm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
 constexpr float kF16WScale = 64.f;  // 2^6 on the weights before the hi / lo split, 2^-6 on the accumulators after
-constexpr float kF16LoScale = 32.f;  // 2^5 on a low half, 2^-5 on the high half it is multiplied with
-
-// One MFMA operand (eight fp32 values: the 32x32x16 f16 instruction's k = 8 (lane / 32) .. + 7) as three f16
-// vectors: hi = f16(v), lo = f16((v - hi) 2^5) (v - hi is exact in fp32), hs = hi 2^-5
-__device__ __forceinline__ void split_f16x8(const float (&v)[8], f16x8 &hi, f16x8 &lo, f16x8 &hs) {
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const _Float16 h = (_Float16)v[t];
-    hi[t] = h;
-    lo[t] = (_Float16)((v[t] - (float)h) * kF16LoScale);
-  }
-  hs = hi * (_Float16)(1.f / kF16LoScale);
-}
 
 constexpr int kDC = 16;          // input channels per chunk
 constexpr int kDM = 128;         // output channels per workgroup
