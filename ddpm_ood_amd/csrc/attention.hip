@@ -147,7 +147,27 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
   };
 
   load_block(qp, i0);
-  store_block(Ql, kQB);
+  if constexpr (F16X3) {
+    // The q tile is the same for every key block: split it once.  It passes through the (still unused) K / V buffer
+    // as fp32 [d][token]; Ql then holds two f16 planes [d / 8][token][8 d] -- hi, and lo scaled by 2^5 -- so that an
+    // MFMA A operand (this lane's eight head-dim channels of one query) is a single ds_read_b128 per plane.
+    store_block(KVl, kQB);
+    __syncthreads();
+    f16x8 *Qh = reinterpret_cast<f16x8 *>(Ql), *Qlo = Qh + (kDH / 8) * kQB;
+#pragma unroll
+    for (int u = 0; u < (kDH / 8) * kQB / 256; ++u) {
+      const int g = (tid >> 6) + 4 * u, tok = tid & 63;
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = KVl[(8 * g + t) * kQB + tok];
+      f16x8 hi, lo, hs;
+      split_f16x8(v, hi, lo, hs);
+      Qh[g * kQB + tok] = hi;
+      Qlo[g * kQB + tok] = lo;
+    }
+  } else {
+    store_block(Ql, kQB);
+  }
   load_block(kp, 0);
   if (tid < kQB) {
     mrow[tid] = -INFINITY;
@@ -177,27 +197,27 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
       f32x16 sacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-      const float *qa = Ql + 8 * lhi * kQB + qi * 32 + l31;
+      const f16x8 *qh = reinterpret_cast<const f16x8 *>(Ql) + lhi * kQB + qi * 32 + l31;
+      const f16x8 *ql = qh + (kDH / 8) * kQB;
       const float *kb = KVl + 8 * lhi * kKB + kj * 32 + l31;
-      float av[2][8], bv[2][8];
+      float bv[2][8];
+      f16x8 ahv[2], alv[2];
+      ahv[0] = qh[0];
+      alv[0] = ql[0];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        av[0][t] = qa[t * kQB];
-        bv[0][t] = kb[t * kKB];
-      }
+      for (int t = 0; t < 8; ++t) bv[0][t] = kb[t * kKB];
 #pragma unroll
       for (int ks = 0; ks < kDH / 16; ++ks) {
         if (ks + 1 < kDH / 16) {
+          ahv[(ks + 1) & 1] = qh[2 * (ks + 1) * kQB];
+          alv[(ks + 1) & 1] = ql[2 * (ks + 1) * kQB];
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            av[(ks + 1) & 1][t] = qa[(16 * (ks + 1) + t) * kQB];
-            bv[(ks + 1) & 1][t] = kb[(16 * (ks + 1) + t) * kKB];
-          }
+          for (int t = 0; t < 8; ++t) bv[(ks + 1) & 1][t] = kb[(16 * (ks + 1) + t) * kKB];
         }
-        f16x8 ah, al, as, bh, bl, bs;
-        split_f16x8(av[ks & 1], ah, al, as);
+        f16x8 bh, bl, bs;
         split_f16x8(bv[ks & 1], bh, bl, bs);
-        DDPM_MFMA_F16X3(sacc, ah, al, as, bh, bl, bs);
+        const f16x8 as = ahv[ks & 1] * (_Float16)(1.f / kF16LoScale);
+        DDPM_MFMA_F16X3(sacc, ahv[ks & 1], alv[ks & 1], as, bh, bl, bs);
       }
       const bool colok = (j0 + kj * 32 + l31) < N;
 #pragma unroll
@@ -257,10 +277,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
       const float mo = mrow[row];
       const float mn = fmaxf(mo, bm);
       float sum = 0.f;
+      float pr[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const float p = __builtin_amdgcn_exp2f(sr[c] - mn);  // scores carry the log2(e) factor already
-        sr[c] = p;
+        if constexpr (F16X3) pr[c] = p; else sr[c] = p;
         sum += p;
       }
       sum += __shfl_xor(sum, 1, 64);
@@ -268,6 +289,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
       const float alpha = __builtin_amdgcn_exp2f(mo - mn);  // exp2(-inf) = 0 on the first block
       store_block(KVl, kLd);              // V block over the K block, row stride 65
       __syncthreads();                    // all 4 readers of mrow[row] are done; V and P are visible
+      if constexpr (F16X3) {
+        // every score has been read: the probabilities replace them as two f16 planes [key / 8][query][8 keys] (hi,
+        // lo 2^5), split once here instead of by each of the four waves -- the PV B operand is one ds_read_b128
+        f16x8 *Ph = reinterpret_cast<f16x8 *>(Sl), *Pl = Ph + (kKB / 8) * kQB;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float v[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) v[t] = pr[8 * u + t];
+          f16x8 hi, lo, hs;
+          split_f16x8(v, hi, lo, hs);
+          Ph[(2 * part + u) * kQB + row] = hi;
+          Pl[(2 * part + u) * kQB + row] = lo;
+        }
+      }
       if (part == 0) {
         mrow[row] = mn;
         lrow[row] = lrow[row] * alpha + sum;
@@ -289,20 +325,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     if constexpr (F16X3) {
       // k-step ks = keys 16 ks .. 16 ks + 15 of the block; A = V rows d (row stride 65), B = P rows i (row stride 65)
       const float *va = KVl + ((wave * 2) * 32 + l31) * kLd + 8 * lhi;
-      const float *pb = Sl + l31 * kLd + 8 * lhi;
+      const f16x8 *ph = reinterpret_cast<const f16x8 *>(Sl) + lhi * kQB + l31;
+      const f16x8 *pl = ph + (kKB / 8) * kQB;
 #pragma unroll
       for (int ks = 0; ks < kKB / 16; ++ks) {
         f16x8 ah[2], al[2], as[2], bh[2], bl[2], bs[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-          float v[8], p[8];
+          float v[8];
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            v[t] = va[a * 32 * kLd + 16 * ks + t];
-            p[t] = pb[a * 32 * kLd + 16 * ks + t];
-          }
+          for (int t = 0; t < 8; ++t) v[t] = va[a * 32 * kLd + 16 * ks + t];
           split_f16x8(v, ah[a], al[a], as[a]);
-          split_f16x8(p, bh[a], bl[a], bs[a]);
+          bh[a] = ph[2 * ks * kQB + 32 * a];
+          bl[a] = pl[2 * ks * kQB + 32 * a];
+          bs[a] = bh[a] * (_Float16)(1.f / kF16LoScale);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
