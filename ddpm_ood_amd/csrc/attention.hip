@@ -1,4 +1,5 @@
-// attention.hip -- fused self-attention core (QK^T -> softmax -> PV -> + residual), fp32 MFMA.
+// attention.hip -- fused self-attention core (QK^T -> softmax -> PV -> + residual): split-f16 products on the f16
+// MFMA (default, see the F16X3 note at the kernel) or f32 MFMA.
 //
 // Replaces torch.baddbmm / softmax / torch.bmm of MONAI-Generative's AttentionBlock._attention
 // (reference call site /root/reference/src/trainers/reconstruct.py:151-153).

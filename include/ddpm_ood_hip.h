@@ -181,7 +181,9 @@ int ddpm_gn_scale_shift_f32(const float *in1, const float *in2, int C1, int C2, 
 
 /* Self-attention core of AttentionBlock (A.3): qkv is [B, 3C, N] (q rows, then k, then v,
  * channel-major exactly as a 1x1 conv over NCHW produces them); out = softmax(scale q^T k) v
- * + residual, written as [B, C, N].  Replaces torch.baddbmm / softmax / torch.bmm.       */
+ * + residual, written as [B, C, N].  Replaces torch.baddbmm / softmax / torch.bmm.  fp32 in and out; the two
+ * contractions multiply on the f16 MFMA with every fp32 product rebuilt from three f16 products (22 mantissa bits,
+ * fp32 accumulate) unless DDPM_ATTN_F16X3=0 (f32 MFMA, bit-exact fp32 products).                              */
 int ddpm_attention_f32(const float *qkv, const float *residual, float *out, int B, int C, int N,
                        int num_heads, float scale, ddpm_stream_t stream);
 

@@ -209,6 +209,33 @@ def test_attention_online_softmax_rescale(device):
     _close(out, torch.einsum("bij,bdj->bdi", s.softmax(-1), v), tol=1e-5)
 
 
+@pytest.mark.parametrize("qs,vs", [(1.0, 1.0), (0.05, 20.0), (3.0, 0.01)])
+def test_attention_split_f16_error(device, qs, vs):
+    """Both contractions run as split-f16 MFMA products (22-bit products, fp32 accumulate): against a float64
+    attention the error is of the order of an fp32 attention's own, over operand scales from flat to peaky softmax."""
+    from ddpm_ood_amd import ops
+
+    B, heads, N = 2, 2, 300  # five key blocks, the last one (and the last query block) ragged
+    C = 256 * heads
+    g = torch.Generator().manual_seed(21)
+    qkv = torch.randn(B, 3 * C, N, generator=g)
+    qkv[:, :2 * C] *= qs
+    qkv[:, 2 * C:] *= vs
+    scale = 1 / 16.0
+    out = ops.attention(qkv.to(device), None, heads, scale).cpu().double()
+
+    def ref(t):
+        q, k, v = (x.reshape(B, heads, 256, N) for x in t.split(C, dim=1))
+        s = torch.einsum("bhdi,bhdj->bhij", q, k) * scale
+        return torch.einsum("bhij,bhdj->bhdi", s.softmax(-1), v).reshape(B, C, N)
+
+    r64 = ref(qkv.double())
+    norm = r64.abs().max().item()
+    err = (out - r64).abs().max().item() / norm
+    err32 = (ref(qkv).double() - r64).abs().max().item() / norm
+    assert math.isfinite(err) and err <= max(4 * err32, 2e-6), (err, err32)
+
+
 def test_timestep_embedding_and_known_answer(device):
     from ddpm_ood_amd import ops
     from oracle.unet import get_timestep_embedding

@@ -392,6 +392,10 @@ def test_bench_roofline_object_is_the_executed_mfma_fraction():
                "ms_in_sample", "algorithmic_GBps"):  # the keys the bench line copies from every class
         assert kk in hbm and kk in bench.rooflines_of({"attention": {"launches": 1, "ms": 1.0, "flops": 1e9, "bytes": 1e6}})["attention"]
     assert abs(hbm["achieved"] - (7 * 600e6 + 3e8) / 1.5e-3 / 1e9) < 0.1 and abs(hbm["frac"] - hbm["achieved"] / 8000.0) < 1e-3
+    att = bench.rooflines_of({"attention": {"launches": 2, "ms": 2.0, "flops": 2 * 140e9, "bytes": 1e8}})["attention"]
+    # split-f16 attention: three f16 MFMAs per fp32 product against the dense f16 peak
+    assert att["peak"] == 2500.0 and abs(att["achieved"] - 3 * 140.0) < 0.01 and abs(att["frac"] - 420.0 / 2500.0) < 1e-3
+    assert abs(att["algorithmic_equiv_tflops"] - 140.0) < 0.01
     r = bench.rooflines_of(prof)
     assert set(r) == {"conv3x3_wino", "conv3x3_wino44", "conv3x3_wino_up", "attention", "conv3d_wino", "conv3d_wino44",
                       "conv3d_"}  # MFMA classes only

@@ -58,6 +58,8 @@ def main(root, out_csv, out_json):
                          ("conv3x3_mfma_gn_silu", r"conv_mfma_kernel<9, 1, true, 128"),
                          ("conv3d_wino44", r"conv_wino44_kernel<false, \d, \d, (?:true|false), true>"),
                          ("conv3d_wino", r"conv_wino_kernel<false, \d, (?:true|false), true>"),
+                         ("conv1x1_dma", r"conv1x1_dma_kernel"),
+                         ("attention", r"attention_kernel"),
                          ("lpips_conv_mfma", r"lpips_conv_mfma_kernel")):
         sel = m[m.kernel.str.contains(pattern)]
         if len(sel):
