@@ -82,6 +82,20 @@ __device__ __forceinline__ void mfma_first_n(f32x16 &c, float a, float b) {
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
 
 // VEC: N % 4 == 0 -> 16-byte global loads of K / V / Q rows
+// Workgroup -> (query block, head, image).  Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own
+// L2, and every workgroup of an (image, head) streams the same K / V rows (8 MB at n = 4096: 64 query blocks read them
+// 64 times).  Dealt in launch order, the query blocks of one image land on all eight L2s and each L2 sees every image;
+// instead XCD x takes the x-th eighth of the (image, head, query block) list, so the workgroups resident on an XCD
+// walk the same K / V blocks at about the same time and all but the first read hits that L2.
+__device__ __forceinline__ void attention_tile(int &qblk, int &hh, int &n) {
+  const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+  unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+  qblk = id % gx;
+  hh = (id / gx) % gy;
+  n = id / (gx * gy);
+}
+
 // F16X3: both contractions on the f16 MFMA, every fp32 product rebuilt from three v_mfma_f32_32x32x16_f16 (common.h
 // split_f16x8; 22 mantissa bits per product, fp32 accumulate -- conv1x1_dma.hip has the error budget).  The operands
 // are split in registers on their way from the fp32 LDS tiles to the MFMA; staging, softmax and epilogue are shared
@@ -101,7 +115,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int qblk = blockIdx.x, hh = blockIdx.y, n = blockIdx.z;
+  int qblk, hh, n;
+  attention_tile(qblk, hh, n);
   const int i0 = qblk * kQB;
 
   const float *qp = qkv + ((size_t)n * 3 * C + hh * kDH) * N;
@@ -405,6 +420,255 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
   }
 }
 
+// ---- eight-wave split-f16 form -----------------------------------------------------------------------------------
+// Same tile (64 queries x 64-key blocks), LDS image and arithmetic as attention_kernel<., true>, with 512 threads: two
+// waves per SIMD, so one wave's staging stores, softmax and barrier waits overlap the other's MFMAs (with four waves
+// ~60 % of a block's cycles were such stalls).  Work split:
+//   QK^T   wave = (head-dim half kh, S quadrant): eight of the sixteen k-steps each; the kh = 1 waves park their partial
+//          scores in Sl, the kh = 0 waves add them to their own (low half + high half: a fixed order), scale and mask
+//   softmax  eight threads per query row, eight keys (= one f16 plane unit) each
+//   PV     wave w owns head-dim rows 32 w .. 32 w + 31 for all 64 queries (two accumulator tiles)
+constexpr int kPF8 = kDH * kKB / 512;  // staging floats per thread (32)
+
+template <bool VEC>
+__global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict__ qkv,
+                                                         const float *__restrict__ residual,
+                                                         float *__restrict__ out, int C, int N, int heads,
+                                                         float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Ql = smem;                    // two f16 planes [32][64][8]: q hi, q lo 2^5
+  float *KVl = Ql + kDH * kQB;         // [256][65]   K block (row stride 64) then V block (row stride 65)
+  float *Sl = KVl + kDH * kLd;         // [64][65]    scores, then two f16 planes [8][64][8] of probabilities
+  float *mrow = Sl + kQB * kLd;
+  float *lrow = mrow + kQB;
+  float *arow = lrow + kQB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int qblk, hh, n;
+  attention_tile(qblk, hh, n);
+  const int i0 = qblk * kQB;
+
+  const float *qp = qkv + ((size_t)n * 3 * C + hh * kDH) * N;
+  const float *kp = qp + (size_t)C * N;
+  const float *vp = kp + (size_t)C * N;
+
+  float pf[kPF8];
+  auto load_block = [&](const float *src, int t0) {
+    if (VEC) {
+#pragma unroll
+      for (int r = 0; r < kPF8 / 4; ++r) {
+        const int e4 = tid + 512 * r;
+        const int d = e4 >> 4, j = (e4 & 15) * 4;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (t0 + j < N) v = *reinterpret_cast<const v4f *>(src + (size_t)d * N + t0 + j);
+        pf[4 * r + 0] = v[0]; pf[4 * r + 1] = v[1]; pf[4 * r + 2] = v[2]; pf[4 * r + 3] = v[3];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < kPF8; ++r) {
+        const int e = tid + 512 * r;
+        const int d = e >> 6, j = e & 63;
+        pf[r] = (t0 + j < N) ? src[(size_t)d * N + t0 + j] : 0.f;
+      }
+    }
+  };
+  auto store_block = [&](float *dst, int ld) {
+    if (VEC) {
+#pragma unroll
+      for (int r = 0; r < kPF8 / 4; ++r) {
+        const int e4 = tid + 512 * r;
+        const int d = e4 >> 4, j = (e4 & 15) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[d * ld + j + c] = pf[4 * r + c];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < kPF8; ++r) {
+        const int e = tid + 512 * r;
+        dst[(e >> 6) * ld + (e & 63)] = pf[r];
+      }
+    }
+  };
+
+  // q tile: fp32 through the K / V buffer, then split once into the two planes
+  load_block(qp, i0);
+  store_block(KVl, kQB);
+  __syncthreads();
+  {
+    f16x8 *Qh = reinterpret_cast<f16x8 *>(Ql), *Qlo = Qh + (kDH / 8) * kQB;
+#pragma unroll
+    for (int u = 0; u < (kDH / 8) * kQB / 512; ++u) {
+      const int g = (tid >> 6) + 8 * u, tok = tid & 63;
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = KVl[(8 * g + t) * kQB + tok];
+      f16x8 hi, lo, hs;
+      split_f16x8(v, hi, lo, hs);
+      Qh[g * kQB + tok] = hi;
+      Qlo[g * kQB + tok] = lo;
+    }
+  }
+  load_block(kp, 0);
+  if (tid < kQB) {
+    mrow[tid] = -INFINITY;
+    lrow[tid] = 0.f;
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+
+  const int quad = wave & 3, kh = wave >> 2;
+  const int qi = quad >> 1, kj = quad & 1;
+
+  for (int j0 = 0; j0 < N; j0 += kKB) {
+    __syncthreads();            // previous PV finished with KVl / Sl; orders the q planes and m / l init
+    store_block(KVl, kKB);      // K block, row stride 64
+    __syncthreads();
+    load_block(vp, j0);         // V of this block flies while QK^T runs
+
+    // ---- partial S quadrant over head-dim channels 128 kh .. 128 kh + 127 ------------------------------
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    {
+      const f16x8 *qh = reinterpret_cast<const f16x8 *>(Ql) + (16 * kh + lhi) * kQB + qi * 32 + l31;
+      const f16x8 *ql = qh + (kDH / 8) * kQB;
+      const float *kb = KVl + (128 * kh + 8 * lhi) * kKB + kj * 32 + l31;
+      float bv[2][8];
+      f16x8 ahv[2], alv[2];
+      ahv[0] = qh[0];
+      alv[0] = ql[0];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) bv[0][t] = kb[t * kKB];
+#pragma unroll
+      for (int ks = 0; ks < kDH / 32; ++ks) {
+        if (ks + 1 < kDH / 32) {
+          ahv[(ks + 1) & 1] = qh[2 * (ks + 1) * kQB];
+          alv[(ks + 1) & 1] = ql[2 * (ks + 1) * kQB];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) bv[(ks + 1) & 1][t] = kb[(16 * (ks + 1) + t) * kKB];
+        }
+        f16x8 bh, bl, bs;
+        split_f16x8(bv[ks & 1], bh, bl, bs);
+        const f16x8 as = ahv[ks & 1] * (_Float16)(1.f / kF16LoScale);
+        DDPM_MFMA_F16X3(sacc, ahv[ks & 1], alv[ks & 1], as, bh, bl, bs);
+      }
+    }
+    if (kh == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        Sl[row * kLd + kj * 32 + l31] = sacc[r];
+      }
+    }
+    __syncthreads();            // high-half partials parked; every wave is done reading the K block
+    if (kh == 0) {
+      const bool colok = (j0 + kj * 32 + l31) < N;
+      // scores are kept in the log2 domain: s * scale * log2(e), so that the softmax below is one v_exp_f32 per key
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float *sp = Sl + row * kLd + kj * 32 + l31;
+        *sp = colok ? (sacc[r] + *sp) * (scale * 1.44269504088896341f) : -INFINITY;
+      }
+    }
+    __syncthreads();            // scores complete
+
+    // ---- online softmax: 8 threads per query row, 8 keys each ------------------------------------------
+    {
+      const int row = tid >> 3, part = tid & 7;
+      const float *sr = Sl + row * kLd + part * 8;
+      float sv[8];
+      float bm = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        sv[c] = sr[c];
+        bm = fmaxf(bm, sv[c]);
+      }
+      bm = fmaxf(bm, __shfl_xor(bm, 1, 64));
+      bm = fmaxf(bm, __shfl_xor(bm, 2, 64));
+      bm = fmaxf(bm, __shfl_xor(bm, 4, 64));
+      const float mo = mrow[row];
+      const float mn = fmaxf(mo, bm);
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        sv[c] = __builtin_amdgcn_exp2f(sv[c] - mn);
+        sum += sv[c];
+      }
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      sum += __shfl_xor(sum, 4, 64);
+      const float alpha = __builtin_amdgcn_exp2f(mo - mn);  // exp2(-inf) = 0 on the first block
+      store_block(KVl, kLd);              // V block over the K block, row stride 65
+      __syncthreads();                    // every score and mrow[row] has been read; V is visible
+      f16x8 *Ph = reinterpret_cast<f16x8 *>(Sl), *Pl = Ph + (kKB / 8) * kQB;
+      f16x8 hi, lo, hs;
+      split_f16x8(sv, hi, lo, hs);
+      Ph[part * kQB + row] = hi;
+      Pl[part * kQB + row] = lo;
+      if (part == 0) {
+        mrow[row] = mn;
+        lrow[row] = lrow[row] * alpha + sum;
+        arow[row] = alpha;
+      }
+    }
+    __syncthreads();
+    if (j0 + kKB < N) load_block(kp, j0 + kKB);  // next K block flies while PV runs
+
+    // ---- O[d][i] = alpha_i * O[d][i] + sum_j V[d][j] P[i][j], d = 32 wave + .. ---------------------------
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float al = arow[b * 32 + l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[b][r] *= al;
+    }
+    {
+      const float *va = KVl + (wave * 32 + l31) * kLd + 8 * lhi;
+      const f16x8 *ph = reinterpret_cast<const f16x8 *>(Sl) + lhi * kQB + l31;
+      const f16x8 *pl = ph + (kKB / 8) * kQB;
+#pragma unroll
+      for (int ks = 0; ks < kKB / 16; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = va[16 * ks + t];
+        f16x8 ah, al, as;
+        split_f16x8(v, ah, al, as);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const f16x8 bh = ph[2 * ks * kQB + 32 * b], bl = pl[2 * ks * kQB + 32 * b];
+          const f16x8 bs = bh * (_Float16)(1.f / kF16LoScale);
+          DDPM_MFMA_F16X3(o[b], ah, al, as, bh, bl, bs);
+        }
+      }
+    }
+  }
+
+  // ---- normalise, add residual, store [B, C, N] ------------------------------------------------
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int i = i0 + b * 32 + l31;
+    if (i < N) {
+      const float inv = 1.0f / lrow[b * 32 + l31];
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        rv[r] = residual ? residual[((size_t)n * C + hh * kDH + d) * N + i] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        out[((size_t)n * C + hh * kDH + d) * N + i] = o[b][r] * inv + rv[r];
+      }
+    }
+  }
+}
+
 int launch_attention(const float *qkv, const float *residual, float *out, int B, int C, int N, int heads, float scale,
                      hipStream_t s) {
   DDPM_CHECK_ARG(qkv && out && B > 0 && N > 0 && heads > 0, "attention: null pointer or empty shape");
@@ -416,14 +680,24 @@ int launch_attention(const float *qkv, const float *residual, float *out, int B,
     for (const void *f : {reinterpret_cast<const void *>(&attention_kernel<true, false>),
                           reinterpret_cast<const void *>(&attention_kernel<false, false>),
                           reinterpret_cast<const void *>(&attention_kernel<true, true>),
-                          reinterpret_cast<const void *>(&attention_kernel<false, true>)})
+                          reinterpret_cast<const void *>(&attention_kernel<false, true>),
+                          reinterpret_cast<const void *>(&attention8_kernel<true>),
+                          reinterpret_cast<const void *>(&attention8_kernel<false>)})
       (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   dim3 grid((N + kQB - 1) / kQB, heads, B);
   ProfScope prof(s, "attention", 4.0 * B * (double)N * N * C, 4.0 * B * C * (double)N * (residual ? 5 : 4));
   static const bool f16x3 = !(getenv("DDPM_ATTN_F16X3") && atoi(getenv("DDPM_ATTN_F16X3")) == 0);
+  // eight-wave form by default (n = 4096: 892 vs 918 us, n = 256: 32.3 vs 34.8 us); DDPM_ATTN_WAVES=4 selects the other
+  static const bool waves8 = !(getenv("DDPM_ATTN_WAVES") && atoi(getenv("DDPM_ATTN_WAVES")) == 4);
   const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv) & 15) == 0);
+  if (f16x3 && waves8) {
+    auto kern8 = vec ? attention8_kernel<true> : attention8_kernel<false>;
+    hipLaunchKernelGGL(kern8, grid, dim3(512), lds, s, qkv, residual, out, C, N, heads, scale);
+    DDPM_CHECK_LAUNCH();
+    return 0;
+  }
   auto kern = f16x3 ? (vec ? attention_kernel<true, true> : attention_kernel<false, true>)
                     : (vec ? attention_kernel<true, false> : attention_kernel<false, false>);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, qkv, residual, out, C, N, heads, scale);

@@ -236,6 +236,48 @@ def test_attention_split_f16_error(device, qs, vs):
     assert math.isfinite(err) and err <= max(4 * err32, 2e-6), (err, err32)
 
 
+@pytest.mark.parametrize("env", [{"DDPM_ATTN_WAVES": "4"}, {"DDPM_ATTN_F16X3": "0"}, {"DDPM_CONV1X1_F16X3": "0"}])
+def test_split_f16_switches_select_working_kernels(device, env):
+    """The A/B switches are read once per process: a child process with each of them set runs the attention core and a
+    DMA-fed 1x1 (plain and GroupNorm-ed) against torch, so the fallback forms (four-wave split-f16 attention, f32 MFMA
+    attention, f32 MFMA 1x1) stay tested while the defaults move on."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import math, torch
+from ddpm_ood_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(3)
+B, heads, N = 2, 2, 200
+C = 256 * heads
+qkv = torch.randn(B, 3 * C, N, generator=g)
+res = torch.randn(B, C, N, generator=g)
+out = ops.attention(qkv.to(dev), res.to(dev), heads, 1 / 16.0).cpu()
+q, k, v = (t.reshape(B, heads, 256, N) for t in qkv.split(C, dim=1))
+s = torch.einsum("bhdi,bhdj->bhij", q, k) / 16.0
+ref = torch.einsum("bhij,bhdj->bhdi", s.softmax(-1), v).reshape(B, C, N) + res
+assert (out - ref).abs().max().item() <= 1e-5 * (1 + ref.abs().max().item())
+x = torch.randn(160, 256, 16, 16, generator=g)
+w = torch.randn(256, 256, 1, 1, generator=g) / 16.0
+b = torch.randn(256, generator=g)
+gamma, beta = torch.randn(256, generator=g), torch.randn(256, generator=g)
+y = ops.conv(x.to(dev), w.to(dev), b.to(dev)).cpu()
+ref = torch.nn.functional.conv2d(x, w, b)
+assert (y - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item())
+gs, gh = ops.gn_scale_shift(x.to(dev), gamma.to(dev), beta.to(dev), 32, 1e-6)
+y = ops.conv(x.to(dev), w.to(dev), b.to(dev), gscale=gs, gshift=gh).cpu()
+ref = torch.nn.functional.conv2d(torch.nn.functional.group_norm(x, 32, gamma, beta, 1e-6), w, b)
+assert (y - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item())
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=root, **env), cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
 def test_timestep_embedding_and_known_answer(device):
     from ddpm_ood_amd import ops
     from oracle.unet import get_timestep_embedding
