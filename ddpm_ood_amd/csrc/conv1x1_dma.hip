@@ -89,8 +89,26 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_des
   const int l31 = lane & 31, lhi = lane >> 5;
   const int wco = (wave & 1) * 64, wpx = (wave >> 1) * 128;  // 4 waves: 2 x 2
   const int HW = a.Ho * a.Wo, Cin = a.C1 + a.C2, nchunks = Cin / kDC;
-  const int nt = blockIdx.y;
-  const long t0 = (long)blockIdx.x * kDP;  // first pixel of the tile in the flattened (n, p) order
+  // Workgroup -> (pixel tile, cout tile).  The cout tiles of one pixel tile read the same input; workgroups are dealt
+  // round-robin to the 8 XCDs (id % 8), each with its own L2, so the cout tiles of a pixel tile take consecutive slots
+  // of ONE XCD: they run side by side and all but the first read of the input hits that L2 (DDPM_CONV1X1_XCD=0: the
+  // plain (pixel tile, cout tile) grid order, where they are a whole grid row apart).
+  int nt;
+  long t0;
+  {
+    const unsigned CT = a.Cout / kDM, PT = (unsigned)(((long)a.B * a.Ho * a.Wo + kDP - 1) / kDP);
+    unsigned ptile;
+    if (gridDim.y == 1) {
+      const unsigned xcd = blockIdx.x & 7, m = blockIdx.x >> 3;
+      ptile = (m / CT) * 8 + xcd;
+      nt = m % CT;
+    } else {
+      ptile = blockIdx.x;
+      nt = blockIdx.y;
+    }
+    if (ptile >= PT) return;  // padding of the last group of eight pixel tiles
+    t0 = (long)ptile * kDP;   // first pixel of the tile in the flattened (n, p) order
+  }
   const long npix = (long)a.B * HW;
 
   // ---- DMA roles.  A: the chunk's 16 x 128 weights are 8 KB contiguous -> pieces 2 wave, 2 wave + 1 of 8.
@@ -273,7 +291,9 @@ int launch_conv1x1_dma(const ddpm_conv_desc &d, hipStream_t s) {
   const int Cin = d.C1 + d.C2;
   ProfScope prof(s, aff ? "conv1x1_dma_gn" : "conv1x1_dma", 2.0 * npix * d.Cout * Cin,
                  4.0 * ((double)npix * Cin + (double)npix * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * Cin));
-  const dim3 grid((unsigned)((npix + kDP - 1) / kDP), d.Cout / kDM);
+  static const bool xcd_order = !(getenv("DDPM_CONV1X1_XCD") && atoi(getenv("DDPM_CONV1X1_XCD")) == 0);
+  const unsigned PT = (unsigned)((npix + kDP - 1) / kDP), CT = d.Cout / kDM;
+  const dim3 grid = xcd_order ? dim3(8 * ((PT + 7) / 8) * CT) : dim3(PT, CT);
   if (aff)
     hipLaunchKernelGGL((conv1x1_dma_kernel<true, true>), grid, dim3(256), lds, s, d);
   else if (f16x3)
