@@ -1,3 +1,7 @@
+#!/bin/bash
+# End-of-session validation on the GPU box (one gpurun call, ~25 min): GPU tests, the bench lines of every config,
+# the rocprofv3 kernel trace of the batch-256 bench, per-kernel-class microbenchmarks and the PMC passes.
+#   gpurun --timeout 2700 -- 'bash tools/final_validation.sh'      (outputs under gpurun_out/; copy into profiles/)
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 | tee gpurun_out/gpu_tests_final.log
 python bench.py --steps 2 --warmup 1 > gpurun_out/bench_cfg2.json 2> gpurun_out/bench_cfg2.err
