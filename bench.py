@@ -1,8 +1,11 @@
 """bench.py -- reconstructions/sec of the multi-t DDPM reconstruction hot path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5] [--scaling weak|strong]
+    python bench.py --gpus N --steps K --warmup W [--config cfg1|cfg2|cfg3|cfg4|cfg5] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its N ranks itself (it re-executes
+this file through torch.distributed.run on 127.0.0.1 and relays the one JSON line), so both command lines work.
 
 Default workload (BASELINE.json configs[1], the configuration the metric is quoted on): FashionMNIST-shaped
 32x32x1 synthetic images, `small` UNet with seeded random weights, 100 PLMS timesteps, inference_skip_factor=4
@@ -12,13 +15,16 @@ reconstructions/s at batch 256 / 512 / 1 024; --batch 256 is the reference's def
 batch of 1 024 images per rank through the whole hot path (noise, add_noise, every PLMS trajectory, clamp + MSE,
 LPIPS, score gather) = 25 600 reconstructions per rank, inputs resident in HBM when timing starts.
 
---scaling weak   (default) every rank gets its own 1 024-image shard of a 1 024*N-image set per step.
---scaling strong a fixed --images set (default 2 048 for cfg2 / cfg3, 8 batches for cfg4 / cfg5) is split round-robin
-                 over the N ranks (each rank's batch is its share, at most --batch); a step is one pass over the
-                 whole set, so the work per step does not grow with N.
-The only collective is the per-step all_gather of the dense score tensor (RCCL).
+--scaling strong (default for N > 1: north_star's target is ">= 6x STRONG scaling 1 -> 8 GPUs") a fixed --images set
+                 (default: ONE batch of the config, 1 024 images for cfg2 / cfg3 -- exactly the N = 1 workload) is split
+                 round-robin over the N ranks (each rank's batch is its share); a step is one pass over the whole set,
+                 so the work per step does not grow with N and the N = 1 line is the same under either mode.
+--scaling weak   (default for N = 1) every rank gets its own 1 024-image shard of a 1 024*N-image set per step.
+The only collective is the per-step all_gather of the dense score tensor (RCCL); the line carries `rccl_world_size`
+and the per-rank device list gathered over that group.
 
 --config selects the other BASELINE configurations (same metric, their own `roofline`):
+    cfg1  32x32x1 `small`, first_n = 16, k = 64 (t in {10, 650}): the latency-bound small-batch regime of configs[0]
     cfg3  32x32x3 `small`                       (batch 1 024, k = 4)
     cfg4  64x64x3 `big` attention-heavy UNet    (batch 16,  k = 2: 50 t-starts, 2 550 forwards per image)
     cfg5  128^3 volumes, README VQ-VAE (4 x stride 2, 256 ch, 2 048 codes) -> [128, 8, 8, 8] latents -> 3-D
@@ -32,6 +38,8 @@ form) of the direct convolution's multiplies: the direct-conv-equivalent rate is
 `algorithmic_equiv_tflops` and is NOT a roofline fraction.  `rooflines` lists every MFMA kernel class the same
 way (cfg4: the attention kernel; cfg5: the 3-D convolutions).  `cpu_baseline` = the CPU oracle timed on this
 box's host cores on a bounded sample of the same workload (rank 0, N = 1, default config only).
+`value_batch256` (N = 1, cfg2 only): the same workload at the reference's default batch of 256 images
+(/root/reference/reconstruct.py:91), two timed steps after the main timed region.
 """
 
 import argparse
@@ -39,6 +47,7 @@ import ctypes
 import json
 import os
 import shutil
+import socket
 import sys
 import tempfile
 import time
@@ -54,6 +63,10 @@ import torch.distributed as dist  # noqa: E402
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
 HBM_PEAK_GBPS = 8000.0
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA (same guide)
+ARITHMETIC = ("fp32 storage, fp32 accumulation and fp32 transforms / reductions everywhere; the MFMA products of the "
+              "1x1 convolutions and attention are split-f16: each fp32 product is rebuilt from "
+              "three v_mfma_f32_32x32x16_f16 (hi x hi + hi x lo + lo x hi, fp32 accumulate) = 22 mantissa bits per product "
+              "(DDPM_*_F16X3=0 restores bit-exact fp32 MFMA products); all other kernels plain fp32")
 SCHED = dict(beta_schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195)
 
 VQ_README = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(256, 256, 256, 256), num_res_layers=3,
@@ -61,6 +74,9 @@ VQ_README = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(25
                  upsample_parameters=((2, 4, 1, 1, 0),) * 4, num_embeddings=2048, embedding_dim=128)
 
 CONFIGS = {
+    "cfg1": dict(model_type="small", channels=1, size=32, spatial=2, skip=64, batch=16, metric_tag="FashionMNIST 32x32, first_n=16",
+                 workload="BASELINE configs[0]: FashionMNIST-shaped 32x32x1, small UNet, 100 PLMS timesteps, "
+                          "inference_skip_factor=64 (2 t-starts: 10 and 650, 68 UNet forwards per image), first_n=16"),
     "cfg2": dict(model_type="small", channels=1, size=32, spatial=2, skip=4, batch=1024, metric_tag="FashionMNIST 32x32",
                  workload="BASELINE configs[1]: FashionMNIST-shaped 32x32x1, small UNet (17.7M params, random init), "
                           "100 PLMS timesteps, inference_skip_factor=4 (25 t-starts, 1250 UNet forwards per image)"),
@@ -176,7 +192,7 @@ def mfma_class(key):
     return None
 
 
-def rooflines_of(prof):
+def rooflines_of(prof, batch=None):
     """Aggregate the in-situ profile by MFMA kernel class.  Per class: executed-MFMA TFLOP/s against the f32 MFMA
     peak (`frac`), the direct-conv-equivalent rate where the kernel executes fewer multiplies than the op it
     replaces, and the algorithmic HBM rate."""
@@ -220,10 +236,17 @@ def rooflines_of(prof):
                  "avg_launch_ms": round(a["ms"] / a["launches"], 4), "ms_in_sample": round(a["ms"], 3),
                  "flops_per_launch": a["flops"] / a["launches"],
                  "algorithmic_GBps": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1), "traffic": None}
+        # HBM bytes per launch from the PMC counters: measured builder-side (separate rocprofv3 --pmc passes, the guide's
+        # gfx950 correction), per batch size; a figure taken at another batch than the timed one is NOT `traffic`
+        at_batch = pmc.get("by_batch", {}).get(str(batch), {})
         for k in (prefix + "_gn_silu", prefix):
+            if k + "_bytes_per_launch" in at_batch:
+                r["traffic"] = at_batch[k + "_bytes_per_launch"]
+                r["traffic_source"] = (f"profiles/pmc_traffic.json by_batch[{batch}] (builder-side rocprofv3 --pmc pass at "
+                                       "the timed batch, not this run)")
+                break
             if k + "_bytes_per_launch" in pmc:
-                r["traffic"] = pmc[k + "_bytes_per_launch"]
-                r["traffic_source"] = "profiles/pmc_traffic.json (builder-side rocprofv3 --pmc pass, not this run)"
+                r["traffic_at_other_batch"] = {"batch": pmc.get("batch", 256), "bytes_per_launch": pmc[k + "_bytes_per_launch"]}
                 break
         out[prefix] = r
     return out
@@ -253,6 +276,21 @@ def write_vqvae(run_root, cfg):
     return str(d / "checkpoint.pth")
 
 
+def self_launch(n: int):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, rendezvous on
+    127.0.0.1 at a free port) and pass their output through; the exit code is the launcher's."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py")] + sys.argv[1:]
+    log(f"no WORLD_SIZE in the environment: launching {n} ranks: {' '.join(cmd)}")
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,9 +298,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per batch (default: the config's)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: strong for --gpus > 1 (fixed image set split over the ranks), weak for 1")
     ap.add_argument("--images", type=int, default=None,
-                    help="--scaling strong: size of the fixed image set (default 8 batches)")
+                    help="--scaling strong: size of the fixed image set (default: one batch of the config)")
+    ap.add_argument("--no-batch256", action="store_true", help="skip the extra batch-256 measurement (cfg2, N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
@@ -270,13 +310,15 @@ def main():
         return cpu_baseline_worker()
     cfg = CONFIGS[a.config]
     batch = a.batch or cfg["batch"]
+    if a.scaling is None:
+        a.scaling = "strong" if a.gpus > 1 else "weak"
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if a.gpus > 1 and world == 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -290,7 +332,7 @@ def main():
     from ddpm_ood_amd.trainer import Reconstruct
 
     lib = _lib.load()
-    n_images, per_rank = shard_sizes(a.scaling, world, batch, a.images or (2048 if cfg["size"] == 32 else 8 * batch))
+    n_images, per_rank = shard_sizes(a.scaling, world, batch, a.images or batch)
     run_root = Path(tempfile.mkdtemp(prefix=f"ddpm_bench_r{rank}_"))
     args = make_args(run_root, cfg, n_images, batch)
     ddpm_channels = cfg["vqvae"]["embedding_dim"] if cfg.get("vqvae") else cfg["channels"]
@@ -339,6 +381,32 @@ def main():
     finally:
         sys.stdout = out_stream
 
+    devices = [f"rank {rank}: {socket.gethostname()} cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"]
+    if world > 1:  # what the RCCL group actually spans: every rank reports its device through the group itself
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
+
+    # the same workload at the reference's default batch (reconstruct.py:91), two timed steps
+    b256 = None
+    if world == 1 and a.config == "cfg2" and batch != 256 and not a.no_batch256:
+        sys.stdout = open(os.devnull, "w")
+        try:
+            l256 = get_data_loader(f"synthetic:blobs:n=256:size={cfg['size']}:channels={cfg['channels']}:seed=0",
+                                   batch_size=256, is_grayscale=bool(args.is_grayscale), spatial_dimension=cfg["spatial"])
+            l256.images = l256.images.to(rec.device)
+            rec.get_scores(l256, "val", cfg["skip"])  # warm-up (workspace of the new shape)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                r256 = rec.get_scores(l256, "val", cfg["skip"])
+            torch.cuda.synchronize()
+            dt256 = time.perf_counter() - t0
+        finally:
+            sys.stdout = out_stream
+        b256 = {"value": round(2 * len(r256) / dt256, 3), "steps": 2, "ms_per_step": round(dt256 / 2 * 1e3, 2)}
+        log(f"batch-256 measurement done: {b256}")
+
     n_t = len({r["t"] for r in rows})
     assert len(rows) == n_images * n_t, (len(rows), n_images, n_t)  # every rank's scores came back through the gather
     recon_per_step = n_images * n_t
@@ -347,7 +415,7 @@ def main():
     buf = ctypes.create_string_buffer(1 << 16)
     n = lib.ddpm_prof_report(buf, len(buf))
     prof = json.loads(buf.value.decode()) if n > 0 else {}
-    rooflines = rooflines_of(prof)
+    rooflines = rooflines_of(prof, batch)
     dominant = max(rooflines.values(), key=lambda r: r["ms_in_sample"]) if rooflines else None
 
     line = {
@@ -355,6 +423,7 @@ def main():
         "unit": "reconstructions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "arithmetic": ARITHMETIC, "rccl_world_size": dist.get_world_size() if world > 1 else 1, "devices": devices,
         "config": {"workload": cfg["workload"], "name": a.config, "images_per_gpu_per_batch": batch,
                    "images_per_step": n_images, "reconstructions_per_step": recon_per_step,
                    "unet_forwards_per_image": rec.last_stats["unet_forwards"] // max(per_rank[rank], 1),
@@ -373,6 +442,9 @@ def main():
                         "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
                     for k, v in prof.items()},
     }
+    if b256:
+        line["value_batch256"] = b256["value"]
+        line["batch256"] = b256
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
         line["cpu_baseline"] = cpu_baseline()
         log(f"cpu baseline done: {line['cpu_baseline']}")

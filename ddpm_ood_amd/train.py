@@ -11,8 +11,16 @@ dict of base.py:166-187.  Differences, on purpose:
     engine reads (``DiffusionModelUNet``) with differentiable ATen ops, so a checkpoint written here loads into the
     HIP inference path unchanged.  Training is off the hot path (it runs once; reconstruction runs per image x
     t_start x step) -- its kernels are rocBLAS / MIOpen via ATen, not hand-written;
-  * multi-GPU: one process per GPU, gradients averaged with ONE flat RCCL all_reduce per step (17.7 M parameters =
-    71 MB for `small`) instead of DistributedDataParallel's bucket hooks;
+  * multi-GPU: one process per GPU; rank 0's initial parameters and buffers are broadcast once (what
+    DistributedDataParallel's constructor does for the reference, base.py:160-163), gradients are averaged with ONE flat
+    RCCL all_reduce per step (17.7 M parameters = 71 MB for `small`) instead of DDP's bucket hooks, and every rank
+    runs the SAME number of steps per epoch on equally long shards (short shards wrap around, as
+    torch.utils.data.DistributedSampler pads) -- a rank with one image less would otherwise issue one all_reduce less
+    and hang the job;
+  * the loss target is the noise for every --prediction_type, as in the reference (ddpm_trainer.py:99-100 regresses
+    onto `noise` also under v_prediction); --augmentation / --cache_data / --num_workers are accepted and have no effect
+    (the reference's two augmentation branches are identical, get_train_and_val_dataloader.py:87-91; the images are
+    resident tensors here);
   * no TensorBoard / matplotlib sample grids (not installed here; off the path).
 """
 
@@ -106,6 +114,7 @@ class DDPMTrainer(BaseTrainer):
         self.seed = int(args.seed)
         for p in self.model.parameters():
             p.requires_grad_(True)
+        self._broadcast_initial_state()
         self.optimizer = torch.optim.Adam(params=self.model.parameters(), lr=2.5e-5)  # base.py:156
         if self.found_checkpoint and self.optimizer_state:
             self.optimizer.load_state_dict(self.optimizer_state)
@@ -115,6 +124,19 @@ class DDPMTrainer(BaseTrainer):
         self.val_loader = get_data_loader(args.validation_ids, rank=self.rank, world=self.world, **kw)
         self.gen = torch.Generator(device=self.device).manual_seed(self.seed * 7919 + self.rank)
         self.history = []  # (epoch, mean train loss)
+
+    def _broadcast_initial_state(self):
+        """Every rank starts from rank 0's parameters and buffers (torch's default init is unseeded per process; a
+        resumed run loads the same file everywhere and the broadcast is a no-op in value)."""
+        if not self.ddp:
+            return
+        tensors = [p.data for p in self.model.parameters()] + [b.data for b in self.model.buffers()]
+        flat = torch.cat([t.reshape(-1).float() for t in tensors])
+        dist.broadcast(flat, src=0)
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off: off + t.numel()].view_as(t).to(t.dtype))
+            off += t.numel()
 
     # ---- one optimisation step (ddpm_trainer.py:77-101) --------------------------------------------------
     def _loss(self, images: torch.Tensor) -> torch.Tensor:
@@ -129,19 +151,20 @@ class DDPMTrainer(BaseTrainer):
             noisy = self.scheduler.add_noise(original_samples=images.contiguous(), noise=noise, timesteps=timesteps,
                                              b_scale=self.b_scale)
         pred = unet_forward_torch(self.model, noisy, timesteps)
-        if self.prediction_type == "v_prediction":
-            ac = self.scheduler.alphas_cumprod.to(self.device)[timesteps].reshape(-1, *([1] * (images.ndim - 1)))
-            target = ac.sqrt() * noise - (1 - ac).sqrt() * images * self.b_scale
-        else:
-            target = noise
-        return F.mse_loss(pred.float(), target.float())
+        # the reference regresses onto the noise whatever --prediction_type says (ddpm_trainer.py:99-100)
+        return F.mse_loss(pred.float(), noise.float())
 
     def _sync_grads(self):
         if not self.ddp:
             return
         grads = [p.grad for p in self.model.parameters() if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat)  # RCCL over xGMI: one collective per step
+        if dist.get_backend() == "gloo" and flat.is_cuda:  # test hook: two ranks on one GPU (see trainer.BaseTrainer)
+            host = flat.cpu()
+            dist.all_reduce(host)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat)  # RCCL over xGMI: one collective per step
         flat /= self.world
         off = 0
         for g in grads:
@@ -150,13 +173,25 @@ class DDPMTrainer(BaseTrainer):
 
     def train_epoch(self, epoch: int) -> float:
         self.model.train()
-        order = torch.randperm(len(self.train_loader.names), generator=torch.Generator().manual_seed(self.seed + epoch))
+        n_local = len(self.train_loader.names)
+        order = torch.randperm(n_local, generator=torch.Generator().manual_seed(self.seed + epoch))
+        if self.ddp:
+            # equal step counts on every rank: shards differ by at most one image, the short ones wrap around
+            n_all = len(getattr(self.train_loader, "all_names", self.train_loader.names))
+            n_even = -(-n_all // self.world)
+            if n_local == 0:
+                raise ValueError(f"rank {self.rank}: empty training shard ({n_all} images over {self.world} ranks)")
+            if n_local < n_even:
+                order = torch.cat([order, order[: n_even - n_local]])
         bs = self.train_loader.batch_size
         epoch_loss, epoch_step = 0.0, 0
         t0 = time.time()
+        src = self.train_loader.images
         for s in range(0, len(order), bs):
             idx = order[s: s + bs]
-            images = self.train_loader.images[idx].to(self.device, non_blocking=True)
+            # a loader over images of different shapes holds a list: stack the selected items
+            images = (src[idx] if torch.is_tensor(src) else torch.stack([src[int(i)] for i in idx])).to(
+                self.device, non_blocking=True)
             self.optimizer.zero_grad(set_to_none=True)
             loss = self._loss(images)
             loss.backward()

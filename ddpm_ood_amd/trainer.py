@@ -91,8 +91,12 @@ def gather_scores(ids: torch.Tensor, scores: torch.Tensor, n_max: int = None):
     payload = torch.full((n_max, n_t * 2 + 1), -1.0, dtype=torch.float32, device=scores.device)
     payload[: ids.shape[0], 0] = ids.to(torch.float32)
     payload[: ids.shape[0], 1:] = scores.reshape(ids.shape[0], n_t * 2)  # (an empty shard has 0 rows)
-    out = torch.empty((world * n_max, n_t * 2 + 1), dtype=torch.float32, device=scores.device)
+    dev = scores.device
+    if dist.get_backend() == "gloo" and payload.is_cuda:  # test hook (2 ranks on one GPU): gloo moves host memory
+        payload = payload.cpu()
+    out = torch.empty((world * n_max, n_t * 2 + 1), dtype=torch.float32, device=payload.device)
     dist.all_gather_into_tensor(out, payload)
+    out = out.to(dev)
     valid = out[:, 0] >= 0
     counts = valid.reshape(world, n_max).sum(dim=1).tolist()
     out = out[valid]
@@ -134,9 +138,12 @@ class BaseTrainer:
             if local_rank != 0:
                 sys.stdout = sys.stderr = open(os.devnull, "w")
             if not dist.is_initialized():
-                # backend "nccl" IS RCCL on ROCm: one process per GPU, xGMI underneath
-                dist.init_process_group(backend="nccl", init_method="env://")
-            self.device = torch.device(f"cuda:{local_rank}")
+                # backend "nccl" IS RCCL on ROCm: one process per GPU, xGMI underneath.  DDPM_DIST_BACKEND=gloo is the
+                # test hook for boxes with fewer GPUs than ranks (RCCL refuses two ranks on one device); with
+                # DDPM_DIST_SHARED_DEVICE=1 every rank then computes on cuda:0 (tests/test_gpu_dist.py)
+                dist.init_process_group(backend=os.environ.get("DDPM_DIST_BACKEND", "nccl"), init_method="env://")
+            shared = os.environ.get("DDPM_DIST_SHARED_DEVICE", "0") == "1"
+            self.device = torch.device("cuda:0" if shared else f"cuda:{local_rank}")
         else:
             self.ddp = False
             self.device = torch.device("cuda:0")

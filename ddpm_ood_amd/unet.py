@@ -196,10 +196,28 @@ class DiffusionModelUNet(nn.Module):
         """Cheap change detector for the packed blob (runs on EVERY forward: ~20 us; the full
         (data_ptr, version) tuple of 182 tensors cost 0.8 ms, more than a small-batch forward): in-place updates
         (optimizer steps, load_state_dict) bump a tensor's version counter, .to() / re-assignment replace storage."""
-        if self._plist is None:
+        self._key_calls = getattr(self, "_key_calls", 0) + 1
+        if self._plist is None or self._key_calls % 64 == 0:
+            # parameters replaced without _apply (setattr of a new nn.Parameter, `p.data = new` on an interior tensor)
+            # leave a stale list behind: rebuild it every 64 calls as a backstop for the hooks below
             self._plist = list(self.parameters())
         ps = self._plist
-        return (str(device), sum(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr())
+        ptrs = 0
+        for p in ps:
+            ptrs ^= p.data_ptr()
+        return (str(device), sum(p._version for p in ps), ptrs, len(ps))
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self._plist = None  # assign=True replaces the parameter objects
+        self._synced_key = None
+        return out
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (torch.nn.Parameter, torch.nn.Module)) and "_plist" in self.__dict__:
+            self.__dict__["_plist"] = None
+            self.__dict__["_synced_key"] = None
+        super().__setattr__(name, value)
 
     def _apply(self, fn, *a, **k):  # .to() / .cuda() / .float(): parameters are replaced
         self._plist = None

@@ -77,7 +77,7 @@ def assert_rows_close(h: pd.DataFrame, o: pd.DataFrame, rel: float, what=""):
 
 
 def assert_z_close(rows_h: dict, rows_o: dict, tol: float = 1e-4, auc_tol: float = 1e-3, plot_target="mse"):
-    """The north-star bar: per-image MSE / LPIPS Z-scores within 1e-4, AUROC within 1e-3 (BASELINE.json)."""
+    """The north-star bar: per-image MSE / LPIPS Z-scores within 1e-4 ABSOLUTE, AUROC within 1e-3 (BASELINE.json)."""
     import oracle
 
     dh, _, auc_h = oracle.z_scores_and_auroc(rows_h["val"], rows_h["in"], rows_h["out"], plot_target=plot_target)
@@ -85,7 +85,7 @@ def assert_z_close(rows_h: dict, rows_o: dict, tol: float = 1e-4, auc_tol: float
     worst = 0.0
     for col in ("z_score_mse", "z_score_perceptual_difference"):
         err = float((dh[col] - do[col]).abs().max())
-        assert err < tol * max(1.0, float(do[col].abs().max())), (col, err)
+        assert err < tol, (col, err)
         worst = max(worst, err)
     assert abs(auc_h - auc_o) <= auc_tol, (auc_h, auc_o)
     return worst, auc_h, auc_o

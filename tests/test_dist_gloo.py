@@ -34,7 +34,7 @@ def _worker(rank, world, port, n_images, q):
     assert counts == [len(partition(n_images, r, world)) for r in range(world)]
     rows = rows_from_scores(gids.tolist(), gsc.numpy(), counts, [10, 50, 90], {i: f"img_{i}.npy" for i in range(99)},
                             2, "in")
-    q.put((rank, gids.tolist(), gsc, rows))
+    q.put((rank, gids.tolist(), gsc.numpy(), rows))  # plain data: a torch tensor on the queue needs this process alive at get()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,7 +65,7 @@ def test_two_rank_gather_equals_one_rank(n_images):
             assert [r["t"] for r in rows[:6]] == [10, 10, 50, 50, 90, 90]
         assert sorted(ids) == list(range(n_images))  # ragged shards: no padding ids, no duplicates (Q6)
         order = torch.tensor(ids).argsort()
-        assert torch.equal(sc[order], ref)
+        assert torch.equal(torch.from_numpy(sc)[order], ref)
         assert ids == [i for r in range(2) for i in range(r, n_images, 2)]  # rank-major order
 
 

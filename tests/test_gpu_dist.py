@@ -46,3 +46,120 @@ def test_rccl_single_rank_gather(device):
     out = subprocess.run([sys.executable, "-c", _SCRIPT, str(ROOT)], env=env, capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0 and "RCCL_OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+# ---- two ranks on ONE GPU: the N > 1 product path end to end ---------------------------------------------------
+# RCCL refuses two ranks on one device, so the ranks rendezvous over gloo (DDPM_DIST_BACKEND) and both compute on
+# cuda:0 (DDPM_DIST_SHARED_DEVICE): everything except the transport of the one collective is the N-rank code path --
+# partition, per-rank batches, static-capacity payload, rank-major row order, rank-0-only CSV.
+
+def _launch_ranks(world, argv, tmp_path, extra_env=None, timeout=900):
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(world), DDPM_DIST_BACKEND="gloo", DDPM_DIST_SHARED_DEVICE="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, *argv], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        assert rc == 0, (o[-1500:], e[-3000:])
+    return outs
+
+
+def test_two_ranks_on_one_gpu_write_the_same_scores_as_one_rank(device, tmp_path):
+    """reconstruct.py as 1 rank and as 2 ranks (reference: torchrun + partition_dataset,
+    /root/reference/src/trainers/base.py:22-33, src/data/get_train_and_val_dataloader.py:21-31; gather at
+    src/trainers/reconstruct.py:238-248).  8 / 7 / 8 images in batches of 4: each rank's batches have the size of the
+    1-rank run's, so the per-image arithmetic is the same launch geometry and the scores must be IDENTICAL; only the
+    row order differs (rank-major, as the reference's all_gather_object list)."""
+    import pandas as pd
+    from ddpm_ood_amd import synthetic
+
+    def run(root, world):
+        model = "fashionmnist_dist"
+        synthetic.write_checkpoint(root / model, "small", 1, seed=1)
+        argv = [str(ROOT / "reconstruct.py"), "--output_dir", str(root), "--model_name", model, "--is_grayscale", "1",
+                "--validation_ids", "synthetic:blobs:n=8:seed=10", "--in_ids", "synthetic:blobs:n=7:seed=11",
+                "--out_ids", "synthetic:noise:n=8:seed=12:name=MNIST",
+                "--beta_schedule", "scaled_linear_beta", "--beta_start", "0.0015", "--beta_end", "0.0195",
+                "--batch_size", "4", "--inference_skip_factor", "32"]
+        if world == 1:
+            out = subprocess.run([sys.executable, *argv], capture_output=True, text=True, timeout=900)
+            assert out.returncode == 0, out.stderr[-3000:]
+        else:
+            _launch_ranks(world, argv, root)
+        return {n: pd.read_csv(root / model / "ood" / f"results_{n}.csv", index_col=0) for n in ("val", "in", "MNIST")}
+
+    (tmp_path / "w1").mkdir()
+    (tmp_path / "w2").mkdir()
+    one, two = run(tmp_path / "w1", 1), run(tmp_path / "w2", 2)
+    for n in one:
+        a, b = one[n], two[n]
+        assert len(a) == len(b) and len(b) == len(b.drop_duplicates(["filename", "t"]))  # no padding duplicates (Q6)
+        # rank-major order: rank 0 holds images 0, 2, 4, 6 -> its first batch comes first
+        names = list(dict.fromkeys(a["filename"]))  # the 1-rank file lists the images in id order within a batch
+        assert list(b["filename"][:4]) == [names[i] for i in (0, 2, 4, 6)]
+        key = ["filename", "t"]
+        a, b = a.sort_values(key).reset_index(drop=True), b.sort_values(key).reset_index(drop=True)
+        assert a.to_csv(index=False) == b.to_csv(index=False)  # byte for byte once the rows are in the same order
+
+
+_TRAIN_SCRIPT = r"""
+import argparse, hashlib, os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from ddpm_ood_amd.train import DDPMTrainer
+a = argparse.Namespace(
+    seed=2, output_dir=sys.argv[2], model_name="ddp_train", training_ids="synthetic:blobs:n=9:seed=1",
+    validation_ids="synthetic:blobs:n=4:seed=10", spatial_dimension=2, image_size=None, image_roi=None, latent_pad=None,
+    vqvae_checkpoint=None, prediction_type="epsilon", model_type="small", beta_schedule="scaled_linear_beta",
+    beta_start=0.0015, beta_end=0.0195, b_scale=1.0, snr_shift=1, simplex_noise=0, batch_size=4, n_epochs=1, eval_freq=1,
+    augmentation=1, num_workers=0, cache_data=1, checkpoint_every=0, ddpm_checkpoint_epoch=None, is_grayscale=1,
+    quick_test=0)
+tr = DDPMTrainer(a)
+h = hashlib.sha256()
+for p in tr.model.parameters():
+    h.update(p.detach().cpu().numpy().tobytes())
+start = h.hexdigest()
+steps = []
+orig = tr._sync_grads
+tr._sync_grads = lambda: (steps.append(1), orig())[1]
+tr.train_epoch(0)
+h = hashlib.sha256()
+for p in tr.model.parameters():
+    h.update(p.detach().cpu().numpy().tobytes())
+sys.__stdout__.write(f"RANK{tr.rank} start={start} end={h.hexdigest()} steps={len(steps)} n_local={len(tr.train_loader.names)}\n")
+sys.__stdout__.flush()
+import torch.distributed as dist
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_two_rank_training_starts_and_stays_in_step(device, tmp_path):
+    """Row f-3 under 2 ranks (reference: DistributedDataParallel's parameter broadcast, base.py:160-163): both ranks
+    start from rank 0's parameters, run the same number of steps although the shards are 5 and 4 images long (batches
+    of 4: two steps each, the short shard wraps), and hold identical parameters after the epoch."""
+    import re
+
+    outs = _launch_ranks(2, ["-c", _TRAIN_SCRIPT, str(ROOT), str(tmp_path)], tmp_path)
+    recs = {}
+    for _, o, _e in outs:
+        m = re.search(r"RANK(\d) start=(\w+) end=(\w+) steps=(\d+) n_local=(\d+)", o)
+        assert m, o[-2000:]
+        recs[int(m.group(1))] = m.groups()[1:]
+    assert recs[0][0] == recs[1][0]            # same initial parameters
+    assert recs[0][1] == recs[1][1] != recs[0][0]  # same parameters after one epoch, and they moved
+    assert recs[0][2] == recs[1][2] == "2" and {recs[0][3], recs[1][3]} == {"5", "4"}
