@@ -14,7 +14,7 @@ import torch
 
 _LIB = None
 LIB_NAME = "libddpm_ood_hip.so"
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HipLibraryMissing(RuntimeError):
@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("Di", C.c_int), ("Do", C.c_int), ("dims", C.c_int), ("reserved0", C.c_int),
         ("w_folded", C.c_void_p), ("out_act", C.c_int), ("reserved", C.c_int), ("w_wino", C.c_void_p),
         ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t), ("w_wino44", C.c_void_p),
+        ("w_wino44h", C.c_void_p),
     ]
 
 
@@ -71,6 +72,8 @@ SIGNATURES = {
     "ddpm_wino44_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_wino44_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_pack_wino3d_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_wino44h_weight_halves": (C.c_size_t, [C.c_int, C.c_int]),
+    "ddpm_pack_wino44h_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_pack_wino44_weight3d_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_folded_upsample_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_fold_upsample_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

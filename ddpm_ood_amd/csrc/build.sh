@@ -8,11 +8,14 @@ obj="${here}/../../build/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 JOBS="${JOBS:-4}"
 mkdir -p "${obj}"
-srcs=(api conv_mfma conv_wino conv_wino44 conv1x1_dma conv_direct conv3d_edge linear_skinny groupnorm attention elementwise lpips vq
+srcs=(api conv_mfma conv_wino conv_wino44 conv_wino44h conv1x1_dma conv_direct conv3d_edge linear_skinny groupnorm attention elementwise lpips vq
       unet_engine)
 common=(--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value)
 # per-file flags: declare an array flags_<source> to add options to one translation unit, e.g.
 #   flags_attention=(-mllvm -amdgpu-mfma-vgpr-form=1)   # measured: 80 vs 86 TFLOP/s at n = 4096, not used
+# conv_wino44h: the SLP vectoriser packs the fp32 transform arithmetic into v_pk_fma_f32 / v_pk_add_f32, which cost more
+# than the scalar forms beside MFMAs (MI355X_MICROARCH.md, price of a filler)
+flags_conv_wino44h=(-fno-slp-vectorize)
 pids=()
 for f in "${srcs[@]}"; do
   extra_name="flags_${f}[@]"

@@ -410,7 +410,8 @@ size_t conv_scratch_floats(const ddpm_conv_desc &d) {
   const bool vol = d.dims == 3 || d.Di > 1 || d.Do > 1;  // the Winograd splits are 2-D only
   const size_t a = vol ? 0 : conv_wino44_scratch_floats(d), b = vol ? 0 : conv_wino_scratch_floats(d);
   const size_t c = linear_skinny_supported(d) ? 0 : conv_mfma_scratch_floats(d);
-  const size_t ab = a > b ? a : b;
+  const size_t h = vol ? 0 : conv_wino44h_scratch_floats(d);
+  const size_t ab = (a > b ? a : b) > h ? (a > b ? a : b) : h;
   return ab > c ? ab : c;
 }
 
@@ -443,6 +444,7 @@ int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
   }
   DDPM_CHECK_ARG(d.Di <= 1 && d.Do <= 1, "conv: Di / Do > 1 needs dims == 3");
   if (linear_skinny_supported(d)) return launch_linear_skinny(d, s);  // Linear over <= 1024 rows: latency, not FLOPs
+  if (conv_wino44h_supported(d)) return launch_conv_wino44h(d, s);  // F(4x4) with split-f16 position GEMMs
   if (conv_wino44_supported(d)) return launch_conv_wino44(d, s);
   if (conv_wino_supported(d)) return launch_conv_wino(d, s);
   if (conv1x1_dma_supported(d) && conv_mfma_supported(d)) return launch_conv1x1_dma(d, s);

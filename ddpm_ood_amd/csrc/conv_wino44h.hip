@@ -1,0 +1,922 @@
+// conv_wino44h.hip -- 3x3 stride-1 convolution as Winograd F(4x4, 3x3) with the position GEMMs on the f16 MFMA pipe
+// (split-f16 products, fp32 accumulate).  Round 3.
+//
+// Same fused op as conv_wino44.hip (GroupNorm-affine + SiLU prologue, virtual concat, bias / temb / residual epilogue;
+// reference call site /root/reference/src/trainers/reconstruct.py:151-153, layer list /root/reference/src/trainers/
+// base.py:66-86) and the same work item (64 output channels x 32 tiles x all input channels, 8 waves = 2 cout blocks x
+// 4 position groups, 9 accumulator tiles per wave), but every M_xi[cout][tile] = sum_c U_xi[cout][c] V_xi[c][tile] runs
+// on v_mfma_f32_32x32x16_f16, which multiplies at 16x the rate of the fp32 MFMA the old kernel is bound by.
+//
+// Arithmetic.  Transforms, activation, accumulation and the output transform stay fp32.  Each operand of a product is
+// carried as TWO f16 numbers, x = xh + xl with xh = f16(x) and xl = f16(x - xh) (the difference is exact in fp32), and the
+// MFMA's K = 16 holds 8 input channels x {hi, lo}:   A[k = 8 p + c] = U_p[c],   B[k] = V_h[c]  (first MFMA),  V_l[c] (second)
+// so that two MFMAs per 8 channels add (Uh + Ul) Vh + (Uh + Ul) Vl = all four partial products, each exact in the fp32
+// accumulator (11 x 11 significant bits).  What is lost is only the representation error of x ~ xh + xl: <= 2^-22 |x|
+// as long as xl is a normal f16.  To keep it normal the operands are pre-scaled by powers of two (exact): U by 2^su when it
+// is packed -- su chosen per layer so that max |2^su U| lies in [2^14, 2^15), i.e. 17 binades of full precision below the
+// layer's largest transformed weight --, V by 2^3 through the activation that feeds the transform; the product of the two
+// scales is stored behind the packed planes and goes back into the epilogue's fused multiply-add.  Full precision holds for
+// |V| in [2^-6, 8188]; below, the absolute error of an operand is <= 2^-28 (V) / 2^-39 of the layer's largest |U|; above, the
+// high half of V overflows to inf (loud).
+//
+// Structure (why it is not the old kernel with other MFMAs).  K = 16 per instruction means 8 channels x 36 positions x
+// (64 + 32) operand rows = 110 KB per K-step: the operand images cannot be double-buffered per chunk any more.  So a chunk
+// of 8 channels is walked in THREE PHASES of 12 positions -- the transform rows (0, 5), (1, 2), (3, 4), which share their
+// inputs -- and V is produced just in time:
+//   waves 0..3  PRODUCERS: lane = (tile, channel pair); a task = the 12 positions of one phase for two channels (pair-packed
+//               f16 stores), done in two halves over two phases; the two wave pairs alternate, so that phase m + 1's V
+//               slot is written during phase m and a TWO-slot V ring suffices.  They also issue the LDS-DMA of the U slot
+//               (24 KB per phase, packed in LDS order in global memory) one phase ahead.
+//   waves 4..7  PIXEL waves: wave = one channel of a 4-channel half-chunk; loads two phases ahead of use, GroupNorm affine +
+//               SiLU (x 2^3) once per pixel into a zero-bordered pixel tile (ring of four 4-channel half-tiles).
+//   all 8 waves: 3 jobs x 2 MFMAs per phase (job = one position x one cout block: A, B_h, B_l by ds_read_b128).
+// Waves w and w + 4 share a SIMD: one producer and one pixel wave each.  The two roles run separate instruction streams
+// (same barrier sequence), so that neither pays for the other's registers.
+// Per item the pipeline is filled (six MFMA-free phases) and drained; the epilogue (output transform through four LDS
+// exchange slabs, as conv_wino44.hip) then owns the operand rings.
+//
+// LDS: U ring 2 x 24 KB + V ring 2 x 12 KB (= the four 18 KB exchange slabs of the epilogue) + pixel ring.
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace ddpm {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+constexpr int kT = 32;                    // tiles per item
+constexpr int kK = 64;                    // output channels per item
+constexpr int kC = 8;                     // input channels per chunk
+constexpr int kX = 36;                    // transform positions
+constexpr int kPP = 12;                   // positions per phase
+constexpr int kUSB = kPP * 2 * kK * 16;   // bytes of one U slot: [pos 12][plane 2][cout 64][8 ch f16]  (24576)
+constexpr int kVSB = kPP * 2 * kT * 16;   // bytes of one V slot: [pos 12][plane 2][tile 32][8 ch f16]  (12288)
+constexpr int kVB0 = 2 * kUSB;            // byte offset of the V ring
+constexpr int kRINGF = (2 * kUSB + 2 * kVSB) / 4;  // floats of both rings (18432)
+constexpr int kXS = kX * 2 * 64;          // exchange slab of the epilogue: [xi][cout block][lane] (4608 floats)
+static_assert(kRINGF == 4 * kXS, "the operand rings are the epilogue's four exchange slabs");
+constexpr float kVScale = 8.f;            // 2^3 on V (through the activation)
+constexpr int kTail = 64;                 // f16 slots behind the packed planes: float [0] = max |U|, float [1] = 1 / (2^3 2^su)
+
+// ---- accumulators.  A wave owns nine 32x32 fp32 tiles.  Eight of them live in a[0:127], addressed BY NAME inside the asm
+// statements: they are not C++ objects, so the compiler can neither spill nor copy them.  (It must not: hipcc does not know
+// that an asm MFMA writes its destination over the next passes -- as C++ variables with "+a" constraints, one tile of the
+// 16x16 / 8x8 variants was spilled around its MFMAs and the store, placed right behind the asm statement, saved stale
+// values: registers 0..3 of that tile wrong by 1e-3, differently on every run.  tools/check_acc_spills.py now fails the build
+// on any compiler-generated AGPR or scratch access inside the MFMA loops.)  The ninth tile is a C++ variable in arch VGPRs
+// (a 512-thread kernel gets 128 + 128 registers); its two MFMAs are ONE asm statement that ends after their last pass.
+#define W44H_CLOB16(b) "a" #b
+__device__ __forceinline__ void reserve_agprs() {  // the only place the compiler learns that a0..a127 are in use
+  asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15",
+               "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31",
+               "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47",
+               "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63",
+               "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79",
+               "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95",
+               "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109",
+               "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123",
+               "a124", "a125", "a126", "a127");
+}
+#undef W44H_CLOB16
+// (register numbers are pasted into the asm text: an "n" operand above 63 would be printed in hex)
+#define W44H_TILES(X) X(0, 0, 15) X(1, 16, 31) X(2, 32, 47) X(3, 48, 63) X(4, 64, 79) X(5, 80, 95) X(6, 96, 111) X(7, 112, 127)
+#define W44H_REGS(X) \
+  X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) \
+  X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) \
+  X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) \
+  X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) X(64) X(65) X(66) X(67) X(68) X(69) X(70) X(71) X(72) X(73) \
+  X(74) X(75) X(76) X(77) X(78) X(79) X(80) X(81) X(82) X(83) X(84) X(85) X(86) X(87) X(88) X(89) X(90) X(91) \
+  X(92) X(93) X(94) X(95) X(96) X(97) X(98) X(99) X(100) X(101) X(102) X(103) X(104) X(105) X(106) X(107) X(108) \
+  X(109) X(110) X(111) X(112) X(113) X(114) X(115) X(116) X(117) X(118) X(119) X(120) X(121) X(122) X(123) X(124) \
+  X(125) X(126) X(127)
+// tile T (0..7) += A B, after at most N LDS operations remain outstanding
+template <int N>
+__device__ __forceinline__ void mfma_pin_wait(int T, const h8 &a, const h8 &b) {
+  switch (T) {
+#define X(t, lo, hi)                                                                                                       \
+  case t:                                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(%2)\n\tv_mfma_f32_32x32x16_f16 a[" #lo ":" #hi "], %0, %1, a[" #lo ":" #hi "]"          \
+                 ::"v"(a), "v"(b), "n"(N));                                                                                \
+    break;
+    W44H_TILES(X)
+#undef X
+  }
+}
+__device__ __forceinline__ void mfma_pin(int T, const h8 &a, const h8 &b) {
+  switch (T) {
+#define X(t, lo, hi)                                                                                                       \
+  case t:                                                                                                                  \
+    asm volatile("v_mfma_f32_32x32x16_f16 a[" #lo ":" #hi "], %0, %1, a[" #lo ":" #hi "]" ::"v"(a), "v"(b));              \
+    break;
+    W44H_TILES(X)
+#undef X
+  }
+}
+__device__ __forceinline__ void zero_pinned_tiles() {
+#define X(r) asm volatile("v_accvgpr_write_b32 a" #r ", 0");
+  W44H_REGS(X)
+#undef X
+}
+__device__ __forceinline__ float read_pinned(int r) {  // register r = 16 T + element
+  float v = 0.f;
+  switch (r) {
+#define X(n)                                                \
+  case n:                                                   \
+    asm volatile("v_accvgpr_read_b32 %0, a" #n : "=v"(v)); \
+    break;
+    W44H_REGS(X)
+#undef X
+  }
+  return v;
+}
+// the ninth tile: both MFMAs of its job and their completion in one statement (8 passes of 4 cycles each; the second
+// issues when the first has finished).  Nothing the compiler places behind this statement can see the tile half-written.
+__device__ __forceinline__ void mfma_v_pair_wait0(f32x16 &c, const h8 &a, const h8 &bh, const h8 &bl) {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\tv_mfma_f32_32x32x16_f16 %0, %1, %3, %0\n\t"
+               "s_nop 15\n\ts_nop 15\n\ts_nop 7"
+               : "+v"(c) : "v"(a), "v"(bh), "v"(bl));
+}
+__device__ __forceinline__ h8 lds_b128(int byte_addr, int imm) {
+  h8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(imm));
+  return v;
+}
+// two floats 16 bytes apart through the scalar cache (lgkmcnt, not vmcnt); the pointer must be wave-uniform
+__device__ __forceinline__ void sload2(const float *p, float &x0, float &x1) {
+  asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(x0), "=&s"(x1) : "s"(p) : "memory");
+}
+
+// 1-D input transform B^T w (as conv_wino44.hip)
+__device__ __forceinline__ void bt6(const float (&w)[6], float (&t)[6]) {
+  const float p = __builtin_fmaf(-4.f, w[2], w[4]), q = __builtin_fmaf(-4.f, w[1], w[3]);
+  const float r = w[4] - w[2], s = w[3] - w[1];
+  t[0] = __builtin_fmaf(4.f, w[0], __builtin_fmaf(-5.f, w[2], w[4]));
+  t[1] = p + q;
+  t[2] = p - q;
+  t[3] = __builtin_fmaf(2.f, s, r);
+  t[4] = __builtin_fmaf(-2.f, s, r);
+  t[5] = __builtin_fmaf(4.f, w[1], __builtin_fmaf(-5.f, w[3], w[5]));
+}
+// 1-D output transform A^T m
+__device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, float m4, float m5, float (&y)[4]) {
+  const float s = m1 + m2, d = m1 - m2, u = m3 + m4, v = m3 - m4;
+  y[0] = (m0 + s) + u;
+  y[1] = __builtin_fmaf(2.f, v, d);
+  y[2] = __builtin_fmaf(4.f, u, s);
+  y[3] = __builtin_fmaf(8.f, v, d) + m5;
+}
+
+// x -> (f16(x), f16(x - f16(x))) for two channels, pair-packed: hi = {h(a), h(b)}, lo = {l(a), l(b)}
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t &hi, uint32_t &lo) {
+  const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+  const h2 h = {ha, hb};
+  // x - f16(x) in one v_fma_mix_f32 (f16 source operand), exact in fp32
+  const h2 l = {(_Float16)__builtin_fmaf((float)ha, -1.0f, a), (_Float16)__builtin_fmaf((float)hb, -1.0f, b)};
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+}  // namespace
+
+struct W44HGeom {
+  int TWc, THr;     // tile columns / rows per image
+  int TI, TR;       // images per item, tile rows per item (per image)
+  int parts;        // items per image along the rows
+  int Cin, NCH, HW; // NCH = chunks of 8 channels
+  int prow;         // pixel-tile rows per image of an item: 4 TR + 2
+  int PW, IS, PCH;  // pixel tile: row length, image stride, floats per channel plane (conv_wino44.hip's padding rules)
+  int HS;           // floats per half-tile: 4 channel planes + 1 (the second half-chunk sits one bank further) + 64 dump floats
+  int UI;           // 64-pixel staging units per image of an item
+  int NRT;          // staging rounds per pixel wave and half-chunk: TI * UI
+  int KT, NIT, IPW, NS, grid;
+  int xmap;
+  int S;            // channel-stream splits per item (1: none)
+  long long pstride;
+  int NIMG;
+};
+
+static int w44h_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+static size_t w44h_lds_bytes(const W44HGeom &g) { return ((size_t)kRINGF + 4 * (size_t)g.HS) * sizeof(float); }
+
+static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false) {
+  const int Cin = d.C1 + d.C2;
+  if (d.dims == 3 || d.ksize != 3 || d.Di > 1 || d.Do > 1 || d.mode != DDPM_CONV_NORMAL) return false;
+  if (d.out_act != DDPM_ACT_NONE || d.act == DDPM_ACT_RELU) return false;
+  if (d.gscale && d.act != DDPM_ACT_SILU) return false;  // the affine variant has SiLU built in
+  if (Cin % 16 || (d.C2 > 0 && d.C1 % 4) || d.Cout % kK) return false;  // an even number of 8-channel chunks, 4-channel halves
+  if ((d.Ho & 3) || (d.Wo & 3) || d.Hi != d.Ho || d.Wi != d.Wo) return false;
+  if ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.residual)) & 15) return false;  // float4 rows
+  if ((double)d.B * (d.C1 > d.C2 ? d.C1 : d.C2) * d.Ho * d.Wo * 4 >= 2147483648.0) return false;  // 32-bit buffer offsets
+  if ((double)d.B * d.Cout * d.Ho * d.Wo * 4 >= 2147483648.0 * 2) return false;
+  g.TWc = d.Wo / 4;
+  g.THr = d.Ho / 4;
+  const int per_img = g.TWc * g.THr;
+  if (per_img >= kT) {
+    if (kT % g.TWc) return false;
+    g.TI = 1;
+    g.TR = kT / g.TWc;
+    if (g.THr % g.TR) return false;
+    g.parts = g.THr / g.TR;
+  } else {
+    if (kT % per_img) return false;
+    g.TI = kT / per_img;
+    g.TR = g.THr;
+    g.parts = 1;
+  }
+  g.Cin = Cin;
+  g.NIMG = d.B;
+  g.NCH = Cin / kC;
+  g.HW = d.Ho * d.Wo;
+  g.prow = 4 * g.TR + 2;
+  auto layout = [&](bool pad) {
+    g.PW = d.Wi + 2;
+    if (pad && g.TWc < 16) g.PW += ((g.TWc - g.PW) % 16 + 16) % 16;
+    g.IS = g.prow * g.PW;
+    if (pad && g.TI > 1 && per_img < 16) g.IS += ((4 * per_img - g.IS) % 64 + 64) % 64;
+    g.PCH = g.TI * g.IS;
+    g.PCH += ((1 - g.PCH) % 4 + 4) % 4;
+    g.HS = 4 * g.PCH + 1 + 64;  // + 64 dump floats for out-of-image lanes
+    return w44h_lds_bytes(g) <= 160 * 1024;
+  };
+  if (!layout(true) && !layout(false)) return false;
+  if (64 % d.Wi) return false;  // a staging unit is 64 pixels = whole rows
+  const int rows = g.prow < d.Hi ? g.prow : d.Hi;
+  g.UI = (rows * d.Wi + 63) / 64;
+  g.NRT = g.TI * g.UI;
+  // kernel variants: one image per item with 9 or 10 units (32x32 / 64x64 images); whole images of 4 units or of 1 unit
+  if (g.TI == 1) {
+    if (g.NRT != 9 && g.NRT != 10) return false;
+    if ((rows - 1) * d.Wi < 64 * (g.NRT - 1)) return false;  // only the last round can reach past the item's rows
+  } else if (!((g.UI == 4 && rows * d.Wi == 256 && g.TI == 2) || (g.UI == 1 && rows * d.Wi == 64 && g.TI == 8))) {
+    return false;
+  }
+  g.KT = d.Cout / kK;
+  g.NIT = (g.NIMG + g.TI - 1) / g.TI;
+  const long items = (long)g.KT * g.parts * g.NIT;
+  const int cus = w44h_cus();
+  const char *sw = getenv("DDPM_CONV_WINO44");  // 2: any launch size (tests)
+  const bool any_size = sw && atoi(sw) == 2;
+  g.S = 1;
+  g.pstride = 0;
+  if (items < cus && !any_size) {
+    const char *sp_env = getenv("DDPM_WINO44_SPLIT");
+    const int sp_max = sp_env ? atoi(sp_env) : 4;
+    for (int sp = 4; sp >= 2; sp >>= 1)  // every workgroup of a split walks an even number of chunks
+      if (sp <= sp_max && items * sp <= cus && g.NCH % (2 * sp) == 0) { g.S = sp; break; }
+    if (g.S == 1 || items * g.S * 4 < (long)cus * 3) return false;  // below three quarters of the chip: conv_wino.hip
+    const size_t out_floats = (size_t)d.B * d.Cout * g.HW;
+    if (!sizing && (!d.scratch || d.scratch_floats < g.S * out_floats)) return false;
+    g.pstride = (long long)out_floats;
+  }
+  g.IPW = (int)((items + cus - 1) / cus);
+  g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW) * g.S;
+  g.grid = g.KT * ((g.NS + 7) / 8) * 8;
+  const char *xm = getenv("DDPM_WINO44_XMAP");
+  g.xmap = (xm ? atoi(xm) != 0 : 1) && (8 % g.KT == 0);
+  if (g.xmap) g.grid = 8 * ((g.NS + 8 / g.KT - 1) / (8 / g.KT));
+  return true;
+}
+
+static bool w44h_enabled() {
+  const char *sw = getenv("DDPM_CONV_WINO44"), *f = getenv("DDPM_WINO44_F16X3");
+  return !(sw && atoi(sw) == 0) && !(f && atoi(f) == 0);
+}
+
+bool conv_wino44h_supported(const ddpm_conv_desc &d) {
+  W44HGeom g;
+  return w44h_enabled() && d.w_wino44h != nullptr && !d.force_direct && w44h_geom(d, g);
+}
+
+size_t conv_wino44h_scratch_floats(const ddpm_conv_desc &d) {
+  W44HGeom g;
+  if (!w44h_enabled() || !d.w_wino44h || d.force_direct || !w44h_geom(d, g, true) || g.S == 1) return 0;
+  return (size_t)g.S * d.B * d.Cout * g.HW;
+}
+
+// NRT = staging rounds of a pixel wave per half-chunk; UIT = 0: one image per item, else units per image (4 or 1)
+template <bool AFFINE, int NRT, int UIT, bool RES>
+__global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_desc a, const W44HGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool ONEIMG = UIT == 0;
+  constexpr int NGS = ONEIMG ? 1 : NRT / UIT;        // images per item = GroupNorm scale / shift pairs per half-chunk
+  constexpr int GD = ONEIMG ? NRT : UIT;             // consecutive rounds that belong to one image
+  constexpr int NVM = NRT + (AFFINE ? 2 * NGS : 0);  // vector-memory loads of one pixel stage
+  float *const P = smem + kRINGF;                    // pixel ring: 4 half-tiles of [4 channels][PCH] + 1 + 64 dump floats
+  char *const smb = reinterpret_cast<char *>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int cb = wave & 1, pg = wave >> 1;  // MFMA role: cout block, position group (positions 3 pg .. 3 pg + 2 of a phase)
+  const bool silu = a.act == DDPM_ACT_SILU;
+
+  // ---- this workgroup's items (as conv_wino44.hip)
+  const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3;
+  int kt = wj % g.KT, slot = (wj / g.KT) * 8 + xcd;
+  if (g.xmap) {
+    kt = xcd % g.KT;
+    slot = wj * (8 / g.KT) + xcd / g.KT;
+  }
+  if (slot >= g.NS) return;
+  const int split = slot % g.S;
+  slot /= g.S;
+  const int part = slot % g.parts, it0 = (slot / g.parts) * g.IPW;
+  const int nitems = min(g.IPW, g.NIT - it0);
+  const int r0 = part * g.TR;
+  const int n_first = it0 * g.TI, n_end = n_first + nitems * g.TI;
+  const int NCHs = g.NCH / g.S, ch_lo = split * NCHs;  // this workgroup's chunk range (even length)
+  const int NPH = 3 * NCHs;                            // MFMA phases per item
+  float *const outp = a.out + (size_t)split * g.pstride;
+
+  // ---- MFMA operand addresses (bytes): A = U slot [pos][plane = lhi][cout][8 ch], B = V slot [pos][plane][tile][8 ch]
+  const int ua = (3 * pg * 2 + lhi) * (kK * 16) + (cb * 32 + l31) * 16;
+  const int va = kVB0 + 3 * pg * (2 * kT * 16) + l31 * 16;
+  f32x16 acc8;  // tiles 0..7: a[0:127] by name (see mfma_pin)
+  reserve_agprs();
+
+  const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(a.w_wino44h), 0, (int)((size_t)kX * a.Cout * g.Cin * 4), 0x00020000);
+  const int ukt = (kt * g.NCH + ch_lo) * 3;  // U slot index of this workgroup's phase 0
+
+  // One phase of MFMA work: 3 jobs (positions 3 pg + i of the phase) x 2 MFMAs; `slice(k)`, k = 0..5, is the role's staging
+  // work pinned between them.  us / vs: ring slots (bytes) of the phase.
+  auto mfma_phase = [&](auto tc, int us, int vs, auto &&slice) {
+    constexpr int t = decltype(tc)::value;
+    const int ua_s = ua + us, va_s = va + vs;
+    h8 A[2], Bh[2], Bl[2];
+    A[0] = lds_b128(ua_s, 0);
+    Bh[0] = lds_b128(va_s, 0);
+    Bl[0] = lds_b128(va_s, kT * 16);
+    A[1] = lds_b128(ua_s, 2 * kK * 16);
+    Bh[1] = lds_b128(va_s, 2 * kT * 16);
+    Bl[1] = lds_b128(va_s, 3 * kT * 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int x = 3 * t + i;  // accumulator tile
+      // job i's three reads are the oldest outstanding: at most the next job's three may stay in flight
+      if (x == 8) {  // (the last job of a phase: nothing else is outstanding)
+        mfma_v_pair_wait0(acc8, A[i & 1], Bh[i & 1], Bl[i & 1]);
+        slice(2 * i);
+        __builtin_amdgcn_sched_barrier(0);
+        slice(2 * i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
+      if (i < 2) mfma_pin_wait<3>(x, A[i & 1], Bh[i & 1]);
+      else mfma_pin_wait<0>(x, A[i & 1], Bh[i & 1]);
+      slice(2 * i);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pin(x, A[i & 1], Bl[i & 1]);
+      if (i == 0) {  // job 2's operands into job 0's registers (the MFMAs that read them have issued)
+        A[0] = lds_b128(ua_s, 4 * kK * 16);
+        Bh[0] = lds_b128(va_s, 4 * kT * 16);
+        Bl[0] = lds_b128(va_s, 5 * kT * 16);
+      }
+      slice(2 * i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto phase_end = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto phase_end_keep_loads = [&]() {  // pixel waves: their global loads stay in flight across the barrier
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- zero borders once (pixel writes only ever touch in-image pixels)
+  for (int i = tid; i < 4 * g.HS; i += 512) P[i] = 0.f;
+  __syncthreads();
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+
+  // ================================================================================================ PRODUCER waves
+  // lane = (tile of 16, channel pair j of 4); wave & 1 = tile half; (wave >> 1) = group: group G runs the first half (channel
+  // 2 j) of the task of phase m + 2 when m + G is even and the second half (channel 2 j + 1, pack, store) of phase m + 1 else.
+  auto producer_item = [&]() {
+    const int grp = (wave >> 1) & 1;
+    const int st = (wave & 1) * 16 + (lane & 15), j = lane >> 4;
+    int tb0;  // pixel-ring offset of this lane's patch origin in channel 2 j (half-chunk j >> 1, plane 2 (j & 1))
+    {
+      const int per = g.TR * g.TWc;
+      const int ti = st / per, rem = st - ti * per;
+      const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
+      tb0 = (j >> 1) * g.HS + 2 * (j & 1) * g.PCH + ti * g.IS + 4 * tr * g.PW + 4 * tc;
+    }
+    int vw0 = kVB0 + st * 16 + 4 * j;  // V store: + slot + (2 pos + plane) 512
+    const int ulane = lane * 16;
+    float R0[12], wA[6], wB[6], drow[6];
+
+    // transfer e (0..5) of this wave's share of the U slot of phase mm (24 x 1 KB per slot, 6 per producer wave)
+    auto dma_u = [&](int e, int mm, int us) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_u, (__attribute__((address_space(3))) void *)(smb + us + (wave + 4 * e) * 1024), 16, ulane,
+          (ukt + mm) * kUSB + (wave + 4 * e) * 1024, 0, 0);
+    };
+    // the transform of one channel of the patch: rows (0, 5), (1, 2) or (3, 4) of B^T d B (conv_wino44.hip's row pairs)
+    //   rows (0, 5): A = d4 - 5 d2 + 4 d0,  B = d5 - 5 d3 + 4 d1
+    //   rows (1, 2): p = d4 - 2 d2 - 2 d2,  q = d3 - 2 d1 - 2 d1,  A = p + q, B = p - q
+    //   rows (3, 4): p = d4 - d2/2 - d2/2,  q = d3 - d1/2 - d1/2,  A = p + 2 q, B = p - 2 q
+    auto rd = [&](int r, int pb) {
+      const float *p = P + pb + r * g.PW;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) drow[q] = p[q];
+    };
+    auto tstep = [&](auto tc, int s, int pb) {
+      constexpr int t = decltype(tc)::value;
+      constexpr bool t0 = t == 0;
+      constexpr float c1 = t0 ? -5.f : t == 1 ? -2.f : -0.5f, c2 = t0 ? 4.f : c1, bm = t0 ? 0.f : t == 1 ? 1.f : 2.f;
+      if (s == 0) {
+        rd(4, pb);
+      } else if (s == 1) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) wA[q] = drow[q];
+        rd(2, pb);
+      } else if (s == 2) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) wA[q] = __builtin_fmaf(c1, drow[q], wA[q]);
+        rd(t0 ? 0 : 2, pb);
+      } else if (s == 3) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) wA[q] = __builtin_fmaf(c2, drow[q], wA[q]);
+        rd(t0 ? 5 : 3, pb);
+      } else if (s == 4) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) wB[q] = drow[q];
+        rd(t0 ? 3 : 1, pb);
+      } else if (s == 5) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) wB[q] = __builtin_fmaf(c1, drow[q], wB[q]);
+        rd(1, pb);
+      } else if (s == 6) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const float qq = __builtin_fmaf(c2, drow[q], wB[q]), pp = wA[q];
+          wA[q] = __builtin_fmaf(bm, qq, pp);
+          wB[q] = t0 ? qq : __builtin_fmaf(-bm, qq, pp);
+        }
+      }
+    };
+    // slices k = 0..5 of a half task.  First half: channel 2 j -> R0.  Second half: channel 2 j + 1, pair-pack with R0, store.
+    auto half_task = [&](auto tc, auto secondc, int k, int pb, int vs) {
+      constexpr bool SECOND = decltype(secondc)::value;
+      if (k == 0) tstep(tc, 0, pb);
+      if (k == 1) { tstep(tc, 1, pb); tstep(tc, 2, pb); }
+      if (k == 2) { tstep(tc, 3, pb); tstep(tc, 4, pb); }
+      if (k == 3) { tstep(tc, 5, pb); tstep(tc, 6, pb); }
+      if (k == 4 || k == 5) {
+        float t6[6];
+        bt6(k == 4 ? wA : wB, t6);
+        const int o = k == 4 ? 0 : 6;
+        if (!SECOND) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) R0[o + q] = t6[q];
+        } else {
+          // ONE address register + immediates (left to itself hipcc materialises a VGPR address per store and spills them:
+          // ring offset + position offset exceed the 16-bit offset field when folded into one constant)
+          int vwa = vw0 + vs;
+          asm volatile("" : "+v"(vwa));
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            uint32_t hi, lo;
+            split_pair(R0[o + q], t6[q], hi, lo);
+            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(hi), "n"((2 * (o + q)) * (kT * 16)) : "memory");
+            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(lo), "n"((2 * (o + q) + 1) * (kT * 16)) : "memory");
+          }
+        }
+      }
+    };
+    // phases m = -6 .. NPH - 1 in blocks of six; Q = m mod 6 is a compile-time constant of each instance
+    auto body = [&](auto qc, int m) {
+      constexpr int Q = decltype(qc)::value;
+      asm volatile("" : "+v"(tb0), "+v"(vw0));  // keep the per-lane bases out of LICM's reach (see conv_wino44.hip)
+      constexpr int us = (Q & 1) * kUSB, vs = (Q & 1) * kVSB;                // ring slots of phase m
+      constexpr int us1 = ((Q + 1) & 1) * kUSB, vs1 = ((Q + 1) & 1) * kVSB;  // ... of phase m + 1
+      constexpr int Q1 = (Q + 1) % 6, Q2 = (Q + 2) % 6;
+      // pixel half-tiles of the chunk a task belongs to: even chunks in ring slots 0, 1, odd chunks in 2, 3
+      constexpr int pb1 = Q1 >= 3 ? 2 : 0, pb2 = Q2 >= 3 ? 2 : 0;
+      const bool first = grp == (Q & 1);  // first half of the task of phase m + 2, else second half of phase m + 1
+      const bool do1 = m + 1 >= 0 && m + 1 < NPH, do2 = m + 2 >= 0 && m + 2 < NPH;
+      const int pbA = tb0 + pb2 * g.HS, pbB = tb0 + g.PCH + pb1 * g.HS;
+      auto slice = [&](int k) {
+        if (k == 0 && do1) {
+#pragma unroll
+          for (int e = 0; e < 6; ++e) dma_u(e, m + 1, us1);
+        }
+        if (first) {
+          if (do2) half_task(std::integral_constant<int, Q2 % 3>{}, std::false_type{}, k, pbA, 0);
+        } else {
+          if (do1) half_task(std::integral_constant<int, Q1 % 3>{}, std::true_type{}, k, pbB, vs1);
+        }
+      };
+      if (m >= 0) {
+        mfma_phase(std::integral_constant<int, Q % 3>{}, us, vs, slice);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          slice(k);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      phase_end();
+    };
+    for (int m = -6; m < NPH; m += 6) {
+      body(std::integral_constant<int, 0>{}, m);
+      body(std::integral_constant<int, 1>{}, m + 1);
+      body(std::integral_constant<int, 2>{}, m + 2);
+      body(std::integral_constant<int, 3>{}, m + 3);
+      body(std::integral_constant<int, 4>{}, m + 4);
+      body(std::integral_constant<int, 5>{}, m + 5);
+    }
+  };
+
+  // ================================================================================================ PIXEL waves
+  // wave - 4 = channel of a 4-channel half-chunk; round k = 64 pixels (unit k of the item: image k / GD, pixels 64 (k % GD) ..).
+  //   phase m = 3 c + 0: loads (set 0) of half 0 of chunk c + 2;  activation (set 1) of half 1 of chunk c + 1
+  //   phase m = 3 c + 1: loads (set 1) of half 1 of chunk c + 2
+  //   phase m = 3 c + 2: activation (set 0) of half 0 of chunk c + 2
+  // i.e. every load has two phases to land, and a half-tile is rewritten one phase after its last reader (the second half of
+  // the task of the last phase of chunk c - 2) has passed its barrier.
+  auto pixel_item = [&](int n_cur) {
+    const int sc = wave - 4;
+    const int row_lo = max(0, 4 * r0 - 1), row_hi = min(a.Ho, 4 * (r0 + g.TR) + 1);
+    const int npx = (row_hi - row_lo) * a.Wo;
+    const int dump = 4 * g.PCH + 1 + lane;  // relative to the half-tile
+    int pix0, pw0, pixL = 0, pwL = 0;
+    {
+      const bool valid = lane < npx;
+      pix0 = valid ? ((row_lo + lane / a.Wo) * a.Wo + lane % a.Wo) * 4 : (int)0x80000000;  // out of range: the load returns 0
+      pw0 = valid ? sc * g.PCH + (row_lo + lane / a.Wo - (4 * r0 - 1)) * g.PW + lane % a.Wo + 1 : dump;
+      if (ONEIMG) {
+        const int eL = lane + 64 * (NRT - 1);
+        const bool vL = eL < npx;
+        pixL = vL ? ((row_lo + eL / a.Wo) * a.Wo + eL % a.Wo) * 4 : (int)0x80000000;
+        pwL = vL ? sc * g.PCH + (row_lo + eL / a.Wo - (4 * r0 - 1)) * g.PW + eL % a.Wo + 1 : dump;
+      }
+    }
+    const int prs = (64 / a.Wo) * g.PW;  // pixel-tile floats between a lane's pixels of consecutive rounds of one image
+    auto pix_of = [&](int k) { return ONEIMG ? (k == NRT - 1 ? pixL : pix0 + 256 * k) : pix0 + 256 * (k % GD); };
+    auto pw_of = [&](int k) { return ONEIMG ? (k == NRT - 1 ? pwL : pw0 + k * prs) : pw0 + (k % GD) * prs + (k / GD) * g.IS; };
+    const int bytes1 = a.B * a.C1 * g.HW * 4, bytes2 = a.B * a.C2 * g.HW * 4;
+    const __amdgpu_buffer_rsrc_t rs_sc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gscale), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sh =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gshift), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
+    int vzero;  // keeps the wave-uniform scale / shift loads on the vector memory path (in-order vmcnt with the pixel loads)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    float praw[2][NRT], gs[2][NGS], gh[2][NGS];
+
+    auto load_stage = [&](auto setc, int c, int half) {
+      constexpr int S = decltype(setc)::value;
+      const int cl = min(max(c, 0), NCHs - 1);  // past the item's last chunk: a harmless repeat (uniform vmcnt bookkeeping)
+      const int cg = (ch_lo + cl) * kC + half * 4 + sc;
+      const bool first = cg < a.C1;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
+      const int cx = first ? a.C1 : a.C2, cgl = first ? cg : cg - a.C1;
+#pragma unroll
+      for (int k = 0; k < NRT; ++k) {
+        const int ni = min(n_cur + (ONEIMG ? 0 : k / GD), g.NIMG - 1);
+        praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pix_of(k), (ni * cx + cgl) * g.HW * 4, 0));
+        if (AFFINE && k % GD == 0) {
+          const int goff = (ni * g.Cin + cg) * 4;
+          gs[S][k / GD] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
+          gh[S][k / GD] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
+        }
+      }
+    };
+    auto activate = [&](auto setc, int k, int ring) {  // pixel value x 2^3: the transform's output is the pre-scaled V
+      constexpr int S = decltype(setc)::value;
+      const float x = praw[S][k];
+      float y;
+      if (AFFINE) {
+        const float sa = gs[S][k / GD], sb = gh[S][k / GD];
+        const float v = __builtin_fmaf(x, sa, sb);
+        const float t = __builtin_fmaf(x, -1.44269504088896341f * sa, -1.44269504088896341f * sb);
+        y = (kVScale * v) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+      } else {
+        y = kVScale * (silu ? silu_fast(x) : x);
+      }
+      P[ring * g.HS + pw_of(k)] = y;
+    };
+    auto body = [&](auto qc, int m, int c) {  // c = chunk of phase m (floor(m / 3); -2, -1 in the fill phases)
+      constexpr int Q = decltype(qc)::value;
+      constexpr int R = Q % 3;
+      asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL));
+      constexpr int us = (Q & 1) * kUSB, vs = (Q & 1) * kVSB;
+      // ring slot of the half-tile written in this phase: even chunks 0 / 1, odd chunks 2 / 3 (a block starts on an even chunk)
+      constexpr int ringB = Q == 0 ? 3 : 1;  // R == 0: half 1 of chunk c + 1
+      constexpr int ringA = Q == 2 ? 0 : 2;  // R == 2: half 0 of chunk c + 2
+      const bool actB = R == 0 && c + 1 >= 0 && c + 1 < NCHs, actA = R == 2 && c + 2 < NCHs;
+      auto slice = [&](int k) {
+        if (k == 0) {
+          if (R == 0) load_stage(I0{}, c + 2, 0);
+          if (R == 1) load_stage(I1{}, c + 2, 1);
+        }
+        if (k >= 1) {
+          // the set being activated was loaded before the NVM loads that may still be in flight (issued last phase / slice 0)
+          if (k == 1 && (actA || actB)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NVM) : "memory");
+#pragma unroll
+          for (int kk = 2 * (k - 1); kk < 2 * k && kk < NRT; ++kk) {
+            if (actB) activate(I1{}, kk, ringB);
+            if (actA) activate(I0{}, kk, ringA);
+          }
+        }
+      };
+      if (m >= 0) {
+        mfma_phase(std::integral_constant<int, Q % 3>{}, us, vs, slice);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          slice(k);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      phase_end_keep_loads();
+    };
+    int c = -2;
+    for (int m = -6; m < NPH; m += 6, c += 2) {
+      body(std::integral_constant<int, 0>{}, m, c);
+      body(std::integral_constant<int, 1>{}, m + 1, c);
+      body(std::integral_constant<int, 2>{}, m + 2, c);
+      body(std::integral_constant<int, 3>{}, m + 3, c + 1);
+      body(std::integral_constant<int, 4>{}, m + 4, c + 1);
+      body(std::integral_constant<int, 5>{}, m + 5, c + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the repeats past the last chunk: nothing may land after the item
+  };
+
+  for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
+    zero_pinned_tiles();
+    {  // (a literal zero vector is materialised THROUGH a0..a15 by hipcc: an opaque zero keeps it in arch VGPRs)
+      float z;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+      acc8 = f32x16{z, z, z, z, z, z, z, z, z, z, z, z, z, z, z, z};
+    }
+    if (wave < 4) producer_item();
+    else pixel_item(n_cur);
+
+    // ---- end of an item: Y = A^T M A through four exchange slabs [xi][cout block][lane] (the operand rings: every stage of
+    // the item has finished).  Pass q moves accumulator registers 4 q .. 4 q + 3 of all 36 positions; wave (cb, pg) then
+    // finishes register 4 q + pg of cout block cb: cout = 32 cb + 8 q + 4 lhi + pg, tile = l31 (as conv_wino44.hip).
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' passes
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int el31 = elane & 31, elhi = elane >> 5;
+    const int per = g.TR * g.TWc;
+    const int ti = el31 / per, rem = el31 - ti * per;
+    const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
+    const int n = n_cur + ti, ncl = min(n, g.NIMG - 1);
+    float *const XS = smem;
+    // 1 / (2^3 2^su): the operands' power-of-two pre-scales, written behind the planes by the pack kernel.  Loaded here, per
+    // item, through the scalar cache: one more live VGPR across the phase loops and hipcc parks a value in a0 (a pinned tile)
+    float kOutScale, unused_umax;
+    sload2(reinterpret_cast<const float *>(a.w_wino44h + (size_t)kX * a.Cout * g.Cin * 2) + 1, kOutScale, unused_umax);
+    (void)unused_umax;
+    // accumulator tile 3 t + i of wave pg holds position s = 3 pg + i of phase t: row (0,5 | 1,2 | 3,4)[s / 6], column s % 6
+    const int rsel = pg >> 1, cofs = 3 * (pg & 1);
+    const int xb0 = (rsel ? 5 : 0) * 6 + cofs, xb1 = (rsel ? 2 : 1) * 6 + cofs, xb2 = (rsel ? 4 : 3) * 6 + cofs;
+    float addv[4];
+    if (ONEIMG) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co0 = kt * kK + cb * 32 + 8 * q + pg;  // lanes 0..31; lanes 32..63 hold co0 + 4
+        float b0 = 0.f, b1 = 0.f, t0v = 0.f, t1v = 0.f;
+        if (a.bias) sload2(a.bias + co0, b0, b1);
+        if (a.chan_add) sload2(a.chan_add + (size_t)min(n_cur, g.NIMG - 1) * a.chan_add_stride + co0, t0v, t1v);
+        addv[q] = elhi ? b1 + t1v : b0 + t0v;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = kt * kK + cb * 32 + 8 * q + 4 * elhi + pg;
+        addv[q] = (a.bias ? a.bias[co] : 0.f) + (a.chan_add ? a.chan_add[(size_t)ncl * a.chan_add_stride + co] : 0.f);
+      }
+    }
+    const size_t co_e = (size_t)kt * kK + cb * 32 + 4 * elhi + pg;
+    const size_t obase0 = ((size_t)ncl * a.Cout + co_e) * g.HW + (size_t)(4 * (r0 + tr)) * a.Wo + 4 * tc;  // pass q: + 8 q HW
+    v4f res[4];
+    auto load_res = [&](int q) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        res[k] = *reinterpret_cast<const v4f *>(a.residual + obase0 + (size_t)(8 * q) * g.HW + (size_t)k * a.Wo);
+    };
+    if (RES) load_res(0);
+    auto pass = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      const size_t obase = obase0 + (size_t)(8 * q) * g.HW;
+      {
+        float *xw = XS + cb * 64 + elane;
+#pragma unroll
+        for (int x = 0; x < 9; ++x) {
+          const int xi = (x < 3 ? xb0 : x < 6 ? xb1 : xb2) + x % 3;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            xw[rr * kXS + xi * 128] = x == 8 ? acc8[4 * q + rr] : read_pinned(16 * (x & 7) + 4 * q + rr);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const float *xr = XS + pg * kXS + cb * 64 + elane;  // + xi * 128
+      const float ad = addv[q];
+      auto half = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        float w[2][6];
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {  // columns of M through two rows of A^T
+          const float m1 = xr[(1 * 6 + jj) * 128], m2 = xr[(2 * 6 + jj) * 128], m3 = xr[(3 * 6 + jj) * 128],
+                      m4 = xr[(4 * 6 + jj) * 128];
+          if (h == 0) {
+            const float m0 = xr[(0 * 6 + jj) * 128];
+            w[0][jj] = (m0 + (m1 + m2)) + (m3 + m4);
+            w[1][jj] = __builtin_fmaf(2.f, m3 - m4, m1 - m2);
+          } else {
+            const float m5 = xr[(5 * 6 + jj) * 128];
+            w[0][jj] = __builtin_fmaf(4.f, m3 + m4, m1 + m2);
+            w[1][jj] = __builtin_fmaf(8.f, m3 - m4, m1 - m2) + m5;
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int k = 2 * h + kk;
+          float y[4];
+          at4(w[kk][0], w[kk][1], w[kk][2], w[kk][3], w[kk][4], w[kk][5], y);
+          // the operands' power-of-two pre-scales come off here (exact), in the same fma that adds bias + temb
+          v4f o = v4f{__builtin_fmaf(y[0], kOutScale, ad), __builtin_fmaf(y[1], kOutScale, ad),
+                      __builtin_fmaf(y[2], kOutScale, ad), __builtin_fmaf(y[3], kOutScale, ad)};
+          if (RES) o += res[k];
+          if (n < g.NIMG) *reinterpret_cast<v4f *>(outp + obase + (size_t)k * a.Wo) = o;
+        }
+      };
+      half(I0{});
+      v4f r01[2];
+      if (RES && q < 3) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          r01[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * g.HW + (size_t)k * a.Wo);
+      }
+      half(I1{});
+      if (RES && q < 3) {
+        res[0] = r01[0];
+        res[1] = r01[1];
+#pragma unroll
+        for (int k = 2; k < 4; ++k)
+          res[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * g.HW + (size_t)k * a.Wo);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    pass(I0{});
+    pass(I1{});
+    pass(I2{});
+    pass(std::integral_constant<int, 3>{});
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s) {
+  W44HGeom g;
+  if (!d.w_wino44h || !w44h_geom(d, g)) {
+    set_error("conv_wino44h: unsupported shape");
+    return DDPM_EINVAL;
+  }
+  const size_t lds = w44h_lds_bytes(g);
+  typedef void (*kern_t)(const ddpm_conv_desc, const W44HGeom);
+  // shapes: one image per item with 9 (32x32) or 10 (64x64) staging units, two 16x16 images, eight 8x8 images
+#define W44H_K(A, N, U) {conv_wino44h_kernel<A, N, U, false>, conv_wino44h_kernel<A, N, U, true>}
+  static const kern_t kerns[2][4][2] = {
+      {W44H_K(false, 9, 0), W44H_K(false, 10, 0), W44H_K(false, 8, 4), W44H_K(false, 8, 1)},
+      {W44H_K(true, 9, 0), W44H_K(true, 10, 0), W44H_K(true, 8, 4), W44H_K(true, 8, 1)}};
+#undef W44H_K
+  static bool attr_done = false;
+  if (!attr_done) {
+    for (int i = 0; i < 16; ++i)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[i / 8][i / 2 % 4][i % 2]),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  ddpm_conv_desc dk = d;
+  if (g.S > 1) {  // partial sums go to the scratch slabs, the addends to the reduce pass
+    dk.out = d.scratch;
+    dk.bias = nullptr;
+    dk.chan_add = nullptr;
+    dk.residual = nullptr;
+  }
+  const int shape = g.TI == 1 ? (g.NRT == 9 ? 0 : 1) : g.UI == 4 ? 2 : 3;
+  kern_t kern = kerns[d.gscale ? 1 : 0][shape][dk.residual ? 1 : 0];
+  const double M = (double)g.NIMG * g.HW;
+  // algorithmic work = the direct convolution's: 2 M Cout Cin 9
+  const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9;
+  const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9);
+  const char *kname = d.gscale ? "conv3x3_wino44h_gn_silu" : "conv3x3_wino44h";
+  char kshape[160];
+  if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {
+    snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);
+    kname = kshape;
+  }
+  ProfScope prof(s, kname, flops, bytes);
+  hipLaunchKernelGGL(kern, dim3(g.grid), dim3(512), lds, s, dk, g);
+  DDPM_CHECK_LAUNCH();
+  if (g.S > 1) return launch_wino_split_reduce(d, g.S, g.pstride, g.HW, s);
+  return 0;
+}
+
+// ---- weights: torch [Cout][Cin][3][3] -> U = 2^su G g G^T (6 x 6) as f16 hi / lo planes in the order the kernel's LDS-DMA
+// lands them:   [cout tile 64][chunk of 8 channels][phase 3][position 12][plane 2][cout 64][channel 8]   (f16)
+// phase t holds transform rows (0, 5), (1, 2), (3, 4); position s = 6 (second row of the pair) + column.  Behind the planes:
+// two floats, max |G g G^T| of the layer and 1 / (2^3 2^su) for the kernel's epilogue (su = 15 - exponent of the maximum).
+__device__ __forceinline__ void wino44h_u(const float *w, double (&u)[6][6]) {
+  const double G[6][3] = {{0.25, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},   {0, 0, 1}};
+  double t[6][3];
+  for (int r = 0; r < 6; ++r)
+    for (int q = 0; q < 3; ++q) t[r][q] = G[r][0] * w[0 * 3 + q] + G[r][1] * w[1 * 3 + q] + G[r][2] * w[2 * 3 + q];
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) u[r][c] = t[r][0] * G[c][0] + t[r][1] * G[c][1] + t[r][2] * G[c][2];
+}
+
+__global__ void wino44h_max_kernel(const float *__restrict__ src, unsigned *__restrict__ tail, int64_t total) {
+  float m = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    double u[6][6];
+    wino44h_u(src + i * 9, u);
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) m = fmaxf(m, fabsf((float)u[r][c]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(tail, __float_as_uint(m));  // non-negative floats order like their bit patterns
+}
+
+__global__ void wino44h_pack_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, int Cout, int Cin) {
+  const int64_t total = (int64_t)Cout * Cin;
+  const int nch = Cin / kC;
+  float *tail = reinterpret_cast<float *>(dst + (size_t)kX * Cout * Cin * 2);
+  int e = 0;
+  const float umax = tail[0];
+  if (umax > 0.f) (void)frexpf(umax, &e);  // umax = f 2^e, f in [0.5, 1)
+  const int su = umax > 0.f ? 15 - e : 0;  // max |2^su U| in [2^14, 2^15)
+  if (blockIdx.x == 0 && threadIdx.x == 0) tail[1] = ldexpf(1.f / kVScale, -su);
+  const int trio_of[6] = {0, 1, 1, 2, 2, 0}, second_of[6] = {0, 0, 1, 0, 1, 1};
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin), o = (int)(i / Cin);
+    double uu[6][6];
+    wino44h_u(src + ((size_t)o * Cin + ci) * 9, uu);
+    const int tile = o / kK, k64 = o % kK, ch = ci / kC, c8 = ci % kC;
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) {
+        const float u = ldexpf((float)uu[r][c], su);
+        const _Float16 hi = (_Float16)u, lo = (_Float16)(u - (float)hi);
+        const int s = second_of[r] * 6 + c;
+        const size_t base = ((((size_t)tile * nch + ch) * 3 + trio_of[r]) * kPP + s) * 2;
+        dst[((base + 0) * kK + k64) * kC + c8] = __builtin_bit_cast(uint16_t, hi);
+        dst[((base + 1) * kK + k64) * kC + c8] = __builtin_bit_cast(uint16_t, lo);
+      }
+  }
+}
+
+size_t wino44h_weight_halves(int Cout, int Cin) {
+  if (Cout % kK || Cin % 16) return 0;
+  return (size_t)kX * Cout * Cin * 2 + kTail;
+}
+
+int launch_pack_wino44h_weight(const float *w_raw, uint16_t *w_wino44h, int Cout, int Cin, hipStream_t s) {
+  DDPM_CHECK_ARG(wino44h_weight_halves(Cout, Cin) != 0, "wino44h pack: Cout %% 64 or Cin %% 16 != 0");
+  const int64_t total = (int64_t)Cout * Cin;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  unsigned *tail = reinterpret_cast<unsigned *>(w_wino44h + (size_t)kX * Cout * Cin * 2);
+  hipError_t e = hipMemsetAsync(tail, 0, kTail * sizeof(uint16_t), s);
+  if (e != hipSuccess) {
+    set_error("wino44h pack: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  hipLaunchKernelGGL(wino44h_max_kernel, dim3(blocks), dim3(256), 0, s, w_raw, tail, total);
+  DDPM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(wino44h_pack_kernel, dim3(blocks), dim3(256), 0, s, w_raw, w_wino44h, Cout, Cin);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace ddpm

@@ -34,6 +34,8 @@ struct ParamSlot {
   size_t wino_base = 0;
   bool has_wino44 = false;      // ... and the F(4x4, 3x3) form
   size_t wino44_base = 0;
+  bool has_wino44h = false;     // ... and its split-f16 form (conv_wino44h.hip); base in floats, 2 f16 per float
+  size_t wino44h_base = 0;
   int Cout = 0, Cin = 0, ksize = 1, cout_offset = 0, Cout_total = 0;
   int dims = 2;                 // 3: [Cout, Cin, k, k, k] packed as k slabs of 2-D taps (one per depth tap)
   bool optional = false;
@@ -41,8 +43,8 @@ struct ParamSlot {
 };
 
 struct ConvRef {  // a conv-like op: weight (raw + packed) and bias locations in the blob
-  size_t w_raw = 0, w_packed = 0, bias = 0, w_folded = 0, w_wino = 0, w_wino44 = 0;
-  bool has_packed = false, has_folded = false, has_wino = false, has_wino44 = false;
+  size_t w_raw = 0, w_packed = 0, bias = 0, w_folded = 0, w_wino = 0, w_wino44 = 0, w_wino44h = 0;
+  bool has_packed = false, has_folded = false, has_wino = false, has_wino44 = false, has_wino44h = false;
   int Cin = 0, Cout = 0, ksize = 1;
   int dims = 2;
 };
@@ -223,6 +225,12 @@ static ResRef build_res(ddpm_unet *u, const std::string &prefix, int Cin, int Co
         cr[i]->w_wino44 = u->alloc(n44);
         ps.has_wino44 = true;
         ps.wino44_base = cr[i]->w_wino44;
+      }
+      if (const size_t nh = wino44h_weight_halves(cr[i]->Cout, cr[i]->Cin)) {
+        cr[i]->has_wino44h = true;
+        cr[i]->w_wino44h = u->alloc(nh / 2);
+        ps.has_wino44h = true;
+        ps.wino44h_base = cr[i]->w_wino44h;
       }
     }
   }
@@ -414,6 +422,10 @@ extern "C" int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *
     rc = launch_pack_wino44_weight(src, h->blob + p.wino44_base, p.Cout, p.Cin, s);
     if (rc) return rc;
   }
+  if (p.has_wino44h) {
+    rc = launch_pack_wino44h_weight(src, reinterpret_cast<uint16_t *>(h->blob + p.wino44h_base), p.Cout, p.Cin, s);
+    if (rc) return rc;
+  }
   if (p.has_folded) {
     rc = launch_fold_upsample_weight(src, h->blob + p.folded_base, p.Cout, p.Cin, s);
     if (rc) return rc;
@@ -476,6 +488,8 @@ struct Runner {
     if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino && c.dims == 2)
       d.w_wino = P(c.w_wino);
     if (mode == DDPM_CONV_NORMAL && c.has_wino44 && c.dims == 2) d.w_wino44 = P(c.w_wino44);
+    if (mode == DDPM_CONV_NORMAL && c.has_wino44h && c.dims == 2)
+      d.w_wino44h = reinterpret_cast<const uint16_t *>(P(c.w_wino44h));
     if (c.dims == 3 && c.ksize == 3 && mode == DDPM_CONV_NORMAL && c.has_wino) d.w_wino = P(c.w_wino);  // F(2x2) per depth tap
     if (c.dims == 3 && c.ksize == 3) {
       // F.conv3d: ONE launch walks the (depth tap, channel group) chunks (w_packed = three depth slabs); a

@@ -74,9 +74,24 @@ def fold_upsample_weight(weight: torch.Tensor) -> torch.Tensor | None:
     return out
 
 
+def pack_wino44h_weight(weight: torch.Tensor) -> torch.Tensor | None:
+    """torch [Cout, Cin, 3, 3] -> F(4x4, 3x3) Winograd-domain weights as split-f16 planes (hi = f16(2^10 U), lo = the
+    remainder) in the order conv_wino44h.hip's LDS-DMA lands them; None without a tiling (Cout % 64, Cin % 16)."""
+    lib = _lib.load()
+    w = require_device_f32(weight, "weight")
+    if w.ndim != 4 or tuple(w.shape[2:]) != (3, 3):
+        return None
+    n = lib.ddpm_wino44h_weight_halves(w.shape[0], w.shape[1])
+    if n == 0:
+        return None
+    out = torch.empty(n, dtype=torch.float16, device=w.device)
+    check(lib.ddpm_pack_wino44h_weight(ptr(w), out.data_ptr(), w.shape[0], w.shape[1], stream_ptr()), "pack_wino44h_weight")
+    return out
+
+
 def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NONE, mode=CONV_NORMAL,
          chan_add=None, chan_add_offset=0, residual=None, packed=None, force_direct=False, folded=None,
-         wino=None, out_act=ACT_NONE, wino44=None):
+         wino=None, out_act=ACT_NONE, wino44=None, wino44h=None):
     """Fused conv / linear.  x: [B, C1, H, W]; x2: optional second source of a virtual concat."""
     lib = _lib.load()
     x = require_device_f32(x, "x")
@@ -128,6 +143,7 @@ def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NON
     d.w_folded = ptr(folded)
     d.w_wino = ptr(wino)
     d.w_wino44 = ptr(wino44)
+    d.w_wino44h = wino44h.data_ptr() if wino44h is not None else None
     d.out_act = out_act
     need = lib.ddpm_conv_scratch_floats(C.byref(d))  # small batches: split-K partial slabs (0 otherwise)
     if need:

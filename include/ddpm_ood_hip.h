@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDPM_ABI_VERSION 5
+#define DDPM_ABI_VERSION 6
 
 #define DDPM_EINVAL (-1)      /* bad argument / unsupported shape      */
 #define DDPM_ENOPARAM (-2)    /* unknown or missing parameter name     */
@@ -114,6 +114,13 @@ typedef struct ddpm_conv_desc {
    * half of the chip (with `scratch`: after a 2- / 4-way channel split), the conv runs as Winograd F(4x4, 3x3): 4x fewer multiplies than the direct form (F(2x2): 2.25x); fp32
    * rounding differs from the direct form by ~3e-6 rms relative.  Takes precedence over w_wino.  */
   const float *w_wino44;
+  /* Optional, 2-D 3x3 DDPM_CONV_NORMAL only (ABI 6): the F(4x4, 3x3) weights as split-f16 planes, packed by
+   * ddpm_pack_wino44h_weight (U = 2^su G g G^T as hi = f16(U), lo = f16(U - hi), in the order the kernel's LDS-DMA lands
+   * them; su per layer, the epilogue scale 1 / (2^3 2^su) stored behind the planes).  When present (Cin % 16 == 0, Cout % 64 == 0, same launch-size rule as w_wino44) the position GEMMs of the
+   * Winograd convolution run on the f16 MFMA pipe with split-f16 products (every fp32 product rebuilt from four exact f16
+   * partial products, fp32 accumulate); transforms and sums stay fp32.  Takes precedence over w_wino44;
+   * DDPM_WINO44_F16X3=0 switches it off.  */
+  const uint16_t *w_wino44h;
 } ddpm_conv_desc;
 
 int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream);
@@ -159,6 +166,11 @@ int ddpm_pack_wino_weight_f32(const float *w_raw, float *w_wino, int Cout, int C
  * (0 if the channel counts have no tiling).                                                              */
 size_t ddpm_wino44_weight_floats(int Cout, int Cin);
 int ddpm_pack_wino44_weight_f32(const float *w_raw, float *w_wino44, int Cout, int Cin, ddpm_stream_t stream);
+/* Split-f16 form of the same (see ddpm_conv_desc.w_wino44h): 2 * 36 * Cout * Cin + 64 f16 values (0: no tiling -- Cout % 64
+ * or Cin % 16).  Replaces the weight operand of F.conv2d inside DiffusionModelUNet's ResnetBlocks
+ * (/root/reference/src/trainers/reconstruct.py:151-153).  */
+size_t ddpm_wino44h_weight_halves(int Cout, int Cin);
+int ddpm_pack_wino44h_weight(const float *w_raw, uint16_t *w_wino44h, int Cout, int Cin, ddpm_stream_t stream);
 
 /* Winograd-domain form of a [Cout, Cin, 3, 3, 3] conv3d weight: U_kd = G w[:, :, kd] G^T for each depth tap (3 * 16 * Cout *
  * Cin floats).  A dims = 3, stride-1 descriptor without GroupNorm / activation prologue (the VQ-VAE residual units) that

@@ -1,0 +1,192 @@
+"""-m gpu: conv_wino44h.hip -- Winograd F(4x4, 3x3) with the position GEMMs on the f16 MFMA (split-f16 products, fp32
+accumulate) against ``F.conv2d`` (the op it replaces inside DiffusionModelUNet's ResnetBlocks,
+/root/reference/src/trainers/reconstruct.py:151-153), against the fp32-MFMA F(4x4) kernel it supersedes, and against a
+float64 convolution over several decades of operand scale (the error budget of the split: DESIGN.md 3.7).
+
+Tolerances are those of tests/test_gpu_ops.py::test_conv_winograd_f4x4 (the fp32 F(4x4) kernel): 2e-4 * (1 + max|ref|) on
+single values, 1e-5 relative on the rms -- the split must not cost accuracy.
+"""
+
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_conv(x, x2, w, b, gn, chan_add, residual, dtype=torch.float32):
+    xin = (x if x2 is None else torch.cat([x, x2], 1)).to(dtype)
+    if gn is not None:
+        gamma, beta = gn
+        xin = F.silu(F.group_norm(xin, 32, gamma.to(dtype), beta.to(dtype), 1e-6))
+    y = F.conv2d(xin, w.to(dtype), b.to(dtype), padding=1)
+    if chan_add is not None:
+        y = y + chan_add.to(dtype)[:, :, None, None]
+    if residual is not None:
+        y = y + residual.to(dtype)
+    return y
+
+
+CASES = [
+    # B, C1, C2, Cout, H, gn, chan_add, residual
+    (2, 64, 0, 64, 32, False, False, False),      # plain: 2 parts per image, one cout tile, 4 chunks
+    (3, 128, 0, 128, 32, True, True, True),
+    (2, 256, 128, 128, 32, True, True, False),    # virtual concat: 48 chunks
+    (5, 256, 0, 256, 16, True, False, True),      # two images per item, ragged last item
+    (19, 128, 128, 64, 8, True, True, True),      # eight images per item, ragged
+    (1, 64, 0, 64, 64, True, False, False),       # W = 64: two tile rows per item, 8 parts
+    (300, 128, 0, 128, 16, True, True, True),     # 2 x 150 items: several items per persistent workgroup
+    (70, 64, 64, 128, 32, True, True, True),      # 2 x 2 x 70 = 280 items, concat boundary inside a chunk's halves
+    (3, 16, 0, 64, 32, False, False, False),      # the smallest stream: two chunks
+    (2, 128, 0, 128, 32, False, True, True),      # no prologue (act = none)
+]
+
+
+def _inputs(case, scale_x=1.0, scale_w=1.0):
+    B, C1, C2, Cout, H, gn, chan, res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    Cin = C1 + C2
+    x = torch.randn(B, C1, H, H, generator=g) * scale_x
+    x2 = (torch.randn(B, C2, H, H, generator=g) * 1.5 + 0.3) * scale_x if C2 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9) * scale_w
+    b = torch.randn(Cout, generator=g)
+    gamma = torch.randn(Cin, generator=g) * 0.2 + 1
+    beta = torch.randn(Cin, generator=g) * 0.2
+    chan_add = torch.randn(B, Cout + 64, generator=g) if chan else None
+    residual = torch.randn(B, Cout, H, H, generator=g) if res else None
+    return x, x2, w, b, gamma, beta, chan_add, residual
+
+
+def _run(device, case, tensors, **which):
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, Cout, H, gn, chan, res = case
+    x, x2, w, b, gamma, beta, chan_add, residual = tensors
+    d = lambda t: None if t is None else t.to(device)
+    gs = gh = None
+    if gn:
+        gs, gh = ops.gn_scale_shift(d(x), d(gamma), d(beta), 32, 1e-6, x2=d(x2))
+    kw = dict(x2=d(x2), gscale=gs, gshift=gh, act=int(gn), chan_add=d(chan_add), chan_add_offset=32, residual=d(residual))
+    return ops.conv(d(x), d(w), d(b), **which, **kw)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_wino44h_vs_conv2d(device, case, monkeypatch):
+    monkeypatch.setenv("DDPM_CONV_WINO44", "2")  # also for launches smaller than the chip
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, Cout, H, gn, chan, res = case
+    t = _inputs(case)
+    x, x2, w, b, gamma, beta, chan_add, residual = t
+    ref = _ref_conv(x, x2, w, b, (gamma, beta) if gn else None, chan_add[:, 32:32 + Cout] if chan else None, residual)
+    wh = ops.pack_wino44h_weight(w.to(device))
+    assert wh is not None and wh.numel() == 2 * 36 * Cout * (C1 + C2) + 64 and wh.dtype == torch.float16
+    y = _run(device, case, t, wino44h=wh)
+    y44 = _run(device, case, t, wino44=ops.pack_wino44_weight(w.to(device)))
+    torch.cuda.synchronize()
+    assert not torch.equal(y, y44)  # the split-f16 kernel really ran (and is not the fp32 F(4x4) kernel)
+    err = y.cpu() - ref
+    assert math.isfinite(err.abs().max().item())
+    assert err.abs().max().item() < 2e-4 * (1 + ref.abs().max().item()), err.abs().max().item()
+    assert err.pow(2).mean().sqrt().item() < 1e-5 * (1 + ref.pow(2).mean().sqrt().item())
+    assert torch.equal(y, _run(device, case, t, wino44h=wh))  # no dependence on leftover LDS state
+
+
+def test_conv_wino44h_is_selected_by_default_and_switchable(device, monkeypatch):
+    """With both packed forms in the descriptor the split-f16 kernel wins; DDPM_WINO44_F16X3=0 restores the fp32 F(4x4)
+    kernel bit for bit (the A/B switch of DESIGN.md 4.1)."""
+    from ddpm_ood_amd import ops
+
+    case = (70, 128, 0, 128, 32, True, True, True)  # 2 x 2 x 70 = 280 items: fills the chip
+    t = _inputs(case)
+    w = t[2].to(device)
+    wh, w44 = ops.pack_wino44h_weight(w), ops.pack_wino44_weight(w)
+    monkeypatch.delenv("DDPM_CONV_WINO44", raising=False)
+    both = _run(device, case, t, wino44h=wh, wino44=w44)
+    only_h = _run(device, case, t, wino44h=wh)
+    only_44 = _run(device, case, t, wino44=w44)
+    monkeypatch.setenv("DDPM_WINO44_F16X3", "0")
+    off = _run(device, case, t, wino44h=wh, wino44=w44)
+    torch.cuda.synchronize()
+    assert torch.equal(both, only_h) and torch.equal(off, only_44) and not torch.equal(both, off)
+
+
+@pytest.mark.parametrize("scale_x,scale_w", [(1.0, 1.0), (1e-3, 1.0), (30.0, 1.0), (1.0, 1e-2), (1.0, 20.0), (1e-2, 10.0)])
+def test_conv_wino44h_error_budget_vs_float64(device, scale_x, scale_w, monkeypatch):
+    """The split's error budget over operand scales (no GroupNorm in front, so that the activation scale reaches the
+    transform): relative rms error against a float64 convolution at most 1.5x the fp32 F(4x4) kernel's + 2e-7, max error
+    at most 2x + 1e-6 of the output scale -- i.e. the 22-bit operand representation is not what limits the accuracy."""
+    monkeypatch.setenv("DDPM_CONV_WINO44", "2")
+    from ddpm_ood_amd import ops
+
+    case = (4, 256, 0, 128, 32, False, False, False)
+    t = _inputs(case, scale_x, scale_w)
+    x, x2, w, b, *_ = t
+    ref = _ref_conv(x, None, w, b, None, None, None, dtype=torch.float64)
+    yh = _run(device, case, t, wino44h=ops.pack_wino44h_weight(w.to(device))).cpu().double()
+    y4 = _run(device, case, t, wino44=ops.pack_wino44_weight(w.to(device))).cpu().double()
+    scale = (ref - b.double()[None, :, None, None]).pow(2).mean().sqrt().item()
+    eh, e4 = (yh - ref), (y4 - ref)
+    rms_h, rms_4 = eh.pow(2).mean().sqrt().item() / scale, e4.pow(2).mean().sqrt().item() / scale
+    max_h, max_4 = eh.abs().max().item() / scale, e4.abs().max().item() / scale
+    print(f"scale x {scale_x:g} w {scale_w:g}: split-f16 rms {rms_h:.2e} max {max_h:.2e} | fp32 F(4x4) rms {rms_4:.2e} max {max_4:.2e}")
+    assert math.isfinite(max_h)
+    assert rms_h <= 1.5 * rms_4 + 2e-7, (rms_h, rms_4)
+    assert max_h <= 2.0 * max_4 + 1e-6, (max_h, max_4)
+
+
+SPLIT_CASES = [
+    # B, C1, C2, Cout, H, gn, chan, res: fewer items than CUs -> S workgroups share an item's channel stream
+    (256, 256, 0, 256, 8, True, True, True),    # 4 x 32 = 128 items, S = 2
+    (16, 128, 256, 128, 32, True, True, False),  # 2 x 4 x 16 = 128 items, 48 chunks, S = 2
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv_wino44h_channel_split(device, case, monkeypatch):
+    monkeypatch.delenv("DDPM_CONV_WINO44", raising=False)
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, Cout, H, gn, chan, res = case
+    t = _inputs(case)
+    x, x2, w, b, gamma, beta, chan_add, residual = t
+    ref = _ref_conv(x, x2, w, b, (gamma, beta), chan_add[:, 32:32 + Cout], residual)
+    wh = ops.pack_wino44h_weight(w.to(device))
+    y = _run(device, case, t, wino44h=wh, wino=ops.pack_wino_weight(w.to(device)))
+    err = y.cpu() - ref
+    assert err.abs().max().item() < 2e-4 * (1 + ref.abs().max().item()), err.abs().max().item()
+    assert err.pow(2).mean().sqrt().item() < 1e-5 * (1 + ref.pow(2).mean().sqrt().item())
+    assert torch.equal(y, _run(device, case, t, wino44h=wh, wino=ops.pack_wino_weight(w.to(device))))  # fixed slab order
+
+
+def test_pack_wino44h_layout(device):
+    """The packed planes against a float64 restatement of U = 2^su G g G^T and of the kernel's slot order
+    [cout tile][chunk][phase: rows (0,5), (1,2), (3,4)][position 12][plane][cout 64][channel 8]; behind them the layer's
+    max |U| and the epilogue scale 1 / (2^3 2^su) with max |2^su U| in [2^14, 2^15); hi + lo reproduces 2^su U to 2^-21 of
+    its magnitude wherever the low half is a normal f16 (|2^su U| >= 2^-3: 17 binades below the maximum)."""
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    Cout, Cin = 128, 32
+    for wscale in (0.05, 5e-4, 40.0):
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * wscale
+        G = torch.tensor([[0.25, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                          [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
+        U = torch.einsum("ra,ocab,sb->ocrs", G, w.double(), G)  # [Cout, Cin, 6, 6]
+        raw = ops.pack_wino44h_weight(w.to(device)).cpu()
+        n = 2 * 36 * Cout * Cin
+        umax, oscale = raw[n:n + 4].view(torch.float32).tolist()
+        assert abs(umax - U.abs().max().item()) <= 1e-6 * umax
+        su = round(-math.log2(oscale * 8))
+        assert oscale == 2.0 ** -(su + 3) and 2.0 ** 14 <= umax * 2.0 ** su < 2.0 ** 15
+        U = U * 2.0 ** su
+        packed = raw[:n].double().reshape(Cout // 64, Cin // 8, 3, 12, 2, 64, 8)
+        for t, (ra, rb) in enumerate([(0, 5), (1, 2), (3, 4)]):
+            for s_ in range(12):
+                r, c = (ra if s_ < 6 else rb), s_ % 6
+                want = U[:, :, r, c].reshape(Cout // 64, 64, Cin // 8, 8).permute(0, 2, 1, 3)  # [tile, chunk, cout, ch]
+                hi, lo = packed[:, :, t, s_, 0], packed[:, :, t, s_, 1]
+                assert ((hi - want).abs() <= 2.0 ** -10 * want.abs() + 2.0 ** -24).all()  # hi plane = f16(2^su U)
+                assert ((hi + lo - want).abs() <= 2.0 ** -21 * want.abs() + 2.0 ** -24).all()
