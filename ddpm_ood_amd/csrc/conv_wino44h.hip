@@ -175,14 +175,16 @@ __device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, floa
   y[3] = __builtin_fmaf(8.f, v, d) + m5;
 }
 
-// x -> (f16(x), f16(x - f16(x))) for two channels, pair-packed: hi = {h(a), h(b)}, lo = {l(a), l(b)}
+// x -> (f16(x), f16(x - f16(x))) for two channels, pair-packed: hi = {h(a), h(b)}, lo = {l(a), l(b)}.  Four instructions:
+// the remainders come from v_fma_mix_f32 reading the packed f16 halves directly (x - h is exact in fp32).  (Left to hipcc
+// the same source became nine: it re-derived each half with v_fma_mixlo / mixhi_f16 from the transform's last fma, converted
+// back and subtracted.)
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t &hi, uint32_t &lo) {
-  const _Float16 ha = (_Float16)a, hb = (_Float16)b;
-  const h2 h = {ha, hb};
-  // x - f16(x) in one v_fma_mix_f32 (f16 source operand), exact in fp32
-  const h2 l = {(_Float16)__builtin_fmaf((float)ha, -1.0f, a), (_Float16)__builtin_fmaf((float)hb, -1.0f, b)};
-  hi = __builtin_bit_cast(uint32_t, h);
-  lo = __builtin_bit_cast(uint32_t, l);
+  float la, lb;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hi), "v"(b));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(la), "v"(lb));
 }
 
 }  // namespace
@@ -270,6 +272,9 @@ static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false)
   } else if (!((g.UI == 4 && rows * d.Wi == 256 && g.TI == 2) || (g.UI == 1 && rows * d.Wi == 64 && g.TI == 8))) {
     return false;
   }
+  // eight 8x8 images per item WITH the GroupNorm prologue: a pixel wave would hold 2 x 8 scale / shift pairs (32 registers)
+  // and hipcc parks a value in a0, a pinned accumulator (tools/check_acc_spills.py) -- those launches stay on conv_wino44.hip
+  if (g.TI == 8 && d.gscale) return false;
   g.KT = d.Cout / kK;
   g.NIT = (g.NIMG + g.TI - 1) / g.TI;
   const long items = (long)g.KT * g.parts * g.NIT;
@@ -406,6 +411,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  auto zero_accumulators = [&]() {
+    zero_pinned_tiles();
+    // (a literal zero vector is materialised THROUGH a0..a15 by hipcc: an opaque zero keeps it in arch VGPRs)
+    float z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    acc8 = f32x16{z, z, z, z, z, z, z, z, z, z, z, z, z, z, z, z};
+  };
+
   // ---- zero borders once (pixel writes only ever touch in-image pixels)
   for (int i = tid; i < 4 * g.HS; i += 512) P[i] = 0.f;
   __syncthreads();
@@ -417,8 +430,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
   // ================================================================================================ PRODUCER waves
   // lane = (tile of 16, channel pair j of 4); wave & 1 = tile half; (wave >> 1) = group: group G runs the first half (channel
   // 2 j) of the task of phase m + 2 when m + G is even and the second half (channel 2 j + 1, pack, store) of phase m + 1 else.
-  auto producer_item = [&]() {
-    const int grp = (wave >> 1) & 1;
+  auto producer_item = [&](auto grpc) {
+    constexpr int GRP = decltype(grpc)::value;  // waves 0, 1: group 0; waves 2, 3: group 1
     const int st = (wave & 1) * 16 + (lane & 15), j = lane >> 4;
     int tb0;  // pixel-ring offset of this lane's patch origin in channel 2 j (half-chunk j >> 1, plane 2 (j & 1))
     {
@@ -429,7 +442,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     }
     int vw0 = kVB0 + st * 16 + 4 * j;  // V store: + slot + (2 pos + plane) 512
     const int ulane = lane * 16;
-    float R0[12], wA[6], wB[6], drow[6];
+    // column-pass results of the task's two channels (carried from its first half to its second) and the row being read
+    float cA[2][6], cB[2][6], drow[6];
 
     // transfer e (0..5) of this wave's share of the U slot of phase mm (24 x 1 KB per slot, 6 per producer wave)
     auto dma_u = [&](int e, int mm, int us) {
@@ -446,10 +460,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
 #pragma unroll
       for (int q = 0; q < 6; ++q) drow[q] = p[q];
     };
-    auto tstep = [&](auto tc, int s, int pb) {
+    // column pass of channel c (0 / 1) in seven steps; every step consumes the row the previous one requested
+    auto cstep = [&](auto tc, int c, int s, int pb) {
       constexpr int t = decltype(tc)::value;
       constexpr bool t0 = t == 0;
       constexpr float c1 = t0 ? -5.f : t == 1 ? -2.f : -0.5f, c2 = t0 ? 4.f : c1, bm = t0 ? 0.f : t == 1 ? 1.f : 2.f;
+      float(&wA)[6] = cA[c], (&wB)[6] = cB[c];
       if (s == 0) {
         rd(4, pb);
       } else if (s == 1) {
@@ -481,36 +497,45 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
         }
       }
     };
-    // slices k = 0..5 of a half task.  First half: channel 2 j -> R0.  Second half: channel 2 j + 1, pair-pack with R0, store.
-    auto half_task = [&](auto tc, auto secondc, int k, int pb, int vs) {
-      constexpr bool SECOND = decltype(secondc)::value;
-      if (k == 0) tstep(tc, 0, pb);
-      if (k == 1) { tstep(tc, 1, pb); tstep(tc, 2, pb); }
-      if (k == 2) { tstep(tc, 3, pb); tstep(tc, 4, pb); }
-      if (k == 3) { tstep(tc, 5, pb); tstep(tc, 6, pb); }
-      if (k == 4 || k == 5) {
-        float t6[6];
-        bt6(k == 4 ? wA : wB, t6);
-        const int o = k == 4 ? 0 : 6;
-        if (!SECOND) {
-#pragma unroll
-          for (int q = 0; q < 6; ++q) R0[o + q] = t6[q];
-        } else {
-          // ONE address register + immediates (left to itself hipcc materialises a VGPR address per store and spills them:
-          // ring offset + position offset exceed the 16-bit offset field when folded into one constant)
-          int vwa = vw0 + vs;
-          asm volatile("" : "+v"(vwa));
-#pragma unroll
-          for (int q = 0; q < 6; ++q) {
-            uint32_t hi, lo;
-            split_pair(R0[o + q], t6[q], hi, lo);
-            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(hi), "n"((2 * (o + q)) * (kT * 16)) : "memory");
-            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(lo), "n"((2 * (o + q) + 1) * (kT * 16)) : "memory");
-          }
-        }
-      }
+    // A task = the 12 positions of one phase for the lane's two channels, in two halves of equal weight:
+    //   first half   the column passes of both channels (2 x 6 row reads, 2 x 48 VALU)          -> cA, cB
+    //   second half  four row passes (4 x 12), pair-split (4 per pair) and the 24 stores of the V slot
+    auto first_half = [&](auto tc, int k, int pb) {
+      const int pb1 = pb + g.PCH;  // channel 2 j + 1: the next plane of the half-tile
+      if (k == 0) cstep(tc, 0, 0, pb);
+      if (k == 1) { cstep(tc, 0, 1, pb); cstep(tc, 0, 2, pb); cstep(tc, 0, 3, pb); }
+      if (k == 2) { cstep(tc, 0, 4, pb); cstep(tc, 0, 5, pb); cstep(tc, 0, 6, pb); cstep(tc, 1, 0, pb1); }
+      if (k == 3) { cstep(tc, 1, 1, pb1); cstep(tc, 1, 2, pb1); cstep(tc, 1, 3, pb1); }
+      if (k == 4) { cstep(tc, 1, 4, pb1); cstep(tc, 1, 5, pb1); }
+      if (k == 5) cstep(tc, 1, 6, pb1);
     };
-    // phases m = -6 .. NPH - 1 in blocks of six; Q = m mod 6 is a compile-time constant of each instance
+    float t0r[6], t1r[6];  // a transformed row of both channels (second half)
+    auto second_half = [&](int k, int vs) {
+      // ONE address register + immediates (left to itself hipcc materialises a VGPR address per store and spills them:
+      // ring offset + position offset exceed the 16-bit offset field when folded into one constant)
+      int vwa = vw0 + vs;
+      asm volatile("" : "+v"(vwa));
+      auto store3 = [&](int o, int q0) {
+#pragma unroll
+        for (int q = q0; q < q0 + 3; ++q) {
+          uint32_t hi, lo;
+          split_pair(t0r[q], t1r[q], hi, lo);
+          asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(hi), "n"((2 * (o + q)) * (kT * 16)) : "memory");
+          asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(lo), "n"((2 * (o + q) + 1) * (kT * 16)) : "memory");
+        }
+      };
+      if (k == 0) { bt6(cA[0], t0r); bt6(cA[1], t1r); }
+      if (k == 1) store3(0, 0);
+      if (k == 2) store3(0, 3);
+      if (k == 3) { bt6(cB[0], t0r); bt6(cB[1], t1r); }
+      if (k == 4) store3(6, 0);
+      if (k == 5) store3(6, 3);
+    };
+    // Phases m = -6 .. NPH - 1 in blocks of six; Q = m mod 6 is a compile-time constant of each instance, and with it the
+    // trio, the ring slots and whether this group runs a first or a second half: no run-time branch inside a phase.  There
+    // are no range guards either: the tasks and DMAs of phases before 0 / after NPH - 1 run on whatever the rings hold (buffer
+    // addressing keeps the DMA in range, their results are overwritten before anyone reads them, everything has landed when
+    // the last phase's barrier opens), and the MFMAs of the six fill phases accumulate garbage that is zeroed afterwards.
     auto body = [&](auto qc, int m) {
       constexpr int Q = decltype(qc)::value;
       asm volatile("" : "+v"(tb0), "+v"(vw0));  // keep the per-lane bases out of LICM's reach (see conv_wino44.hip)
@@ -519,32 +544,23 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       constexpr int Q1 = (Q + 1) % 6, Q2 = (Q + 2) % 6;
       // pixel half-tiles of the chunk a task belongs to: even chunks in ring slots 0, 1, odd chunks in 2, 3
       constexpr int pb1 = Q1 >= 3 ? 2 : 0, pb2 = Q2 >= 3 ? 2 : 0;
-      const bool first = grp == (Q & 1);  // first half of the task of phase m + 2, else second half of phase m + 1
-      const bool do1 = m + 1 >= 0 && m + 1 < NPH, do2 = m + 2 >= 0 && m + 2 < NPH;
-      const int pbA = tb0 + pb2 * g.HS, pbB = tb0 + g.PCH + pb1 * g.HS;
+      constexpr bool FIRST = GRP == (Q & 1);  // first half of the task of phase m + 2 (reads the pixel ring), else second half
+                                              // of the task of phase m + 1 (registers -> V slot)
+      (void)pb1;
+      const int pb = tb0 + pb2 * g.HS;
       auto slice = [&](int k) {
-        if (k == 0 && do1) {
+        if (k == 0) {
 #pragma unroll
           for (int e = 0; e < 6; ++e) dma_u(e, m + 1, us1);
         }
-        if (first) {
-          if (do2) half_task(std::integral_constant<int, Q2 % 3>{}, std::false_type{}, k, pbA, 0);
-        } else {
-          if (do1) half_task(std::integral_constant<int, Q1 % 3>{}, std::true_type{}, k, pbB, vs1);
-        }
+        if (FIRST) first_half(std::integral_constant<int, Q2 % 3>{}, k, pb);
+        else second_half(k, vs1);
       };
-      if (m >= 0) {
-        mfma_phase(std::integral_constant<int, Q % 3>{}, us, vs, slice);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          slice(k);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+      mfma_phase(std::integral_constant<int, Q % 3>{}, us, vs, slice);
       phase_end();
     };
     for (int m = -6; m < NPH; m += 6) {
+      if (m == 0) zero_accumulators();
       body(std::integral_constant<int, 0>{}, m);
       body(std::integral_constant<int, 1>{}, m + 1);
       body(std::integral_constant<int, 2>{}, m + 2);
@@ -623,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       }
       P[ring * g.HS + pw_of(k)] = y;
     };
-    auto body = [&](auto qc, int m, int c) {  // c = chunk of phase m (floor(m / 3); -2, -1 in the fill phases)
+    auto body = [&](auto qc, int c) {  // c = chunk of the phase (floor(m / 3); -2, -1 in the fill phases)
       constexpr int Q = decltype(qc)::value;
       constexpr int R = Q % 3;
       asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL));
@@ -631,53 +647,41 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       // ring slot of the half-tile written in this phase: even chunks 0 / 1, odd chunks 2 / 3 (a block starts on an even chunk)
       constexpr int ringB = Q == 0 ? 3 : 1;  // R == 0: half 1 of chunk c + 1
       constexpr int ringA = Q == 2 ? 0 : 2;  // R == 2: half 0 of chunk c + 2
-      const bool actB = R == 0 && c + 1 >= 0 && c + 1 < NCHs, actA = R == 2 && c + 2 < NCHs;
+      // (no range guards: a half-tile activated for a chunk outside the item is overwritten before anyone reads it)
       auto slice = [&](int k) {
         if (k == 0) {
           if (R == 0) load_stage(I0{}, c + 2, 0);
           if (R == 1) load_stage(I1{}, c + 2, 1);
         }
-        if (k >= 1) {
+        if (k >= 1 && R != 1) {
           // the set being activated was loaded before the NVM loads that may still be in flight (issued last phase / slice 0)
-          if (k == 1 && (actA || actB)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NVM) : "memory");
+          if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NVM) : "memory");
 #pragma unroll
           for (int kk = 2 * (k - 1); kk < 2 * k && kk < NRT; ++kk) {
-            if (actB) activate(I1{}, kk, ringB);
-            if (actA) activate(I0{}, kk, ringA);
+            if (R == 0) activate(I1{}, kk, ringB);
+            if (R == 2) activate(I0{}, kk, ringA);
           }
         }
       };
-      if (m >= 0) {
-        mfma_phase(std::integral_constant<int, Q % 3>{}, us, vs, slice);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          slice(k);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+      mfma_phase(std::integral_constant<int, Q % 3>{}, us, vs, slice);
       phase_end_keep_loads();
     };
     int c = -2;
     for (int m = -6; m < NPH; m += 6, c += 2) {
-      body(std::integral_constant<int, 0>{}, m, c);
-      body(std::integral_constant<int, 1>{}, m + 1, c);
-      body(std::integral_constant<int, 2>{}, m + 2, c);
-      body(std::integral_constant<int, 3>{}, m + 3, c + 1);
-      body(std::integral_constant<int, 4>{}, m + 4, c + 1);
-      body(std::integral_constant<int, 5>{}, m + 5, c + 1);
+      if (m == 0) zero_accumulators();
+      body(std::integral_constant<int, 0>{}, c);
+      body(std::integral_constant<int, 1>{}, c);
+      body(std::integral_constant<int, 2>{}, c);
+      body(std::integral_constant<int, 3>{}, c + 1);
+      body(std::integral_constant<int, 4>{}, c + 1);
+      body(std::integral_constant<int, 5>{}, c + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the repeats past the last chunk: nothing may land after the item
   };
 
   for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
-    zero_pinned_tiles();
-    {  // (a literal zero vector is materialised THROUGH a0..a15 by hipcc: an opaque zero keeps it in arch VGPRs)
-      float z;
-      asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-      acc8 = f32x16{z, z, z, z, z, z, z, z, z, z, z, z, z, z, z, z};
-    }
-    if (wave < 4) producer_item();
+    if (wave < 2) producer_item(I0{});
+    else if (wave < 4) producer_item(I1{});
     else pixel_item(n_cur);
 
     // ---- end of an item: Y = A^T M A through four exchange slabs [xi][cout block][lane] (the operand rings: every stage of
@@ -809,7 +813,7 @@ int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s) {
 #define W44H_K(A, N, U) {conv_wino44h_kernel<A, N, U, false>, conv_wino44h_kernel<A, N, U, true>}
   static const kern_t kerns[2][4][2] = {
       {W44H_K(false, 9, 0), W44H_K(false, 10, 0), W44H_K(false, 8, 4), W44H_K(false, 8, 1)},
-      {W44H_K(true, 9, 0), W44H_K(true, 10, 0), W44H_K(true, 8, 4), W44H_K(true, 8, 1)}};
+      {W44H_K(true, 9, 0), W44H_K(true, 10, 0), W44H_K(true, 8, 4), W44H_K(false, 8, 1) /* never selected: w44h_geom */}};
 #undef W44H_K
   static bool attr_done = false;
   if (!attr_done) {
