@@ -363,51 +363,83 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       const_cast<uint16_t *>(a.w_wino44h), 0, (int)((size_t)kX * a.Cout * g.Cin * 4), 0x00020000);
   const int ukt = (kt * g.NCH + ch_lo) * 3;  // U slot index of this workgroup's phase 0
 
+#ifdef W44H_PROBE  // timing experiment: cycle stamps of workgroup 0, waves 0 / 2 / 4, block of phases 12..17 -> desc.scratch
+  int probe_m = -100;
+#define W44H_STAMP(i)                                                                                                   \
+  if (blockIdx.x == 0 && (wave == 0 || wave == 2 || wave == 4) && probe_m >= 12 && probe_m < 18 && lane == 0 && a.scratch) \
+    reinterpret_cast<unsigned long long *>(a.scratch)[((wave >> 1) * 6 + (probe_m - 12)) * 8 + (i)] = __builtin_readcyclecounter();
+#else
+#define W44H_STAMP(i)
+#endif
   // One phase of MFMA work: 3 jobs (positions 3 pg + i of the phase) x 2 MFMAs; `slice(k)`, k = 0..5, is the role's staging
   // work pinned between them.  us / vs: ring slots (bytes) of the phase.
   auto mfma_phase = [&](auto tc, int us, int vs, auto &&slice) {
     constexpr int t = decltype(tc)::value;
     const int ua_s = ua + us, va_s = va + vs;
-    h8 A[2], Bh[2], Bl[2];
-    A[0] = lds_b128(ua_s, 0);
-    Bh[0] = lds_b128(va_s, 0);
-    Bl[0] = lds_b128(va_s, kT * 16);
-    A[1] = lds_b128(ua_s, 2 * kK * 16);
-    Bh[1] = lds_b128(va_s, 2 * kT * 16);
-    Bl[1] = lds_b128(va_s, 3 * kT * 16);
+    // all nine operand reads of the phase up front: with one job of read-ahead the LDS latency under load (250 .. 300
+    // cycles) WAS the job time (probe: 280 cycles per job of two 32-cycle MFMAs)
+    h8 A[3], Bh[3], Bl[3];
+    W44H_STAMP(0)
+#ifdef W44H_NO_MFMA
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      slice(k);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    (void)A; (void)Bh; (void)Bl; (void)ua_s; (void)va_s; (void)t;
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      A[i] = lds_b128(ua_s, 2 * i * kK * 16);
+      Bh[i] = lds_b128(va_s, 2 * i * kT * 16);
+      Bl[i] = lds_b128(va_s, (2 * i + 1) * kT * 16);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int x = 3 * t + i;  // accumulator tile
-      // job i's three reads are the oldest outstanding: at most the next job's three may stay in flight
-      if (x == 8) {  // (the last job of a phase: nothing else is outstanding)
-        mfma_v_pair_wait0(acc8, A[i & 1], Bh[i & 1], Bl[i & 1]);
+      // job i's three reads are the oldest outstanding: the later jobs' may stay in flight (plus whatever the slices issue)
+      if (x == 8) {  // (the last job of a phase)
+        mfma_v_pair_wait0(acc8, A[i], Bh[i], Bl[i]);
         slice(2 * i);
         __builtin_amdgcn_sched_barrier(0);
         slice(2 * i + 1);
         __builtin_amdgcn_sched_barrier(0);
+        W44H_STAMP(1 + i)
         continue;
       }
-      if (i < 2) mfma_pin_wait<3>(x, A[i & 1], Bh[i & 1]);
-      else mfma_pin_wait<0>(x, A[i & 1], Bh[i & 1]);
+      if (i == 0) mfma_pin_wait<6>(x, A[i], Bh[i]);
+      else if (i == 1) mfma_pin_wait<3>(x, A[i], Bh[i]);
+      else mfma_pin_wait<0>(x, A[i], Bh[i]);
       slice(2 * i);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_pin(x, A[i & 1], Bl[i & 1]);
-      if (i == 0) {  // job 2's operands into job 0's registers (the MFMAs that read them have issued)
-        A[0] = lds_b128(ua_s, 4 * kK * 16);
-        Bh[0] = lds_b128(va_s, 4 * kT * 16);
-        Bl[0] = lds_b128(va_s, 5 * kT * 16);
-      }
+      mfma_pin(x, A[i], Bl[i]);
       slice(2 * i + 1);
       __builtin_amdgcn_sched_barrier(0);
+      W44H_STAMP(1 + i)
     }
   };
-  auto phase_end = [&]() {
+  auto phase_end = [&]() {  // pixel waves: the U slot they fetched has landed (and with it their older pixel loads)
+#ifdef W44H_PROBE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    W44H_STAMP(4)
+    asm volatile("s_barrier" ::: "memory");
+    W44H_STAMP(5)
+#else
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto phase_end_keep_loads = [&]() {  // pixel waves: their global loads stay in flight across the barrier
+  auto phase_end_lds = [&]() {  // producers: no vector memory traffic
+#ifdef W44H_PROBE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W44H_STAMP(4)
+    asm volatile("s_barrier" ::: "memory");
+    W44H_STAMP(5)
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -442,15 +474,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     }
     int vw0 = kVB0 + st * 16 + 4 * j;  // V store: + slot + (2 pos + plane) 512
     const int ulane = lane * 16;
+    // The U slot of phase m + 1 (24 transfers of 1 KB; an LDS-DMA issue costs 100 .. 150 cycles) is fetched by the waves with
+    // slack: 16 transfers by the four pixel waves, 8 by the two producer waves that run the lighter FIRST half this phase
+    auto dma_u = [&](int e, int mm, int us) {
+      const int piece = 16 + (wave & 1) * 4 + e;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (__attribute__((address_space(3))) void *)(smb + us + piece * 1024), 16,
+                                               ulane, (ukt + mm) * kUSB + piece * 1024, 0, 0);
+    };
     // column-pass results of the task's two channels (carried from its first half to its second) and the row being read
     float cA[2][6], cB[2][6], drow[6];
 
-    // transfer e (0..5) of this wave's share of the U slot of phase mm (24 x 1 KB per slot, 6 per producer wave)
-    auto dma_u = [&](int e, int mm, int us) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rs_u, (__attribute__((address_space(3))) void *)(smb + us + (wave + 4 * e) * 1024), 16, ulane,
-          (ukt + mm) * kUSB + (wave + 4 * e) * 1024, 0, 0);
-    };
     // the transform of one channel of the patch: rows (0, 5), (1, 2) or (3, 4) of B^T d B (conv_wino44.hip's row pairs)
     //   rows (0, 5): A = d4 - 5 d2 + 4 d0,  B = d5 - 5 d3 + 4 d1
     //   rows (1, 2): p = d4 - 2 d2 - 2 d2,  q = d3 - 2 d1 - 2 d1,  A = p + q, B = p - q
@@ -510,26 +543,29 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       if (k == 5) cstep(tc, 1, 6, pb1);
     };
     float t0r[6], t1r[6];  // a transformed row of both channels (second half)
+    uint32_t hi6[6], lo6[6];
     auto second_half = [&](int k, int vs) {
       // ONE address register + immediates (left to itself hipcc materialises a VGPR address per store and spills them:
       // ring offset + position offset exceed the 16-bit offset field when folded into one constant)
       int vwa = vw0 + vs;
       asm volatile("" : "+v"(vwa));
-      auto store3 = [&](int o, int q0) {
+      // a row: six independent 4-instruction splits (ILP), then its twelve stores; the last slice of a phase has no LDS
+      // traffic, so that the closing lgkmcnt(0) finds the queue almost drained
+      auto split_row = [&]() {
 #pragma unroll
-        for (int q = q0; q < q0 + 3; ++q) {
-          uint32_t hi, lo;
-          split_pair(t0r[q], t1r[q], hi, lo);
-          asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(hi), "n"((2 * (o + q)) * (kT * 16)) : "memory");
-          asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(lo), "n"((2 * (o + q) + 1) * (kT * 16)) : "memory");
+        for (int q = 0; q < 6; ++q) split_pair(t0r[q], t1r[q], hi6[q], lo6[q]);
+      };
+      auto store_row = [&](int o) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(hi6[q]), "n"((2 * (o + q)) * (kT * 16)) : "memory");
+          asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(lo6[q]), "n"((2 * (o + q) + 1) * (kT * 16)) : "memory");
         }
       };
-      if (k == 0) { bt6(cA[0], t0r); bt6(cA[1], t1r); }
-      if (k == 1) store3(0, 0);
-      if (k == 2) store3(0, 3);
-      if (k == 3) { bt6(cB[0], t0r); bt6(cB[1], t1r); }
-      if (k == 4) store3(6, 0);
-      if (k == 5) store3(6, 3);
+      if (k == 0) { bt6(cA[0], t0r); bt6(cA[1], t1r); split_row(); }
+      if (k == 1) { store_row(0); bt6(cB[0], t0r); }
+      if (k == 2) { bt6(cB[1], t1r); split_row(); }
+      if (k == 3) store_row(6);
     };
     // Phases m = -6 .. NPH - 1 in blocks of six; Q = m mod 6 is a compile-time constant of each instance, and with it the
     // trio, the ring slots and whether this group runs a first or a second half: no run-time branch inside a phase.  There
@@ -538,26 +574,33 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     // the last phase's barrier opens), and the MFMAs of the six fill phases accumulate garbage that is zeroed afterwards.
     auto body = [&](auto qc, int m) {
       constexpr int Q = decltype(qc)::value;
+#ifdef W44H_PROBE
+      probe_m = m;
+#endif
       asm volatile("" : "+v"(tb0), "+v"(vw0));  // keep the per-lane bases out of LICM's reach (see conv_wino44.hip)
       constexpr int us = (Q & 1) * kUSB, vs = (Q & 1) * kVSB;                // ring slots of phase m
-      constexpr int us1 = ((Q + 1) & 1) * kUSB, vs1 = ((Q + 1) & 1) * kVSB;  // ... of phase m + 1
-      constexpr int Q1 = (Q + 1) % 6, Q2 = (Q + 2) % 6;
+      constexpr int us1 = ((Q + 1) & 1) * kUSB, vs1 = ((Q + 1) & 1) * kVSB;  // ring slots of phase m + 1
+      constexpr int Q2 = (Q + 2) % 6;
       // pixel half-tiles of the chunk a task belongs to: even chunks in ring slots 0, 1, odd chunks in 2, 3
-      constexpr int pb1 = Q1 >= 3 ? 2 : 0, pb2 = Q2 >= 3 ? 2 : 0;
+      constexpr int pb2 = Q2 >= 3 ? 2 : 0;
       constexpr bool FIRST = GRP == (Q & 1);  // first half of the task of phase m + 2 (reads the pixel ring), else second half
                                               // of the task of phase m + 1 (registers -> V slot)
-      (void)pb1;
       const int pb = tb0 + pb2 * g.HS;
       auto slice = [&](int k) {
-        if (k == 0) {
+#ifndef W44H_NO_DMA  // (timing experiments: -DW44H_NO_DMA / _NO_PROD / _NO_PIXEL / _NO_MFMA build wrong-result variants)
+        if (FIRST && k == 0) {
 #pragma unroll
-          for (int e = 0; e < 6; ++e) dma_u(e, m + 1, us1);
+          for (int e = 0; e < 4; ++e) dma_u(e, m + 1, us1);
         }
+#endif
+#ifndef W44H_NO_PROD
         if (FIRST) first_half(std::integral_constant<int, Q2 % 3>{}, k, pb);
         else second_half(k, vs1);
+#endif
       };
       mfma_phase(std::integral_constant<int, Q % 3>{}, us, vs, slice);
-      phase_end();
+      if (FIRST) phase_end();
+      else phase_end_lds();
     };
     for (int m = -6; m < NPH; m += 6) {
       if (m == 0) zero_accumulators();
@@ -605,6 +648,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     int vzero;  // keeps the wave-uniform scale / shift loads on the vector memory path (in-order vmcnt with the pixel loads)
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     float praw[2][NRT], gs[2][NGS], gh[2][NGS];
+    const int ulane = lane * 16;
+    // transfer e (0..3) of this wave's share of the U slot of phase mm (see the producers' dma_u)
+    auto dma_u = [&](int e, int mm, int us) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_u, (__attribute__((address_space(3))) void *)(smb + us + (sc + 4 * e) * 1024), 16, ulane,
+          (ukt + mm) * kUSB + (sc + 4 * e) * 1024, 0, 0);
+    };
 
     auto load_stage = [&](auto setc, int c, int half) {
       constexpr int S = decltype(setc)::value;
@@ -641,7 +691,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     };
     auto body = [&](auto qc, int c) {  // c = chunk of the phase (floor(m / 3); -2, -1 in the fill phases)
       constexpr int Q = decltype(qc)::value;
+      const int m = 3 * c + Q % 3;
+#ifdef W44H_PROBE
+      probe_m = m;
+#endif
       constexpr int R = Q % 3;
+      constexpr int us1 = ((Q + 1) & 1) * kUSB;  // U slot of phase m + 1
       asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL));
       constexpr int us = (Q & 1) * kUSB, vs = (Q & 1) * kVSB;
       // ring slot of the half-tile written in this phase: even chunks 0 / 1, odd chunks 2 / 3 (a block starts on an even chunk)
@@ -649,13 +704,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       constexpr int ringA = Q == 2 ? 0 : 2;  // R == 2: half 0 of chunk c + 2
       // (no range guards: a half-tile activated for a chunk outside the item is overwritten before anyone reads it)
       auto slice = [&](int k) {
-        if (k == 0) {
+        if (k == 0) {  // pixel loads first, then the U slot of the next phase (waited for at the end of this phase)
+#ifndef W44H_NO_PIXEL
           if (R == 0) load_stage(I0{}, c + 2, 0);
           if (R == 1) load_stage(I1{}, c + 2, 1);
+#endif
+#ifndef W44H_NO_DMA
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dma_u(e, m + 1, us1);
+#endif
         }
+#ifdef W44H_NO_PIXEL
+        return;
+#endif
         if (k >= 1 && R != 1) {
-          // the set being activated was loaded before the NVM loads that may still be in flight (issued last phase / slice 0)
-          if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NVM) : "memory");
+          // the set being activated landed with an earlier phase's closing vmcnt(0); in flight now: this phase's loads + DMA
+          if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R == 0 ? NVM : 0) + 4) : "memory");
 #pragma unroll
           for (int kk = 2 * (k - 1); kk < 2 * k && kk < NRT; ++kk) {
             if (R == 0) activate(I1{}, kk, ringB);
@@ -664,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
         }
       };
       mfma_phase(std::integral_constant<int, Q % 3>{}, us, vs, slice);
-      phase_end_keep_loads();
+      phase_end();
     };
     int c = -2;
     for (int m = -6; m < NPH; m += 6, c += 2) {
