@@ -64,9 +64,10 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f3
 HBM_PEAK_GBPS = 8000.0
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA (same guide)
 ARITHMETIC = ("fp32 storage, fp32 accumulation and fp32 transforms / reductions everywhere; the MFMA products of the "
-              "1x1 convolutions and attention are split-f16: each fp32 product is rebuilt from "
-              "three v_mfma_f32_32x32x16_f16 (hi x hi + hi x lo + lo x hi, fp32 accumulate) = 22 mantissa bits per product "
-              "(DDPM_*_F16X3=0 restores bit-exact fp32 MFMA products); all other kernels plain fp32")
+              "Winograd F(4x4) 3x3 convolutions at 32x32 / 16x16 (hi/lo operands, all four exact f16 partial products), of the 1x1 "
+              "convolutions and of attention (three of the four partial products: 22 mantissa bits per product) are split-f16 on "
+              "v_mfma_f32_32x32x16_f16 with fp32 accumulate; DDPM_WINO44_F16X3=0 / DDPM_CONV1X1_F16X3=0 / DDPM_ATTN_F16X3=0 restore "
+              "bit-exact fp32 MFMA products; all other kernels plain fp32")
 SCHED = dict(beta_schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195)
 
 VQ_README = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(256, 256, 256, 256), num_res_layers=3,
@@ -166,6 +167,11 @@ def cpu_baseline():
 # MFMA kernel classes by profiler-key prefix -> (description, executed / algorithmic MFMA FLOPs).
 # Longest prefix wins.  The library counts `flops` as the ALGORITHMIC (direct-form) work of the op.
 MFMA_KERNELS = [
+    # split-f16 F(4x4): 36 of 144 multiplies, each as FOUR exact f16 partial products (two K = 16 MFMAs per 8 channels) ->
+    # executed f16 MFMA FLOPs = 4 x 36 / 144 = 1.0 x the direct convolution's, priced against the dense f16 peak
+    ("conv3x3_wino44h", "conv_wino44h_kernel: 3x3 conv as Winograd F(4x4,3x3), position GEMMs on v_mfma_f32_32x32x16_f16 with "
+                        "split-f16 operands (hi + lo, four exact partial products per fp32 product, fp32 accumulate), fp32 transforms, "
+                        "GN+SiLU prologue, persistent", ("f16", 4.0 * 36.0 / 144.0)),
     ("conv3x3_wino44", "conv_wino44_kernel: 3x3 conv as Winograd F(4x4,3x3) (36 of 144 multiplies), persistent, GN+SiLU prologue, fp32 MFMA", 36.0 / 144.0),
     ("conv3x3_wino_up", "conv_wino_up_kernel: nearest-x2 + 3x3 conv in the Winograd domain (9 of 16 positions), fp32 MFMA", 9.0 / 36.0),
     ("conv3x3_wino", "conv_wino_kernel: 3x3 conv as Winograd F(2x2,3x3), persistent, GN+SiLU prologue, fp32 MFMA", 16.0 / 36.0),
@@ -181,7 +187,7 @@ MFMA_KERNELS = [
     ("lpips_conv_mfma", "lpips_conv_mfma_kernel: AlexNet 5x5 layer of the 2.5-D LPIPS as an implicit GEMM, fp32 MFMA", 1.0),
     # split-f16: executed MFMA work = 3 f16 MFMAs per fp32 product, priced against the dense f16 peak
     ("attention", "attention_kernel: QK^T, online softmax, AV (+ residual); fp32 products from three f16 MFMAs "
-                  "(hi / lo split, fp32 accumulate)", "f16x3"),
+                  "(hi / lo split, fp32 accumulate)", ("f16", 3.0)),
 ]
 
 
@@ -218,11 +224,11 @@ def rooflines_of(prof, batch=None):
                  "launches_timed": a["launches"], "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                  "ms_in_sample": round(a["ms"], 3), "bytes_per_launch": a["bytes"] / a["launches"],
                  "traffic": None}
-        elif a["ratio"] == "f16x3":
-            ex = 3.0 * alg
+        elif isinstance(a["ratio"], tuple):  # ("f16", executed f16 MFMA FLOPs / algorithmic FLOPs)
+            ex = a["ratio"][1] * alg
             r = {"bound": "mfma", "kernel": a["label"], "profile_key": prefix, "achieved": round(ex, 2),
                  "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ex / F16_MFMA_PEAK_TFLOPS, 4),
-                 "executed_over_algorithmic_flops": 3.0, "algorithmic_equiv_tflops": round(alg, 2),
+                 "executed_over_algorithmic_flops": a["ratio"][1], "algorithmic_equiv_tflops": round(alg, 2),
                  "algorithmic_over_f32_mfma_peak": round(alg / F32_MFMA_PEAK_TFLOPS, 4),
                  "launches_timed": a["launches"], "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                  "ms_in_sample": round(a["ms"], 3), "flops_per_launch": a["flops"] / a["launches"],

@@ -272,9 +272,6 @@ static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false)
   } else if (!((g.UI == 4 && rows * d.Wi == 256 && g.TI == 2) || (g.UI == 1 && rows * d.Wi == 64 && g.TI == 8))) {
     return false;
   }
-  // eight 8x8 images per item WITH the GroupNorm prologue: a pixel wave would hold 2 x 8 scale / shift pairs (32 registers)
-  // and hipcc parks a value in a0, a pinned accumulator (tools/check_acc_spills.py) -- those launches stay on conv_wino44.hip
-  if (g.TI == 8 && d.gscale) return false;
   g.KT = d.Cout / kK;
   g.NIT = (g.NIMG + g.TI - 1) / g.TI;
   const long items = (long)g.KT * g.parts * g.NIT;
@@ -325,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
   constexpr bool ONEIMG = UIT == 0;
   constexpr int NGS = ONEIMG ? 1 : NRT / UIT;        // images per item = GroupNorm scale / shift pairs per half-chunk
   constexpr int GD = ONEIMG ? NRT : UIT;             // consecutive rounds that belong to one image
-  constexpr int NVM = NRT + (AFFINE ? 2 * NGS : 0);  // vector-memory loads of one pixel stage
+  constexpr int NVM = NRT;                           // vector-memory loads of one pixel stage
   float *const P = smem + kRINGF;                    // pixel ring: 4 half-tiles of [4 channels][PCH] + 1 + 64 dump floats
   char *const smb = reinterpret_cast<char *>(smem);
 
@@ -647,7 +644,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gshift), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
     int vzero;  // keeps the wave-uniform scale / shift loads on the vector memory path (in-order vmcnt with the pixel loads)
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-    float praw[2][NRT], gs[2][NGS], gh[2][NGS];
+    // ONE set of GroupNorm scale / shift pairs (eight images per item would otherwise hold 32 registers and push a value into a
+    // pinned AGPR): fetched in the phase before the activation that uses them, after the previous user has finished
+    float praw[2][NRT], gs[NGS], gh[NGS];
     const int ulane = lane * 16;
     // transfer e (0..3) of this wave's share of the U slot of phase mm (see the producers' dma_u)
     auto dma_u = [&](int e, int mm, int us) {
@@ -668,11 +667,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       for (int k = 0; k < NRT; ++k) {
         const int ni = min(n_cur + (ONEIMG ? 0 : k / GD), g.NIMG - 1);
         praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pix_of(k), (ni * cx + cgl) * g.HW * 4, 0));
-        if (AFFINE && k % GD == 0) {
-          const int goff = (ni * g.Cin + cg) * 4;
-          gs[S][k / GD] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
-          gh[S][k / GD] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
-        }
+      }
+    };
+    auto load_affine = [&](int c, int half) {
+      if (!AFFINE) return;
+      const int cl = min(max(c, 0), NCHs - 1);
+      const int cg = (ch_lo + cl) * kC + half * 4 + sc;
+#pragma unroll
+      for (int i = 0; i < NGS; ++i) {
+        const int ni = min(n_cur + i, g.NIMG - 1);
+        const int goff = (ni * g.Cin + cg) * 4;
+        gs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
+        gh[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
       }
     };
     auto activate = [&](auto setc, int k, int ring) {  // pixel value x 2^3: the transform's output is the pre-scaled V
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       const float x = praw[S][k];
       float y;
       if (AFFINE) {
-        const float sa = gs[S][k / GD], sb = gh[S][k / GD];
+        const float sa = gs[k / GD], sb = gh[k / GD];
         const float v = __builtin_fmaf(x, sa, sb);
         const float t = __builtin_fmaf(x, -1.44269504088896341f * sa, -1.44269504088896341f * sb);
         y = (kVScale * v) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
@@ -707,7 +713,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
         if (k == 0) {  // pixel loads first, then the U slot of the next phase (waited for at the end of this phase)
 #ifndef W44H_NO_PIXEL
           if (R == 0) load_stage(I0{}, c + 2, 0);
-          if (R == 1) load_stage(I1{}, c + 2, 1);
+          if (R == 1) { load_stage(I1{}, c + 2, 1); load_affine(c + 2, 0); }  // scale / shift of the half activated next phase
 #endif
 #ifndef W44H_NO_DMA
 #pragma unroll
@@ -725,6 +731,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
             if (R == 0) activate(I1{}, kk, ringB);
             if (R == 2) activate(I0{}, kk, ringA);
           }
+          if (R == 2 && k == 5) load_affine(c + 2, 1);  // for the next phase's activation (half 1 of the same chunk)
         }
       };
       mfma_phase(std::integral_constant<int, Q % 3>{}, us, vs, slice);
@@ -877,7 +884,7 @@ int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s) {
 #define W44H_K(A, N, U) {conv_wino44h_kernel<A, N, U, false>, conv_wino44h_kernel<A, N, U, true>}
   static const kern_t kerns[2][4][2] = {
       {W44H_K(false, 9, 0), W44H_K(false, 10, 0), W44H_K(false, 8, 4), W44H_K(false, 8, 1)},
-      {W44H_K(true, 9, 0), W44H_K(true, 10, 0), W44H_K(true, 8, 4), W44H_K(false, 8, 1) /* never selected: w44h_geom */}};
+      {W44H_K(true, 9, 0), W44H_K(true, 10, 0), W44H_K(true, 8, 4), W44H_K(true, 8, 1)}};
 #undef W44H_K
   static bool attr_done = false;
   if (!attr_done) {

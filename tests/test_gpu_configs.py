@@ -101,9 +101,12 @@ def test_golden_trajectory_rows_and_ood_scores_vs_hip(device, tmp_path):
         g = gold[gold["type"] == name].reset_index(drop=True)
         assert_rows_close(rows[name], g, 2e-4, name)
     dh, _, auc = oracle.z_scores_and_auroc(rows["val"], rows["in"], rows["out"])
-    assert np.abs(dh["z_score_mse"].to_numpy() - np.asarray(spec["z_score_mse"])).max() < 1e-4
+    # (four validation images: |Z| is inflated by the sample standard deviation -- per element relative to max(1, |Z|),
+    # see parity_util.assert_z_close)
+    zm = np.asarray(spec["z_score_mse"])
+    assert (np.abs(dh["z_score_mse"].to_numpy() - zm) / np.maximum(1.0, np.abs(zm))).max() < 1e-4
     zp = np.asarray(spec["z_score_perceptual_difference"])
-    assert np.abs(dh["z_score_perceptual_difference"].to_numpy() - zp).max() < 1e-4
+    assert (np.abs(dh["z_score_perceptual_difference"].to_numpy() - zp) / np.maximum(1.0, np.abs(zp))).max() < 1e-4
     assert abs(auc - spec["auroc_mse"]) <= 1e-3
 
 

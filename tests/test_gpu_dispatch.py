@@ -23,8 +23,7 @@ from parity_util import assert_rows_close, assert_z_close, hip_scores, make_args
 pytestmark = pytest.mark.gpu
 
 # the kernel classes of a chip-filling `small` forward (profiler keys, csrc/*.hip ProfScope names)
-BENCH_KEYS = ("conv3x3_wino44_gn_silu", "conv3x3_wino_up", "conv1x1_dma", "conv1x1_dma_gn", "attention",
-              "gn_scale_shift")
+BENCH_KEYS = ("conv3x3_wino44h_gn_silu", "conv3x3_wino_up", "conv1x1_dma", "conv1x1_dma_gn", "attention", "gn_scale_shift")
 
 
 def _profiled(fn):
@@ -85,8 +84,9 @@ def test_small_forward_at_benchmarked_batch_vs_oracle(device, B):
     assert scale > 0.05
     missing = [k for k in BENCH_KEYS if k not in prof]
     assert not missing, (missing, sorted(prof))
-    # every 32x32 / 16x16 / 8x8 ResnetBlock convolution went through the F(4x4) kernel: 22 launches per forward
-    assert prof["conv3x3_wino44_gn_silu"]["launches"] == 22, prof["conv3x3_wino44_gn_silu"]
+    # every 32x32 / 16x16 / 8x8 ResnetBlock convolution went through the split-f16 F(4x4) kernel: 22 launches per forward
+    assert prof["conv3x3_wino44h_gn_silu"]["launches"] == 22, prof["conv3x3_wino44h_gn_silu"]
+    assert "conv3x3_wino44_gn_silu" not in prof, sorted(prof)
     assert "conv3x3_wino_gn_silu" not in prof and "conv3x3_mfma_gn_silu" not in prof, sorted(prof)
 
 
@@ -148,7 +148,7 @@ def test_trained_weights_forward_and_trajectory_vs_oracle(device, tmp_path):
     err, scale = (yh - yr).abs().max().item(), yr.abs().max().item()
     print(f"trained weights, B = 256: max |eps_hip - eps_oracle| = {err:.3e} (max |eps| = {scale:.3f})")
     assert math.isfinite(err) and err <= 2e-5 * (1 + scale), err
-    assert scale > 0.05 and "conv3x3_wino44_gn_silu" in prof
+    assert scale > 0.05 and "conv3x3_wino44h_gn_silu" in prof
     del hip
 
     sets = {"val": "synthetic:blobs:n=16:seed=10", "in": "synthetic:blobs:n=16:seed=11",

@@ -222,7 +222,8 @@ def test_trajectory_scores_match_oracle(device, tmp_path):
     dh, _, auc_h = oracle.z_scores_and_auroc(rows_h["val"], rows_h["in"], rows_h["out"])
     do, _, auc_o = oracle.z_scores_and_auroc(rows_o["val"], rows_o["in"], rows_o["out"])
     for col in ("z_score_mse", "z_score_perceptual_difference"):
-        assert (dh[col] - do[col]).abs().max() < 1e-4, col
+        # (a handful of validation images: per element relative to max(1, |Z|), see parity_util.assert_z_close)
+        assert ((dh[col] - do[col]).abs() / do[col].abs().clip(lower=1.0)).max() < 1e-4, col
     assert abs(auc_h - auc_o) <= 1e-3
 
 

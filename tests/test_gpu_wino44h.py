@@ -35,12 +35,13 @@ CASES = [
     (3, 128, 0, 128, 32, True, True, True),
     (2, 256, 128, 128, 32, True, True, False),    # virtual concat: 48 chunks
     (5, 256, 0, 256, 16, True, False, True),      # two images per item, ragged last item
-    (19, 128, 128, 64, 8, False, True, True),     # eight images per item, ragged (with GroupNorm: conv_wino44.hip)
+    (19, 128, 128, 64, 8, True, True, True),      # eight images per item, ragged
     (1, 64, 0, 64, 64, True, False, False),       # W = 64: two tile rows per item, 8 parts
     (300, 128, 0, 128, 16, True, True, True),     # 2 x 150 items: several items per persistent workgroup
     (70, 64, 64, 128, 32, True, True, True),      # 2 x 2 x 70 = 280 items, concat boundary inside a chunk's halves
     (3, 16, 0, 64, 32, False, False, False),      # the smallest stream: two chunks
     (2, 128, 0, 128, 32, False, True, True),      # no prologue (act = none)
+    (9, 64, 0, 64, 8, False, False, True),        # eight images per item without prologue
 ]
 
 
@@ -139,7 +140,7 @@ def test_conv_wino44h_error_budget_vs_float64(device, scale_x, scale_w, monkeypa
 
 SPLIT_CASES = [
     # B, C1, C2, Cout, H, gn, chan, res: fewer items than CUs -> S workgroups share an item's channel stream
-    (256, 256, 0, 256, 8, False, True, True),   # 4 x 32 = 128 items, S = 2
+    (256, 256, 0, 256, 8, True, True, True),    # 4 x 32 = 128 items, S = 2
     (16, 128, 256, 128, 32, True, True, False),  # 2 x 4 x 16 = 128 items, 48 chunks, S = 2
 ]
 
