@@ -72,6 +72,7 @@ SIGNATURES = {
     "ddpm_wino44_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_wino44_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_pack_wino3d_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_convnd_generic_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 12 + [C.c_void_p]),
     "ddpm_wino44h_weight_halves": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_wino44h_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_pack_wino44_weight3d_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -155,6 +155,13 @@ extern "C" int ddpm_pack_wino44_weight_f32(const float *w_raw, float *w_wino44, 
   return launch_pack_wino44_weight(w_raw, w_wino44, Cout, Cin, as_stream(stream));
 }
 
+extern "C" int ddpm_convnd_generic_f32(const float *in, const float *w, const float *bias, const float *residual, float *out,
+                                       int B, int Cin, int Cout, int Di, int Hi, int Wi, int dims, int ksize, int stride,
+                                       int pad, int transposed, int relu, ddpm_stream_t stream) {
+  return launch_convnd_generic(in, w, bias, residual, out, B, Cin, Cout, Di, Hi, Wi, dims, ksize, stride, pad, transposed, relu,
+                               as_stream(stream));
+}
+
 extern "C" size_t ddpm_wino44h_weight_halves(int Cout, int Cin) { return wino44h_weight_halves(Cout, Cin); }
 
 extern "C" int ddpm_pack_wino44h_weight(const float *w_raw, uint16_t *w_wino44h, int Cout, int Cin, ddpm_stream_t stream) {

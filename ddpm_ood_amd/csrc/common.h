@@ -140,6 +140,9 @@ int launch_conv3d_k4s2_cin1(const float *in, const float *w, const float *bias, 
                             int H, int W, int relu, hipStream_t s);
 int launch_convT3d_k4s2_cout1(const float *in, const float *w, const float *bias, float *out, int B, int Cin, int D,
                               int H, int W, hipStream_t s);
+int launch_convnd_generic(const float *in, const float *w, const float *bias, const float *residual, float *out, int B, int Cin,
+                          int Cout, int Di, int Hi, int Wi, int dims, int k, int stride, int pad, int transposed, int relu,
+                          hipStream_t s);
 int launch_gn_scale_shift(const float *in1, const float *in2, int C1, int C2, const float *gamma, const float *beta,
                           float *scale, float *shift, int B, int HW, int groups, float eps, hipStream_t s);
 int launch_attention(const float *qkv, const float *residual, float *out, int B, int C, int N, int heads, float scale,

@@ -125,4 +125,84 @@ int launch_convT3d_k4s2_cout1(const float *in, const float *w, const float *bias
   return 0;
 }
 
+// ---- generic (transposed) convolution, 2-D or 3-D, any channel counts: the VQ-VAE layers that have no MFMA tiling (channel
+// counts that are not multiples of 4 / 128).  One thread per output element, taps and input channels in a fixed order, fp32
+// fmaf chain -- the slow, always-available form behind the MFMA kernels (the product never leaves the HIP library: there is no
+// PyTorch-ROCm / MIOpen route).  Reference ops: Conv3d / ConvTranspose3d inside generative's VQVAE,
+// /root/reference/src/trainers/reconstruct.py:124,166.
+__global__ __launch_bounds__(256) void convnd_generic_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                             const float *__restrict__ bias,
+                                                             const float *__restrict__ residual, float *__restrict__ out,
+                                                             int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho,
+                                                             int Wo, int kd, int k, int stride, int pad, int padd,
+                                                             int transposed, int relu) {
+  const long long total = (long long)B * Cout * Do * Ho * Wo;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho), z = (int)((i / ((long long)Wo * Ho)) % Do);
+    const int co = (int)((i / ((long long)Wo * Ho * Do)) % Cout), n = (int)(i / ((long long)Wo * Ho * Do * Cout));
+    float acc = bias ? bias[co] : 0.f;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float *src = in + ((size_t)n * Cin + ci) * Di * Hi * Wi;
+      // torch layouts: Conv [Cout, Cin, kd, k, k]; ConvTranspose [Cin, Cout, kd, k, k]
+      const float *wt = w + (transposed ? ((size_t)ci * Cout + co) : ((size_t)co * Cin + ci)) * kd * k * k;
+      for (int a = 0; a < kd; ++a) {
+        int iz;
+        if (!transposed) {
+          iz = z * (kd == 1 ? 1 : stride) - padd + a;
+        } else {  // out[z] receives in[iz] w[a] with z = iz * stride - pad + a
+          const int tz = z + padd - a;
+          if (kd > 1 && (tz < 0 || tz % stride)) continue;
+          iz = kd == 1 ? z : tz / stride;
+        }
+        if (iz < 0 || iz >= Di) continue;
+        for (int b = 0; b < k; ++b) {
+          int iy;
+          if (!transposed) {
+            iy = y * stride - pad + b;
+          } else {
+            const int ty = y + pad - b;
+            if (ty < 0 || ty % stride) continue;
+            iy = ty / stride;
+          }
+          if (iy < 0 || iy >= Hi) continue;
+          for (int c = 0; c < k; ++c) {
+            int ix;
+            if (!transposed) {
+              ix = x * stride - pad + c;
+            } else {
+              const int tx = x + pad - c;
+              if (tx < 0 || tx % stride) continue;
+              ix = tx / stride;
+            }
+            if (ix < 0 || ix >= Wi) continue;
+            acc = __builtin_fmaf(src[((size_t)iz * Hi + iy) * Wi + ix], wt[(a * k + b) * k + c], acc);
+          }
+        }
+      }
+    }
+    if (residual) acc += residual[i];
+    out[i] = relu ? fmaxf(acc, 0.f) : acc;
+  }
+}
+
+int launch_convnd_generic(const float *in, const float *w, const float *bias, const float *residual, float *out, int B, int Cin,
+                          int Cout, int Di, int Hi, int Wi, int dims, int k, int stride, int pad, int transposed, int relu,
+                          hipStream_t s) {
+  DDPM_CHECK_ARG(in && w && out && B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0, "convnd_generic: null tensor or empty shape");
+  DDPM_CHECK_ARG((dims == 2 || dims == 3) && k >= 1 && k <= 7 && (stride == 1 || stride == 2) && pad >= 0 && pad < k,
+                 "convnd_generic: dims 2 / 3, kernel 1 .. 7, stride 1 / 2");
+  DDPM_CHECK_ARG(dims == 3 || Di == 1, "convnd_generic: a 2-D convolution has depth 1");
+  const int kd = dims == 3 ? k : 1, padd = dims == 3 ? pad : 0;
+  auto ext = [&](int e, int kk, int pp) { return transposed ? (e - 1) * stride - 2 * pp + kk : (e + 2 * pp - kk) / stride + 1; };
+  const int Do = dims == 3 ? ext(Di, k, pad) : 1, Ho = ext(Hi, k, pad), Wo = ext(Wi, k, pad);
+  DDPM_CHECK_ARG(Do > 0 && Ho > 0 && Wo > 0, "convnd_generic: empty output");
+  const long long total = (long long)B * Cout * Do * Ho * Wo;
+  const int blocks = (int)((total + 255) / 256 > 65535 * 16 ? 65535 * 16 : (total + 255) / 256);
+  ProfScope prof(s, "convnd_generic", 2.0 * total * Cin * kd * k * k, 4.0 * ((double)B * Cin * Di * Hi * Wi + total));
+  hipLaunchKernelGGL(convnd_generic_kernel, dim3(blocks), dim3(256), 0, s, in, w, bias, residual, out, B, Cin, Cout, Di, Hi, Wi,
+                     Do, Ho, Wo, kd, k, stride, pad, padd, transposed, relu);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
 }  // namespace ddpm

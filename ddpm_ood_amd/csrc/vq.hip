@@ -63,6 +63,37 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float *__restrict
   }
 }
 
+// any embedding_dim (the built sizes above keep z in registers; this one re-reads it, cached, per code): same arithmetic order
+__global__ __launch_bounds__(256) void vq_nearest_generic_kernel(const float *__restrict__ x, const float *__restrict__ e,
+                                                                 const float *__restrict__ e2, int *__restrict__ idx,
+                                                                 float *__restrict__ out, int D, int S, int K, long npos) {
+  const long pos = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pos >= npos) return;
+  const long b = pos / S, p = pos - b * S;
+  const float *xp = x + (size_t)b * D * S + p;
+  float z2 = 0.f;
+  for (int d = 0; d < D; ++d) z2 += xp[(size_t)d * S] * xp[(size_t)d * S];
+  float best = INFINITY;
+  int besti = 0;
+  for (int k = 0; k < K; ++k) {
+    const float *ek = e + (size_t)k * D;
+    float dot = 0.f;
+    for (int d = 0; d < D; ++d) dot = fmaf(xp[(size_t)d * S], ek[d], dot);
+    const float dist = (z2 + e2[k]) - 2.f * dot;
+    if (dist < best) {
+      best = dist;
+      besti = k;
+    }
+  }
+  idx[pos] = besti;
+  const float *ek = e + (size_t)besti * D;
+  float *op = out + (size_t)b * D * S + p;
+  for (int d = 0; d < D; ++d) {
+    const float zd = xp[(size_t)d * S];
+    op[(size_t)d * S] = zd + (ek[d] - zd);
+  }
+}
+
 __global__ void vq_code_norms_kernel(const float *__restrict__ e, float *__restrict__ e2, int K, int D) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
@@ -75,8 +106,7 @@ int launch_vq_nearest(const float *x, const float *codebook, float *code_norms, 
                       int K, hipStream_t s) {
   DDPM_CHECK_ARG(x && codebook && code_norms && idx && out, "vq_nearest: null pointer");
   DDPM_CHECK_ARG(B > 0 && S > 0 && K > 0, "vq_nearest: empty shape");
-  DDPM_CHECK_ARG(D == 8 || D == 16 || D == 32 || D == 64 || D == 128, "vq_nearest: embedding_dim %d is not built "
-                 "(8, 16, 32, 64, 128)", D);
+  DDPM_CHECK_ARG(D > 0, "vq_nearest: embedding_dim %d", D);
   DDPM_CHECK_ARG(S < (1L << 31), "vq_nearest: too many positions per image");
   const long npos = (long)B * S;
   hipLaunchKernelGGL(vq_code_norms_kernel, dim3((K + 255) / 256), dim3(256), 0, s, codebook, code_norms, K, D);
@@ -92,6 +122,10 @@ int launch_vq_nearest(const float *x, const float *codebook, float *code_norms, 
     DDPM_VQ_CASE(32)
     DDPM_VQ_CASE(64)
     DDPM_VQ_CASE(128)
+    default:  // other embedding sizes: the generic kernel (x and out must not alias)
+      hipLaunchKernelGGL(vq_nearest_generic_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, s, x, codebook, code_norms,
+                         idx, out, D, (int)S, K, npos);
+      break;
   }
 #undef DDPM_VQ_CASE
   DDPM_CHECK_LAUNCH();

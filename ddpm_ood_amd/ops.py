@@ -304,6 +304,33 @@ def conv_transpose(x, weight, bias=None, *, out_act=ACT_NONE, packed=None):
     return out
 
 
+def convnd_generic(x, weight, bias=None, *, stride=1, padding=1, transposed=False, residual=None, relu=False):
+    """Generic (transposed) conv2d / conv3d on the HIP library for shapes without an MFMA tiling (any channel counts):
+    x [B, Cin, (D,) H, W], torch weight layout, symmetric kernel / stride / padding, output_padding 0."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    w = require_device_f32(weight, "weight")
+    dims = x.ndim - 2
+    if dims not in (2, 3) or w.ndim != x.ndim or len(set(w.shape[2:])) != 1:
+        raise ValueError("convnd_generic: needs x [B, C, (D,) H, W] and a cubic / square kernel")
+    k = w.shape[2]
+    cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    if x.shape[1] != cin:
+        raise ValueError(f"convnd_generic: input has {x.shape[1]} channels, weight expects {cin}")
+    ext = (lambda e: (e - 1) * stride - 2 * padding + k) if transposed else (lambda e: (e + 2 * padding - k) // stride + 1)
+    out = torch.empty((x.shape[0], cout) + tuple(ext(e) for e in x.shape[2:]), dtype=torch.float32, device=x.device)
+    if bias is not None:
+        bias = require_device_f32(bias, "bias")
+    if residual is not None:
+        residual = require_device_f32(residual, "residual")
+        if residual.shape != out.shape:
+            raise ValueError("convnd_generic: residual shape")
+    D, H, W = (1,) * (3 - dims) + tuple(x.shape[2:])
+    check(lib.ddpm_convnd_generic_f32(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out), x.shape[0], cin, cout, D, H, W, dims, k,
+                                      stride, padding, int(transposed), int(relu), stream_ptr()), "convnd_generic")
+    return out
+
+
 def conv3d_k4s2_cin1(x, weight, bias=None, relu: bool = False):
     """First VQ-VAE encoder layer: relu?(F.conv3d(x[B, 1, D, H, W], weight[Cout, 1, 4, 4, 4], bias, stride 2, pad 1))."""
     lib = _lib.load()

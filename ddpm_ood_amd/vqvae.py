@@ -47,12 +47,19 @@ class PassthroughVQVAE(torch.nn.Module):
 _FALLBACK_WARNED = set()
 
 
-def _warn_fallback(what: str) -> None:
+def _note_generic(what: str) -> None:
+    """One line per layer shape that has no MFMA tiling and takes the generic HIP kernel (slow, same library)."""
     if what not in _FALLBACK_WARNED:
         _FALLBACK_WARNED.add(what)
         import sys
 
-        print(f"WARNING: VQ-VAE layer {what} has no HIP tiling; it runs on PyTorch-ROCm ops", file=sys.stderr, flush=True)
+        print(f"NOTE: VQ-VAE layer {what} has no MFMA tiling; it runs on the generic HIP convolution (ddpm_convnd_generic_f32)",
+              file=sys.stderr, flush=True)
+
+
+def _require_device(x):
+    if not x.is_cuda:
+        raise RuntimeError("VQVAE: the HIP path has no CPU fallback (the CPU oracle under oracle/ is test infrastructure only)")
 
 
 class _Convolution(nn.Module):
@@ -113,13 +120,17 @@ class _Convolution(nn.Module):
             return ops.conv_transpose(x, w.detach(), b.detach(), packed=self._packed[1], out_act=out_act)
         if kind == "conv_cin1":
             return ops.conv3d_k4s2_cin1(x.float().contiguous(), w.detach(), b.detach(), relu=not self.conv_only)
-        if kind == "convT_cout1":
-            y = ops.convT3d_k4s2_cout1(x.float().contiguous(), w.detach(), b.detach())
-            return y if self.conv_only else F.relu(y)
-        if x.is_cuda:
-            _warn_fallback(f"{type(self.conv).__name__}{tuple(w.shape)}")
-        x = self.conv(x)
-        return x if self.conv_only else F.relu(x)
+        if kind == "convT_cout1" and self.conv_only:
+            return ops.convT3d_k4s2_cout1(x.float().contiguous(), w.detach(), b.detach())
+        # no MFMA tiling (channel counts, 2-D, other kernel / stride): the generic kernel of the same library -- never PyTorch
+        _require_device(x)
+        sd, k, s, dil, pad, opad = self.geom
+        if dil != 1 or opad != 0 or s not in (1, 2):
+            raise NotImplementedError(f"VQVAE: {type(self.conv).__name__} with dilation {dil} / output_padding {opad} / "
+                                      f"stride {s} is not built (no BASELINE configuration uses it)")
+        _note_generic(f"{type(self.conv).__name__}{tuple(w.shape)}")
+        return ops.convnd_generic(x.float().contiguous(), w.detach(), b.detach() if b is not None else None, stride=s,
+                                  padding=pad, transposed=self.is_transposed, relu=not self.conv_only)
 
 
 class _ResidualUnit(nn.Module):
@@ -151,7 +162,13 @@ class _ResidualUnit(nn.Module):
                            wino44=v1)
             return ops.conv3d(h, w2.detach(), self.conv2.conv.bias.detach(), residual=x, out_act=ops.ACT_RELU,
                               packed=p2, wino=u2, wino44=v2)
-        return F.relu(x + self.conv2(self.conv1(x)))
+        _require_device(x)
+        x = x.float().contiguous()
+        h = self.conv1(x)  # generic kernel, ReLU fused
+        c2 = self.conv2
+        sd, k, s, dil, pad, opad = c2.geom
+        return ops.convnd_generic(h, c2.conv.weight.detach(), c2.conv.bias.detach() if c2.conv.bias is not None else None,
+                                  stride=s, padding=pad, residual=x, relu=True)
 
 
 class _Stack(nn.Module):
@@ -172,25 +189,14 @@ class _EMAQuantizer(nn.Module):
         self.register_buffer("ema_cluster_size", torch.zeros(num_embeddings))
         self.register_buffer("ema_w", self.embedding.weight.data.clone())
 
-    _HIP_DIMS = (8, 16, 32, 64, 128)
-
     def quantize(self, x):
-        """nearest code by squared L2 over channel-last flattened inputs -> indices [B, *spatial]"""
-        if x.is_cuda and x.shape[1] in self._HIP_DIMS:
-            return ops.vq_nearest(x.float().contiguous(), self.embedding.weight.detach())[0]
-        shape = x.shape
-        flat = x.movedim(1, -1).reshape(-1, shape[1]).float()
-        e = self.embedding.weight
-        dist = (flat ** 2).sum(dim=1, keepdim=True) + (e.t() ** 2).sum(dim=0, keepdim=True) - 2 * flat @ e.t()
-        idx = torch.max(-dist, dim=1)[1]
-        return idx.view(shape[0], *shape[2:])
+        """nearest code by squared L2 over channel-last flattened inputs -> indices [B, *spatial] (HIP: vq.hip)"""
+        _require_device(x)
+        return ops.vq_nearest(x.float().contiguous(), self.embedding.weight.detach())[0]
 
     def forward(self, x):
-        if x.is_cuda and x.shape[1] in self._HIP_DIMS:  # search + lookup + straight-through form in one HIP kernel
-            return ops.vq_nearest(x.float().contiguous(), self.embedding.weight.detach())[1]
-        idx = self.quantize(x)
-        q = self.embedding(idx).movedim(-1, 1).contiguous()
-        return x + (q - x)  # straight-through form of the eval path (no gradient here)
+        _require_device(x)  # search + lookup + straight-through form x + (q - x) in one HIP kernel
+        return ops.vq_nearest(x.float().contiguous(), self.embedding.weight.detach())[1]
 
 
 class _VectorQuantizer(nn.Module):

@@ -150,6 +150,14 @@ int ddpm_pack_convtr_weight_f32(const float *w_raw, float *w_packed, int Cin, in
  * (first encoder / last decoder layer at src/trainers/reconstruct.py:124,166; torch weight layouts, no packing).   */
 int ddpm_conv3d_k4s2_cin1_f32(const float *in, const float *w, const float *bias, float *out, int B, int Cout, int D,
                               int H, int W, int relu, ddpm_stream_t stream);
+/* Generic (transposed) convolution, dims = 2 ([B, C, 1, H, W] with Di = 1) or 3, any channel counts, symmetric kernel / stride
+ * (1 or 2) / padding, torch weight layouts ([Cout, Cin, k..] or, transposed, [Cin, Cout, k..]; output_padding 0), optional
+ * residual and ReLU epilogue: the always-available form behind the MFMA kernels, used by the VQ-VAE layers whose channel
+ * counts have no MFMA tiling (nn.Conv3d / nn.ConvTranspose3d of generative's VQVAE, /root/reference/src/trainers/
+ * reconstruct.py:124,166).  out extents: (e + 2 pad - k) / stride + 1, transposed (e - 1) stride - 2 pad + k.  */
+int ddpm_convnd_generic_f32(const float *in, const float *w, const float *bias, const float *residual, float *out, int B, int Cin,
+                            int Cout, int Di, int Hi, int Wi, int dims, int ksize, int stride, int pad, int transposed, int relu,
+                            ddpm_stream_t stream);
 int ddpm_convtr3d_k4s2_cout1_f32(const float *in, const float *w, const float *bias, float *out, int B, int Cin, int D,
                                 int H, int W, ddpm_stream_t stream);
 

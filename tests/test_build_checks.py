@@ -1,0 +1,21 @@
+"""CPU: build-time property of the inline-asm MFMA kernels -- no compiler-generated access to an accumulator register.
+
+conv_wino44h.hip addresses eight accumulator tiles by NAME (a[0:127]) inside its asm statements, so the compiler must
+never allocate an AGPR for anything of its own, and nothing may spill inside the MFMA loops (hipcc does not know that
+an asm MFMA writes its destination asynchronously: a spill store behind it saves stale values -- the bug that produced
+run-to-run different 1e-3 errors on the 16x16 variant before the tiles were pinned).  tools/check_acc_spills.py compiles
+the file for gfx950 (cross-compilation: no GPU needed) and inspects the assembly."""
+
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_wino44h_accumulators_are_never_touched_by_compiler_code():
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "check_acc_spills.py"),
+                          str(ROOT / "ddpm_ood_amd" / "csrc" / "conv_wino44h.hip"), "-fno-slp-vectorize"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert out.stdout.count(": OK") == 16, out.stdout  # 2 (affine) x 4 (shapes) x 2 (residual) instantiations

@@ -1092,3 +1092,43 @@ def test_vq_nearest(device, case):
         assert diff.float().mean().item() < 1e-3
     same = ~diff
     assert torch.equal(out.cpu().movedim(1, -1)[same], out_ref.movedim(1, -1)[same])
+
+
+@pytest.mark.parametrize("dims,cin,cout,k,stride,pad,transposed", [
+    (3, 5, 7, 3, 1, 1, False), (3, 1, 6, 4, 2, 1, False), (3, 6, 3, 4, 2, 1, True), (2, 3, 8, 3, 1, 1, False),
+    (2, 8, 5, 4, 2, 1, True), (3, 16, 32, 3, 1, 1, False), (2, 4, 4, 1, 1, 0, False)])
+def test_convnd_generic_vs_torch(device, dims, cin, cout, k, stride, pad, transposed):
+    """ddpm_convnd_generic_f32: the always-available convolution behind the MFMA kernels (any channel counts, 2-D / 3-D,
+    stride 1 / 2, transposed), with the residual + ReLU epilogue -- what the VQ-VAE layers without an MFMA tiling run on
+    instead of PyTorch-ROCm ops (nn.Conv3d / nn.ConvTranspose3d of the reference's VQVAE, reconstruct.py:124,166)."""
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(dims * 100 + cin * 10 + cout)
+    sp = (6, 8, 10)[3 - dims:]
+    x = torch.randn(2, cin, *sp, generator=g)
+    w = torch.randn(*((cin, cout) if transposed else (cout, cin)), *([k] * dims), generator=g) / math.sqrt(cin * k ** dims)
+    b = torch.randn(cout, generator=g)
+    f = {(2, False): F.conv2d, (3, False): F.conv3d, (2, True): F.conv_transpose2d, (3, True): F.conv_transpose3d}[dims, transposed]
+    ref = f(x, w, b, stride=stride, padding=pad)
+    res = torch.randn(ref.shape, generator=g)
+    y = ops.convnd_generic(x.to(device), w.to(device), b.to(device), stride=stride, padding=pad, transposed=transposed)
+    assert y.shape == ref.shape
+    _close(y, ref, tol=2e-6)
+    y2 = ops.convnd_generic(x.to(device), w.to(device), b.to(device), stride=stride, padding=pad, transposed=transposed,
+                            residual=res.to(device), relu=True)
+    _close(y2, F.relu(ref + res), tol=2e-6)
+
+
+def test_vq_nearest_generic_embedding_dim(device):
+    """An embedding size without a register-resident instantiation (12) takes the generic quantiser kernel: same indices as
+    a brute-force search, straight-through output x + (e_k - x)."""
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 12, 4, 4, 4, generator=g)
+    e = torch.randn(32, 12, generator=g) * 2
+    idx, out = ops.vq_nearest(x.to(device), e.to(device))
+    flat = x.movedim(1, -1).reshape(-1, 12)
+    brute = ((flat[:, None, :] - e[None]) ** 2).sum(-1).argmin(1)
+    assert torch.equal(idx.cpu().reshape(-1), brute)
+    assert torch.allclose(out.cpu().movedim(1, -1).reshape(-1, 12), e[brute], atol=1e-6)

@@ -235,7 +235,8 @@ VQ_CFG = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(16, 3
 def test_ldm_trajectory_3d_matches_oracle(device, tmp_path):
     """cfg5-shaped (scaled down): 32^3 volumes -> VQ-VAE (2 stride-2 levels, 64 codes x 128) -> latents
     [B, 128, 8, 8, 8] -> `small` 3-D UNet PLMS trajectories (t = 10, 650) -> re-quantise + decode -> 2.5-D LPIPS
-    + MSE.  HIP path (UNet / PLMS / MSE on HIP, VQ-VAE + LPIPS on PyTorch-ROCm ops) vs the CPU oracle."""
+    + MSE.  Everything on the HIP library -- the 16 / 32-channel VQ-VAE layers have no MFMA tiling and take the generic
+    kernel (ddpm_convnd_generic_f32); there is no PyTorch-ROCm / MIOpen route in the product -- vs the CPU oracle, 2e-4."""
     import json
 
     import oracle
@@ -275,7 +276,7 @@ def test_ldm_trajectory_3d_matches_oracle(device, tmp_path):
     assert list(rows_h["t"]) == list(rows_o["t"]) == [10, 10, 650, 650]
     for col in ("mse", "perceptual_difference"):
         rel = ((rows_h[col] - rows_o[col]).abs() / (rows_o[col].abs() + 1e-9)).max()
-        assert rel < 1e-3, (col, rel, rows_h[col].tolist(), rows_o[col].tolist())
+        assert rel < 2e-4, (col, rel, rows_h[col].tolist(), rows_o[col].tolist())
 
 
 def test_trajectory_native_28x28_lpips_pad_branch(device, tmp_path):
