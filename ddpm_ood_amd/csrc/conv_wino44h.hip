@@ -373,6 +373,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
   auto mfma_phase = [&](auto tc, int us, int vs, auto &&slice) {
     constexpr int t = decltype(tc)::value;
     const int ua_s = ua + us, va_s = va + vs;
+#ifndef W44H_PREFETCH2
     // all nine operand reads of the phase up front: with one job of read-ahead the LDS latency under load (250 .. 300
     // cycles) WAS the job time (probe: 280 cycles per job of two 32-cycle MFMAs)
     h8 A[3], Bh[3], Bl[3];
@@ -416,6 +417,40 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       __builtin_amdgcn_sched_barrier(0);
       W44H_STAMP(1 + i)
     }
+#else  // one job of read-ahead (two operand register sets)
+    h8 A[2], Bh[2], Bl[2];
+    A[0] = lds_b128(ua_s, 0);
+    Bh[0] = lds_b128(va_s, 0);
+    Bl[0] = lds_b128(va_s, kT * 16);
+    A[1] = lds_b128(ua_s, 2 * kK * 16);
+    Bh[1] = lds_b128(va_s, 2 * kT * 16);
+    Bl[1] = lds_b128(va_s, 3 * kT * 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int x = 3 * t + i;
+      if (x == 8) {
+        mfma_v_pair_wait0(acc8, A[i & 1], Bh[i & 1], Bl[i & 1]);
+        slice(2 * i);
+        __builtin_amdgcn_sched_barrier(0);
+        slice(2 * i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
+      if (i < 2) mfma_pin_wait<3>(x, A[i & 1], Bh[i & 1]);
+      else mfma_pin_wait<0>(x, A[i & 1], Bh[i & 1]);
+      slice(2 * i);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pin(x, A[i & 1], Bl[i & 1]);
+      if (i == 0) {
+        A[0] = lds_b128(ua_s, 4 * kK * 16);
+        Bh[0] = lds_b128(va_s, 4 * kT * 16);
+        Bl[0] = lds_b128(va_s, 5 * kT * 16);
+      }
+      slice(2 * i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
   };
   auto phase_end = [&]() {  // pixel waves: the U slot they fetched has landed (and with it their older pixel loads)
 #ifdef W44H_PROBE
@@ -425,6 +460,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     W44H_STAMP(5)
 #else
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto phase_end_keep = [&](auto nc) {  // pixel waves: all but their N newest vector-memory operations have completed
+    constexpr int N = decltype(nc)::value;
+#ifdef W44H_PROBE
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    W44H_STAMP(4)
+    asm volatile("s_barrier" ::: "memory");
+    W44H_STAMP(5)
+#else
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 #endif
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -710,22 +757,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       constexpr int ringA = Q == 2 ? 0 : 2;  // R == 2: half 0 of chunk c + 2
       // (no range guards: a half-tile activated for a chunk outside the item is overwritten before anyone reads it)
       auto slice = [&](int k) {
-        if (k == 0) {  // pixel loads first, then the U slot of the next phase (waited for at the end of this phase)
-#ifndef W44H_NO_PIXEL
-          if (R == 0) load_stage(I0{}, c + 2, 0);
-          if (R == 1) { load_stage(I1{}, c + 2, 1); load_affine(c + 2, 0); }  // scale / shift of the half activated next phase
-#endif
+        if (k == 0) {  // the U slot of the next phase first (waited for at the end of this phase), then the pixel loads, which
+                       // stay in flight across the barrier: they are consumed two phases later
 #ifndef W44H_NO_DMA
 #pragma unroll
           for (int e = 0; e < 4; ++e) dma_u(e, m + 1, us1);
+#endif
+#ifndef W44H_NO_PIXEL
+          if (R == 0) load_stage(I0{}, c + 2, 0);
+          if (R == 1) { load_stage(I1{}, c + 2, 1); load_affine(c + 2, 0); }  // scale / shift of the half activated next phase
 #endif
         }
 #ifdef W44H_NO_PIXEL
         return;
 #endif
         if (k >= 1 && R != 1) {
-          // the set being activated landed with an earlier phase's closing vmcnt(0); in flight now: this phase's loads + DMA
-          if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R == 0 ? NVM : 0) + 4) : "memory");
+          // (the set being activated landed with an earlier phase's closing wait; in flight now: this phase's DMA and loads)
 #pragma unroll
           for (int kk = 2 * (k - 1); kk < 2 * k && kk < NRT; ++kk) {
             if (R == 0) activate(I1{}, kk, ringB);
@@ -735,7 +782,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
         }
       };
       mfma_phase(std::integral_constant<int, Q % 3>{}, us, vs, slice);
-      phase_end();
+      // the DMAs (issued first) have landed; the pixel loads of this phase -- NVM, + 2 NGS scale / shift loads in R == 1 --
+      // stay in flight, those of earlier phases have landed too (in-order retirement): every load gets two phases
+      if (R == 0) phase_end_keep(std::integral_constant<int, NVM>{});
+      else if (R == 1) phase_end_keep(std::integral_constant<int, NVM + (AFFINE ? 2 * NGS : 0)>{});
+      else phase_end_keep(std::integral_constant<int, (AFFINE ? 2 * NGS : 0)>{});  // R == 2: the scale / shift loads of its last slice
     };
     int c = -2;
     for (int m = -6; m < NPH; m += 6, c += 2) {

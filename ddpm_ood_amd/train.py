@@ -5,8 +5,8 @@ Mirrors /root/reference/src/trainers/ddpm_trainer.py:16-124 (epoch loop, best-lo
 training step: random timesteps, Gaussian noise, ``scheduler.add_noise(images * b_scale)``, MSE between the UNet
 output and the noise) with Adam(lr = 2.5e-5) as at /root/reference/src/trainers/base.py:156 and the checkpoint
 dict of base.py:166-187.  Differences, on purpose:
-  * fp32 throughout (the reference trains under fp16 autocast + GradScaler; reduced precision would be the
-    deviation here, not the other way round);
+  * fp32 by default; ``--amp 1`` mirrors the reference's fp16 autocast + GradScaler
+    (/root/reference/src/trainers/ddpm_trainer.py:96-109, base.py:122) over the same ATen ops;
   * the backward pass is PyTorch-ROCm autograd: ``unet_forward_torch`` evaluates the SAME parameter holders the HIP
     engine reads (``DiffusionModelUNet``) with differentiable ATen ops, so a checkpoint written here loads into the
     HIP inference path unchanged.  Training is off the hot path (it runs once; reconstruction runs per image x
@@ -112,6 +112,8 @@ class DDPMTrainer(BaseTrainer):
         self.quick_test = bool(getattr(args, "quick_test", 0))
         self.num_epochs = args.n_epochs
         self.seed = int(args.seed)
+        self.amp = bool(getattr(args, "amp", 0))
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp)
         for p in self.model.parameters():
             p.requires_grad_(True)
         self._broadcast_initial_state()
@@ -150,9 +152,10 @@ class DDPMTrainer(BaseTrainer):
             noise = torch.randn(images.shape, device=self.device, generator=self.gen)
             noisy = self.scheduler.add_noise(original_samples=images.contiguous(), noise=noise, timesteps=timesteps,
                                              b_scale=self.b_scale)
-        pred = unet_forward_torch(self.model, noisy, timesteps)
-        # the reference regresses onto the noise whatever --prediction_type says (ddpm_trainer.py:99-100)
-        return F.mse_loss(pred.float(), noise.float())
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.amp):
+            pred = unet_forward_torch(self.model, noisy, timesteps)
+            # the reference regresses onto the noise whatever --prediction_type says (ddpm_trainer.py:99-100)
+            return F.mse_loss(pred.float(), noise.float())
 
     def _sync_grads(self):
         if not self.ddp:
@@ -194,9 +197,10 @@ class DDPMTrainer(BaseTrainer):
                 self.device, non_blocking=True)
             self.optimizer.zero_grad(set_to_none=True)
             loss = self._loss(images)
-            loss.backward()
+            self.scaler.scale(loss).backward()  # (identity without --amp)
             self._sync_grads()
-            self.optimizer.step()
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
             epoch_loss += loss.item()
             self.global_step += images.shape[0]
             epoch_step += images.shape[0]

@@ -1,7 +1,10 @@
 """Aggregate rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE / SQ / GRBM runs of
 tools/microbench.py) into per-kernel HBM traffic and MFMA utilisation.
 
-    python tools/pmc_summary.py gpurun_out/pmc profiles/r01_pmc_per_kernel.csv profiles/pmc_traffic.json
+    python tools/pmc_summary.py gpurun_out/pmc profiles/r01_pmc_per_kernel.csv profiles/pmc_traffic.json [--merge] [--batch N]
+
+--batch N: the passes ran tools/microbench.py --batch N; the per-kernel figures go under "by_batch"[N] of the JSON (what
+bench.py quotes as roofline.traffic when N is the timed batch) instead of replacing the top-level (batch 256) ones.
 
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are KB; on gfx950
 FETCH_SIZE reports half of a wide coalesced read, so reads are 2 x FETCH_SIZE x 1024 (an upper
@@ -47,13 +50,19 @@ def main(root, out_csv, out_json):
     m = m.sort_values("dur_us", ascending=False)[cols]
     m.to_csv(out_csv, index=False, float_format="%.4g")
     print(m.head(12).to_string())
-    out = json.load(open(out_json)) if len(sys.argv) > 4 and sys.argv[4] == "--merge" else {}
+    out = json.load(open(out_json)) if "--merge" in sys.argv else {}
+    batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else None
+    top = out
+    if batch is not None:
+        out = top.setdefault("by_batch", {}).setdefault(str(batch), {})
     out["source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/microbench.py, B=256 (2-D kernels) and "
                      "tools/vqvae_bench.py (3-D kernels); reads = 2 x FETCH_SIZE KB (gfx950 correction), launch-weighted mean "
                      "over the kernel's launches")
     # profiler key of bench.py's roofline object -> the kernel instantiations behind it
     # (a regular expression on the instantiation name; the last template argument of the Winograd kernels is the 3-D form)
-    for key, pattern in (("conv3x3_wino44_gn_silu", r"conv_wino44_kernel<true, \d, \d, (?:true|false), false>"),
+    for key, pattern in (("conv3x3_wino44h_gn_silu", r"conv_wino44h_kernel<true"),
+                         ("conv3x3_wino_up", r"conv_wino_up_kernel"),
+                         ("conv3x3_wino44_gn_silu", r"conv_wino44_kernel<true, \d, \d, (?:true|false), false>"),
                          ("conv3x3_wino_gn_silu", r"conv_wino_kernel<true, \d, (?:true|false), false>"),
                          ("conv3x3_mfma_gn_silu", r"conv_mfma_kernel<9, 1, true, 128"),
                          ("conv3d_wino44", r"conv_wino44_kernel<false, \d, \d, (?:true|false), true>"),
@@ -67,7 +76,9 @@ def main(root, out_csv, out_json):
             out[key + "_bytes_per_launch"] = float((sel.hbm_MB_per_launch * wgt).sum() * 1e6)
             out[key + "_mfma_util"] = float((sel.mfma_util * sel.dur_us * sel.launches).sum() / (sel.dur_us * sel.launches).sum())
             out[key + "_avg_launch_us"] = float((sel.dur_us * wgt).sum())
-    json.dump(out, open(out_json, "w"), indent=1)
+    if batch is not None:
+        out["source"] = out["source"].replace("B=256", f"B={batch}")
+    json.dump(top, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -28,6 +28,9 @@ def parse_args(argv=None):
         if typ not in (None, str):
             kw["type"] = typ
         parser.add_argument(f"--{name}", **kw)
+    ext = parser.add_argument_group("extensions (defaults: fp32 training)")
+    ext.add_argument("--amp", type=int, default=0,
+                     help="1: fp16 autocast + GradScaler as the reference trains (ddpm_trainer.py:96-109); default 0 = fp32")
     return parser.parse_args(argv)
 
 
