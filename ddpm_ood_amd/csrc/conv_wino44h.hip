@@ -801,6 +801,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the repeats past the last chunk: nothing may land after the item
   };
 
+#ifdef W44H_PRIO  // experiment: the producers are the critical path of every phase; the pixel wave of their SIMD yields to them
+  if (wave < 4) asm volatile("s_setprio 1");
+#endif
   for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
     if (wave < 2) producer_item(I0{});
     else if (wave < 4) producer_item(I1{});

@@ -100,12 +100,16 @@ def test_one_adam_step_on_rocm_matches_cpu_torch(device, tmp_path):
     pr, ph = dict(ref.named_parameters()), dict(hip.named_parameters())
     assert set(pr) == set(ph)
     worst = 0.0
+    gmax = max(float(p.grad.abs().max()) for p in pr.values() if p.grad is not None)
     for k in pr:
         gr, gh = pr[k].grad, ph[k].grad
         if gr is None:  # (proj_attn: present in the state_dict, unused in the forward)
             assert gh is None or float(gh.abs().max()) == 0.0, k
             continue
-        rel = float((gh.cpu() - gr).abs().max() / (gr.abs().max() + 1e-20))
+        # (to_k.bias has an analytically ZERO gradient -- softmax over keys ignores a per-query constant -- so both sides hold
+        # rounding noise there: the error is measured against the parameter's own gradient scale, floored at 1e-5 of the
+        # model's largest gradient)
+        rel = float((gh.cpu() - gr).abs().max() / max(float(gr.abs().max()), 1e-5 * gmax))
         worst = max(worst, rel)
         assert rel <= 1e-4, (k, rel)
     opt_r.step()
@@ -114,6 +118,6 @@ def test_one_adam_step_on_rocm_matches_cpu_torch(device, tmp_path):
         if pr[k].grad is None:
             continue
         d = (ph[k].detach().cpu() - pr[k].detach()).abs()
-        solid = pr[k].grad.abs() > 1e-3 * pr[k].grad.abs().max()
-        assert float(d[solid].max()) <= 2e-6 and float(d.max()) <= 5.1e-5, (k, float(d.max()))
+        solid = pr[k].grad.abs() > max(1e-3 * float(pr[k].grad.abs().max()), 1e-5 * gmax)
+        assert (not bool(solid.any()) or float(d[solid].max()) <= 2e-6) and float(d.max()) <= 5.1e-5, (k, float(d.max()))
     print(f"one Adam step: loss {loss_r.item():.6f}, worst gradient max-norm relative error {worst:.2e}")
