@@ -1,6 +1,7 @@
 """CPU: host-side logic of the product package (no GPU, no HIP compute calls)."""
 
 import json
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -428,3 +429,29 @@ def test_product_code_never_imports_the_oracle():
     assert offenders == []
     bench = (root / "bench.py").read_text()
     assert len(pat.findall(bench)) == 1 and "def cpu_baseline_worker" in bench.split("import oracle")[0]
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE) re-executes itself through torch.distributed.run
+    with N ranks on 127.0.0.1 and passes the arguments through; for N > 1 the default is strong scaling."""
+    import subprocess
+    import types
+
+    import bench
+
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"] = cmd
+        return types.SimpleNamespace(returncode=7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert bench.shard_sizes("strong", 8, 1024, 1024) == (1024, [128] * 8)  # the default strong set: one batch over the ranks
