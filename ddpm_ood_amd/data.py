@@ -14,7 +14,8 @@ duplicates).  File formats:
 ``.npy`` (the reference's computer-vision datasets), single-file NIfTI-1 ``.nii`` / ``.nii.gz`` (its
 Medical-Decathlon volumes; read here with numpy as nibabel's ``get_fdata`` would: Fortran order,
 ``scl_slope`` / ``scl_inter`` applied, no reorientation -- what MONAI's ``LoadImage`` hands on), ``.npz``
-archives and synthetic specs.  PIL formats are not read.
+archives and synthetic specs; of the PIL formats MONAI's LoadImage reads: PNG (8 / 16-bit grey, grey + alpha, RGB, RGBA,
+non-interlaced) and binary PGM / PPM, with PILReader's axis swap -- JPEG / TIFF are not read.
 
 Synthetic id specs (no dataset can be downloaded here):
     synthetic:<kind>[:n=N][:size=S][:channels=C][:seed=K][:mix=P][:name=X]
@@ -154,9 +155,12 @@ def channel_first(a: torch.Tensor, path: str, is_grayscale: bool, spatial_dimens
     information, so it is taken as channel-less.  Colour data (``is_grayscale=0``) gets no EnsureChannelFirst
     in the reference: the file has to be channel-first already.  Anything else is ambiguous and raises."""
     nifti = path.endswith((".nii", ".nii.gz"))
+    pil = path.lower().endswith(PIL_SUFFIXES)
     if is_grayscale:
         if nifti and a.ndim == 4 and spatial_dimension == 3:
             a = a.movedim(-1, 0)
+        elif pil and a.ndim == 3 and spatial_dimension == 2:
+            a = a.movedim(-1, 0)  # colour image file: PILReader marks the last axis as the channel, x[0, None] keeps R
         elif a.ndim == spatial_dimension:
             a = a[None]
         else:
@@ -200,12 +204,113 @@ def transform_image(a: torch.Tensor, image_roi=None, image_size=None, add_vflip=
     return a.contiguous()
 
 
+def _png_unfilter(raw: bytes, height: int, stride: int, bpp: int) -> np.ndarray:
+    """PNG scanline filters 0..4 (None, Sub, Up, Average, Paeth; PNG specification section 9) -> [height, stride] uint8."""
+    out = np.zeros((height, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    pos = 0
+    for y in range(height):
+        ft = raw[pos]
+        line = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=pos + 1).astype(np.int32)
+        pos += stride + 1
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        elif ft in (1, 3, 4):
+            cur = line.copy()
+            for x in range(stride):  # sequential by definition (left neighbour of the RECONSTRUCTED line)
+                a = cur[x - bpp] if x >= bpp else 0
+                b = prev[x]
+                if ft == 1:
+                    pred = a
+                elif ft == 3:
+                    pred = (a + b) >> 1
+                else:
+                    c = prev[x - bpp] if x >= bpp else 0
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pred = a if pa <= pb and pa <= pc else b if pb <= pc else c
+                cur[x] = (cur[x] + pred) & 255
+        else:
+            raise ValueError(f"PNG: unknown filter type {ft}")
+        out[y] = cur
+        prev = cur
+    return out
+
+
+def read_png(path: str) -> np.ndarray:
+    """Minimal PNG reader (zlib + the five scanline filters): 8 / 16-bit greyscale, greyscale + alpha, RGB, RGBA,
+    non-interlaced -- what the reference's ``LoadImaged`` gets from PIL for such files.  -> [H, W] or [H, W, C] float32."""
+    import struct
+    import zlib
+
+    data = open(path, "rb").read()
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError(f"{path}: not a PNG file")
+    pos, idat, hdr = 8, [], None
+    while pos < len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if kind == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif kind == b"IDAT":
+            idat.append(body)
+        elif kind == b"IEND":
+            break
+    if hdr is None:
+        raise ValueError(f"{path}: PNG without IHDR")
+    w, h, depth, ctype, _, _, interlace = hdr
+    channels = {0: 1, 2: 3, 4: 2, 6: 4}.get(ctype)
+    if channels is None or depth not in (8, 16) or interlace:
+        raise NotImplementedError(f"{path}: PNG colour type {ctype} / bit depth {depth} / interlace {interlace} is not read "
+                                  "(greyscale, greyscale + alpha, RGB, RGBA at 8 or 16 bits, non-interlaced are)")
+    bpp = channels * depth // 8
+    rows = _png_unfilter(zlib.decompress(b"".join(idat)), h, w * bpp, bpp)
+    a = rows.reshape(h, w, channels, depth // 8)
+    a = a[..., 0].astype(np.float32) if depth == 8 else (a[..., 0].astype(np.float32) * 256 + a[..., 1])
+    return a[..., 0] if channels == 1 else a
+
+
+def read_pnm(path: str) -> np.ndarray:
+    """Binary PGM (P5) / PPM (P6) -> [H, W] or [H, W, 3] float32."""
+    data = open(path, "rb").read()
+    toks, pos = [], 0
+    while len(toks) < 4:
+        while data[pos:pos + 1].isspace():
+            pos += 1
+        if data[pos:pos + 1] == b"#":
+            pos = data.index(b"\n", pos) + 1
+            continue
+        end = pos
+        while not data[end:end + 1].isspace():
+            end += 1
+        toks.append(data[pos:end])
+        pos = end
+    magic, w, h, maxv = toks[0], int(toks[1]), int(toks[2]), int(toks[3])
+    if magic not in (b"P5", b"P6"):
+        raise NotImplementedError(f"{path}: only binary PGM (P5) / PPM (P6) are read")
+    c = 1 if magic == b"P5" else 3
+    dt = np.dtype(">u2") if maxv > 255 else np.uint8
+    a = np.frombuffer(data, dtype=dt, count=w * h * c, offset=pos + 1).reshape(h, w, c).astype(np.float32)
+    return a[..., 0] if c == 1 else a
+
+
+PIL_SUFFIXES = (".png", ".pgm", ".ppm")
+
+
 def read_image(path: str) -> torch.Tensor:
     if path.endswith((".nii", ".nii.gz")):
         return torch.from_numpy(read_nifti(path))
     if path.endswith(".npy"):
         return torch.from_numpy(np.load(path).astype(np.float32))
-    raise NotImplementedError(f"{path}: .npy and NIfTI-1 (.nii / .nii.gz) files are ingested; PIL formats are not")
+    if path.lower().endswith(PIL_SUFFIXES):
+        # MONAI's PILReader (reverse_indexing=True, its default) swaps the first two axes of what PIL returns, so that the
+        # array is [W, H(, C)] like the other readers' -- SURVEY Appendix A, recalled; the channel stays LAST
+        a = read_png(path) if path.lower().endswith(".png") else read_pnm(path)
+        return torch.from_numpy(np.ascontiguousarray(np.swapaxes(a, 0, 1)))
+    raise NotImplementedError(f"{path}: .npy, NIfTI-1 (.nii / .nii.gz), .png and binary .pgm / .ppm files are ingested; "
+                              "other PIL formats (JPEG, TIFF, ...) are not")
 
 
 def load_ids(ids: str, is_grayscale: bool = False, first_n=None, spatial_dimension: int = 2, **transform):

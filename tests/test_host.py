@@ -259,7 +259,7 @@ def test_nifti_ingest(tmp_path):
     (tmp_path / "bad.nii").write_bytes(b"\0" * 400)
     with pytest.raises(ValueError):
         read_nifti(tmp_path / "bad.nii")
-    (tmp_path / "ids2.csv").write_text(f"{tmp_path / 'x.png'}\n")
+    (tmp_path / "ids2.csv").write_text(f"{tmp_path / 'x.jpg'}\n")
     with pytest.raises(NotImplementedError):
         get_data_loader(str(tmp_path / "ids2.csv"), batch_size=1)
 
@@ -369,7 +369,8 @@ def test_training_forward_and_cli(tmp_path):
                if "proj_attn" in n or "conv" in n)
     flags = json.load(open(G / "train_cli_flags.json"))
     a = train_ddpm.parse_args(["--model_name", "m", "--output_dir", "o"])
-    assert set(flags) == set(vars(a)), set(flags) ^ set(vars(a))
+    assert set(flags) == set(vars(a)) - {"amp"}, set(flags) ^ set(vars(a))  # --amp: this repo's extension (default: fp32)
+    assert a.amp == 0
     for k, v in flags.items():
         assert getattr(a, k) == v["default"] or k in ("model_name", "output_dir"), k
 
@@ -455,3 +456,77 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert bench.shard_sizes("strong", 8, 1024, 1024) == (1024, [128] * 8)  # the default strong set: one batch over the ranks
+
+
+def test_png_and_pnm_ingest(tmp_path):
+    """PIL-format ingest (the reference's LoadImaged reads PNG through PIL; get_train_and_val_dataloader.py:60-76):
+    a minimal PNG / PGM / PPM reader, every PNG scanline filter, 8- and 16-bit, grey and colour; axes swapped as
+    MONAI's PILReader does; a colour file under --is_grayscale=1 keeps its first channel."""
+    import struct
+    import zlib
+
+    from ddpm_ood_amd.data import get_data_loader, read_image
+
+    rng = np.random.default_rng(0)
+
+    def write_png(path, arr, depth=8, filters=(0, 1, 2, 3, 4)):
+        h, w = arr.shape[:2]
+        c = 1 if arr.ndim == 2 else arr.shape[2]
+        ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+        bpp = c * depth // 8
+        raw = arr.astype(">u2" if depth == 16 else np.uint8).reshape(h, -1).view(np.uint8).reshape(h, w * bpp).astype(np.int32)
+        out, prev = bytearray(), np.zeros(w * bpp, dtype=np.int32)
+        for y in range(h):
+            ft, cur = filters[y % len(filters)], raw[y]
+            a = np.concatenate([np.zeros(bpp, dtype=np.int32), cur[:-bpp]])
+            cprev = np.concatenate([np.zeros(bpp, dtype=np.int32), prev[:-bpp]])
+            if ft == 0:
+                line = cur
+            elif ft == 1:
+                line = cur - a
+            elif ft == 2:
+                line = cur - prev
+            elif ft == 3:
+                line = cur - ((a + prev) >> 1)
+            else:
+                pa, pb, pc = np.abs(prev - cprev), np.abs(a - cprev), np.abs(a + prev - 2 * cprev)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, cprev))
+                line = cur - pred
+            out += bytes([ft]) + (line & 255).astype(np.uint8).tobytes()
+            prev = cur
+
+        def chunk(kind, body):
+            return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
+
+        blob = zlib.compress(bytes(out))
+        path.write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+                         + chunk(b"IDAT", blob[:50]) + chunk(b"IDAT", blob[50:]) + chunk(b"IEND", b""))
+
+    grey = rng.integers(0, 256, (28, 20))
+    write_png(tmp_path / "g.png", grey)
+    assert torch.equal(read_image(str(tmp_path / "g.png")), torch.from_numpy(grey.T.astype(np.float32)))
+    rgb = rng.integers(0, 256, (9, 11, 3))
+    write_png(tmp_path / "c.png", rgb)
+    assert torch.equal(read_image(str(tmp_path / "c.png")), torch.from_numpy(np.swapaxes(rgb, 0, 1).astype(np.float32)))
+    g16 = rng.integers(0, 65536, (6, 7))
+    write_png(tmp_path / "g16.png", g16, depth=16)
+    assert torch.equal(read_image(str(tmp_path / "g16.png")), torch.from_numpy(g16.T.astype(np.float32)))
+    (tmp_path / "p.pgm").write_bytes(b"P5\n# comment\n20 28\n255\n" + grey.astype(np.uint8).tobytes())
+    assert torch.equal(read_image(str(tmp_path / "p.pgm")), torch.from_numpy(grey.T.astype(np.float32)))
+    (tmp_path / "p.ppm").write_bytes(b"P6 11 9 255\n" + rgb.astype(np.uint8).tobytes())
+    assert torch.equal(read_image(str(tmp_path / "p.ppm")), torch.from_numpy(np.swapaxes(rgb, 0, 1).astype(np.float32)))
+    # through the loader: a greyscale run over a grey and a colour file (first channel), min-max scaled
+    sq = rng.integers(0, 256, (16, 16))
+    write_png(tmp_path / "a.png", sq)
+    write_png(tmp_path / "b.png", np.stack([sq, sq // 2, sq // 3], axis=-1))
+    (tmp_path / "ids.csv").write_text(f"{tmp_path / 'a.png'},{tmp_path / 'b.png'}\n")
+    ld = get_data_loader(str(tmp_path / "ids.csv"), 2, is_grayscale=True)
+    x = next(iter(ld))["image"]
+    want = torch.from_numpy(sq.T.astype(np.float32))
+    want = (want - want.min()) / (want.max() - want.min())
+    assert x.shape == (2, 1, 16, 16) and torch.allclose(x[0, 0], want) and torch.allclose(x[1, 0], want)
+    with pytest.raises(ValueError, match="not channel-first"):
+        get_data_loader(str(tmp_path / "ids.csv"), 2, is_grayscale=False)
+    (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff")
+    with pytest.raises(NotImplementedError, match="JPEG"):
+        read_image(str(tmp_path / "x.jpg"))
