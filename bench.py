@@ -176,6 +176,9 @@ MFMA_KERNELS = [
     ("conv3x3_wino_up", "conv_wino_up_kernel: nearest-x2 + 3x3 conv in the Winograd domain (9 of 16 positions), fp32 MFMA", 9.0 / 36.0),
     ("conv3x3_wino", "conv_wino_kernel: 3x3 conv as Winograd F(2x2,3x3), persistent, GN+SiLU prologue, fp32 MFMA", 16.0 / 36.0),
     ("conv3x3_mfma_up_folded", "conv_mfma_kernel<4>: nearest-x2 + 3x3 conv folded into four 2x2-tap convs, fp32 MFMA", 16.0 / 36.0),
+    ("conv3d_wino44h", "conv_wino44h_kernel, 3-D: Winograd F(4x4,3x3) per depth tap with split-f16 position GEMMs on "
+                       "v_mfma_f32_32x32x16_f16 (four exact partial products per fp32 product, fp32 accumulate), taps accumulated in "
+                       "the transform domain", ("f16", 4.0 * 36.0 / 144.0)),
     ("conv3d_wino44", "conv_wino44_kernel, 3-D: Winograd F(4x4,3x3) per depth tap (36 of 144 multiplies), taps accumulated in the transform domain, fp32 MFMA", 36.0 / 144.0),
     ("conv3d_wino", "conv_wino_kernel, 3-D: Winograd F(2x2,3x3) per depth tap, taps accumulated in the transform domain, fp32 MFMA", 16.0 / 36.0),
     ("conv3d_", "conv_mfma_kernel: 3-D convolution (depth taps merged into one chunk stream), fp32 MFMA", 1.0),

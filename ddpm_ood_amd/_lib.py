@@ -75,6 +75,7 @@ SIGNATURES = {
     "ddpm_convnd_generic_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 12 + [C.c_void_p]),
     "ddpm_wino44h_weight_halves": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_wino44h_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_pack_wino44h_weight3d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_pack_wino44_weight3d_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_folded_upsample_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_fold_upsample_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -169,6 +169,11 @@ extern "C" int ddpm_pack_wino44h_weight(const float *w_raw, uint16_t *w_wino44h,
   return launch_pack_wino44h_weight(w_raw, w_wino44h, Cout, Cin, as_stream(stream));
 }
 
+extern "C" int ddpm_pack_wino44h_weight3d(const float *w_raw, uint16_t *w_wino44h, int Cout, int Cin, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(w_raw && w_wino44h, "wino44h 3d pack: NULL pointer");
+  return launch_pack_wino44h_weight(w_raw, w_wino44h, Cout, Cin, as_stream(stream), 3);
+}
+
 extern "C" int ddpm_pack_wino44_weight3d_f32(const float *w_raw, float *w_wino44, int Cout, int Cin, ddpm_stream_t stream) {
   DDPM_CHECK_ARG(w_raw && w_wino44, "wino44 3d pack: NULL pointer");
   return launch_pack_wino44_weight(w_raw, w_wino44, Cout, Cin, as_stream(stream), 3);

@@ -436,7 +436,8 @@ int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
     if (is3d && d.mode == DDPM_CONV_UPSAMPLE2) DDPM_CHECK_ARG(Do == 2 * Di, "conv3d: upsample needs Do == 2 Di");
     if (is3d && d.mode == DDPM_CONV_STRIDE2)
       DDPM_CHECK_ARG(Do == (d.ksize == 3 ? (Di + 1) / 2 : Di / 2) && Do > 0, "conv3d: stride-2 output depth");
-    if (is3d && conv_wino44_supported(d)) return launch_conv_wino44(d, s);           // VQ-VAE residual units
+    if (is3d && conv_wino44h_supported(d)) return launch_conv_wino44h(d, s);         // VQ-VAE residual units, split-f16
+    if (is3d && conv_wino44_supported(d)) return launch_conv_wino44(d, s);
     if (is3d && d.w_wino && conv_wino_supported(d)) return launch_conv_wino(d, s);
     DDPM_CHECK_ARG(conv_mfma_supported(d),
                    "conv: 3-D / k4 / transposed convolutions need an MFMA tiling (Cin %% 4 (8), Cout %% 128, packed weights)");

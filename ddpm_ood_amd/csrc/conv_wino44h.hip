@@ -204,6 +204,13 @@ struct W44HGeom {
   int S;            // channel-stream splits per item (1: none)
   long long pstride;
   int NIMG;
+  // 3-D (dims = 3, the VQ-VAE residual units; as conv_wino44.hip): an "image" is one (n, d) slice, the chunk stream of an item
+  // walks (depth tap, channel chunk) -- 2-D F(4x4) per depth tap, the taps accumulated in the transform domain
+  int D;            // slices per batch item (1: plain 2-D)
+  int CS;           // channel stride of the tensors in floats: D * HW
+  int NCHc;         // channel chunks per depth tap; NCH = nkd * NCHc
+  int kd0, nkd;     // depth taps kd0 .. kd0 + nkd - 1 (a depth-1 volume only has its centre tap)
+  int nkd_w;        // depth-tap slabs per cout tile in w_wino44h: 3 for a 3x3x3 weight, else 1
 };
 
 static int w44h_cus() {
@@ -222,14 +229,19 @@ static size_t w44h_lds_bytes(const W44HGeom &g) { return ((size_t)kRINGF + 4 * (
 
 static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false) {
   const int Cin = d.C1 + d.C2;
-  if (d.dims == 3 || d.ksize != 3 || d.Di > 1 || d.Do > 1 || d.mode != DDPM_CONV_NORMAL) return false;
-  if (d.out_act != DDPM_ACT_NONE || d.act == DDPM_ACT_RELU) return false;
+  const bool is3d = d.dims == 3;
+  if (d.ksize != 3 || (!is3d && (d.Di > 1 || d.Do > 1)) || d.mode != DDPM_CONV_NORMAL) return false;
+  if ((d.out_act != DDPM_ACT_NONE && !(is3d && d.out_act == DDPM_ACT_RELU)) || d.act == DDPM_ACT_RELU) return false;
   if (d.gscale && d.act != DDPM_ACT_SILU) return false;  // the affine variant has SiLU built in
+  // 3-D: no GroupNorm / activation prologue (zero padding along the depth must stay zero), no concat, no temb
+  if (is3d && (d.gscale || d.act != DDPM_ACT_NONE || d.C2 || d.chan_add)) return false;
+  const int Dd = is3d ? (d.Di > 1 ? d.Di : 1) : 1;
+  if (is3d && (d.Do > 1 ? d.Do : 1) != Dd) return false;
   if (Cin % 16 || (d.C2 > 0 && d.C1 % 4) || d.Cout % kK) return false;  // an even number of 8-channel chunks, 4-channel halves
   if ((d.Ho & 3) || (d.Wo & 3) || d.Hi != d.Ho || d.Wi != d.Wo) return false;
   if ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.residual)) & 15) return false;  // float4 rows
-  if ((double)d.B * (d.C1 > d.C2 ? d.C1 : d.C2) * d.Ho * d.Wo * 4 >= 2147483648.0) return false;  // 32-bit buffer offsets
-  if ((double)d.B * d.Cout * d.Ho * d.Wo * 4 >= 2147483648.0 * 2) return false;
+  if ((double)d.B * (d.C1 > d.C2 ? d.C1 : d.C2) * Dd * d.Ho * d.Wo * 4 >= 2147483648.0) return false;  // 32-bit buffer offsets
+  if ((double)d.B * d.Cout * Dd * d.Ho * d.Wo * 4 >= 2147483648.0 * 2) return false;
   g.TWc = d.Wo / 4;
   g.THr = d.Ho / 4;
   const int per_img = g.TWc * g.THr;
@@ -245,10 +257,17 @@ static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false)
     g.TR = g.THr;
     g.parts = 1;
   }
+  if (is3d && g.TI != 1) return false;  // slices smaller than 32 tiles stay on conv_wino.hip / the direct kernel
   g.Cin = Cin;
-  g.NIMG = d.B;
-  g.NCH = Cin / kC;
+  g.D = Dd;
+  g.NIMG = d.B * Dd;
+  g.NCHc = Cin / kC;
+  g.kd0 = is3d && Dd == 1 ? 1 : 0;
+  g.nkd = is3d && Dd > 1 ? 3 : 1;
+  g.nkd_w = is3d ? 3 : 1;
+  g.NCH = g.nkd * g.NCHc;
   g.HW = d.Ho * d.Wo;
+  g.CS = Dd * g.HW;
   g.prow = 4 * g.TR + 2;
   auto layout = [&](bool pad) {
     g.PW = d.Wi + 2;
@@ -281,6 +300,7 @@ static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false)
   g.S = 1;
   g.pstride = 0;
   if (items < cus && !any_size) {
+    if (is3d) return false;
     const char *sp_env = getenv("DDPM_WINO44_SPLIT");
     const int sp_max = sp_env ? atoi(sp_env) : 4;
     for (int sp = 4; sp >= 2; sp >>= 1)  // every workgroup of a split walks an even number of chunks
@@ -316,7 +336,9 @@ size_t conv_wino44h_scratch_floats(const ddpm_conv_desc &d) {
 }
 
 // NRT = staging rounds of a pixel wave per half-chunk; UIT = 0: one image per item, else units per image (4 or 1)
-template <bool AFFINE, int NRT, int UIT, bool RES>
+// D3: the 3-D form (images = (n, d) slices, chunk stream = (depth tap, channel chunk)); a template parameter so that the 2-D
+// instantiations carry none of its address arithmetic
+template <bool AFFINE, int NRT, int UIT, bool RES, bool D3 = false>
 __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_desc a, const W44HGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool ONEIMG = UIT == 0;
@@ -357,8 +379,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
   reserve_agprs();
 
   const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t *>(a.w_wino44h), 0, (int)((size_t)kX * a.Cout * g.Cin * 4), 0x00020000);
-  const int ukt = (kt * g.NCH + ch_lo) * 3;  // U slot index of this workgroup's phase 0
+      const_cast<uint16_t *>(a.w_wino44h), 0, (int)((size_t)kX * a.Cout * g.Cin * g.nkd_w * 4), 0x00020000);
+  // U slot index of this workgroup's phase 0 (slots: [cout tile][depth tap][channel chunk][phase])
+  const int ukt = ((kt * g.nkd_w + g.kd0) * g.NCHc + ch_lo) * 3;
 
 #ifdef W44H_PROBE  // timing experiment: cycle stamps of workgroup 0, waves 0 / 2 / 4, block of phases 12..17 -> desc.scratch
   int probe_m = -100;
@@ -684,7 +707,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     const int prs = (64 / a.Wo) * g.PW;  // pixel-tile floats between a lane's pixels of consecutive rounds of one image
     auto pix_of = [&](int k) { return ONEIMG ? (k == NRT - 1 ? pixL : pix0 + 256 * k) : pix0 + 256 * (k % GD); };
     auto pw_of = [&](int k) { return ONEIMG ? (k == NRT - 1 ? pwL : pw0 + k * prs) : pw0 + (k % GD) * prs + (k / GD) * g.IS; };
-    const int bytes1 = a.B * a.C1 * g.HW * 4, bytes2 = a.B * a.C2 * g.HW * 4;
+    const int bytes1 = a.B * a.C1 * (D3 ? g.CS : g.HW) * 4, bytes2 = a.B * a.C2 * g.HW * 4;
     const __amdgpu_buffer_rsrc_t rs_sc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gscale), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_sh =
@@ -705,7 +728,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     auto load_stage = [&](auto setc, int c, int half) {
       constexpr int S = decltype(setc)::value;
       const int cl = min(max(c, 0), NCHs - 1);  // past the item's last chunk: a harmless repeat (uniform vmcnt bookkeeping)
-      const int cg = (ch_lo + cl) * kC + half * 4 + sc;
+      int cg = (ch_lo + cl) * kC + half * 4 + sc;
+      int soff3 = 0;
+      bool dok = true;  // D3: the depth tap's slice lies inside the volume
+      if (D3) {  // stream chunk -> (depth tap, channel chunk); image -> (batch item, slice); one image per item
+        const int kdi = cl / g.NCHc;
+        cg = (cl - kdi * g.NCHc) * kC + half * 4 + sc;
+        const int ni = min(n_cur, g.NIMG - 1);
+        const int nb = ni / g.D, dsl = ni - nb * g.D + g.kd0 + kdi - 1;
+        dok = dsl >= 0 && dsl < g.D;
+        soff3 = ((nb * a.C1 + cg) * g.D + (dok ? dsl : 0)) * g.HW * 4;
+      }
       const bool first = cg < a.C1;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
@@ -713,7 +746,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
 #pragma unroll
       for (int k = 0; k < NRT; ++k) {
         const int ni = min(n_cur + (ONEIMG ? 0 : k / GD), g.NIMG - 1);
-        praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pix_of(k), (ni * cx + cgl) * g.HW * 4, 0));
+        // D3: a depth tap outside the volume reads zeros -- the range check of a raw buffer load is on the VGPR offset, and
+        // 0x80000000 is past every resource (as for the out-of-image lanes in pix0)
+        const int soff = D3 ? soff3 : (ni * cx + cgl) * g.HW * 4;
+        const int voff = D3 && !dok ? (int)0x80000000 : pix_of(k);
+        praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
       }
     };
     auto load_affine = [&](int c, int half) {
@@ -820,11 +857,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     const int ti = el31 / per, rem = el31 - ti * per;
     const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
     const int n = n_cur + ti, ncl = min(n, g.NIMG - 1);
+    const int nbat = D3 ? ncl / g.D : ncl, dsl_o = D3 ? ncl - nbat * g.D : 0;  // (batch item, slice)
+    const int cstr = D3 ? g.CS : g.HW;                                        // channel stride
     float *const XS = smem;
     // 1 / (2^3 2^su): the operands' power-of-two pre-scales, written behind the planes by the pack kernel.  Loaded here, per
     // item, through the scalar cache: one more live VGPR across the phase loops and hipcc parks a value in a0 (a pinned tile)
     float kOutScale, unused_umax;
-    sload2(reinterpret_cast<const float *>(a.w_wino44h + (size_t)kX * a.Cout * g.Cin * 2) + 1, kOutScale, unused_umax);
+    sload2(reinterpret_cast<const float *>(a.w_wino44h + (size_t)kX * a.Cout * g.Cin * 2 * g.nkd_w) + 1, kOutScale, unused_umax);
     (void)unused_umax;
     // accumulator tile 3 t + i of wave pg holds position s = 3 pg + i of phase t: row (0,5 | 1,2 | 3,4)[s / 6], column s % 6
     const int rsel = pg >> 1, cofs = 3 * (pg & 1);
@@ -847,17 +886,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       }
     }
     const size_t co_e = (size_t)kt * kK + cb * 32 + 4 * elhi + pg;
-    const size_t obase0 = ((size_t)ncl * a.Cout + co_e) * g.HW + (size_t)(4 * (r0 + tr)) * a.Wo + 4 * tc;  // pass q: + 8 q HW
+    const size_t obase0 = (D3 ? (((size_t)nbat * a.Cout + co_e) * g.D + dsl_o) * g.HW : ((size_t)ncl * a.Cout + co_e) * g.HW) +
+                          (size_t)(4 * (r0 + tr)) * a.Wo + 4 * tc;  // pass q: + 8 q cstr
     v4f res[4];
     auto load_res = [&](int q) {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        res[k] = *reinterpret_cast<const v4f *>(a.residual + obase0 + (size_t)(8 * q) * g.HW + (size_t)k * a.Wo);
+        res[k] = *reinterpret_cast<const v4f *>(a.residual + obase0 + (size_t)(8 * q) * cstr + (size_t)k * a.Wo);
     };
     if (RES) load_res(0);
     auto pass = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      const size_t obase = obase0 + (size_t)(8 * q) * g.HW;
+      const size_t obase = obase0 + (size_t)(8 * q) * cstr;
       {
         float *xw = XS + cb * 64 + elane;
 #pragma unroll
@@ -897,6 +937,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
           v4f o = v4f{__builtin_fmaf(y[0], kOutScale, ad), __builtin_fmaf(y[1], kOutScale, ad),
                       __builtin_fmaf(y[2], kOutScale, ad), __builtin_fmaf(y[3], kOutScale, ad)};
           if (RES) o += res[k];
+          if (D3 && a.out_act == DDPM_ACT_RELU) o = v4f{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)};
           if (n < g.NIMG) *reinterpret_cast<v4f *>(outp + obase + (size_t)k * a.Wo) = o;
         }
       };
@@ -905,7 +946,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       if (RES && q < 3) {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-          r01[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * g.HW + (size_t)k * a.Wo);
+          r01[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * cstr + (size_t)k * a.Wo);
       }
       half(I1{});
       if (RES && q < 3) {
@@ -913,7 +954,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
         res[1] = r01[1];
 #pragma unroll
         for (int k = 2; k < 4; ++k)
-          res[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * g.HW + (size_t)k * a.Wo);
+          res[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * cstr + (size_t)k * a.Wo);
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
@@ -956,11 +997,23 @@ int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s) {
   }
   const int shape = g.TI == 1 ? (g.NRT == 9 ? 0 : 1) : g.UI == 4 ? 2 : 3;
   kern_t kern = kerns[d.gscale ? 1 : 0][shape][dk.residual ? 1 : 0];
+  if (d.dims == 3) {  // only reached without prologue and with whole slices per item (w44h_geom)
+    static const kern_t kerns3d[2][2] = {{conv_wino44h_kernel<false, 9, 0, false, true>, conv_wino44h_kernel<false, 9, 0, true, true>},
+                                         {conv_wino44h_kernel<false, 10, 0, false, true>, conv_wino44h_kernel<false, 10, 0, true, true>}};
+    static bool attr3_done = false;
+    if (!attr3_done) {
+      for (int i = 0; i < 4; ++i)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns3d[i / 2][i % 2]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+      attr3_done = true;
+    }
+    kern = kerns3d[g.NRT == 9 ? 0 : 1][d.residual ? 1 : 0];
+  }
   const double M = (double)g.NIMG * g.HW;
-  // algorithmic work = the direct convolution's: 2 M Cout Cin 9
-  const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9;
-  const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9);
-  const char *kname = d.gscale ? "conv3x3_wino44h_gn_silu" : "conv3x3_wino44h";
+  // algorithmic work = the direct convolution's: 2 M Cout Cin 9 (x 3 depth taps)
+  const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9 * g.nkd;
+  const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9 * g.nkd);
+  const char *kname = d.dims == 3 ? "conv3d_wino44h" : d.gscale ? "conv3x3_wino44h_gn_silu" : "conv3x3_wino44h";
   char kshape[160];
   if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {
     snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);
@@ -987,6 +1040,8 @@ __device__ __forceinline__ void wino44h_u(const float *w, double (&u)[6][6]) {
     for (int c = 0; c < 6; ++c) u[r][c] = t[r][0] * G[c][0] + t[r][1] * G[c][1] + t[r][2] * G[c][2];
 }
 
+// (a 3x3x3 weight, nkd = 3, is transformed per depth tap: total counts (cout, cin, kd) triples, 9 floats each -- torch's
+// [Cout][Cin][kd][3][3] order)
 __global__ void wino44h_max_kernel(const float *__restrict__ src, unsigned *__restrict__ tail, int64_t total) {
   float m = 0.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -999,10 +1054,10 @@ __global__ void wino44h_max_kernel(const float *__restrict__ src, unsigned *__re
   if ((threadIdx.x & 63) == 0) atomicMax(tail, __float_as_uint(m));  // non-negative floats order like their bit patterns
 }
 
-__global__ void wino44h_pack_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, int Cout, int Cin) {
-  const int64_t total = (int64_t)Cout * Cin;
+__global__ void wino44h_pack_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, int Cout, int Cin, int nkd) {
+  const int64_t total = (int64_t)Cout * Cin * nkd;
   const int nch = Cin / kC;
-  float *tail = reinterpret_cast<float *>(dst + (size_t)kX * Cout * Cin * 2);
+  float *tail = reinterpret_cast<float *>(dst + (size_t)kX * Cout * Cin * 2 * nkd);
   int e = 0;
   const float umax = tail[0];
   if (umax > 0.f) (void)frexpf(umax, &e);  // umax = f 2^e, f in [0.5, 1)
@@ -1010,16 +1065,17 @@ __global__ void wino44h_pack_kernel(const float *__restrict__ src, uint16_t *__r
   if (blockIdx.x == 0 && threadIdx.x == 0) tail[1] = ldexpf(1.f / kVScale, -su);
   const int trio_of[6] = {0, 1, 1, 2, 2, 0}, second_of[6] = {0, 0, 1, 0, 1, 1};
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % Cin), o = (int)(i / Cin);
+    const int kd = (int)(i % nkd);
+    const int ci = (int)((i / nkd) % Cin), o = (int)(i / ((int64_t)nkd * Cin));
     double uu[6][6];
-    wino44h_u(src + ((size_t)o * Cin + ci) * 9, uu);
+    wino44h_u(src + i * 9, uu);
     const int tile = o / kK, k64 = o % kK, ch = ci / kC, c8 = ci % kC;
     for (int r = 0; r < 6; ++r)
       for (int c = 0; c < 6; ++c) {
         const float u = ldexpf((float)uu[r][c], su);
         const _Float16 hi = (_Float16)u, lo = (_Float16)(u - (float)hi);
         const int s = second_of[r] * 6 + c;
-        const size_t base = ((((size_t)tile * nch + ch) * 3 + trio_of[r]) * kPP + s) * 2;
+        const size_t base = (((((size_t)tile * nkd + kd) * nch + ch) * 3 + trio_of[r]) * kPP + s) * 2;
         dst[((base + 0) * kK + k64) * kC + c8] = __builtin_bit_cast(uint16_t, hi);
         dst[((base + 1) * kK + k64) * kC + c8] = __builtin_bit_cast(uint16_t, lo);
       }
@@ -1031,11 +1087,11 @@ size_t wino44h_weight_halves(int Cout, int Cin) {
   return (size_t)kX * Cout * Cin * 2 + kTail;
 }
 
-int launch_pack_wino44h_weight(const float *w_raw, uint16_t *w_wino44h, int Cout, int Cin, hipStream_t s) {
-  DDPM_CHECK_ARG(wino44h_weight_halves(Cout, Cin) != 0, "wino44h pack: Cout %% 64 or Cin %% 16 != 0");
-  const int64_t total = (int64_t)Cout * Cin;
+int launch_pack_wino44h_weight(const float *w_raw, uint16_t *w_wino44h, int Cout, int Cin, hipStream_t s, int nkd) {
+  DDPM_CHECK_ARG(wino44h_weight_halves(Cout, Cin) != 0 && (nkd == 1 || nkd == 3), "wino44h pack: Cout %% 64 or Cin %% 16 != 0");
+  const int64_t total = (int64_t)Cout * Cin * nkd;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  unsigned *tail = reinterpret_cast<unsigned *>(w_wino44h + (size_t)kX * Cout * Cin * 2);
+  unsigned *tail = reinterpret_cast<unsigned *>(w_wino44h + (size_t)kX * Cout * Cin * 2 * nkd);
   hipError_t e = hipMemsetAsync(tail, 0, kTail * sizeof(uint16_t), s);
   if (e != hipSuccess) {
     set_error("wino44h pack: %s", hipGetErrorString(e));
@@ -1043,7 +1099,7 @@ int launch_pack_wino44h_weight(const float *w_raw, uint16_t *w_wino44h, int Cout
   }
   hipLaunchKernelGGL(wino44h_max_kernel, dim3(blocks), dim3(256), 0, s, w_raw, tail, total);
   DDPM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(wino44h_pack_kernel, dim3(blocks), dim3(256), 0, s, w_raw, w_wino44h, Cout, Cin);
+  hipLaunchKernelGGL(wino44h_pack_kernel, dim3(blocks), dim3(256), 0, s, w_raw, w_wino44h, Cout, Cin, nkd);
   DDPM_CHECK_LAUNCH();
   return 0;
 }

@@ -218,8 +218,22 @@ def pack_convT_weight(weight: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_wino44h_3d_weight(weight: torch.Tensor) -> torch.Tensor | None:
+    """torch [Cout, Cin, 3, 3, 3] -> split-f16 F(4x4, 3x3) planes per depth tap (conv_wino44h.hip, 3-D form)."""
+    lib = _lib.load()
+    w = require_device_f32(weight, "weight")
+    if w.ndim != 5 or tuple(w.shape[2:]) != (3, 3, 3):
+        return None
+    n = lib.ddpm_wino44h_weight_halves(w.shape[0], w.shape[1])
+    if n == 0:
+        return None
+    out = torch.empty(3 * (n - 64) + 64, dtype=torch.float16, device=w.device)
+    check(lib.ddpm_pack_wino44h_weight3d(ptr(w), out.data_ptr(), w.shape[0], w.shape[1], stream_ptr()), "pack_wino44h_3d_weight")
+    return out
+
+
 def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=None, packed=None, stride: int = 1,
-           wino=None, out=None, wino44=None):
+           wino=None, out=None, wino44=None, wino44h=None):
     """F.conv3d(act(x), weight, bias, stride, padding=1) (+ residual, + output activation) on NCDHW tensors:
     kernel 3 stride 1, or kernel 4 stride 2.  ONE launch of the MFMA kernel: the depth taps are part of its chunk
     stream (chunk = (depth tap, channel group)), so the output is written once.  ``wino`` (pack_wino3d_weight): a
@@ -246,7 +260,7 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
         bias = require_device_f32(bias, "bias")
     if residual is not None:
         residual = require_device_f32(residual, "residual")
-    if (wino is not None or wino44 is not None) and stride == 1 and B > 1:
+    if (wino is not None or wino44 is not None or wino44h is not None) and stride == 1 and B > 1:
         # the Winograd kernel addresses pixels with 32-bit buffer offsets (tensors < 2 GiB): a larger batch is walked
         # in sub-batches (views along dim 0, no copies) instead of dropping to the direct kernel
         per = max(Cc, cout) * D * H * W * 4
@@ -254,7 +268,8 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
         if B > nb:
             for s0 in range(0, B, nb):
                 conv3d(x[s0:s0 + nb], w, bias, act=act, out_act=out_act, packed=packed, stride=stride, wino=wino,
-                       wino44=wino44, residual=None if residual is None else residual[s0:s0 + nb], out=out[s0:s0 + nb])
+                       wino44=wino44, wino44h=wino44h, residual=None if residual is None else residual[s0:s0 + nb],
+                       out=out[s0:s0 + nb])
             return out
     d = ConvDesc()
     d.in1, d.C1 = ptr(x), Cc
@@ -267,6 +282,8 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
         d.w_wino = ptr(wino)
     if wino44 is not None and stride == 1:
         d.w_wino44 = ptr(wino44)
+    if wino44h is not None and stride == 1:
+        d.w_wino44h = wino44h.data_ptr()
     need = lib.ddpm_conv_scratch_floats(C_byref(d))  # launches smaller than the chip: split-K partial slabs
     if need:
         scratch = torch.empty(need, dtype=torch.float32, device=x.device)

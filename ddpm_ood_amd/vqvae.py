@@ -112,11 +112,12 @@ class _Convolution(nn.Module):
                 k3 = kind == "conv" and self.geom[1:3] == (3, 1)
                 wino = ops.pack_wino3d_weight(w.detach()) if k3 else None
                 wino44 = ops.pack_wino44_3d_weight(w.detach()) if k3 else None
-                self._packed = (key, pack(w.detach()), wino, wino44)
+                wino44h = ops.pack_wino44h_3d_weight(w.detach()) if k3 else None
+                self._packed = (key, pack(w.detach()), wino, wino44, wino44h)
             x = x.float().contiguous()
             if kind == "conv":
                 return ops.conv3d(x, w.detach(), b.detach(), packed=self._packed[1], out_act=out_act,
-                                  stride=self.geom[2], wino=self._packed[2], wino44=self._packed[3])
+                                  stride=self.geom[2], wino=self._packed[2], wino44=self._packed[3], wino44h=self._packed[4])
             return ops.conv_transpose(x, w.detach(), b.detach(), packed=self._packed[1], out_act=out_act)
         if kind == "conv_cin1":
             return ops.conv3d_k4s2_cin1(x.float().contiguous(), w.detach(), b.detach(), relu=not self.conv_only)
@@ -147,7 +148,8 @@ class _ResidualUnit(nn.Module):
         if self._packed is None or self._packed[0] != key:
             self._packed = (key, ops.pack_conv3d_weight(w1.detach()), ops.pack_conv3d_weight(w2.detach()),
                             ops.pack_wino3d_weight(w1.detach()), ops.pack_wino3d_weight(w2.detach()),
-                            ops.pack_wino44_3d_weight(w1.detach()), ops.pack_wino44_3d_weight(w2.detach()))
+                            ops.pack_wino44_3d_weight(w1.detach()), ops.pack_wino44_3d_weight(w2.detach()),
+                            ops.pack_wino44h_3d_weight(w1.detach()), ops.pack_wino44h_3d_weight(w2.detach()))
         return self._packed[1:]
 
     def forward(self, x):
@@ -156,12 +158,12 @@ class _ResidualUnit(nn.Module):
             # 95 % of the decoder's FLOPs: both 3x3x3 convolutions on the fp32 MFMA pipe, one launch each (Winograd
             # per depth tap -- F(4x4) from 32^3 up, F(2x2) at 16^3; the direct kernel below that), ReLU /
             # residual fused into the epilogues
-            p1, p2, u1, u2, v1, v2 = self._hip_weights()
+            p1, p2, u1, u2, v1, v2, h1, h2 = self._hip_weights()
             x = x.float().contiguous()
             h = ops.conv3d(x, w1.detach(), self.conv1.conv.bias.detach(), out_act=ops.ACT_RELU, packed=p1, wino=u1,
-                           wino44=v1)
+                           wino44=v1, wino44h=h1)
             return ops.conv3d(h, w2.detach(), self.conv2.conv.bias.detach(), residual=x, out_act=ops.ACT_RELU,
-                              packed=p2, wino=u2, wino44=v2)
+                              packed=p2, wino=u2, wino44=v2, wino44h=h2)
         _require_device(x)
         x = x.float().contiguous()
         h = self.conv1(x)  # generic kernel, ReLU fused

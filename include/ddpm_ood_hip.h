@@ -114,7 +114,7 @@ typedef struct ddpm_conv_desc {
    * half of the chip (with `scratch`: after a 2- / 4-way channel split), the conv runs as Winograd F(4x4, 3x3): 4x fewer multiplies than the direct form (F(2x2): 2.25x); fp32
    * rounding differs from the direct form by ~3e-6 rms relative.  Takes precedence over w_wino.  */
   const float *w_wino44;
-  /* Optional, 2-D 3x3 DDPM_CONV_NORMAL only (ABI 6): the F(4x4, 3x3) weights as split-f16 planes, packed by
+  /* Optional, 3x3 DDPM_CONV_NORMAL only (2-D, or dims = 3 with ddpm_pack_wino44h_weight3d; ABI 6): the F(4x4, 3x3) weights as split-f16 planes, packed by
    * ddpm_pack_wino44h_weight (U = 2^su G g G^T as hi = f16(U), lo = f16(U - hi), in the order the kernel's LDS-DMA lands
    * them; su per layer, the epilogue scale 1 / (2^3 2^su) stored behind the planes).  When present (Cin % 16 == 0, Cout % 64 == 0, same launch-size rule as w_wino44) the position GEMMs of the
    * Winograd convolution run on the f16 MFMA pipe with split-f16 products (every fp32 product rebuilt from four exact f16
@@ -179,6 +179,9 @@ int ddpm_pack_wino44_weight_f32(const float *w_raw, float *w_wino44, int Cout, i
  * (/root/reference/src/trainers/reconstruct.py:151-153).  */
 size_t ddpm_wino44h_weight_halves(int Cout, int Cin);
 int ddpm_pack_wino44h_weight(const float *w_raw, uint16_t *w_wino44h, int Cout, int Cin, ddpm_stream_t stream);
+/* The same for a [Cout, Cin, 3, 3, 3] weight (dims = 3 descriptors: the VQ-VAE residual units, nn.Conv3d inside generative's
+ * VQVAE, /root/reference/src/trainers/reconstruct.py:124,166): one slab per depth tap, 3 * (halves - 64) + 64 f16 values.  */
+int ddpm_pack_wino44h_weight3d(const float *w_raw, uint16_t *w_wino44h, int Cout, int Cin, ddpm_stream_t stream);
 
 /* Winograd-domain form of a [Cout, Cin, 3, 3, 3] conv3d weight: U_kd = G w[:, :, kd] G^T for each depth tap (3 * 16 * Cout *
  * Cin floats).  A dims = 3, stride-1 descriptor without GroupNorm / activation prologue (the VQ-VAE residual units) that

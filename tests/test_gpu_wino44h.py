@@ -191,3 +191,44 @@ def test_pack_wino44h_layout(device):
                 hi, lo = packed[:, :, t, s_, 0], packed[:, :, t, s_, 1]
                 assert ((hi - want).abs() <= 2.0 ** -10 * want.abs() + 2.0 ** -24).all()  # hi plane = f16(2^su U)
                 assert ((hi + lo - want).abs() <= 2.0 ** -21 * want.abs() + 2.0 ** -24).all()
+
+
+CASES_3D = [
+    # B, C, Cout, D, H, residual + ReLU
+    (1, 64, 128, 4, 32, False),      # slices of 64 tiles: two items per slice
+    (2, 128, 128, 3, 32, True),      # the VQ-VAE residual unit's second conv: + x, ReLU
+    (1, 64, 128, 6, 64, True),       # 64 x 64 slices: two tile rows per item
+    (1, 64, 128, 1, 32, False),      # a depth-1 volume only has its centre tap
+]
+
+
+@pytest.mark.parametrize("case", CASES_3D)
+def test_conv3d_wino44h_vs_conv3d(device, case, monkeypatch):
+    """The 3-D form (2-D F(4x4) per depth tap, the taps accumulated in the transform domain; out-of-volume taps read zeros):
+    the stride-1 3x3x3 convolutions of the VQ-VAE residual units (nn.Conv3d inside generative's VQVAE,
+    /root/reference/src/trainers/reconstruct.py:124,166) against F.conv3d, and against the fp32-MFMA 3-D F(4x4) kernel."""
+    monkeypatch.setenv("DDPM_CONV_WINO44", "2")
+    from ddpm_ood_amd import ops
+
+    B, C, Cout, D, H, res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(B, C, D, H, H, generator=g)
+    w = torch.randn(Cout, C, 3, 3, 3, generator=g) / math.sqrt(27 * C)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, Cout, D, H, H, generator=g) if res else None
+    ref = F.conv3d(x, w, b, padding=1)
+    if res:
+        ref = F.relu(ref + r)
+    d = lambda t: None if t is None else t.to(device)
+    kw = dict(residual=d(r), out_act=ops.ACT_RELU if res else ops.ACT_NONE)
+    wh = ops.pack_wino44h_3d_weight(d(w))
+    assert wh is not None and wh.numel() == 3 * 2 * 36 * Cout * C + 64
+    y = ops.conv3d(d(x), d(w), d(b), wino44h=wh, **kw)
+    y4 = ops.conv3d(d(x), d(w), d(b), wino44=ops.pack_wino44_3d_weight(d(w)), **kw)
+    torch.cuda.synchronize()
+    assert not torch.equal(y, y4)  # the split-f16 kernel ran
+    for got in (y, y4):
+        err = got.cpu() - ref
+        assert err.abs().max().item() < 2e-4 * (1 + ref.abs().max().item()), err.abs().max().item()
+        assert err.pow(2).mean().sqrt().item() < 1e-5 * (1 + ref.pow(2).mean().sqrt().item())
+    assert torch.equal(y, ops.conv3d(d(x), d(w), d(b), wino44h=wh, **kw))

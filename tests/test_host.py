@@ -404,6 +404,8 @@ def test_bench_roofline_object_is_the_executed_mfma_fraction():
     h = bench.rooflines_of({"conv3x3_wino44h_gn_silu": {"launches": 2, "ms": 1.0, "flops": 2 * 200e9, "bytes": 1e9}})
     assert set(h) == {"conv3x3_wino44h"} and h["conv3x3_wino44h"]["peak"] == 2500.0
     assert abs(h["conv3x3_wino44h"]["achieved"] - 400.0) < 0.01  # 4 partial products x 36 / 144 of the multiplies = 1.0 x algorithmic
+    h3 = bench.rooflines_of({"conv3d_wino44h": {"launches": 1, "ms": 1.0, "flops": 3e11, "bytes": 1e9}})
+    assert set(h3) == {"conv3d_wino44h"} and h3["conv3d_wino44h"]["peak"] == 2500.0  # not priced as the fp32 3-D kernel
     assert set(r) == {"conv3x3_wino", "conv3x3_wino44", "conv3x3_wino_up", "attention", "conv3d_wino", "conv3d_wino44",
                       "conv3d_"}  # MFMA classes only
     assert r["conv3d_wino44"]["executed_over_algorithmic_flops"] == 0.25
