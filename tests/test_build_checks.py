@@ -19,3 +19,19 @@ def test_wino44h_accumulators_are_never_touched_by_compiler_code():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:]
     assert out.stdout.count(": OK") == 20, out.stdout  # 2 (affine) x 4 (shapes) x 2 (residual) + 4 three-dimensional instantiations
+
+
+def test_older_mfma_kernels_do_not_spill_accumulators_inside_their_loops():
+    """The kernels whose accumulators are C++ variables bound to asm MFMAs ("+a" / "+v"): the same stale-spill hazard exists
+    wherever hipcc decides to move an accumulator inside an MFMA loop.  --loops-only: compiler-generated AGPR traffic or
+    scratch accesses inside loops of depth >= 2 fail; epilogue reads are expected."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def check(name):
+        return name, subprocess.run([sys.executable, str(ROOT / "tools" / "check_acc_spills.py"),
+                                     str(ROOT / "ddpm_ood_amd" / "csrc" / f"{name}.hip"), "--loops-only"],
+                                    capture_output=True, text=True, timeout=1200)
+
+    with ThreadPoolExecutor(3) as pool:
+        for name, out in pool.map(check, ["conv_wino44", "conv_wino", "attention"]):
+            assert out.returncode == 0, (name, out.stdout[-2000:])
