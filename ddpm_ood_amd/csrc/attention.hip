@@ -491,6 +491,36 @@ __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict
     }
   };
 
+  // K block (round 3): loaded as (group of 8 head-dim channels, key) units and split ONCE, at staging, into the two MFMA-ready
+  // f16 planes [d / 8][key][8 d] (hi, lo 2^5) -- as the q tile.  Before, every wave split the K values it multiplied (each
+  // value by two waves) right before the MFMA: 8 split_f16x8 and 64 ds_read_b32 per lane and key block; now 4 splits per
+  // thread at staging and 16 ds_read_b128 in the QK^T loop.
+  auto load_k = [&](int t0) {
+    const int key = tid & 63;
+    const bool ok = t0 + key < N;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int gq = (tid >> 6) + 8 * u;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) pf[8 * u + t] = ok ? kp[(size_t)(8 * gq + t) * N + t0 + key] : 0.f;
+    }
+  };
+  auto store_k_planes = [&]() {
+    f16x8 *Kh = reinterpret_cast<f16x8 *>(KVl), *Kl = Kh + (kDH / 8) * kKB;
+    const int key = tid & 63;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int gq = (tid >> 6) + 8 * u;
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = pf[8 * u + t];
+      f16x8 hi, lo, hs;
+      split_f16x8(v, hi, lo, hs);
+      Kh[gq * kKB + key] = hi;
+      Kl[gq * kKB + key] = lo;
+    }
+  };
+
   // q tile: fp32 through the K / V buffer, then split once into the two planes
   load_block(qp, i0);
   store_block(KVl, kQB);
@@ -509,7 +539,7 @@ __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict
       Qlo[g * kQB + tok] = lo;
     }
   }
-  load_block(kp, 0);
+  load_k(0);
   if (tid < kQB) {
     mrow[tid] = -INFINITY;
     lrow[tid] = 0.f;
@@ -526,7 +556,7 @@ __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict
 
   for (int j0 = 0; j0 < N; j0 += kKB) {
     __syncthreads();            // previous PV finished with KVl / Sl; orders the q planes and m / l init
-    store_block(KVl, kKB);      // K block, row stride 64
+    store_k_planes();           // K block as two f16 planes
     __syncthreads();
     load_block(vp, j0);         // V of this block flies while QK^T runs
 
@@ -537,25 +567,24 @@ __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict
     {
       const f16x8 *qh = reinterpret_cast<const f16x8 *>(Ql) + (16 * kh + lhi) * kQB + qi * 32 + l31;
       const f16x8 *ql = qh + (kDH / 8) * kQB;
-      const float *kb = KVl + (128 * kh + 8 * lhi) * kKB + kj * 32 + l31;
-      float bv[2][8];
-      f16x8 ahv[2], alv[2];
+      const f16x8 *kbh = reinterpret_cast<const f16x8 *>(KVl) + (16 * kh + lhi) * kKB + kj * 32 + l31;
+      const f16x8 *kbl = kbh + (kDH / 8) * kKB;
+      f16x8 ahv[2], alv[2], bhv[2], blv[2];
       ahv[0] = qh[0];
       alv[0] = ql[0];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) bv[0][t] = kb[t * kKB];
+      bhv[0] = kbh[0];
+      blv[0] = kbl[0];
 #pragma unroll
       for (int ks = 0; ks < kDH / 32; ++ks) {
         if (ks + 1 < kDH / 32) {
           ahv[(ks + 1) & 1] = qh[2 * (ks + 1) * kQB];
           alv[(ks + 1) & 1] = ql[2 * (ks + 1) * kQB];
-#pragma unroll
-          for (int t = 0; t < 8; ++t) bv[(ks + 1) & 1][t] = kb[(16 * (ks + 1) + t) * kKB];
+          bhv[(ks + 1) & 1] = kbh[2 * (ks + 1) * kKB];
+          blv[(ks + 1) & 1] = kbl[2 * (ks + 1) * kKB];
         }
-        f16x8 bh, bl, bs;
-        split_f16x8(bv[ks & 1], bh, bl, bs);
         const f16x8 as = ahv[ks & 1] * (_Float16)(1.f / kF16LoScale);
-        DDPM_MFMA_F16X3(sacc, ahv[ks & 1], alv[ks & 1], as, bh, bl, bs);
+        const f16x8 bs = bhv[ks & 1] * (_Float16)(1.f / kF16LoScale);
+        DDPM_MFMA_F16X3(sacc, ahv[ks & 1], alv[ks & 1], as, bhv[ks & 1], blv[ks & 1], bs);
       }
     }
     if (kh == 1) {
@@ -618,7 +647,7 @@ __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict
       }
     }
     __syncthreads();
-    if (j0 + kKB < N) load_block(kp, j0 + kKB);  // next K block flies while PV runs
+    if (j0 + kKB < N) load_k(j0 + kKB);  // next K block flies while PV runs
 
     // ---- O[d][i] = alpha_i * O[d][i] + sum_j V[d][j] P[i][j], d = 32 wave + .. ---------------------------
 #pragma unroll
