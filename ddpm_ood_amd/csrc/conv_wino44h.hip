@@ -417,6 +417,32 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       Bl[i] = lds_b128(va_s, (2 * i + 1) * kT * 16);
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef W44H_SLICE_FIRST  // experiment: the first staging slice runs while the operand reads are in flight (slices shifted by one)
+    slice(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int x = 3 * t + i;
+      if (x == 8) {
+        mfma_v_pair_wait0(acc8, A[i], Bh[i], Bl[i]);
+        slice(2 * i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        W44H_STAMP(1 + i)
+        continue;
+      }
+      // (slice ops are newer than all nine operand reads: "at most N outstanding" still implies job i's reads have landed,
+      // only more strictly)
+      if (i == 0) mfma_pin_wait<6>(x, A[i], Bh[i]);
+      else if (i == 1) mfma_pin_wait<3>(x, A[i], Bh[i]);
+      else mfma_pin_wait<0>(x, A[i], Bh[i]);
+      slice(2 * i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pin(x, A[i], Bl[i]);
+      if (i < 2) slice(2 * i + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      W44H_STAMP(1 + i)
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int x = 3 * t + i;  // accumulator tile
@@ -440,6 +466,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       __builtin_amdgcn_sched_barrier(0);
       W44H_STAMP(1 + i)
     }
+#endif
 #else  // one job of read-ahead (two operand register sets)
     h8 A[2], Bh[2], Bl[2];
     A[0] = lds_b128(ua_s, 0);
@@ -545,8 +572,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     // slack: 16 transfers by the four pixel waves, 8 by the two producer waves that run the lighter FIRST half this phase
     auto dma_u = [&](int e, int mm, int us) {
       const int piece = 16 + (wave & 1) * 4 + e;
+      // (the guard-free fill / tail phases ask for slots -5 .. -1 and NPH: clamped into the item's own range -- the scalar
+      // offset of a raw buffer load is not part of its range check, so it must never point outside the packed planes)
+      const int mc = min(max(mm, 0), NPH - 1);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (__attribute__((address_space(3))) void *)(smb + us + piece * 1024), 16,
-                                               ulane, (ukt + mm) * kUSB + piece * 1024, 0, 0);
+                                               ulane, (ukt + mc) * kUSB + piece * 1024, 0, 0);
     };
     // column-pass results of the task's two channels (carried from its first half to its second) and the row being read
     float cA[2][6], cB[2][6], drow[6];
@@ -720,9 +750,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     const int ulane = lane * 16;
     // transfer e (0..3) of this wave's share of the U slot of phase mm (see the producers' dma_u)
     auto dma_u = [&](int e, int mm, int us) {
+      const int mc = min(max(mm, 0), NPH - 1);  // (see the producers' dma_u)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rs_u, (__attribute__((address_space(3))) void *)(smb + us + (sc + 4 * e) * 1024), 16, ulane,
-          (ukt + mm) * kUSB + (sc + 4 * e) * 1024, 0, 0);
+          (ukt + mc) * kUSB + (sc + 4 * e) * 1024, 0, 0);
     };
 
     auto load_stage = [&](auto setc, int c, int half) {
@@ -811,7 +842,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
         if (k >= 1 && R != 1) {
           // (the set being activated landed with an earlier phase's closing wait; in flight now: this phase's DMA and loads)
 #pragma unroll
-          for (int kk = 2 * (k - 1); kk < 2 * k && kk < NRT; ++kk) {
+          for (int kk = 3 * (k - 1); kk < 3 * k && kk < NRT; ++kk) {  // three rounds per slice: done by slice 4
             if (R == 0) activate(I1{}, kk, ringB);
             if (R == 2) activate(I0{}, kk, ringA);
           }
