@@ -14,7 +14,7 @@ import torch
 
 _LIB = None
 LIB_NAME = "libddpm_ood_hip.so"
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HipLibraryMissing(RuntimeError):
@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
         ("Di", C.c_int), ("Do", C.c_int), ("dims", C.c_int), ("reserved0", C.c_int),
         ("w_folded", C.c_void_p), ("out_act", C.c_int), ("reserved", C.c_int), ("w_wino", C.c_void_p),
         ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t), ("w_wino44", C.c_void_p),
-        ("w_wino44h", C.c_void_p),
+        ("w_wino44h", C.c_void_p), ("stats_out", C.c_void_p),
     ]
 
 
@@ -57,6 +57,7 @@ SIGNATURES = {
     "ddpm_last_error": (C.c_char_p, []),
     "ddpm_conv_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "ddpm_conv_scratch_floats": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "ddpm_conv_stats_parts": (C.c_int, [C.POINTER(ConvDesc)]),
     "ddpm_packed_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ddpm_pack_conv_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p]),
@@ -81,6 +82,9 @@ SIGNATURES = {
     "ddpm_fold_upsample_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_gn_scale_shift_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "ddpm_gn_finalize_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "ddpm_channel_stats_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_float, C.c_void_p]),
     "ddpm_timestep_embedding_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -92,6 +92,11 @@ extern "C" size_t ddpm_conv_scratch_floats(const ddpm_conv_desc *d) {
   return conv_scratch_floats(*d);
 }
 
+extern "C" int ddpm_conv_stats_parts(const ddpm_conv_desc *d) {
+  if (!d) return 0;
+  return conv_stats_parts(*d);
+}
+
 extern "C" size_t ddpm_packed_conv_weight_floats(int Cout, int Cin, int ksize) {
   return packed_conv_weight_floats(Cout, Cin, ksize);
 }
@@ -192,6 +197,17 @@ extern "C" int ddpm_fold_upsample_weight_f32(const float *w_raw, float *w_folded
                                              ddpm_stream_t stream) {
   DDPM_CHECK_ARG(w_raw && w_folded, "fold: NULL pointer");
   return launch_fold_upsample_weight(w_raw, w_folded, Cout, Cin, as_stream(stream));
+}
+
+extern "C" int ddpm_gn_finalize_f32(const float *st1, int parts1, int C1, const float *st2, int parts2, int C2,
+                                    const float *gamma, const float *beta, float *scale, float *shift, int B, int HW,
+                                    int groups, float eps, ddpm_stream_t stream) {
+  return launch_gn_finalize(st1, parts1, C1, st2, parts2, C2, gamma, beta, scale, shift, B, HW, groups, eps,
+                            as_stream(stream));
+}
+
+extern "C" int ddpm_channel_stats_f32(const float *in, float *stats, int B, int C, int HW, ddpm_stream_t stream) {
+  return launch_channel_stats(in, stats, B, C, HW, as_stream(stream));
 }
 
 extern "C" int ddpm_gn_scale_shift_f32(const float *in1, const float *in2, int C1, int C2, const float *gamma,

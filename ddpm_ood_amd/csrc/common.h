@@ -58,6 +58,32 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Pairwise (Chan) merge of per-lane {mean, M2} of `cnt` values each over aligned groups of 4 / 16 / 32 lanes on the VALU's
+// DPP path (no LDS traffic): row_shr:1, 2, 4, 8 then row_bcast:15 -- lane i takes in the finished half to its left, so the
+// group's statistics are valid in its LAST lane only (other lanes end with partial garbage).  Exact to rounding whatever the
+// means are, fixed order -> bit-reproducible.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov0(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ void chan_merge_dpp(float &mean, float &m2, float &halfn) {
+  const float mo = dpp_mov0<CTRL>(mean), qo = dpp_mov0<CTRL>(m2);
+  const float dl = mo - mean;
+  m2 = (m2 + qo) + dl * dl * halfn;
+  mean = 0.5f * (mean + mo);
+  halfn += halfn;
+}
+__device__ __forceinline__ void group_moments_last_lane(float &mean, float &m2, float cnt, int lanes) {  // lanes: 4, 16, 32
+  float halfn = 0.5f * cnt;
+  chan_merge_dpp<0x111>(mean, m2, halfn);
+  chan_merge_dpp<0x112>(mean, m2, halfn);
+  if (lanes > 4) {
+    chan_merge_dpp<0x114>(mean, m2, halfn);
+    chan_merge_dpp<0x118>(mean, m2, halfn);
+  }
+  if (lanes > 16) chan_merge_dpp<0x142>(mean, m2, halfn);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -127,6 +153,9 @@ size_t wino44_weight_floats(int Cout, int Cin);
 bool conv_wino44h_supported(const ddpm_conv_desc &d);
 int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_wino44h_scratch_floats(const ddpm_conv_desc &d);
+int conv_wino44h_stats_parts(const ddpm_conv_desc &d);
+int conv_wino_stats_parts(const ddpm_conv_desc &d);
+int conv_stats_parts(const ddpm_conv_desc &d);
 size_t wino44h_weight_halves(int Cout, int Cin);
 int launch_pack_wino44h_weight(const float *w_raw, uint16_t *w_wino44h, int Cout, int Cin, hipStream_t s, int nkd = 1);
 int launch_pack_wino44_weight(const float *w_raw, float *w_wino44, int Cout, int Cin, hipStream_t s, int nkd = 1);
@@ -145,6 +174,9 @@ int launch_convnd_generic(const float *in, const float *w, const float *bias, co
                           hipStream_t s);
 int launch_gn_scale_shift(const float *in1, const float *in2, int C1, int C2, const float *gamma, const float *beta,
                           float *scale, float *shift, int B, int HW, int groups, float eps, hipStream_t s);
+int launch_gn_finalize(const float *st1, int parts1, int C1, const float *st2, int parts2, int C2, const float *gamma,
+                       const float *beta, float *scale, float *shift, int B, int HW, int groups, float eps, hipStream_t s);
+int launch_channel_stats(const float *in, float *stats, int B, int C, int HW, hipStream_t s);
 int launch_attention(const float *qkv, const float *residual, float *out, int B, int C, int N, int heads, float scale,
                      hipStream_t s);
 int launch_timestep_embedding(const int64_t *t, const float *freqs, float *out, int B, int dim, hipStream_t s);

@@ -415,6 +415,16 @@ size_t conv_scratch_floats(const ddpm_conv_desc &d) {
   return ab > c ? ab : c;
 }
 
+// mirrors conv_dispatch: which kernel takes d, and whether its epilogue writes desc.stats_out
+int conv_stats_parts(const ddpm_conv_desc &d) {
+  const bool is3d = d.dims == 3 && d.ksize != 1;
+  if (is3d || d.ksize != 3 || d.Di > 1 || d.Do > 1 || linear_skinny_supported(d)) return 0;
+  if (conv_wino44h_supported(d)) return conv_wino44h_stats_parts(d);
+  if (conv_wino44_supported(d)) return 0;
+  if (conv_wino_supported(d)) return conv_wino_stats_parts(d);  // (the Upsample form only)
+  return 0;
+}
+
 int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
   DDPM_CHECK_ARG(d.in1 && d.out && d.B > 0 && d.Cout > 0 && d.C1 > 0, "conv: null tensor or empty shape");
   DDPM_CHECK_ARG(d.C2 == 0 || d.in2, "conv: C2 > 0 but in2 is NULL");

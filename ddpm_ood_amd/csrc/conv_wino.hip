@@ -182,6 +182,15 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   return true;
 }
 
+// slices per (image, cout) of the statistics conv_wino_up_kernel writes to desc.stats_out (0: not emitted)
+int conv_wino_stats_parts(const ddpm_conv_desc &d) {
+  WinoGeom g;
+  if (d.mode != DDPM_CONV_UPSAMPLE2 || d.dims == 3 || !d.w_wino || d.force_direct || !wino_geom(d, g) || g.S != 1) return 0;
+  const int per = g.TR * g.TWc;
+  if (g.TI == 1) return 2 * g.parts <= 8 ? 2 * g.parts : 0;
+  return per == 4 || per == 16 || per == 32 ? 1 : 0;
+}
+
 bool conv_wino_supported(const ddpm_conv_desc &d) {
   static const bool enabled = !(getenv("DDPM_CONV_WINOGRAD") && atoi(getenv("DDPM_CONV_WINOGRAD")) == 0);
   WinoGeom g;
@@ -843,6 +852,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_up_kernel(const ddpm_conv_de
     if (hf == 0) send(std::integral_constant<int, 0>{});
     else send(std::integral_constant<int, 1>{});
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // GroupNorm statistics of the produced tensor (desc.stats_out, as conv_wino44h.hip): a wave finishes 32 tiles = one
+    // slice of the image (TI == 1: 2 * parts slices of 32 low-res pixels) or whole images (`per` consecutive lanes each)
+    const bool emit_stats = a.stats_out != nullptr;
+    const int st_lanes = g.TI == 1 ? 32 : per;
+    const int st_parts = g.TI == 1 ? 2 * g.parts : 1, st_slice = g.TI == 1 ? 2 * part + tb : 0;
     auto finish = [&](auto hf_c) {
       constexpr int HF = decltype(hf_c)::value;
       const float *xr = smem + cbuf + (((wave & 3) * 2 + (1 - HF)) * 32) * 64 + elane;
@@ -857,6 +871,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino_up_kernel(const ddpm_conv_de
           const size_t o = obase + (size_t)((rr & 3) + 8 * (rr >> 2)) * g.HW;
           *reinterpret_cast<f2 *>(a.out + o) = f2{yy[0], yy[1]};
           *reinterpret_cast<f2 *>(a.out + o + a.Wo) = f2{yy[2], yy[3]};
+        }
+        if (emit_stats) {
+          float mean = 0.25f * ((yy[0] + yy[1]) + (yy[2] + yy[3]));
+          const float d0 = yy[0] - mean, d1 = yy[1] - mean, d2 = yy[2] - mean, d3 = yy[3] - mean;
+          float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          group_moments_last_lane(mean, m2, 4.f, st_lanes);
+          if (((elane & 31) & (st_lanes - 1)) == st_lanes - 1 && n < a.B) {
+            const size_t co = (size_t)co_base + (rr & 3) + 8 * (rr >> 2);
+            *reinterpret_cast<float2 *>(a.stats_out + (((size_t)n * a.Cout + co) * st_parts + st_slice) * 2) =
+                make_float2(mean, m2);
+          }
         }
       }
     };

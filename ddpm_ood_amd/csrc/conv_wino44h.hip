@@ -324,6 +324,16 @@ static bool w44h_enabled() {
   return !(sw && atoi(sw) == 0) && !(f && atoi(f) == 0);
 }
 
+// slices per (image, cout) of the GroupNorm statistics the epilogue writes to desc.stats_out (0: none -- 3-D, split
+// launches, tile counts per image that are not a power of two)
+int conv_wino44h_stats_parts(const ddpm_conv_desc &d) {
+  W44HGeom g;
+  if (!w44h_enabled() || !d.w_wino44h || d.force_direct || d.dims == 3 || !w44h_geom(d, g, true)) return 0;
+  const int per = g.TR * g.TWc;
+  if (g.S != 1 || (per != 4 && per != 16 && per != 32) || g.parts > 8) return 0;
+  return g.parts;
+}
+
 bool conv_wino44h_supported(const ddpm_conv_desc &d) {
   W44HGeom g;
   return w44h_enabled() && d.w_wino44h != nullptr && !d.force_direct && w44h_geom(d, g);
@@ -926,9 +936,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
         res[k] = *reinterpret_cast<const v4f *>(a.residual + obase0 + (size_t)(8 * q) * cstr + (size_t)k * a.Wo);
     };
     if (RES) load_res(0);
+    // GroupNorm statistics of the tensor this launch produces (desc.stats_out): per (image, cout, part) the mean and the
+    // sum of squared deviations M2 of the item's pixels of that channel, merged pairwise (Chan) in a fixed order
+    const bool emit_stats = !D3 && a.stats_out != nullptr && g.S == 1;
     auto pass = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
       const size_t obase = obase0 + (size_t)(8 * q) * cstr;
+      float st_p = 0.f, st_s1 = 0.f, st_s2 = 0.f;  // this lane's 4x4 tile about a pivot (its first value)
       {
         float *xw = XS + cb * 64 + elane;
 #pragma unroll
@@ -970,6 +984,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
           if (RES) o += res[k];
           if (D3 && a.out_act == DDPM_ACT_RELU) o = v4f{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)};
           if (n < g.NIMG) *reinterpret_cast<v4f *>(outp + obase + (size_t)k * a.Wo) = o;
+          if (emit_stats) {
+            if (k == 0) st_p = o[0];
+            const v4f dd = o - st_p;
+            st_s1 += (dd[0] + dd[1]) + (dd[2] + dd[3]);
+            st_s2 += (dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]);
+          }
         }
       };
       half(I0{});
@@ -986,6 +1006,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
 #pragma unroll
         for (int k = 2; k < 4; ++k)
           res[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * cstr + (size_t)k * a.Wo);
+      }
+      if (emit_stats) {
+        // lane: {mean, M2} of its tile; the item's tiles of one image are `per` consecutive lanes (4, 16 or 32)
+        float mean = st_p + st_s1 * (1.f / 16.f);
+        float m2 = fmaxf(st_s2 - st_s1 * st_s1 * (1.f / 16.f), 0.f);
+        group_moments_last_lane(mean, m2, 16.f, per);
+        if (rem == per - 1 && n < g.NIMG) {
+          const size_t co = (size_t)kt * kK + cb * 32 + 8 * q + 4 * elhi + pg;
+          *reinterpret_cast<float2 *>(a.stats_out + (((size_t)n * a.Cout + co) * g.parts + part) * 2) = make_float2(mean, m2);
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };

@@ -190,6 +190,148 @@ __global__ __launch_bounds__(256) void gn_scale_shift_wave_kernel(const float *_
   }
 }
 
+// ---- statistics produced elsewhere (ddpm_conv_desc.stats_out / channel_stats_kernel): scale / shift without a pass over
+// the activation.  One workgroup per image: thread c folds channel c's slices to {sum of means, M2 about the channel's
+// own mean} in LDS, thread g then merges its group's channels (the group mean first, then the squared deviations about
+// it: the two-pass formula on pre-reduced slices) in a fixed order, and the channels' threads write scale / shift.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ st1, int parts1, int C1,
+                                                          const float *__restrict__ st2, int parts2, int C2,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float *__restrict__ scale,
+                                                          float *__restrict__ shift, int HW, int G, float eps) {
+  extern __shared__ float sm[];  // [C] channel means, [C] channel M2, [G] group mean, [G] group rstd
+  const int C = C1 + C2, cpg = C / G;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float *cmean = sm, *cm2 = sm + C, *gmean = sm + 2 * C, *grstd = sm + 2 * C + G;
+  for (int c = tid; c < C; c += 256) {
+    const bool first = c < C1;
+    const int parts = first ? parts1 : parts2;
+    const float2 *e = first ? reinterpret_cast<const float2 *>(st1) + ((size_t)n * C1 + c) * parts1
+                            : reinterpret_cast<const float2 *>(st2) + ((size_t)n * C2 + (c - C1)) * parts2;
+    float2 v[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v[p] = p < parts ? e[p] : make_float2(0.f, 0.f);
+    float ms = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) ms += v[p].x;
+    const float mean = ms / (float)parts;  // equal slices
+    float q = 0.f, dv = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      if (p < parts) {
+        const float dl = v[p].x - mean;
+        q += v[p].y;
+        dv += dl * dl;
+      }
+    }
+    cmean[c] = mean;
+    cm2[c] = q + (float)(HW / parts) * dv;
+  }
+  __syncthreads();
+  for (int g = tid; g < G; g += 256) {
+    const int c0 = g * cpg;
+    float ms = 0.f;
+    for (int c = c0; c < c0 + cpg; ++c) ms += cmean[c];
+    const float mean = ms / (float)cpg;  // every channel has HW values
+    float q = 0.f, dv = 0.f;
+    for (int c = c0; c < c0 + cpg; ++c) {
+      const float dl = cmean[c] - mean;
+      q += cm2[c];
+      dv += dl * dl;
+    }
+    const float var = (q + (float)HW * dv) / ((float)cpg * (float)HW);  // biased, as torch
+    gmean[g] = mean;
+    grstd[g] = 1.0f / sqrtf(var + eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float sc = grstd[g] * gamma[c];
+    scale[(size_t)n * C + c] = sc;
+    shift[(size_t)n * C + c] = -sc * gmean[g] + beta[c];
+  }
+}
+
+int launch_gn_finalize(const float *st1, int parts1, int C1, const float *st2, int parts2, int C2, const float *gamma,
+                       const float *beta, float *scale, float *shift, int B, int HW, int groups, float eps, hipStream_t s) {
+  const int C = C1 + C2;
+  DDPM_CHECK_ARG(st1 && gamma && beta && scale && shift, "gn_finalize: null pointer");
+  DDPM_CHECK_ARG(C2 == 0 || (st2 && parts2 > 0), "gn_finalize: C2 > 0 but no second slab");
+  DDPM_CHECK_ARG(groups > 0 && C % groups == 0, "gn_finalize: C %% groups != 0");
+  DDPM_CHECK_ARG(B > 0 && HW > 0 && parts1 > 0 && parts1 <= 8 && parts2 <= 8 && HW % parts1 == 0 &&
+                     (C2 == 0 || HW % parts2 == 0),
+                 "gn_finalize: bad B / HW / parts (1 .. 8 equal slices)");
+  const size_t lds = (size_t)(2 * C + 2 * groups) * sizeof(float);
+  DDPM_CHECK_ARG(lds <= 48 * 1024, "gn_finalize: too many channels");
+  ProfScope prof(s, "gn_finalize", 6.0 * B * C * parts1, 8.0 * B * (double)(C1 * parts1 + C2 * parts2) + 8.0 * B * C);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), lds, s, st1, parts1, C1, st2, parts2, C2, gamma, beta, scale,
+                     shift, HW, groups, eps);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+// Per-channel {mean, M2} of a tensor whose producer does not emit them: one wave per (image, channel), two passes (the
+// plane stays in registers up to 64 * 4 * kCHold floats, larger planes are re-read from L2).
+template <int kCHold>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float *__restrict__ in, float *__restrict__ stats,
+                                                            int HW, int total) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);  // (image, channel)
+  if (item >= total) return;
+  const float *pl = in + (size_t)item * HW;
+  float mean, q = 0.f;
+  if (kCHold > 0) {
+    const int n4 = HW >> 2;
+    float4 v[kCHold > 0 ? kCHold : 1];
+#pragma unroll
+    for (int i = 0; i < kCHold; ++i) {
+      const int e = lane + 64 * i;
+      v[i] = e < n4 ? reinterpret_cast<const float4 *>(pl)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < kCHold; ++i) sm += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    mean = wave_sum(sm) / (float)HW;
+#pragma unroll
+    for (int i = 0; i < kCHold; ++i) {
+      if (lane + 64 * i < n4) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+  } else {
+    float sm = 0.f;
+    for (int e = lane; e < HW; e += 64) sm += pl[e];
+    mean = wave_sum(sm) / (float)HW;
+    for (int e = lane; e < HW; e += 64) {
+      const float a = pl[e] - mean;
+      q += a * a;
+    }
+  }
+  q = wave_sum(q);
+  if (lane == 0) reinterpret_cast<float2 *>(stats)[item] = make_float2(mean, q);
+}
+
+int launch_channel_stats(const float *in, float *stats, int B, int C, int HW, hipStream_t s) {
+  DDPM_CHECK_ARG(in && stats && B > 0 && C > 0 && HW > 0, "channel_stats: bad argument");
+  ProfScope prof(s, "gn_channel_stats", 5.0 * B * C * HW, 4.0 * B * C * (double)HW);
+  const long total = (long)B * C;
+  DDPM_CHECK_ARG(total < (1l << 31) - 4, "channel_stats: too many planes");
+  const dim3 grid((unsigned)((total + 3) / 4));
+  const bool v4 = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+  const int n4 = HW >> 2;
+  if (v4 && n4 <= 64)
+    hipLaunchKernelGGL(channel_stats_kernel<1>, grid, dim3(256), 0, s, in, stats, HW, (int)total);
+  else if (v4 && n4 <= 64 * 4)
+    hipLaunchKernelGGL(channel_stats_kernel<4>, grid, dim3(256), 0, s, in, stats, HW, (int)total);
+  else if (v4 && n4 <= 64 * 16)
+    hipLaunchKernelGGL(channel_stats_kernel<16>, grid, dim3(256), 0, s, in, stats, HW, (int)total);
+  else
+    hipLaunchKernelGGL(channel_stats_kernel<0>, grid, dim3(256), 0, s, in, stats, HW, (int)total);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
 int launch_gn_scale_shift(const float *in1, const float *in2, int C1, int C2, const float *gamma, const float *beta,
                           float *scale, float *shift, int B, int HW, int groups, float eps, hipStream_t s) {
   const int C = C1 + C2;

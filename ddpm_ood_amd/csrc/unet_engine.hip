@@ -14,6 +14,7 @@
 //                or conv3x3[...] -> h2 ; conv1x1(x)[+bias, +h2]      -> out     (Cin != Cout)
 // torch.cat is virtual (two source pointers), nearest-x2 upsample and stride-2 are input
 // indexing, the 11 time_emb_proj Linears are ONE GEMM, to_q/to_k/to_v are ONE 1x1 conv.
+#include <deque>
 #include <map>
 #include <tuple>
 #include <vector>
@@ -452,9 +453,15 @@ struct Bump {
   void release(size_t m) { off = m; }
 };
 
+constexpr int kMaxStatParts = 8;  // slices per (image, channel) of a GroupNorm statistics slab (ddpm_conv_desc.stats_out)
+
 struct Act {  // an activation tensor [B, C, H, W] (D == 1) or [B, C, D, H, W]
   float *p = nullptr;
   int C = 0, H = 0, W = 0, D = 1;
+  // per-channel GroupNorm statistics [B, C, *sparts, 2] written by the tensor's producer (or by gn_channel_stats on first
+  // use); *sparts == 0: not computed.  The counter lives in the Runner so that copies of the Act (skip stack) share it.
+  float *stats = nullptr;
+  int *sparts = nullptr;
   size_t voxels() const { return (size_t)D * H * W; }
 };
 
@@ -465,11 +472,15 @@ struct Runner {
   int B;
   int rc = 0;
   float *temb = nullptr;  // [B, temb_total]
+  std::deque<int> spool;  // Act::sparts storage (stable addresses)
+  bool fuse_stats = !(getenv("DDPM_GN_FUSED") && atoi(getenv("DDPM_GN_FUSED")) == 0);  // 0: every GroupNorm reads its input
+  bool eager_stats = false;  // large launches: per-channel slabs for every tensor (a skip connection is reduced once, not twice)
 
   const float *P(size_t off) const { return u->blob + off; }
 
   void conv(const ConvRef &c, const Act &in1, const Act *in2, const float *gsc, const float *gsh, int act, int mode,
-            const float *chan_add, int chan_stride, const float *residual, float *out, int Ho, int Wo, int Do = 1) {
+            const float *chan_add, int chan_stride, const float *residual, float *out, int Ho, int Wo, int Do = 1,
+            const Act *outact = nullptr) {
     if (rc) return;
     ddpm_conv_desc d{};
     d.in1 = in1.p; d.C1 = in1.C;
@@ -508,11 +519,39 @@ struct Runner {
       d.scratch_floats = need;
     }
     if (ws.dry) return;
+    if (outact && outact->stats && fuse_stats) {  // the epilogue leaves the next GroupNorm's statistics behind
+      const int sp = conv_stats_parts(d);
+      if (sp > 0 && sp <= kMaxStatParts) {
+        d.stats_out = outact->stats;
+        *outact->sparts = sp;
+      }
+    }
     rc = conv_dispatch(d, s);
   }
 
+  // GroupNorm -> scale / shift.  Sources whose producer left per-channel statistics need no pass over the activation; a
+  // source without them is reduced per channel once (and keeps the slab for its later uses, e.g. as a skip connection) when
+  // the other source has them; with no statistics at all the round-2 kernel reads the input(s).
   void gn(const GNRef &g, const Act &in1, const Act *in2, float *sc, float *sh) {
     if (ws.dry || rc) return;
+    const bool h1 = in1.sparts && *in1.sparts > 0, h2 = in2 && in2->sparts && *in2->sparts > 0;
+    const bool can1 = in1.stats != nullptr, can2 = !in2 || in2->stats != nullptr;
+    if (fuse_stats && can1 && can2 && (h1 || h2 || eager_stats)) {
+      const int HW = (int)in1.voxels();
+      if (!h1) {
+        rc = launch_channel_stats(in1.p, in1.stats, B, in1.C, HW, s);
+        *in1.sparts = 1;
+      }
+      if (!rc && in2 && !h2) {
+        rc = launch_channel_stats(in2->p, in2->stats, B, in2->C, HW, s);
+        *in2->sparts = 1;
+      }
+      if (!rc)
+        rc = launch_gn_finalize(in1.stats, *in1.sparts, in1.C, in2 ? in2->stats : nullptr, in2 ? *in2->sparts : 0,
+                                in2 ? in2->C : 0, P(g.gamma), P(g.beta), sc, sh, B, HW, u->cfg.norm_num_groups,
+                                u->cfg.norm_eps, s);
+      return;
+    }
     rc = launch_gn_scale_shift(in1.p, in2 ? in2->p : nullptr, in1.C, in2 ? in2->C : 0, P(g.gamma), P(g.beta), sc, sh,
                                B, (int)in1.voxels(), u->cfg.norm_num_groups, u->cfg.norm_eps, s);
   }
@@ -524,17 +563,18 @@ struct Runner {
     const size_t hw = in1.voxels();
     float *sc1 = ws.get((size_t)B * r.Cin), *sh1 = ws.get((size_t)B * r.Cin);
     gn(r.n1, in1, in2, sc1, sh1);
-    Act h1{ws.get((size_t)B * r.Cout * hw), r.Cout, H, W, D};
+    Act h1 = new_act(r.Cout, H, W, D);
     conv(r.c1, in1, in2, sc1, sh1, DDPM_ACT_SILU, DDPM_CONV_NORMAL, temb + r.temb_off, u->temb_total, nullptr, h1.p,
-         H, W, D);
+         H, W, D, &h1);
     float *sc2 = ws.get((size_t)B * r.Cout), *sh2 = ws.get((size_t)B * r.Cout);
     gn(r.n2, h1, nullptr, sc2, sh2);
     if (!r.has_skip) {
-      conv(r.c2, h1, nullptr, sc2, sh2, DDPM_ACT_SILU, DDPM_CONV_NORMAL, nullptr, 0, in1.p, out.p, H, W, D);
+      conv(r.c2, h1, nullptr, sc2, sh2, DDPM_ACT_SILU, DDPM_CONV_NORMAL, nullptr, 0, in1.p, out.p, H, W, D, &out);
     } else {
+      // skip_connection(x) first, conv2 adds it: the block's output then comes from the kernel that emits statistics
       Act h2{ws.get((size_t)B * r.Cout * hw), r.Cout, H, W, D};
-      conv(r.c2, h1, nullptr, sc2, sh2, DDPM_ACT_SILU, DDPM_CONV_NORMAL, nullptr, 0, nullptr, h2.p, H, W, D);
-      conv(r.skip, in1, in2, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, h2.p, out.p, H, W, D);
+      conv(r.skip, in1, in2, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, nullptr, h2.p, H, W, D);
+      conv(r.c2, h1, nullptr, sc2, sh2, DDPM_ACT_SILU, DDPM_CONV_NORMAL, nullptr, 0, h2.p, out.p, H, W, D, &out);
     }
     ws.release(m);
   }
@@ -558,10 +598,20 @@ struct Runner {
     ws.release(m);
   }
 
-  Act new_act(int C, int H, int W, int D = 1) { return Act{ws.get((size_t)B * C * D * H * W), C, H, W, D}; }
+  Act new_act(int C, int H, int W, int D = 1) {
+    Act a{ws.get((size_t)B * C * D * H * W), C, H, W, D};
+    if (D == 1) {  // (the 3-D levels keep the reading GroupNorm: their producers emit no statistics)
+      a.stats = ws.get((size_t)B * C * kMaxStatParts * 2);
+      if (ws.dry) a.stats = reinterpret_cast<float *>(16);  // non-NULL marker: the dry run takes the same decisions
+      spool.push_back(0);
+      a.sparts = &spool.back();
+    }
+    return a;
+  }
 
   int run(const float *x, const int64_t *timesteps, float *out, int H, int W, int D = 1) {
     const ddpm_unet_config &cfg = u->cfg;
+    eager_stats = (size_t)B * H * W >= 64 * 1024;
     // ---- timestep embedding + MLP + all time projections ------------------------------------------
     Act temb0{ws.get((size_t)B * u->ch0), u->ch0, 1, 1};
     if (!ws.dry && !rc) rc = launch_timestep_embedding(timesteps, P(u->freqs_off), temb0.p, B, u->ch0, s);
@@ -577,7 +627,7 @@ struct Runner {
     Act xin{const_cast<float *>(x), cfg.in_channels, H, W, D};
     Act h = new_act(u->ch0, H, W, D);
     conv(u->conv_in, xin, nullptr, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, nullptr, h.p, H, W,
-         D);
+         D, &h);
     std::vector<Act> skips;
     skips.push_back(h);
     for (size_t i = 0; i < u->down.size(); ++i) {
@@ -597,7 +647,7 @@ struct Runner {
         const int Ho = (h.H + 1) / 2, Wo = (h.W + 1) / 2, Do = h.D > 1 ? (h.D + 1) / 2 : 1;
         Act o = new_act(h.C, Ho, Wo, Do);
         conv(d.down, h, nullptr, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_STRIDE2, nullptr, 0, nullptr, o.p, Ho, Wo,
-             Do);
+             Do, &o);
         h = o;
         skips.push_back(h);
       }
@@ -637,7 +687,7 @@ struct Runner {
         const int Do = cfg.spatial_dims == 3 ? 2 * h.D : 1;  // nearest x2 doubles a depth of 1 as well
         Act o = new_act(h.C, 2 * h.H, 2 * h.W, Do);
         conv(b.up, h, nullptr, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_UPSAMPLE2, nullptr, 0, nullptr, o.p, 2 * h.H,
-             2 * h.W, Do);
+             2 * h.W, Do, &o);
         h = o;
       }
     }

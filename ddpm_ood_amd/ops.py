@@ -91,8 +91,9 @@ def pack_wino44h_weight(weight: torch.Tensor) -> torch.Tensor | None:
 
 def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NONE, mode=CONV_NORMAL,
          chan_add=None, chan_add_offset=0, residual=None, packed=None, force_direct=False, folded=None,
-         wino=None, out_act=ACT_NONE, wino44=None, wino44h=None):
-    """Fused conv / linear.  x: [B, C1, H, W]; x2: optional second source of a virtual concat."""
+         wino=None, out_act=ACT_NONE, wino44=None, wino44h=None, want_stats=False):
+    """Fused conv / linear.  x: [B, C1, H, W]; x2: optional second source of a virtual concat.
+    want_stats: return (out, stats) with the produced tensor's per-channel GroupNorm statistics (ddpm_conv_desc.stats_out)."""
     lib = _lib.load()
     x = require_device_f32(x, "x")
     w = require_device_f32(weight, "weight")
@@ -150,7 +151,15 @@ def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NON
         scratch = torch.empty(need, dtype=torch.float32, device=x.device)
         keep.append(scratch)
         d.scratch, d.scratch_floats = ptr(scratch), need
+    stats = None
+    if want_stats:  # GroupNorm statistics of the produced tensor from the epilogue: [B, Cout, parts, 2] (None: not emitted)
+        parts = lib.ddpm_conv_stats_parts(C.byref(d))
+        if parts > 0:
+            stats = torch.empty((B, cout, parts, 2), dtype=torch.float32, device=x.device)
+            d.stats_out = ptr(stats)
     check(lib.ddpm_conv_f32(C.byref(d), stream_ptr()), "conv")
+    if want_stats:
+        return out, stats
     return out[:, :, 0, 0] if was_linear else out
 
 
@@ -396,6 +405,36 @@ def gn_scale_shift(x, gamma, beta, groups: int, eps: float, x2=None):
     check(lib.ddpm_gn_scale_shift_f32(ptr(x), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(scale), ptr(shift), B, hw,
                                       groups, eps, stream_ptr()), "gn_scale_shift")
     return scale, shift
+
+
+def gn_finalize(stats, gamma, beta, groups: int, eps: float, hw: int, stats2=None):
+    """scale / shift of F.group_norm from per-channel statistics slabs [B, C, parts, 2] = {mean, M2} per slice (the
+    `stats` of conv(..., want_stats=True) or channel_stats); stats2: second source of a virtual concat."""
+    lib = _lib.load()
+    stats = require_device_f32(stats, "stats")
+    B, C1, parts1, _ = stats.shape
+    C2 = parts2 = 0
+    if stats2 is not None:
+        stats2 = require_device_f32(stats2, "stats2")
+        _, C2, parts2, _ = stats2.shape
+    gamma = require_device_f32(gamma, "gamma")
+    beta = require_device_f32(beta, "beta")
+    scale = torch.empty((B, C1 + C2), dtype=torch.float32, device=stats.device)
+    shift = torch.empty_like(scale)
+    check(lib.ddpm_gn_finalize_f32(ptr(stats), parts1, C1, ptr(stats2), parts2, C2, ptr(gamma), ptr(beta), ptr(scale),
+                                   ptr(shift), B, hw, groups, eps, stream_ptr()), "gn_finalize")
+    return scale, shift
+
+
+def channel_stats(x):
+    """[B, C, 1, 2] = per-channel {mean, sum of squared deviations} of x [B, C, ...]."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    B, Cc = x.shape[:2]
+    hw = x[0, 0].numel()
+    stats = torch.empty((B, Cc, 1, 2), dtype=torch.float32, device=x.device)
+    check(lib.ddpm_channel_stats_f32(ptr(x), ptr(stats), B, Cc, hw, stream_ptr()), "channel_stats")
+    return stats
 
 
 def attention(qkv, residual, num_heads: int, scale: float):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDPM_ABI_VERSION 6
+#define DDPM_ABI_VERSION 7
 
 #define DDPM_EINVAL (-1)      /* bad argument / unsupported shape      */
 #define DDPM_ENOPARAM (-2)    /* unknown or missing parameter name     */
@@ -121,11 +121,21 @@ typedef struct ddpm_conv_desc {
    * partial products, fp32 accumulate); transforms and sums stay fp32.  Takes precedence over w_wino44;
    * DDPM_WINO44_F16X3=0 switches it off.  */
   const uint16_t *w_wino44h;
+  /* Optional (ABI 7): GroupNorm statistics of the PRODUCED tensor, written by the convolution's epilogue so that the
+   * following F.group_norm (reference call site src/trainers/reconstruct.py:151-153 -> generative ResnetBlock.norm2 /
+   * the next block's norm1) needs no pass of its own over the activation.  Layout [B, Cout, parts, 2] floats:
+   * {mean, sum of squared deviations} of each channel over one of `parts` equal slices of the image's pixels
+   * (parts = ddpm_conv_stats_parts(d); 0 = this dispatch does not emit them and stats_out is ignored).  Merged pairwise
+   * in a fixed order (no atomics): bit-reproducible.  ddpm_gn_finalize_f32 turns them into scale / shift.  */
+  float *stats_out;
 } ddpm_conv_desc;
 
 int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream);
 /* Floats of scratch this descriptor can use (0: none); device- and shape-dependent, constant for a given process.  */
 size_t ddpm_conv_scratch_floats(const ddpm_conv_desc *d);
+/* Slices per (image, channel) of the statistics ddpm_conv_f32 writes to d->stats_out for this descriptor (1 .. 8), or 0
+ * when the kernel it dispatches to does not emit them (the caller then runs ddpm_gn_scale_shift_f32 on the tensor).  */
+int ddpm_conv_stats_parts(const ddpm_conv_desc *d);
 
 /* Number of floats of the packed form of a [Cout, Cin, k, k] weight (0 if unpackable). */
 size_t ddpm_packed_conv_weight_floats(int Cout, int Cin, int ksize);
@@ -201,6 +211,17 @@ int ddpm_fold_upsample_weight_f32(const float *w_raw, float *w_folded, int Cout,
 int ddpm_gn_scale_shift_f32(const float *in1, const float *in2, int C1, int C2, const float *gamma,
                             const float *beta, float *scale, float *shift, int B, int HW, int groups,
                             float eps, ddpm_stream_t stream);
+
+/* The same scale / shift from per-channel statistics slabs (ddpm_conv_desc.stats_out of the producing convolutions, or
+ * ddpm_channel_stats_f32): st1 is [B, C1, parts1, 2], st2 [B, C2, parts2, 2] or NULL (C2 = 0); every entry covers
+ * HW / parts pixels.  One thread per (image, group) merges the entries in a fixed order (mean, then squared deviations
+ * about it): no pass over the activation.  */
+int ddpm_gn_finalize_f32(const float *st1, int parts1, int C1, const float *st2, int parts2, int C2, const float *gamma,
+                         const float *beta, float *scale, float *shift, int B, int HW, int groups, float eps,
+                         ddpm_stream_t stream);
+/* Per-channel statistics slab [B, C, 1, 2] = {mean, sum of squared deviations} of a [B, C, HW] tensor whose producer does
+ * not emit them (one wave per (image, channel), two passes over registers).  */
+int ddpm_channel_stats_f32(const float *in, float *stats, int B, int C, int HW, ddpm_stream_t stream);
 
 /* Self-attention core of AttentionBlock (A.3): qkv is [B, 3C, N] (q rows, then k, then v,
  * channel-major exactly as a 1x1 conv over NCHW produces them); out = softmax(scale q^T k) v

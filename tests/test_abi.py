@@ -41,12 +41,12 @@ def test_struct_layouts_match_header(lib):
     from ddpm_ood_amd._lib import ConvDesc, UNetConfig
 
     # field order of the C structs (pointers 8 B, ints 4 B): sizes computed by hand from the header
-    assert C.sizeof(ConvDesc) == 8 + 8 + 4 + 4 + 8 * 5 + 8 + 8 + 8 + 8 + 4 * 10 + 4 * 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # incl. padding after stride; + scratch, scratch_floats, w_wino44, w_wino44h
+    assert C.sizeof(ConvDesc) == 8 + 8 + 4 + 4 + 8 * 5 + 8 + 8 + 8 + 8 + 4 * 10 + 4 * 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # incl. padding after stride; + scratch, scratch_floats, w_wino44, w_wino44h, stats_out
     assert C.sizeof(UNetConfig) == 4 * 4 + 4 * 8 * 4 + 4 + 4 + 4
 
 
 def test_host_only_entry_points(lib):
-    assert lib.ddpm_abi_version() == 6
+    assert lib.ddpm_abi_version() == 7
     assert lib.ddpm_packed_conv_weight_floats(128, 128, 3) == 128 * 128 * 9
     assert lib.ddpm_packed_conv_weight_floats(96, 128, 3) == 0      # Cout % 128
     assert lib.ddpm_packed_conv_weight_floats(128, 3, 3) == 0       # Cin % 8

@@ -1064,6 +1064,35 @@ def test_conv_upsample_winograd(device, case):
         assert (y - y_folded).abs().max().item() < 4e-5 * (1 + ref.abs().max().item())
 
 
+@pytest.mark.parametrize("case", UP_WINO_CASES)
+def test_conv_upsample_winograd_emits_groupnorm_statistics(device, case):
+    """desc.stats_out of the Upsample kernel: per-(image, cout, slice) {mean, M2} of the tensor it wrote."""
+    from ddpm_ood_amd import ops
+
+    B, Cin, Cout, H, extra = case
+    g = torch.Generator().manual_seed(B * 13 + H)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    residual = torch.randn(B, Cout, 2 * H, 2 * H, generator=g) if extra else None
+    d = lambda t: None if t is None else t.to(device)
+    wino = ops.pack_wino_weight(d(w))
+    y_plain = ops.conv(d(x), d(w), d(b), mode=ops.CONV_UPSAMPLE2, residual=d(residual), wino=wino)
+    y, st = ops.conv(d(x), d(w), d(b), mode=ops.CONV_UPSAMPLE2, residual=d(residual), wino=wino, want_stats=True)
+    assert torch.equal(y, y_plain)
+    parts = {16: 8, 8: 2, 4: 1, 32: None}[H]
+    if parts is None:  # 32 slices per image: more than a slab holds
+        assert st is None
+        return
+    assert st is not None and tuple(st.shape) == (B, Cout, parts, 2)
+    yd = y.double().cpu().view(B, Cout, parts, -1)
+    mean = yd.mean(-1)
+    m2 = (yd - mean[..., None]).pow(2).sum(-1)
+    st = st.cpu().double()
+    assert (st[..., 0] - mean).abs().max().item() <= 2e-6 * (1 + mean.abs().max().item() + (m2 / yd.shape[-1]).sqrt().max().item())
+    assert ((st[..., 1] - m2).abs() / (m2 + 1e-3 * m2.mean())).max().item() <= 2e-5
+
+
 @pytest.mark.parametrize("case", [(3, 128, (8, 8, 8), 2048), (2, 32, (4, 5, 6), 100), (5, 8, (7, 9), 17)])
 def test_vq_nearest(device, case):
     """VQ-VAE quantiser on the HIP kernel vs the oracle's formula (argmin of the expanded squared distance)."""
@@ -1132,3 +1161,40 @@ def test_vq_nearest_generic_embedding_dim(device):
     brute = ((flat[:, None, :] - e[None]) ** 2).sum(-1).argmin(1)
     assert torch.equal(idx.cpu().reshape(-1), brute)
     assert torch.allclose(out.cpu().movedim(1, -1).reshape(-1, 12), e[brute], atol=1e-6)
+
+
+# ---- GroupNorm from per-channel statistics slabs (ABI 7) ------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [(3, 128, 0, 1024), (5, 256, 128, 256), (2, 256, 256, 64), (2, 64, 0, 4096), (3, 32, 0, 100)])
+def test_gn_finalize_from_channel_stats_matches_group_norm(device, shape):
+    """channel_stats + gn_finalize == the reading kernel == F.group_norm's statistics, incl. a virtual concat whose groups
+    straddle the seam (384 = 256 + 128 channels, 12 per group) and slabs with different slice counts per source."""
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, HW = shape
+    g = torch.Generator().manual_seed(B * 1000 + C1 + HW)
+    x = torch.randn(B, C1, HW, generator=g) * 1.7 + 0.6
+    x2 = torch.randn(B, C2, HW, generator=g) * 0.4 - 2.0 if C2 else None
+    C = C1 + C2
+    gamma, beta = torch.randn(C, generator=g) * 0.3 + 1, torch.randn(C, generator=g) * 0.3
+    d = lambda t: None if t is None else t.to(device)
+    st1 = ops.channel_stats(d(x))
+    xd = x.double()
+    assert (st1[:, :, 0, 0].cpu().double() - xd.mean(-1)).abs().max().item() < 2e-6
+    m2 = (xd - xd.mean(-1, keepdim=True)).pow(2).sum(-1)
+    assert ((st1[:, :, 0, 1].cpu().double() - m2).abs() / m2).max().item() < 1e-5
+    st2 = ops.channel_stats(d(x2)) if C2 else None
+    if C2 and HW % 4 == 0:  # the second source as a 4-slice slab (what a producer with 4 items per image leaves behind)
+        x2d = x2.double().view(B, C2, 4, HW // 4)
+        mu = x2d.mean(-1)
+        st2 = torch.stack([mu, (x2d - mu[..., None]).pow(2).sum(-1)], -1).float().to(device).contiguous()
+    sc, sh = ops.gn_finalize(st1, d(gamma), d(beta), 32, 1e-6, HW, stats2=st2)
+    sc_r, sh_r = ops.gn_scale_shift(d(x), d(gamma), d(beta), 32, 1e-6, x2=d(x2))
+    xin = (x if x2 is None else torch.cat([x, x2], 1)).double()
+    ref = torch.nn.functional.group_norm(xin, 32, gamma.double(), beta.double(), 1e-6)
+    got = xin * sc.cpu().double()[:, :, None] + sh.cpu().double()[:, :, None]
+    old = xin * sc_r.cpu().double()[:, :, None] + sh_r.cpu().double()[:, :, None]
+    e_new, e_old = (got - ref).abs().max().item(), (old - ref).abs().max().item()
+    assert e_new <= 5e-6 and e_new <= 2 * e_old + 1e-6, (e_new, e_old)
+    sc2, sh2 = ops.gn_finalize(st1, d(gamma), d(beta), 32, 1e-6, HW, stats2=st2)
+    assert torch.equal(sc, sc2) and torch.equal(sh, sh2)

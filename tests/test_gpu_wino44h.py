@@ -232,3 +232,50 @@ def test_conv3d_wino44h_vs_conv3d(device, case, monkeypatch):
         assert err.abs().max().item() < 2e-4 * (1 + ref.abs().max().item()), err.abs().max().item()
         assert err.pow(2).mean().sqrt().item() < 1e-5 * (1 + ref.pow(2).mean().sqrt().item())
     assert torch.equal(y, ops.conv3d(d(x), d(w), d(b), wino44h=wh, **kw))
+
+
+# ---- GroupNorm statistics from the epilogue (ddpm_conv_desc.stats_out, ABI 7) ------------------------------------------
+
+STATS_PARTS = {32: 2, 16: 1, 8: 1, 64: 8}  # image extent -> slices per (image, channel): items per image of the kernel
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_wino44h_emits_groupnorm_statistics(device, case, monkeypatch):
+    """The epilogue's per-(image, cout, slice) {mean, M2} equal those of the tensor it wrote (float64 reference over the
+    kernel's own output), the output is bit-identical with and without them, and they are bit-reproducible."""
+    monkeypatch.setenv("DDPM_CONV_WINO44", "2")
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, Cout, H, gn, chan, res = case
+    t = _inputs(case)
+    wh = ops.pack_wino44h_weight(t[2].to(device))
+    y_plain = _run(device, case, t, wino44h=wh)
+    y, st = _run(device, case, t, wino44h=wh, want_stats=True)
+    assert torch.equal(y, y_plain)
+    parts = STATS_PARTS[H]
+    assert st is not None and tuple(st.shape) == (B, Cout, parts, 2), None if st is None else st.shape
+    # slice p = tile rows [p TR, (p + 1) TR) = a contiguous slab of H / parts pixel rows
+    yd = y.double().cpu().view(B, Cout, parts, (H // parts) * H)
+    mean = yd.mean(-1)
+    m2 = (yd - mean[..., None]).pow(2).sum(-1)
+    st = st.cpu().double()
+    sd = (m2 / yd.shape[-1]).sqrt()
+    assert (st[..., 0] - mean).abs().max().item() <= 2e-6 * (1 + mean.abs().max().item() + sd.max().item())
+    assert ((st[..., 1] - m2).abs() / (m2 + 1e-3 * m2.mean())).max().item() <= 2e-5
+    y2, st2 = _run(device, case, t, wino44h=wh, want_stats=True)
+    assert torch.equal(st2.cpu().double(), st)
+
+
+def test_conv_stats_parts_zero_where_not_emitted(device, monkeypatch):
+    """Dispatches without the emitting epilogue (a split launch smaller than the chip, kernels other than conv_wino44h)
+    report 0 parts: the caller falls back to a reading GroupNorm."""
+    from ddpm_ood_amd import ops
+
+    monkeypatch.delenv("DDPM_CONV_WINO44", raising=False)
+    case = (4, 128, 0, 128, 32, True, True, True)  # 2 x 2 x 4 = 16 items: channel-split launch with a reduce pass
+    t = _inputs(case)
+    w = t[2].to(device)
+    y, st = _run(device, case, t, wino44h=ops.pack_wino44h_weight(w), want_stats=True)
+    assert st is None
+    y, st = _run(device, case, t, wino44=ops.pack_wino44_weight(w), want_stats=True)
+    assert st is None
