@@ -314,7 +314,9 @@ static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false)
   g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW) * g.S;
   g.grid = g.KT * ((g.NS + 7) / 8) * 8;
   const char *xm = getenv("DDPM_WINO44_XMAP");
-  g.xmap = (xm ? atoi(xm) != 0 : 1) && (8 % g.KT == 0);
+  // default 0: the cout tiles of a slot are neighbours on ONE XCD, so that the KT re-reads of the slot's input hit that XCD's L2
+  // (rocprofv3 FETCH_SIZE / WRITE_SIZE at B = 1 024: 1.14 GB per launch against 1.49 GB with one cout tile per XCD, same time)
+  g.xmap = (xm ? atoi(xm) != 0 : 0) && (8 % g.KT == 0);
   if (g.xmap) g.grid = 8 * ((g.NS + 8 / g.KT - 1) / (8 / g.KT));
   return true;
 }
