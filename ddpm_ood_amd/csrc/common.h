@@ -74,7 +74,7 @@ __device__ __forceinline__ void chan_merge_dpp(float &mean, float &m2, float &ha
   mean = 0.5f * (mean + mo);
   halfn += halfn;
 }
-__device__ __forceinline__ void group_moments_last_lane(float &mean, float &m2, float cnt, int lanes) {  // lanes: 4, 16, 32
+__device__ __forceinline__ void group_moments_last_lane(float &mean, float &m2, float cnt, int lanes) {  // lanes: 4, 16, 32, 64
   float halfn = 0.5f * cnt;
   chan_merge_dpp<0x111>(mean, m2, halfn);
   chan_merge_dpp<0x112>(mean, m2, halfn);
@@ -83,6 +83,7 @@ __device__ __forceinline__ void group_moments_last_lane(float &mean, float &m2, 
     chan_merge_dpp<0x118>(mean, m2, halfn);
   }
   if (lanes > 16) chan_merge_dpp<0x142>(mean, m2, halfn);
+  if (lanes > 32) chan_merge_dpp<0x143>(mean, m2, halfn);  // row_bcast:31
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -144,6 +145,7 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s);
 size_t wino_weight_floats(int Cout, int Cin);
 size_t conv_wino_scratch_floats(const ddpm_conv_desc &d);
 int launch_wino_split_reduce(const ddpm_conv_desc &d, int S, long long pstride, int HW, hipStream_t s);
+int wino_split_reduce_stats_parts(int HW);  // slices of desc.stats_out the reduce pass writes for planes of HW floats (0: none)
 size_t conv_wino44_scratch_floats(const ddpm_conv_desc &d);
 size_t conv_mfma_scratch_floats(const ddpm_conv_desc &d);
 size_t conv_scratch_floats(const ddpm_conv_desc &d);  // what conv_dispatch can use: the largest of the kernels' needs

@@ -600,7 +600,11 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g_in, hipStre
   ProfScope prof(s, kname, flops, bytes);
   hipLaunchKernelGGL((conv_mfma_kernel<NTAPS, NPOS, AFFINE, MT, KG>), grid, dim3(256), lds, s, dk, g);
   DDPM_CHECK_LAUNCH();
-  if (g.ksplit > 1) return launch_wino_split_reduce(d, g.ksplit, g.pstride, g.Do * g.HWo, s);
+  if (g.ksplit > 1) {
+    ddpm_conv_desc dr = d;
+    dr.stats_out = nullptr;  // (ddpm_conv_stats_parts is 0 for this kernel: the field is ignored)
+    return launch_wino_split_reduce(dr, g.ksplit, g.pstride, g.Do * g.HWo, s);
+  }
   return 0;
 }
 

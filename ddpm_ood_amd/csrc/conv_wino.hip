@@ -1197,15 +1197,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(const ddpm_conv_desc
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-// out = sum of the S partial slabs (fixed order 0, 1, ..) + bias + temb + residual: the epilogue of a split launch
+// out = sum of the S partial slabs (fixed order 0, 1, ..) + bias + temb + residual: the epilogue of a split launch.
+// STATS: also the GroupNorm statistics of the finished tensor (desc.stats_out): a plane of HW4 float4 is GL = min(HW4, 64)
+// consecutive lanes per slice; lanes merge {mean, M2} pairwise on the DPP path, the slice's last lane stores them.
+template <bool STATS>
 __global__ __launch_bounds__(256) void wino_split_reduce_kernel(const float *__restrict__ part, long long pstride, int S,
                                                                 const float *__restrict__ bias,
                                                                 const float *__restrict__ chan_add, int chan_stride,
                                                                 const float *__restrict__ residual,
                                                                 float *__restrict__ out, int Cout, int HW4,
-                                                                long long total4) {
+                                                                long long total4, float *__restrict__ stats, int GL) {
   const long long i = blockIdx.x * 256LL + threadIdx.x;
-  if (i >= total4) return;
+  if (i >= total4) return;  // (whole slices leave: total4 is a multiple of HW4)
   const int c = (int)((i / HW4) % Cout), n = (int)(i / ((long long)HW4 * Cout));
   v4f v = reinterpret_cast<const v4f *>(part)[i];
   for (int sp = 1; sp < S; ++sp) v += reinterpret_cast<const v4f *>(part + sp * pstride)[i];
@@ -1214,13 +1217,36 @@ __global__ __launch_bounds__(256) void wino_split_reduce_kernel(const float *__r
   v += add;
   if (residual) v += reinterpret_cast<const v4f *>(residual)[i];
   reinterpret_cast<v4f *>(out)[i] = v;
+  if (STATS) {
+    float mean = 0.25f * ((v[0] + v[1]) + (v[2] + v[3]));
+    const v4f dv = v - mean;
+    float m2 = (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+    group_moments_last_lane(mean, m2, 4.f, GL);
+    const int e = (int)(i % HW4);
+    if ((e & (GL - 1)) == GL - 1)
+      reinterpret_cast<float2 *>(stats)[((size_t)n * Cout + c) * (HW4 / GL) + e / GL] = make_float2(mean, m2);
+  }
 }
 
-// d.out = sum of the S slabs of d.scratch + d.bias + d.chan_add + d.residual (shared with conv_wino44.hip)
+int wino_split_reduce_stats_parts(int HW) {
+  if (HW & 3) return 0;
+  const int HW4 = HW / 4;
+  if (HW4 == 4 || HW4 == 16 || HW4 == 64) return 1;
+  return HW4 % 64 == 0 && HW4 / 64 <= 8 ? HW4 / 64 : 0;
+}
+
+// d.out = sum of the S slabs of d.scratch + d.bias + d.chan_add + d.residual (shared with conv_wino44.hip); d.stats_out: the
+// caller has checked wino_split_reduce_stats_parts(HW) > 0
 int launch_wino_split_reduce(const ddpm_conv_desc &d, int S, long long pstride, int HW, hipStream_t s) {
   const long long total4 = (long long)d.B * d.Cout * HW / 4;  // H, W even: HW % 4 == 0
-  hipLaunchKernelGGL(wino_split_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, d.scratch, pstride,
-                     S, d.bias, d.chan_add, d.chan_add_stride, d.residual, d.out, d.Cout, HW / 4, total4);
+  const int HW4 = HW / 4, GL = HW4 < 64 ? HW4 : 64;
+  const dim3 grid((unsigned)((total4 + 255) / 256));
+  if (d.stats_out && wino_split_reduce_stats_parts(HW) > 0)
+    hipLaunchKernelGGL(wino_split_reduce_kernel<true>, grid, dim3(256), 0, s, d.scratch, pstride, S, d.bias, d.chan_add,
+                       d.chan_add_stride, d.residual, d.out, d.Cout, HW4, total4, d.stats_out, GL);
+  else
+    hipLaunchKernelGGL(wino_split_reduce_kernel<false>, grid, dim3(256), 0, s, d.scratch, pstride, S, d.bias, d.chan_add,
+                       d.chan_add_stride, d.residual, d.out, d.Cout, HW4, total4, nullptr, GL);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
@@ -1327,7 +1353,11 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   ProfScope prof(s, kname, flops, bytes);
   hipLaunchKernelGGL(kern, dim3(g.grid), dim3(threads), lds_bytes, s, dk, g);
   DDPM_CHECK_LAUNCH();
-  if (g.S > 1) return launch_wino_split_reduce(d, g.S, g.pstride, g.HW, s);
+  if (g.S > 1) {
+    ddpm_conv_desc dr = d;
+    dr.stats_out = nullptr;  // (ddpm_conv_stats_parts is 0 for this kernel: the field is ignored)
+    return launch_wino_split_reduce(dr, g.S, g.pstride, g.HW, s);
+  }
   return 0;
 }
 

@@ -806,7 +806,11 @@ int launch_conv_wino44(const ddpm_conv_desc &d, hipStream_t s) {
   ProfScope prof(s, kname, flops, bytes);
   hipLaunchKernelGGL(kern, dim3(g.grid), dim3(512), lds, s, dk, g);
   DDPM_CHECK_LAUNCH();
-  if (g.S > 1) return launch_wino_split_reduce(d, g.S, g.pstride, g.HW, s);
+  if (g.S > 1) {
+    ddpm_conv_desc dr = d;
+    dr.stats_out = nullptr;  // (ddpm_conv_stats_parts is 0 for this kernel: the field is ignored)
+    return launch_wino_split_reduce(dr, g.S, g.pstride, g.HW, s);
+  }
   return 0;
 }
 

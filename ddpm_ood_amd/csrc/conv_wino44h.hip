@@ -332,7 +332,8 @@ int conv_wino44h_stats_parts(const ddpm_conv_desc &d) {
   W44HGeom g;
   if (!w44h_enabled() || !d.w_wino44h || d.force_direct || d.dims == 3 || !w44h_geom(d, g, true)) return 0;
   const int per = g.TR * g.TWc;
-  if (g.S != 1 || (per != 4 && per != 16 && per != 32) || g.parts > 8) return 0;
+  if (g.S != 1) return wino_split_reduce_stats_parts(g.HW);  // a channel-split launch: the reduce pass writes them
+  if ((per != 4 && per != 16 && per != 32) || g.parts > 8) return 0;
   return g.parts;
 }
 

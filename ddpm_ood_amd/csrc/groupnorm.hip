@@ -203,6 +203,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
   const int C = C1 + C2, cpg = C / G;
   const int n = blockIdx.x, tid = threadIdx.x;
   float *cmean = sm, *cm2 = sm + C, *gmean = sm + 2 * C, *grstd = sm + 2 * C + G;
+  // (gamma / beta of the thread's first two channels are requested now: one memory round trip less on the 7 us critical path)
+  const float ga0 = tid < C ? gamma[tid] : 0.f, be0 = tid < C ? beta[tid] : 0.f;
+  const float ga1 = tid + 256 < C ? gamma[tid + 256] : 0.f, be1 = tid + 256 < C ? beta[tid + 256] : 0.f;
   for (int c = tid; c < C; c += 256) {
     const bool first = c < C1;
     const int parts = first ? parts1 : parts2;
@@ -246,9 +249,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
     const int g = c / cpg;
-    const float sc = grstd[g] * gamma[c];
+    const float ga = c == tid ? ga0 : c == tid + 256 ? ga1 : gamma[c], be = c == tid ? be0 : c == tid + 256 ? be1 : beta[c];
+    const float sc = grstd[g] * ga;
     scale[(size_t)n * C + c] = sc;
-    shift[(size_t)n * C + c] = -sc * gmean[g] + beta[c];
+    shift[(size_t)n * C + c] = -sc * gmean[g] + be;
   }
 }
 

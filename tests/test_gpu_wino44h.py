@@ -266,16 +266,49 @@ def test_conv_wino44h_emits_groupnorm_statistics(device, case, monkeypatch):
     assert torch.equal(st2.cpu().double(), st)
 
 
-def test_conv_stats_parts_zero_where_not_emitted(device, monkeypatch):
-    """Dispatches without the emitting epilogue (a split launch smaller than the chip, kernels other than conv_wino44h)
-    report 0 parts: the caller falls back to a reading GroupNorm."""
+def _check_stats(y, st, parts):
+    B, Cout, H = y.shape[0], y.shape[1], y.shape[2]
+    assert st is not None and tuple(st.shape) == (B, Cout, parts, 2), None if st is None else st.shape
+    yd = y.double().cpu().view(B, Cout, parts, (H // parts) * H)
+    mean = yd.mean(-1)
+    m2 = (yd - mean[..., None]).pow(2).sum(-1)
+    st = st.cpu().double()
+    sd = (m2 / yd.shape[-1]).sqrt()
+    assert (st[..., 0] - mean).abs().max().item() <= 2e-6 * (1 + mean.abs().max().item() + sd.max().item())
+    assert ((st[..., 1] - m2).abs() / (m2 + 1e-3 * m2.mean())).max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("case,parts", [((16, 128, 0, 128, 32, True, True, True), 4), ((32, 256, 0, 256, 16, True, True, True), 1),
+                                        ((128, 256, 256, 256, 8, True, False, False), 1)])  # 64 items each: four-way split
+def test_conv_wino44h_split_launch_statistics_from_reduce_pass(device, case, parts, monkeypatch):
+    """A launch smaller than the chip splits the channel stream over 2 / 4 workgroups; the reduce pass that adds the partial
+    slabs (+ bias / temb / residual) then writes the statistics: 256-float slices of the plane (4 at 32x32)."""
     from ddpm_ood_amd import ops
 
     monkeypatch.delenv("DDPM_CONV_WINO44", raising=False)
-    case = (4, 128, 0, 128, 32, True, True, True)  # 2 x 2 x 4 = 16 items: channel-split launch with a reduce pass
+    t = _inputs(case)
+    wh = ops.pack_wino44h_weight(t[2].to(device))
+    y_plain = _run(device, case, t, wino44h=wh)
+    y, st = _run(device, case, t, wino44h=wh, want_stats=True)
+    assert torch.equal(y, y_plain)
+    monkeypatch.setenv("DDPM_CONV_WINO44", "2")
+    y_unsplit = _run(device, case, t, wino44h=wh)
+    assert not torch.equal(y, y_unsplit)  # (the split launch really ran: partial sums are added in another order)
+    _check_stats(y, st, parts)
+
+
+def test_conv_stats_parts_zero_where_not_emitted(device, monkeypatch):
+    """Dispatches without an emitting epilogue (kernels other than conv_wino44h / the Upsample kernel) report 0 parts: the
+    caller falls back to a reading GroupNorm."""
+    from ddpm_ood_amd import ops
+
+    monkeypatch.delenv("DDPM_CONV_WINO44", raising=False)
+    case = (4, 128, 0, 128, 32, True, True, True)
     t = _inputs(case)
     w = t[2].to(device)
-    y, st = _run(device, case, t, wino44h=ops.pack_wino44h_weight(w), want_stats=True)
-    assert st is None
     y, st = _run(device, case, t, wino44=ops.pack_wino44_weight(w), want_stats=True)
+    assert st is None
+    y, st = _run(device, case, t, wino=ops.pack_wino_weight(w), want_stats=True)
+    assert st is None
+    y, st = _run(device, case, t, want_stats=True)  # direct MFMA kernel
     assert st is None
