@@ -201,6 +201,7 @@ struct W44HGeom {
   int NRT;          // staging rounds per pixel wave and half-chunk: TI * UI
   int KT, NIT, IPW, NS, grid;
   int xmap;
+  int up, HWin;     // 1: DDPM_CONV_UPSAMPLE2 -- the pixel waves read the nearest-x2 image from the stored low-res one (HWin pixels)
   int S;            // channel-stream splits per item (1: none)
   long long pstride;
   int NIMG;
@@ -230,7 +231,16 @@ static size_t w44h_lds_bytes(const W44HGeom &g) { return ((size_t)kRINGF + 4 * (
 static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false) {
   const int Cin = d.C1 + d.C2;
   const bool is3d = d.dims == 3;
-  if (d.ksize != 3 || (!is3d && (d.Di > 1 || d.Do > 1)) || d.mode != DDPM_CONV_NORMAL) return false;
+  const bool up = d.mode == DDPM_CONV_UPSAMPLE2;
+  if (d.ksize != 3 || (!is3d && (d.Di > 1 || d.Do > 1)) || (d.mode != DDPM_CONV_NORMAL && !up)) return false;
+  // Upsample convolutions (F.interpolate(nearest, x2) + conv3x3 of generative's Upsample, between the up levels): plain
+  // convolution of the virtual upsampled image; 64-pixel staging units must be an even number of rows (Wo <= 32)
+  if (up) {
+    static const bool up_on = !(getenv("DDPM_UP_WINO44H") && atoi(getenv("DDPM_UP_WINO44H")) == 0);
+    if (!up_on || is3d || d.gscale || d.act != DDPM_ACT_NONE || d.C2 || d.chan_add || d.residual || d.out_act != DDPM_ACT_NONE)
+      return false;
+    if (d.Ho != 2 * d.Hi || d.Wo != 2 * d.Wi || d.Wo > 32) return false;
+  }
   if ((d.out_act != DDPM_ACT_NONE && !(is3d && d.out_act == DDPM_ACT_RELU)) || d.act == DDPM_ACT_RELU) return false;
   if (d.gscale && d.act != DDPM_ACT_SILU) return false;  // the affine variant has SiLU built in
   // 3-D: no GroupNorm / activation prologue (zero padding along the depth must stay zero), no concat, no temb
@@ -238,7 +248,7 @@ static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false)
   const int Dd = is3d ? (d.Di > 1 ? d.Di : 1) : 1;
   if (is3d && (d.Do > 1 ? d.Do : 1) != Dd) return false;
   if (Cin % 16 || (d.C2 > 0 && d.C1 % 4) || d.Cout % kK) return false;  // an even number of 8-channel chunks, 4-channel halves
-  if ((d.Ho & 3) || (d.Wo & 3) || d.Hi != d.Ho || d.Wi != d.Wo) return false;
+  if ((d.Ho & 3) || (d.Wo & 3) || (!up && (d.Hi != d.Ho || d.Wi != d.Wo))) return false;
   if ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.residual)) & 15) return false;  // float4 rows
   if ((double)d.B * (d.C1 > d.C2 ? d.C1 : d.C2) * Dd * d.Ho * d.Wo * 4 >= 2147483648.0) return false;  // 32-bit buffer offsets
   if ((double)d.B * d.Cout * Dd * d.Ho * d.Wo * 4 >= 2147483648.0 * 2) return false;
@@ -267,10 +277,12 @@ static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false)
   g.nkd_w = is3d ? 3 : 1;
   g.NCH = g.nkd * g.NCHc;
   g.HW = d.Ho * d.Wo;
+  g.up = up;
+  g.HWin = up ? d.Hi * d.Wi : g.HW;
   g.CS = Dd * g.HW;
   g.prow = 4 * g.TR + 2;
   auto layout = [&](bool pad) {
-    g.PW = d.Wi + 2;
+    g.PW = d.Wo + 2;
     if (pad && g.TWc < 16) g.PW += ((g.TWc - g.PW) % 16 + 16) % 16;
     g.IS = g.prow * g.PW;
     if (pad && g.TI > 1 && per_img < 16) g.IS += ((4 * per_img - g.IS) % 64 + 64) % 64;
@@ -280,15 +292,15 @@ static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false)
     return w44h_lds_bytes(g) <= 160 * 1024;
   };
   if (!layout(true) && !layout(false)) return false;
-  if (64 % d.Wi) return false;  // a staging unit is 64 pixels = whole rows
-  const int rows = g.prow < d.Hi ? g.prow : d.Hi;
-  g.UI = (rows * d.Wi + 63) / 64;
+  if (64 % d.Wo) return false;  // a staging unit is 64 pixels = whole rows (of the image the convolution sees)
+  const int rows = g.prow < d.Ho ? g.prow : d.Ho;
+  g.UI = (rows * d.Wo + 63) / 64;
   g.NRT = g.TI * g.UI;
   // kernel variants: one image per item with 9 or 10 units (32x32 / 64x64 images); whole images of 4 units or of 1 unit
   if (g.TI == 1) {
     if (g.NRT != 9 && g.NRT != 10) return false;
-    if ((rows - 1) * d.Wi < 64 * (g.NRT - 1)) return false;  // only the last round can reach past the item's rows
-  } else if (!((g.UI == 4 && rows * d.Wi == 256 && g.TI == 2) || (g.UI == 1 && rows * d.Wi == 64 && g.TI == 8))) {
+    if ((rows - 1) * d.Wo < 64 * (g.NRT - 1)) return false;  // only the last round can reach past the item's rows
+  } else if (!((g.UI == 4 && rows * d.Wo == 256 && g.TI == 2) || (g.UI == 1 && rows * d.Wo == 64 && g.TI == 8))) {
     return false;
   }
   g.KT = d.Cout / kK;
@@ -351,7 +363,7 @@ size_t conv_wino44h_scratch_floats(const ddpm_conv_desc &d) {
 // NRT = staging rounds of a pixel wave per half-chunk; UIT = 0: one image per item, else units per image (4 or 1)
 // D3: the 3-D form (images = (n, d) slices, chunk stream = (depth tap, channel chunk)); a template parameter so that the 2-D
 // instantiations carry none of its address arithmetic
-template <bool AFFINE, int NRT, int UIT, bool RES, bool D3 = false>
+template <bool AFFINE, int NRT, int UIT, bool RES, bool D3 = false, bool UP = false>
 __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_desc a, const W44HGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr bool ONEIMG = UIT == 0;
@@ -738,19 +750,23 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     int pix0, pw0, pixL = 0, pwL = 0;
     {
       const bool valid = lane < npx;
-      pix0 = valid ? ((row_lo + lane / a.Wo) * a.Wo + lane % a.Wo) * 4 : (int)0x80000000;  // out of range: the load returns 0
+      // byte offset of pixel (row, col) of the image the convolution sees inside a stored channel plane; UP: nearest x2 of the
+      // low-res plane -- a round of 64 pixels is an even number of rows, so rounds stay a constant stride apart (64 bytes)
+      auto src_of = [&](int row, int col) { return UP ? ((row >> 1) * (a.Wo >> 1) + (col >> 1)) * 4 : (row * a.Wo + col) * 4; };
+      pix0 = valid ? src_of(row_lo + lane / a.Wo, lane % a.Wo) : (int)0x80000000;  // out of range: the load returns 0
       pw0 = valid ? sc * g.PCH + (row_lo + lane / a.Wo - (4 * r0 - 1)) * g.PW + lane % a.Wo + 1 : dump;
       if (ONEIMG) {
         const int eL = lane + 64 * (NRT - 1);
         const bool vL = eL < npx;
-        pixL = vL ? ((row_lo + eL / a.Wo) * a.Wo + eL % a.Wo) * 4 : (int)0x80000000;
+        pixL = vL ? src_of(row_lo + eL / a.Wo, eL % a.Wo) : (int)0x80000000;
         pwL = vL ? sc * g.PCH + (row_lo + eL / a.Wo - (4 * r0 - 1)) * g.PW + eL % a.Wo + 1 : dump;
       }
     }
     const int prs = (64 / a.Wo) * g.PW;  // pixel-tile floats between a lane's pixels of consecutive rounds of one image
-    auto pix_of = [&](int k) { return ONEIMG ? (k == NRT - 1 ? pixL : pix0 + 256 * k) : pix0 + 256 * (k % GD); };
+    constexpr int kRoundBytes = UP ? 64 : 256;
+    auto pix_of = [&](int k) { return ONEIMG ? (k == NRT - 1 ? pixL : pix0 + kRoundBytes * k) : pix0 + kRoundBytes * (k % GD); };
     auto pw_of = [&](int k) { return ONEIMG ? (k == NRT - 1 ? pwL : pw0 + k * prs) : pw0 + (k % GD) * prs + (k / GD) * g.IS; };
-    const int bytes1 = a.B * a.C1 * (D3 ? g.CS : g.HW) * 4, bytes2 = a.B * a.C2 * g.HW * 4;
+    const int bytes1 = a.B * a.C1 * (D3 ? g.CS : UP ? g.HWin : g.HW) * 4, bytes2 = a.B * a.C2 * g.HW * 4;
     const __amdgpu_buffer_rsrc_t rs_sc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gscale), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_sh =
@@ -792,7 +808,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
         const int ni = min(n_cur + (ONEIMG ? 0 : k / GD), g.NIMG - 1);
         // D3: a depth tap outside the volume reads zeros -- the range check of a raw buffer load is on the VGPR offset, and
         // 0x80000000 is past every resource (as for the out-of-image lanes in pix0)
-        const int soff = D3 ? soff3 : (ni * cx + cgl) * g.HW * 4;
+        const int soff = D3 ? soff3 : (ni * cx + cgl) * (UP ? g.HWin : g.HW) * 4;
         const int voff = D3 && !dok ? (int)0x80000000 : pix_of(k);
         praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
       }
@@ -1061,6 +1077,17 @@ int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s) {
   }
   const int shape = g.TI == 1 ? (g.NRT == 9 ? 0 : 1) : g.UI == 4 ? 2 : 3;
   kern_t kern = kerns[d.gscale ? 1 : 0][shape][dk.residual ? 1 : 0];
+  if (g.up) {  // no prologue, no residual (w44h_geom)
+    static const kern_t kerns_up[4] = {conv_wino44h_kernel<false, 9, 0, false, false, true>, conv_wino44h_kernel<false, 10, 0, false, false, true>,
+                                       conv_wino44h_kernel<false, 8, 4, false, false, true>, conv_wino44h_kernel<false, 8, 1, false, false, true>};
+    static bool attr_up_done = false;
+    if (!attr_up_done) {
+      for (int i = 0; i < 4; ++i)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns_up[i]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_up_done = true;
+    }
+    kern = kerns_up[shape];
+  }
   if (d.dims == 3) {  // only reached without prologue and with whole slices per item (w44h_geom)
     static const kern_t kerns3d[2][2] = {{conv_wino44h_kernel<false, 9, 0, false, true>, conv_wino44h_kernel<false, 9, 0, true, true>},
                                          {conv_wino44h_kernel<false, 10, 0, false, true>, conv_wino44h_kernel<false, 10, 0, true, true>}};
@@ -1076,8 +1103,8 @@ int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s) {
   const double M = (double)g.NIMG * g.HW;
   // algorithmic work = the direct convolution's: 2 M Cout Cin 9 (x 3 depth taps)
   const double flops = 2.0 * M * d.Cout * (double)g.Cin * 9 * g.nkd;
-  const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9 * g.nkd);
-  const char *kname = d.dims == 3 ? "conv3d_wino44h" : d.gscale ? "conv3x3_wino44h_gn_silu" : "conv3x3_wino44h";
+  const double bytes = 4.0 * ((g.up ? 0.25 : 1.0) * M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9 * g.nkd);
+  const char *kname = d.dims == 3 ? "conv3d_wino44h" : g.up ? "conv3x3_wino44h_up" : d.gscale ? "conv3x3_wino44h_gn_silu" : "conv3x3_wino44h";
   char kshape[160];
   if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {
     snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);

@@ -349,6 +349,12 @@ extern "C" ddpm_unet *ddpm_unet_create(const ddpm_unet_config *cfg) {
           ps.has_wino = true;
           ps.wino_base = b.up.w_wino;
         }
+        if (const size_t nh = wino44h_weight_halves(out_c, out_c)) {  // split-f16 F(4x4) on the upsampled image (conv_wino44h.hip)
+          b.up.has_wino44h = true;
+          b.up.w_wino44h = u->alloc(nh / 2);
+          ps.has_wino44h = true;
+          ps.wino44h_base = b.up.w_wino44h;
+        }
       }
     }
     u->up.push_back(b);
@@ -499,7 +505,7 @@ struct Runner {
     if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino && c.dims == 2)
       d.w_wino = P(c.w_wino);
     if (mode == DDPM_CONV_NORMAL && c.has_wino44 && c.dims == 2) d.w_wino44 = P(c.w_wino44);
-    if (mode == DDPM_CONV_NORMAL && c.has_wino44h && c.dims == 2)
+    if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino44h && c.dims == 2)
       d.w_wino44h = reinterpret_cast<const uint16_t *>(P(c.w_wino44h));
     if (c.dims == 3 && c.ksize == 3 && mode == DDPM_CONV_NORMAL && c.has_wino) d.w_wino = P(c.w_wino);  // F(2x2) per depth tap
     if (c.dims == 3 && c.ksize == 3) {

@@ -18,7 +18,7 @@ def test_wino44h_accumulators_are_never_touched_by_compiler_code():
                           str(ROOT / "ddpm_ood_amd" / "csrc" / "conv_wino44h.hip"), "-fno-slp-vectorize"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:]
-    assert out.stdout.count(": OK") == 20, out.stdout  # 2 (affine) x 4 (shapes) x 2 (residual) + 4 three-dimensional instantiations
+    assert out.stdout.count(": OK") == 24, out.stdout  # 2 (affine) x 4 (shapes) x 2 (residual) + 4 three-dimensional instantiations
 
 
 def test_older_mfma_kernels_do_not_spill_accumulators_inside_their_loops():

@@ -23,7 +23,7 @@ from parity_util import assert_rows_close, assert_z_close, hip_scores, make_args
 pytestmark = pytest.mark.gpu
 
 # the kernel classes of a chip-filling `small` forward (profiler keys, csrc/*.hip ProfScope names)
-BENCH_KEYS = ("conv3x3_wino44h_gn_silu", "conv3x3_wino_up", "conv1x1_dma", "conv1x1_dma_gn", "attention", "gn_finalize")
+BENCH_KEYS = ("conv3x3_wino44h_gn_silu", "conv3x3_wino44h_up", "conv1x1_dma", "conv1x1_dma_gn", "attention", "gn_finalize")
 
 
 def _profiled(fn):
@@ -87,6 +87,8 @@ def test_small_forward_at_benchmarked_batch_vs_oracle(device, B):
     # every 32x32 / 16x16 / 8x8 ResnetBlock convolution went through the split-f16 F(4x4) kernel: 22 launches per forward
     assert prof["conv3x3_wino44h_gn_silu"]["launches"] == 22, prof["conv3x3_wino44h_gn_silu"]
     assert "conv3x3_wino44_gn_silu" not in prof, sorted(prof)
+    # ... and so did the two Upsample convolutions (nearest x2 read on the fly by the same kernel)
+    assert prof["conv3x3_wino44h_up"]["launches"] == 2 and "conv3x3_wino_up" not in prof, sorted(prof)
     # GroupNorm statistics come from the producers' epilogues: 27 finalize launches, no reading GroupNorm kernel, and a
     # per-channel reduction only for the tensors of other producers (conv_in, Downsample, Upsample, attention outputs)
     assert prof["gn_finalize"]["launches"] == 27, prof["gn_finalize"]

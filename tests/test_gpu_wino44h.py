@@ -312,3 +312,43 @@ def test_conv_stats_parts_zero_where_not_emitted(device, monkeypatch):
     assert st is None
     y, st = _run(device, case, t, want_stats=True)  # direct MFMA kernel
     assert st is None
+
+
+# ---- Upsample convolutions on the same kernel (nearest x2 read on the fly by the pixel waves) ------------------------------
+
+UP_CASES = [
+    # B, Cin, Cout, low-res H
+    (2, 256, 256, 16),    # the 16 -> 32 Upsample of the small UNet: one image per item, 2 parts
+    (3, 256, 256, 8),     # 8 -> 16: two images per item, ragged
+    (11, 64, 128, 4),     # 4 -> 8: eight images per item, ragged
+    (70, 128, 64, 16),    # 2 x 70 items: several per persistent workgroup
+]
+
+
+@pytest.mark.parametrize("case", UP_CASES)
+def test_conv_wino44h_upsample_vs_interpolate_conv2d(device, case, monkeypatch):
+    """F.interpolate(scale_factor=2, mode="nearest") + conv3x3 (generative's Upsample, between the levels of the up path,
+    /root/reference/src/trainers/reconstruct.py:151-153) as split-f16 F(4x4) over the virtual upsampled image, with the
+    GroupNorm statistics of the output from the epilogue."""
+    monkeypatch.setenv("DDPM_CONV_WINO44", "2")
+    from ddpm_ood_amd import ops
+
+    B, Cin, Cout, H = case
+    g = torch.Generator().manual_seed(B * 7 + H)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    d = lambda t: t.to(device)
+    wh = ops.pack_wino44h_weight(d(w))
+    y, st = ops.conv(d(x), d(w), d(b), mode=ops.CONV_UPSAMPLE2, wino44h=wh, want_stats=True)
+    y_up = ops.conv(d(x), d(w), d(b), mode=ops.CONV_UPSAMPLE2, wino=ops.pack_wino_weight(d(w)))  # the F(2x2) Upsample kernel
+    torch.cuda.synchronize()
+    assert not torch.equal(y, y_up)
+    err = y.cpu().double() - ref
+    assert err.abs().max().item() < 2e-4 * (1 + ref.abs().max().item()), err.abs().max().item()
+    assert err.pow(2).mean().sqrt().item() < 1e-5 * (1 + ref.pow(2).mean().sqrt().item())
+    _check_stats(y, st, STATS_PARTS[2 * H])
+    monkeypatch.setenv("DDPM_UP_WINO44H", "1")
+    y2, _ = ops.conv(d(x), d(w), d(b), mode=ops.CONV_UPSAMPLE2, wino44h=wh, want_stats=True)
+    assert torch.equal(y, y2)
