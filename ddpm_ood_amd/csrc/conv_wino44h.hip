@@ -442,32 +442,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       Bl[i] = lds_b128(va_s, (2 * i + 1) * kT * 16);
     }
     __builtin_amdgcn_sched_barrier(0);
-#ifdef W44H_SLICE_FIRST  // experiment: the first staging slice runs while the operand reads are in flight (slices shifted by one)
-    slice(0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int x = 3 * t + i;
-      if (x == 8) {
-        mfma_v_pair_wait0(acc8, A[i], Bh[i], Bl[i]);
-        slice(2 * i + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        W44H_STAMP(1 + i)
-        continue;
-      }
-      // (slice ops are newer than all nine operand reads: "at most N outstanding" still implies job i's reads have landed,
-      // only more strictly)
-      if (i == 0) mfma_pin_wait<6>(x, A[i], Bh[i]);
-      else if (i == 1) mfma_pin_wait<3>(x, A[i], Bh[i]);
-      else mfma_pin_wait<0>(x, A[i], Bh[i]);
-      slice(2 * i + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_pin(x, A[i], Bl[i]);
-      if (i < 2) slice(2 * i + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      W44H_STAMP(1 + i)
-    }
-#else
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int x = 3 * t + i;  // accumulator tile
@@ -491,7 +465,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       __builtin_amdgcn_sched_barrier(0);
       W44H_STAMP(1 + i)
     }
-#endif
 #else  // one job of read-ahead (two operand register sets)
     h8 A[2], Bh[2], Bl[2];
     A[0] = lds_b128(ua_s, 0);
@@ -684,6 +657,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
           asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(lo6[q]), "n"((2 * (o + q) + 1) * (kT * 16)) : "memory");
         }
       };
+      // (closing the FIRST half with the first row pass + split instead -- hi6 / lo6 carried in place of cA -- measured 4-8 %
+      // slower: the first-half phases also carry the wave's LDS-DMA issues and the twelve patch-row reads)
       if (k == 0) { bt6(cA[0], t0r); bt6(cA[1], t1r); split_row(); }
       if (k == 1) { store_row(0); bt6(cB[0], t0r); }
       if (k == 2) { bt6(cB[1], t1r); split_row(); }
