@@ -11,6 +11,13 @@ python bench.py --config cfg3 --steps 1 --warmup 1 > gpurun_out/bench_cfg3.json 
 python bench.py --config cfg4 --steps 1 --warmup 1 > gpurun_out/bench_cfg4.json 2> gpurun_out/bench_cfg4.err
 python bench.py --config cfg5 --steps 1 --warmup 0 > gpurun_out/bench_cfg5.json 2> gpurun_out/bench_cfg5.err
 bash tools/r03_profile.sh > gpurun_out/r03_profile.log 2>&1
+python bench.py --batch 128 --steps 1 --warmup 1 --no-cpu-baseline --no-batch256 > gpurun_out/bench_cfg2_b128.json 2> gpurun_out/bench_cfg2_b128.err  # what a rank holds at N = 8 (strong scaling)
+DDPM_PROF_SHAPES=1 python tools/microbench.py --batch 1024 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_microbench_small_b1024_per_shape.log
+python tools/microbench.py --batch 128 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_microbench_small_b128.log
+PMC_CMD="python tools/vqvae_bench.py 1" bash tools/pmc_collect.sh gpurun_out/pmc_vqvae > gpurun_out/pmc_vqvae_collect.log 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_vqvae gpurun_out/r03_pmc_per_kernel_vqvae.csv gpurun_out/pmc_traffic_vqvae_scratch.json > gpurun_out/pmc_vqvae_summary.log 2>&1
+rm -rf gpurun_out/pmc_vqvae/*/pmc_counter_collection.csv
+python tools/up_ab.py 1024 2>&1 | grep -v amdgpu.ids > gpurun_out/up_ab_final.log
 python tools/wino_ab.py 256 2>&1 | grep -v amdgpu.ids > gpurun_out/wino_ab_final.log
 python tools/wino_ab.py 1024 2>&1 | grep -v amdgpu.ids >> gpurun_out/wino_ab_final.log
 DDPM_WINO44_F16X3=0 python tools/wino_ab.py 1024 2>&1 | grep -v amdgpu.ids >> gpurun_out/wino_ab_final.log
