@@ -43,6 +43,40 @@ def test_unet_forward_small(device, channels, B, H):
     assert yr.abs().max() > 0.05  # not vacuous (finding 12)
 
 
+@pytest.mark.parametrize("channels,B,H", [(1, 96, 32), (3, 70, 32), (1, 300, 16), (1, 20, 64), (1, 90, 28)])
+def test_unet_forward_fused_groupnorm_statistics_vs_reading_groupnorm(device, channels, B, H, monkeypatch):
+    """Launch sets of >= 64 K pixels take the GroupNorm statistics from the producers' epilogues: the forward
+    must agree with the reading GroupNorm (DDPM_GN_FUSED=0) to fp32 rounding and with the CPU oracle -- across image sizes
+    with 1, 2 and 8 slices per image, a size the F(4x4) kernel has no tiling for (28: statistics from channel_stats), and
+    concatenations whose groups straddle the seam (384 = 256 + 128 channels)."""
+    from ddpm_ood_amd import _lib
+
+    ref, hip = _pair(device, channels)
+    g = torch.Generator().manual_seed(B + H)
+    x = torch.randn(B, channels, H, H, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    import ctypes
+    import json
+
+    lib = _lib.load()
+    lib.ddpm_prof_enable(1)
+    y_fused = hip(x.to(device), timesteps=t.to(device)).cpu()
+    torch.cuda.synchronize()
+    lib.ddpm_prof_enable(0)
+    buf = ctypes.create_string_buffer(1 << 18)
+    prof = json.loads(buf.value.decode()) if lib.ddpm_prof_report(buf, len(buf)) > 0 else {}
+    assert "gn_finalize" in prof and "gn_scale_shift" not in prof, sorted(prof)
+    monkeypatch.setenv("DDPM_GN_FUSED", "0")
+    y_read = hip(x.to(device), timesteps=t.to(device)).cpu()
+    scale = y_read.abs().max().item()
+    assert scale > 0.05
+    assert (y_fused - y_read).abs().max().item() <= 2e-5 * (1 + scale)
+    n = min(B, 8)  # (the oracle runs on the host: a few images are enough)
+    with torch.no_grad():
+        yr = ref(x[:n], timesteps=t[:n])
+    assert (y_fused[:n] - yr).abs().max().item() <= 1e-4 * (1 + yr.abs().max().item())
+
+
 def test_unet_forward_generic_config_and_proj_attn(device):
     """Channel counts without an MFMA tiling (64/96) run entirely on the direct kernels; also covers
     use_proj_attn=True, 2 res blocks and attention at an upper level with n = 256 tokens."""
