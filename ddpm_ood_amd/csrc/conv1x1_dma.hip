@@ -75,7 +75,7 @@ bool conv1x1_dma_supported(const ddpm_conv_desc &d) {
   // threshold).  Split-f16: half a chip of workgroups already wins (8x8 skip at B = 256, 128 workgroups: 83 -> 55 us;
   // the `big` UNet's q / k / v at B = 16, 192 workgroups: 115 -> 70 us); the f32 loop needed 1.5 waves of the chip
   static const long min_wg = getenv("DDPM_CONV1X1_DMA_MIN_WG") ? atol(getenv("DDPM_CONV1X1_DMA_MIN_WG"))
-                             : conv1x1_f16x3_enabled()         ? 128
+                             : conv1x1_f16x3_enabled()         ? 64  // (8x8 skip at B = 128, 64 workgroups: 62 -> 50 us)
                                                                : 384;
   return tiles * (d.Cout / kDM) >= min_wg;
 }
