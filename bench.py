@@ -331,10 +331,15 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # test hooks (the trainer's): DDPM_DIST_BACKEND=gloo + DDPM_DIST_SHARED_DEVICE=1 run the N-rank bench on ONE GPU
+    # (RCCL refuses two ranks per device) -- everything but the transport of the collectives is the N-rank path
+    backend = os.environ.get("DDPM_DIST_BACKEND", "nccl")
+    if os.environ.get("DDPM_DIST_SHARED_DEVICE", "0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=backend, init_method="env://")
 
     from ddpm_ood_amd import _lib, synthetic
     from ddpm_ood_amd.data import get_data_loader
@@ -384,7 +389,7 @@ def main():
         dt = time.perf_counter() - t0
         log(f"timed region done: {a.steps} step(s) in {dt:.2f} s")
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=rec.device)
+            tt = torch.tensor([dt], dtype=torch.float64, device=rec.device if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
     finally:
@@ -432,7 +437,8 @@ def main():
         "unit": "reconstructions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": ARITHMETIC, "rccl_world_size": dist.get_world_size() if world > 1 else 1, "devices": devices,
+        "arithmetic": ARITHMETIC, "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+        **({"dist_backend": backend} if backend != "nccl" else {}), "devices": devices,
         "config": {"workload": cfg["workload"], "name": a.config, "images_per_gpu_per_batch": batch,
                    "images_per_step": n_images, "reconstructions_per_step": recon_per_step,
                    "unet_forwards_per_image": rec.last_stats["unet_forwards"] // max(per_rank[rank], 1),

@@ -163,3 +163,24 @@ def test_two_rank_training_starts_and_stays_in_step(device, tmp_path):
     assert recs[0][0] == recs[1][0]            # same initial parameters
     assert recs[0][1] == recs[1][1] != recs[0][0]  # same parameters after one epoch, and they moved
     assert recs[0][2] == recs[1][2] == "2" and {recs[0][3], recs[1][3]} == {"5", "4"}
+
+
+def test_bench_self_launches_two_ranks_on_one_gpu(device):
+    """`python bench.py --gpus 2` as the driver runs it (no launcher): bench.py starts its own ranks through
+    torch.distributed.run, shards the fixed image set (strong scaling is the default for N > 1), brackets the timed region
+    with barriers, takes the MAX over ranks and rank 0 prints ONE JSON line.  Two ranks share the GPU here (gloo transport,
+    DESIGN 4.1 hooks); on a multi-GPU node the same command runs over RCCL."""
+    import json
+
+    env = dict(os.environ, DDPM_DIST_BACKEND="gloo", DDPM_DIST_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "32",
+                          "--images", "64"], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2 and d["scaling"] == "strong" and d["dist_backend"] == "gloo"
+    assert d["config"]["images_per_step"] == 64 and d["config"]["reconstructions_per_step"] == 64 * 25
+    assert len(d["devices"]) == 2 and d["devices"][0].startswith("rank 0") and d["devices"][1].startswith("rank 1")
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
