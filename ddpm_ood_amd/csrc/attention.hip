@@ -521,6 +521,48 @@ __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict
     }
   };
 
+  // V block (round 3): as the K block -- (head-dim row d, 8 consecutive keys) units, split once at staging into the f16 planes
+  // [key / 8][d][8 keys] (hi, lo 2^5) the PV A operand reads with ONE ds_read_b128 per plane and k-step (was: eight
+  // ds_read_b32 of the fp32 block + a split_f16x8 per k-step in the PV loop, and 32 ds_write_b32 per thread at staging).
+  // Plane stride 257 units: the eight key groups a thread octet stores land on disjoint banks.
+  constexpr int kVG = kDH + 1;
+  auto load_v = [&](int t0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e8 = tid + 512 * r;
+      const int d = e8 >> 3, j = (e8 & 7) * 8;
+      const float *src = vp + (size_t)d * N + t0 + j;
+      if (VEC) {
+        v4f v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (t0 + j < N) v0 = *reinterpret_cast<const v4f *>(src);
+        if (t0 + j + 4 < N) v1 = *reinterpret_cast<const v4f *>(src + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          pf[8 * r + c] = v0[c];
+          pf[8 * r + 4 + c] = v1[c];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pf[8 * r + c] = (t0 + j + c < N) ? src[c] : 0.f;
+      }
+    }
+  };
+  auto store_v_planes = [&]() {
+    f16x8 *Vh = reinterpret_cast<f16x8 *>(KVl), *Vl = Vh + (kKB / 8) * kVG;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e8 = tid + 512 * r;
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = pf[8 * r + t];
+      f16x8 hi, lo, hs;
+      split_f16x8(v, hi, lo, hs);
+      Vh[(e8 & 7) * kVG + (e8 >> 3)] = hi;
+      Vl[(e8 & 7) * kVG + (e8 >> 3)] = lo;
+    }
+  };
+  static_assert(2 * (kKB / 8) * (kDH + 1) * 16 <= kDH * kLd * 4, "the V planes fit the K / V buffer");
+
   // q tile: fp32 through the K / V buffer, then split once into the two planes
   load_block(qp, i0);
   store_block(KVl, kQB);
@@ -558,7 +600,7 @@ __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict
     __syncthreads();            // previous PV finished with KVl / Sl; orders the q planes and m / l init
     store_k_planes();           // K block as two f16 planes
     __syncthreads();
-    load_block(vp, j0);         // V of this block flies while QK^T runs
+    load_v(j0);                 // V of this block flies while QK^T runs
 
     // ---- partial S quadrant over head-dim channels 128 kh .. 128 kh + 127 ------------------------------
     f32x16 sacc;
@@ -633,7 +675,7 @@ __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict
       sum += __shfl_xor(sum, 2, 64);
       sum += __shfl_xor(sum, 4, 64);
       const float alpha = __builtin_amdgcn_exp2f(mo - mn);  // exp2(-inf) = 0 on the first block
-      store_block(KVl, kLd);              // V block over the K block, row stride 65
+      store_v_planes();                   // V block over the K block, as two f16 planes
       __syncthreads();                    // every score and mrow[row] has been read; V is visible
       f16x8 *Ph = reinterpret_cast<f16x8 *>(Sl), *Pl = Ph + (kKB / 8) * kQB;
       f16x8 hi, lo, hs;
@@ -657,16 +699,14 @@ __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict
       for (int r = 0; r < 16; ++r) o[b][r] *= al;
     }
     {
-      const float *va = KVl + (wave * 32 + l31) * kLd + 8 * lhi;
+      const f16x8 *vh = reinterpret_cast<const f16x8 *>(KVl) + lhi * kVG + wave * 32 + l31;
+      const f16x8 *vl = vh + (kKB / 8) * kVG;
       const f16x8 *ph = reinterpret_cast<const f16x8 *>(Sl) + lhi * kQB + l31;
       const f16x8 *pl = ph + (kKB / 8) * kQB;
 #pragma unroll
       for (int ks = 0; ks < kKB / 16; ++ks) {
-        float v[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = va[16 * ks + t];
-        f16x8 ah, al, as;
-        split_f16x8(v, ah, al, as);
+        const f16x8 ah = vh[2 * ks * kVG], al = vl[2 * ks * kVG];
+        const f16x8 as = ah * (_Float16)(1.f / kF16LoScale);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const f16x8 bh = ph[2 * ks * kQB + 32 * b], bl = pl[2 * ks * kQB + 32 * b];
