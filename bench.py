@@ -182,6 +182,9 @@ MFMA_KERNELS = [
     ("conv3d_wino44", "conv_wino44_kernel, 3-D: Winograd F(4x4,3x3) per depth tap (36 of 144 multiplies), taps accumulated in the transform domain, fp32 MFMA", 36.0 / 144.0),
     ("conv3d_wino", "conv_wino_kernel, 3-D: Winograd F(2x2,3x3) per depth tap, taps accumulated in the transform domain, fp32 MFMA", 16.0 / 36.0),
     ("conv3d_", "conv_mfma_kernel: 3-D convolution (depth taps merged into one chunk stream), fp32 MFMA", 1.0),
+    # split-f16 direct convolution: four exact f16 partial products per fp32 product (two K = 16 MFMAs per 8 channels and tap)
+    ("conv3x3_s2h", "conv_s2h_kernel: Downsample 3x3 stride-2 conv, direct form on v_mfma_f32_32x32x16_f16 with split-f16 operands "
+                    "(hi + lo, four exact partial products per fp32 product, fp32 accumulate)", ("f16", 4.0)),
     ("conv3x3_mfma", "conv_mfma_kernel<9>: direct 3x3 conv (stride 2, ragged extents, 3-D depth-tap launches), fp32 MFMA", 1.0),
     # split-f16: three v_mfma_f32_32x32x16_f16 per fp32 product, 16x the f32 MFMA rate -> the layer is HBM-bound
     ("conv1x1_dma", "conv1x1_dma_kernel: LDS-DMA-fed 1x1 conv (skip connections; with GroupNorm prologue: q / k / v), "

@@ -155,6 +155,10 @@ size_t wino44_weight_floats(int Cout, int Cin);
 bool conv_wino44h_supported(const ddpm_conv_desc &d);
 int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_wino44h_scratch_floats(const ddpm_conv_desc &d);
+bool conv_s2h_supported(const ddpm_conv_desc &d);
+int launch_conv_s2h(const ddpm_conv_desc &d, hipStream_t s);
+size_t conv_s2h_weight_halves(int Cout, int Cin);
+int launch_pack_conv_s2h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, hipStream_t s);
 int conv_wino44h_stats_parts(const ddpm_conv_desc &d);
 int conv_wino_stats_parts(const ddpm_conv_desc &d);
 int conv_stats_parts(const ddpm_conv_desc &d);

@@ -458,6 +458,7 @@ int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
   if (conv_wino44h_supported(d)) return launch_conv_wino44h(d, s);  // F(4x4) with split-f16 position GEMMs
   if (conv_wino44_supported(d)) return launch_conv_wino44(d, s);
   if (conv_wino_supported(d)) return launch_conv_wino(d, s);
+  if (conv_s2h_supported(d)) return launch_conv_s2h(d, s);  // Downsample: direct 3x3 stride 2 on the f16 MFMA, split-f16 operands
   if (conv1x1_dma_supported(d) && conv_mfma_supported(d)) return launch_conv1x1_dma(d, s);
   if (conv_mfma_supported(d)) return launch_conv_mfma(d, s);
   return launch_conv_direct(d, s);

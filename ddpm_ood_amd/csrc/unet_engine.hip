@@ -37,6 +37,7 @@ struct ParamSlot {
   size_t wino44_base = 0;
   bool has_wino44h = false;     // ... and its split-f16 form (conv_wino44h.hip); base in floats, 2 f16 per float
   size_t wino44h_base = 0;
+  bool has_s2h = false;         // Downsample conv: split-f16 planes of the direct stride-2 kernel (conv_s2h.hip), in wino44h_base
   int Cout = 0, Cin = 0, ksize = 1, cout_offset = 0, Cout_total = 0;
   int dims = 2;                 // 3: [Cout, Cin, k, k, k] packed as k slabs of 2-D taps (one per depth tap)
   bool optional = false;
@@ -308,7 +309,16 @@ extern "C" ddpm_unet *ddpm_unet_create(const ddpm_unet_config *cfg) {
       if (d.with_attn)
         d.att.push_back(build_attn(u, bp + ".attentions." + std::to_string(j), out_c, cfg->num_head_channels[i]));
     }
-    if (d.has_down) d.down = u->add_conv(bp + ".downsampler.op.conv", out_c, out_c, 3, false, sd);
+    if (d.has_down) {
+      d.down = u->add_conv(bp + ".downsampler.op.conv", out_c, out_c, 3, false, sd);
+      if (const size_t nh = sd == 2 ? conv_s2h_weight_halves(out_c, out_c) : 0) {  // split-f16 planes for conv_s2h.hip
+        d.down.has_wino44h = true;
+        d.down.w_wino44h = u->alloc(nh / 2);
+        ParamSlot &ps = u->params[u->index[bp + ".downsampler.op.conv.weight"]];
+        ps.has_s2h = true;
+        ps.wino44h_base = d.down.w_wino44h;
+      }
+    }
     u->down.push_back(d);
   }
   const int cm = cfg->num_channels[L - 1];
@@ -433,6 +443,10 @@ extern "C" int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *
     rc = launch_pack_wino44h_weight(src, reinterpret_cast<uint16_t *>(h->blob + p.wino44h_base), p.Cout, p.Cin, s);
     if (rc) return rc;
   }
+  if (p.has_s2h) {
+    rc = launch_pack_conv_s2h_weight(src, reinterpret_cast<uint16_t *>(h->blob + p.wino44h_base), p.Cout, p.Cin, s);
+    if (rc) return rc;
+  }
   if (p.has_folded) {
     rc = launch_fold_upsample_weight(src, h->blob + p.folded_base, p.Cout, p.Cin, s);
     if (rc) return rc;
@@ -505,7 +519,7 @@ struct Runner {
     if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino && c.dims == 2)
       d.w_wino = P(c.w_wino);
     if (mode == DDPM_CONV_NORMAL && c.has_wino44 && c.dims == 2) d.w_wino44 = P(c.w_wino44);
-    if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino44h && c.dims == 2)
+    if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2 || mode == DDPM_CONV_STRIDE2) && c.has_wino44h && c.dims == 2)
       d.w_wino44h = reinterpret_cast<const uint16_t *>(P(c.w_wino44h));
     if (c.dims == 3 && c.ksize == 3 && mode == DDPM_CONV_NORMAL && c.has_wino) d.w_wino = P(c.w_wino);  // F(2x2) per depth tap
     if (c.dims == 3 && c.ksize == 3) {

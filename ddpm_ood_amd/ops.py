@@ -89,6 +89,21 @@ def pack_wino44h_weight(weight: torch.Tensor) -> torch.Tensor | None:
     return out
 
 
+def pack_conv_s2h_weight(w):
+    """[Cout, Cin, 3, 3] -> split-f16 planes of the direct stride-2 kernel (conv_s2h.hip), or None if the shape has no tiling.
+    Pass it as conv(..., mode=CONV_STRIDE2, wino44h=...)."""
+    lib = _lib.load()
+    w = require_device_f32(w, "weight")
+    if w.ndim != 4 or w.shape[2] != 3 or w.shape[3] != 3:
+        return None
+    n = lib.ddpm_conv_s2h_weight_halves(w.shape[0], w.shape[1])
+    if n == 0:
+        return None
+    out = torch.empty(n, dtype=torch.float16, device=w.device)
+    check(lib.ddpm_pack_conv_s2h_weight(ptr(w), out.data_ptr(), w.shape[0], w.shape[1], stream_ptr()), "pack_conv_s2h_weight")
+    return out
+
+
 def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NONE, mode=CONV_NORMAL,
          chan_add=None, chan_add_offset=0, residual=None, packed=None, force_direct=False, folded=None,
          wino=None, out_act=ACT_NONE, wino44=None, wino44h=None, want_stats=False):

@@ -193,6 +193,15 @@ int ddpm_pack_wino44h_weight(const float *w_raw, uint16_t *w_wino44h, int Cout, 
  * VQVAE, /root/reference/src/trainers/reconstruct.py:124,166): one slab per depth tap, 3 * (halves - 64) + 64 f16 values.  */
 int ddpm_pack_wino44h_weight3d(const float *w_raw, uint16_t *w_wino44h, int Cout, int Cin, ddpm_stream_t stream);
 
+/* Downsample convolutions (3x3, stride 2, padding 1, 2-D, plain: bias only -- generative's Downsample between the levels of the
+ * down path, reference call site src/trainers/reconstruct.py:151-153): the [Cout, Cin, 3, 3] weight as split-f16 planes for the
+ * direct f16-MFMA kernel (conv_s2h.hip; Cin % 8 == 0, Cout % 64 == 0, even input extent): Cout * Cin * 18 + 64 f16 values,
+ * carried in ddpm_conv_desc.w_wino44h of a DDPM_CONV_STRIDE2 descriptor (the field has no other meaning in that mode).
+ * Same arithmetic as ddpm_pack_wino44h_weight's kernel: four exact f16 partial products per fp32 product, fp32 accumulate.
+ * DDPM_DOWN_S2H=0 keeps such descriptors on the fp32 MFMA kernel.  */
+size_t ddpm_conv_s2h_weight_halves(int Cout, int Cin);
+int ddpm_pack_conv_s2h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, ddpm_stream_t stream);
+
 /* Winograd-domain form of a [Cout, Cin, 3, 3, 3] conv3d weight: U_kd = G w[:, :, kd] G^T for each depth tap (3 * 16 * Cout *
  * Cin floats).  A dims = 3, stride-1 descriptor without GroupNorm / activation prologue (the VQ-VAE residual units) that
  * carries it in w_wino runs as 2-D Winograd F(2x2, 3x3) per depth tap, the taps accumulated in the transform domain.     */

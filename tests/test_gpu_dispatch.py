@@ -89,6 +89,8 @@ def test_small_forward_at_benchmarked_batch_vs_oracle(device, B):
     assert "conv3x3_wino44_gn_silu" not in prof, sorted(prof)
     # ... and so did the two Upsample convolutions (nearest x2 read on the fly by the same kernel)
     assert prof["conv3x3_wino44h_up"]["launches"] == 2 and "conv3x3_wino_up" not in prof, sorted(prof)
+    # the two Downsample convolutions: direct stride-2 kernel with split-f16 operands (conv_s2h.hip)
+    assert prof["conv3x3_s2h"]["launches"] == 2, sorted(prof)
     # GroupNorm statistics come from the producers' epilogues: 27 finalize launches, no reading GroupNorm kernel, and a
     # per-channel reduction only for the tensors of other producers (conv_in, Downsample, Upsample, attention outputs)
     assert prof["gn_finalize"]["launches"] == 27, prof["gn_finalize"]

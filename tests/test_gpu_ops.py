@@ -1198,3 +1198,56 @@ def test_gn_finalize_from_channel_stats_matches_group_norm(device, shape):
     assert e_new <= 5e-6 and e_new <= 2 * e_old + 1e-6, (e_new, e_old)
     sc2, sh2 = ops.gn_finalize(st1, d(gamma), d(beta), 32, 1e-6, HW, stats2=st2)
     assert torch.equal(sc, sc2) and torch.equal(sh, sh2)
+
+
+# ---- Downsample convolution on the f16 MFMA (conv_s2h.hip) -----------------------------------------------------------------
+
+S2H_CASES = [
+    # B, Cin, Cout, input H
+    (3, 128, 128, 32),    # the 32 -> 16 Downsample of the small UNet: two tiles per image
+    (5, 256, 256, 16),    # 16 -> 8: two images per tile, ragged
+    (2, 64, 128, 64),     # 64 -> 32: four rows per tile
+    (11, 64, 64, 8),      # 8 -> 4: eight images per tile, ragged
+    (300, 8, 64, 16),     # one chunk, many workgroups
+]
+
+
+@pytest.mark.parametrize("case", S2H_CASES)
+def test_conv_stride2_split_f16_vs_conv2d(device, case):
+    """F.conv2d(x, w, b, stride=2, padding=1) (generative's Downsample, /root/reference/src/trainers/reconstruct.py:151-153)
+    as a direct convolution with split-f16 operands: against float64, no worse than the fp32 MFMA kernel it replaces, and
+    bit-reproducible; DDPM_DOWN_S2H=0 is covered by the child-process switch test."""
+    from ddpm_ood_amd import ops
+
+    B, Cin, Cout, H = case
+    g = torch.Generator().manual_seed(B + Cin + H)
+    x = torch.randn(B, Cin, H, H, generator=g) * 1.3 + 0.2
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    d = lambda t: t.to(device)
+    ws = ops.pack_conv_s2h_weight(d(w))
+    assert ws is not None and ws.numel() == Cout * Cin * 18 + 64
+    y = ops.conv(d(x), d(w), d(b), mode=ops.CONV_STRIDE2, wino44h=ws)
+    y32 = ops.conv(d(x), d(w), d(b), mode=ops.CONV_STRIDE2)
+    torch.cuda.synchronize()
+    assert not torch.equal(y, y32)  # the split-f16 kernel really ran
+    scale = ref.abs().max().item()
+    e_new = (y.cpu().double() - ref).abs().max().item() / scale
+    e_old = (y32.cpu().double() - ref).abs().max().item() / scale
+    assert math.isfinite(e_new) and e_new <= max(2 * e_old, 2e-6), (e_new, e_old)
+    assert torch.equal(y, ops.conv(d(x), d(w), d(b), mode=ops.CONV_STRIDE2, wino44h=ws))
+
+
+def test_conv_stride2_split_f16_operand_range(device):
+    """Operand scales over several decades (the per-layer weight scale 2^su and the 2^3 input scale keep the lo halves normal)."""
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    for sx, sw in ((1e-3, 1.0), (30.0, 1.0), (1.0, 1e-2), (1.0, 20.0)):
+        x = torch.randn(4, 64, 16, 16, generator=g) * sx
+        w = torch.randn(64, 64, 3, 3, generator=g) / 24 * sw
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), None, stride=2, padding=1)
+        y = ops.conv(x.to(device), w.to(device), None, mode=ops.CONV_STRIDE2, wino44h=ops.pack_conv_s2h_weight(w.to(device)))
+        err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= (4e-6 if sx < 1e-2 else 2e-6), (sx, sw, err)  # (inputs below 2^-9: their lo halves go subnormal)
