@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256, 2) void conv_s2h_kernel(const ddpm_conv_desc a
   // LDS with plain loads, so the compiler's own vmcnt bookkeeping lets the younger set stay in flight.
   typedef float v4f_t __attribute__((ext_vector_type(4)));
   typedef float v2f_t __attribute__((ext_vector_type(2)));
-  float xr[2][kS2NP][2][kS2C];  // [set][round][column of the pair][channel]
+  v2f_t xr[2][kS2NP][kS2C];  // [set][round][channel] = the pair's two columns (kept packed: unpacking at the load made hipcc wait for
+                             // the data right there, i.e. no prefetch at all)
   v4f_t wr[2][5];
   const v4f_t *wsrc = reinterpret_cast<const v4f_t *>(a.w_wino44h + (size_t)ct * g.nch * (kS2A / 2)) + tid;
   auto load = [&](auto setc, int q) {
@@ -170,14 +171,12 @@ __global__ __launch_bounds__(256, 2) void conv_s2h_kernel(const ddpm_conv_desc a
 #pragma unroll
         for (int c = 0; c < kS2C; ++c) {
 #ifdef S2H_NO_XLOAD  // (timing experiments: wrong results)
-          xr[S][r][0][c] = xr[S][r][1][c] = (float)q;
+          xr[S][r][c] = v2f_t{(float)q, (float)q};
 #else
           // (a plain 8-byte load: this toolchain lowers __builtin_amdgcn_raw_buffer_load_b64 to ONE buffer_load_dword)
           // unconditional (rows outside the image read the tensor's first pair and are zeroed when they are split): a
           // branch per load kept hipcc from issuing the sixteen loads back to back
-          const v2f_t v = *reinterpret_cast<const v2f_t *>(xsrc[r] + (size_t)(q * kS2C + c) * HWin);
-          xr[S][r][0][c] = v[0];
-          xr[S][r][1][c] = v[1];
+          xr[S][r][c] = *reinterpret_cast<const v2f_t *>(xsrc[r] + (size_t)(q * kS2C + c) * HWin);
 #endif
         }
       }
@@ -212,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2h_kernel(const ddpm_conv_desc a
           f16x8 hi, lo;
 #pragma unroll
           for (int c = 0; c < kS2C; ++c) {
-            const float v = xr[S][r][col][c] * xmul[r];
+            const float v = xr[S][r][c][col] * xmul[r];
             const _Float16 h = (_Float16)v;
             hi[c] = h;
             lo[c] = (_Float16)(v - (float)h);
