@@ -52,7 +52,7 @@ struct S2Geom {
 };
 
 static bool s2h_geom(const ddpm_conv_desc &d, S2Geom &g) {
-  static const bool on = !(getenv("DDPM_DOWN_S2H") && atoi(getenv("DDPM_DOWN_S2H")) == 0);
+  static const bool on = !(getenv("DDPM_DOWN_S2H") && atoi(getenv("DDPM_DOWN_S2H")) == 0);  // (2 / 3: force a kernel form)
   if (!on || d.force_direct || !d.w_wino44h) return false;
   if (d.mode != DDPM_CONV_STRIDE2 || d.ksize != 3 || d.dims == 3 || d.Di > 1 || d.Do > 1) return false;
   if (d.gscale || d.act != DDPM_ACT_NONE || d.C2 || d.chan_add || d.residual || d.out_act != DDPM_ACT_NONE) return false;
@@ -297,6 +297,217 @@ __global__ __launch_bounds__(256, 2) void conv_s2h_kernel(const ddpm_conv_desc a
   }
 }
 
+// ---- the chip-filling form: 128 couts x FOUR 128-pixel tiles per workgroup -------------------------------------------------
+// conv_s2h_kernel moves 2.35 GB per launch through L2 (5 TB/s, close to what the chip streams into LDS): every workgroup
+// re-fetches its chunk's weights and both cout tiles stage the same input window.  Here a workgroup (512 threads, one per CU)
+// keeps a chunk's weights of TWO cout tiles (36 KB) resident while FOUR consecutive pixel tiles pass under them -- eight
+// accumulator tiles per wave (64 couts x 32 pixels x 4 tiles = 128 registers): weight traffic / 4, input traffic / 2.
+// A step = (chunk q, tile sub): the next step's input window is requested before the step's 36 MFMAs and split / stored after
+// them; the next chunk's weights are requested at sub 0 and stored after sub 3; one barrier per step.
+constexpr int kS2A2 = 2 * kS2A;  // a chunk's weights of two cout tiles
+
+__global__ __launch_bounds__(512, 1) void conv_s2h4_kernel(const ddpm_conv_desc a, const S2Geom g) {
+  extern __shared__ __attribute__((aligned(16))) char smb[];
+  typedef float v4f_t __attribute__((ext_vector_type(4)));
+  typedef float v2f_t __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int cb2 = wave >> 2, pb = wave & 3;  // cout tile of the pair, 32-pixel block of the tile
+  const int Cin = a.C1, HWin = a.Hi * a.Wi, HWo = a.Ho * a.Wo;
+  const int CT2 = g.CT / 2, PG = (g.PT + 3) / 4;
+
+  const unsigned xcd = blockIdx.x & 7, mm = blockIdx.x >> 3;
+  const unsigned pgrp = (mm / CT2) * 8 + xcd;
+  const int ct2 = mm % CT2;
+  if (pgrp >= (unsigned)PG) return;
+  const int xbytes = g.units * 16;
+  char *const XB = smb + 2 * kS2A2;  // X buffers: [2][hi | lo]
+
+  // ---- staging roles: column pair e = tid (one round: pairs <= 512) of each of the four tiles
+  const bool own = tid < g.pairs;
+  int u0 = 0;
+  const float *xsrc[4];
+  float xmul[4];
+  {
+    int ti = 0, row = 0, j = 0;
+    if (own) {
+      ti = tid / (g.R * a.Wo);
+      const int rem = tid - ti * (g.R * a.Wo);
+      row = rem / a.Wo;
+      j = rem - row * a.Wo;
+      u0 = ti * g.IU + row * g.RU + j;
+    }
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const int st = 4 * pgrp + sub;
+      int n0, y0;
+      if (g.TI == 1) {
+        n0 = st / g.TPI;
+        y0 = (st - n0 * g.TPI) * g.TH;
+      } else {
+        n0 = st * g.TI;
+        y0 = 0;
+      }
+      const int n = n0 + ti, rin = 2 * y0 - 1 + row;
+      const bool ok = own && st < g.PT && n < a.B && rin >= 0 && rin < a.Hi;
+      xsrc[sub] = a.in1 + (ok ? (size_t)(n * Cin) * HWin + rin * a.Wi + 2 * j : 0);
+      xmul[sub] = ok ? kS2XScale : 0.f;
+    }
+  }
+  for (int e = tid; e < 4 * g.TI * g.R; e += 512) {  // column -1: a zero unit per row, both buffers and planes, once
+    const int w = e / (g.TI * g.R), rr = e - w * (g.TI * g.R);
+    const int ti = rr / g.R, row = rr - ti * g.R;
+    f16x8 z;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) z[c] = (_Float16)0.f;
+    reinterpret_cast<f16x8 *>(XB + (w >> 1) * 2 * xbytes + (w & 1) * xbytes)[ti * g.IU + row * g.RU] = z;
+  }
+  // weights: 2 304 units of 16 bytes per chunk; unit u -> cout tile u / 1 152 of the pair
+  const v4f_t *wsrc[5];
+  int wu[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int u = j < 4 ? tid + 512 * j : 2048 + (tid & 255);
+    wu[j] = u;
+    const int t = u / (kS2A / 16), r = u - t * (kS2A / 16);
+    wsrc[j] = reinterpret_cast<const v4f_t *>(a.w_wino44h + (size_t)(2 * ct2 + t) * g.nch * (kS2A / 2)) + r;
+  }
+  v2f_t xr[kS2C];
+  v4f_t wr[5];
+  auto load_x = [&](auto subc, int q) {
+    constexpr int SUB = decltype(subc)::value;
+#pragma unroll
+    for (int c = 0; c < kS2C; ++c) xr[c] = *reinterpret_cast<const v2f_t *>(xsrc[SUB] + (size_t)(q * kS2C + c) * HWin);
+  };
+  auto store_x = [&](auto subc, int xbuf) {
+    constexpr int SUB = decltype(subc)::value;
+    if (!own) return;
+    f16x8 *Xh = reinterpret_cast<f16x8 *>(XB + xbuf * 2 * xbytes), *Xl = Xh + g.units;
+#pragma unroll
+    for (int col = 0; col < 2; ++col) {
+      f16x8 hi, lo;
+#pragma unroll
+      for (int c = 0; c < kS2C; ++c) {
+        const float v = xr[c][col] * xmul[SUB];
+        const _Float16 h = (_Float16)v;
+        hi[c] = h;
+        lo[c] = (_Float16)(v - (float)h);
+      }
+      const int u = u0 + (col ? 1 : g.PWh);
+      Xh[u] = hi;
+      Xl[u] = lo;
+    }
+  };
+  auto load_w = [&](int q) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr[j] = wsrc[j][(size_t)q * (kS2A / 16)];
+    if (tid < 256) wr[4] = wsrc[4][(size_t)q * (kS2A / 16)];
+  };
+  auto store_w = [&](int abuf) {
+    v4f_t *Aw = reinterpret_cast<v4f_t *>(smb + abuf * kS2A2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Aw[wu[j]] = wr[j];
+    if (tid < 256) Aw[wu[4]] = wr[4];
+  };
+
+  // ---- MFMA operand addresses
+  const int aoff = cb2 * kS2A + (lhi * kS2K + l31) * 16;
+  int boff, pti, pty, pxx;
+  {
+    const int p = pb * 32 + l31;
+    pti = p / g.per;
+    const int rem = p - pti * g.per;
+    pty = rem / a.Wo;
+    pxx = rem - pty * a.Wo;
+    boff = (pti * g.IU + 2 * pty * g.RU + pxx) * 16;
+  }
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+  auto mfma_step = [&](auto subc, int abuf, int xbuf) {
+    constexpr int SUB = decltype(subc)::value;
+    const char *A = smb + abuf * kS2A2 + aoff;
+    const char *Xh = XB + xbuf * 2 * xbytes + boff, *Xl = Xh + xbytes;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap % 3;
+      const int toff = (ky * g.RU + (kx & 1) * g.PWh + (kx >> 1)) * 16;
+      const f16x8 a0 = *reinterpret_cast<const f16x8 *>(A + tap * 2048), a1 = *reinterpret_cast<const f16x8 *>(A + tap * 2048 + 512);
+      const f16x8 bh = *reinterpret_cast<const f16x8 *>(Xh + toff), bl = *reinterpret_cast<const f16x8 *>(Xl + toff);
+      acc[SUB][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bh, acc[SUB][0], 0, 0, 0);
+      acc[SUB][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bh, acc[SUB][1], 0, 0, 0);
+      acc[SUB][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bl, acc[SUB][0], 0, 0, 0);
+      acc[SUB][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bl, acc[SUB][1], 0, 0, 0);
+    }
+  };
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  using T2 = std::integral_constant<int, 2>;
+  using T3 = std::integral_constant<int, 3>;
+
+  load_w(0);
+  load_x(T0{}, 0);
+  store_w(0);
+  store_x(T0{}, 0);
+  __syncthreads();
+  for (int q = 0; q < g.nch; ++q) {
+    const int ab = q & 1;  // steps 4 q + sub use X buffer sub & 1
+    const bool more = q + 1 < g.nch;
+    if (more) load_w(q + 1);
+    load_x(T1{}, q);
+    mfma_step(T0{}, ab, 0);
+    store_x(T1{}, 1);
+    __syncthreads();
+    load_x(T2{}, q);
+    mfma_step(T1{}, ab, 1);
+    store_x(T2{}, 0);
+    __syncthreads();
+    load_x(T3{}, q);
+    mfma_step(T2{}, ab, 0);
+    store_x(T3{}, 1);
+    __syncthreads();
+    if (more) load_x(T0{}, q + 1);
+    mfma_step(T3{}, ab, 1);
+    if (more) {
+      store_w(ab ^ 1);
+      store_x(T0{}, 0);
+    }
+    __syncthreads();
+  }
+
+  const float oscale = reinterpret_cast<const float *>(a.w_wino44h + (size_t)a.Cout * Cin * 18)[1];
+  const int co0 = (2 * ct2 + cb2) * kS2K + 4 * lhi;
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    const int st = 4 * pgrp + sub;
+    int n0, y0;
+    if (g.TI == 1) {
+      n0 = st / g.TPI;
+      y0 = (st - n0 * g.TPI) * g.TH;
+    } else {
+      n0 = st * g.TI;
+      y0 = 0;
+    }
+    const int n = n0 + pti;
+    if (st < g.PT && n < a.B) {
+      const size_t obase = ((size_t)n * a.Cout + co0) * HWo + (size_t)(y0 + pty) * a.Wo + pxx;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dco = 32 * i + (r & 3) + 8 * (r >> 2);
+          const float b = a.bias ? a.bias[co0 + dco] : 0.f;
+          a.out[obase + (size_t)dco * HWo] = __builtin_fmaf(acc[sub][i][r], oscale, b);
+        }
+    }
+  }
+}
+
 int launch_conv_s2h(const ddpm_conv_desc &d, hipStream_t s) {
   S2Geom g;
   if (!s2h_geom(d, g)) {
@@ -312,6 +523,30 @@ int launch_conv_s2h(const ddpm_conv_desc &d, hipStream_t s) {
   const double M = (double)d.B * d.Ho * d.Wo;
   ProfScope prof(s, "conv3x3_s2h", 2.0 * M * d.Cout * (double)d.C1 * 9,
                  4.0 * ((double)d.B * d.C1 * d.Hi * d.Wi + M * d.Cout) + 2.0 * (double)d.Cout * d.C1 * 18);
+  // launches of at least one workgroup per CU in the four-tile form take it (weights resident over four pixel tiles, both
+  // cout tiles of a pair on one staged input window); DDPM_DOWN_S2H=2 / 3 force the small / the four-tile form (tests)
+  static const int force = getenv("DDPM_DOWN_S2H") ? atoi(getenv("DDPM_DOWN_S2H")) : 1;
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  const int PG = (g.PT + 3) / 4;
+  const size_t lds4 = 2 * (size_t)kS2A2 + 4 * (size_t)g.units * 16;
+  const bool can4 = d.Cout % (2 * kS2K) == 0 && g.pairs <= 512 && lds4 <= 160 * 1024;
+  if (can4 && force != 2 && (force == 3 || (long)PG * (g.CT / 2) >= cus)) {
+    static bool attr4_done = false;
+    if (!attr4_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_s2h4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr4_done = true;
+    }
+    const unsigned grid4 = 8u * (unsigned)((PG + 7) / 8) * (unsigned)(g.CT / 2);
+    hipLaunchKernelGGL(conv_s2h4_kernel, dim3(grid4), dim3(512), lds4, s, d, g);
+    DDPM_CHECK_LAUNCH();
+    return 0;
+  }
   const unsigned grid = 8u * (unsigned)((g.PT + 7) / 8) * (unsigned)g.CT;
   hipLaunchKernelGGL(conv_s2h_kernel, dim3(grid), dim3(256), lds, s, d, g);
   DDPM_CHECK_LAUNCH();

@@ -1209,6 +1209,7 @@ S2H_CASES = [
     (2, 64, 128, 64),     # 64 -> 32: four rows per tile
     (11, 64, 64, 8),      # 8 -> 4: eight images per tile, ragged
     (300, 8, 64, 16),     # one chunk, many workgroups
+    (513, 16, 128, 32),   # 1 026 tiles: the four-tile form (one workgroup per CU and more), ragged last group
 ]
 
 
