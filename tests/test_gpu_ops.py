@@ -1210,6 +1210,8 @@ S2H_CASES = [
     (11, 64, 64, 8),      # 8 -> 4: eight images per tile, ragged
     (300, 8, 64, 16),     # one chunk, many workgroups
     (513, 16, 128, 32),   # 1 026 tiles: the four-tile form (one workgroup per CU and more), ragged last group
+    (4, 24, 64, 16),      # an odd number of chunks (three)
+    (130, 40, 256, 64),   # 1 040 tiles x two cout-tile pairs in the four-tile form, five chunks
 ]
 
 
