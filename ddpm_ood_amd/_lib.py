@@ -14,7 +14,7 @@ import torch
 
 _LIB = None
 LIB_NAME = "libddpm_ood_hip.so"
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class HipLibraryMissing(RuntimeError):
@@ -106,6 +106,10 @@ SIGNATURES = {
     "ddpm_lpips_layer_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "ddpm_prof_enable": (C.c_int, [C.c_int]),
     "ddpm_prof_report": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "ddpm_status_read": (C.c_int, [C.POINTER(C.c_uint), C.c_int, C.c_void_p]),
+    "ddpm_set_split_f16": (C.c_int, [C.c_int]),
+    "ddpm_get_split_f16": (C.c_int, []),
+    "ddpm_reload_env": (C.c_int, []),
     "ddpm_unet_create": (C.c_void_p, [C.POINTER(UNetConfig)]),
     "ddpm_unet_destroy": (None, [C.c_void_p]),
     "ddpm_unet_param_blob_floats": (C.c_size_t, [C.c_void_p]),
@@ -176,3 +180,34 @@ def ptr(t) -> int | None:
 
 def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+# ---- numeric guard (include/ddpm_ood_hip.h, "Numeric guard of the split-f16 kernel families") -------------------
+STATUS_BITS = {1: "non-finite UNet output (eps) at a PLMS step", 2: "non-finite reconstruction at clamp + MSE",
+               4: "non-finite latent at the VQ-VAE quantiser"}
+
+
+def status_read(clear: bool = True) -> int:
+    """The device status word of the current device (synchronises the current stream)."""
+    word = C.c_uint(0)
+    check(load().ddpm_status_read(C.byref(word), int(clear), stream_ptr()), "status_read")
+    return int(word.value)
+
+
+def status_text(word: int) -> str:
+    return "; ".join(t for b, t in STATUS_BITS.items() if word & b) or "clean"
+
+
+def set_split_f16(on: bool) -> bool:
+    """False: every split-f16 kernel family runs its fp32-MFMA form.  Returns the previous setting."""
+    return bool(load().ddpm_set_split_f16(int(bool(on))))
+
+
+def split_f16() -> bool:
+    return bool(load().ddpm_get_split_f16())
+
+
+def reload_env() -> None:
+    """Parse the DDPM_* switches again (the library reads them once per process)."""
+    if _LIB is not None:
+        _LIB.ddpm_reload_env()

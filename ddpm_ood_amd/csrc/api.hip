@@ -19,6 +19,54 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+// ---- run-time switches --------------------------------------------------------------------------
+static Switches g_sw;
+static bool g_sw_loaded = false;
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+static void load_switches() {
+  const bool keep = g_sw.split_f16;
+  Switches n;
+  n.conv_wino44 = env_int("DDPM_CONV_WINO44", 1);
+  n.wino44_f16x3 = env_int("DDPM_WINO44_F16X3", 1) != 0;
+  n.wino44_split = env_int("DDPM_WINO44_SPLIT", 4);
+  n.wino44_xmap = env_int("DDPM_WINO44_XMAP", -1);
+  n.w44_abl = env_int("DDPM_W44_ABL", 0);
+  n.up_wino44h = env_int("DDPM_UP_WINO44H", 1) != 0;
+  n.down_s2h = env_int("DDPM_DOWN_S2H", 1);
+  n.conv1x1_f16x3 = env_int("DDPM_CONV1X1_F16X3", 1) != 0;
+  n.attn_f16x3 = env_int("DDPM_ATTN_F16X3", 1) != 0;
+  n.conv_splitk = env_int("DDPM_CONV_SPLITK", 1) != 0;
+  n.gn_fused = env_int("DDPM_GN_FUSED", 1) != 0;
+  n.prof_shapes = getenv("DDPM_PROF_SHAPES") != nullptr;
+  n.split_f16 = g_sw_loaded ? keep : true;
+  g_sw = n;
+  g_sw_loaded = true;
+}
+const Switches &sw() {
+  if (!g_sw_loaded) load_switches();
+  return g_sw;
+}
+
+// ---- device status word -------------------------------------------------------------------------
+static unsigned *g_status[64] = {};
+unsigned *status_word() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!g_status[dev]) {
+    unsigned *p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess) {
+      (void)hipFree(p);
+      return nullptr;
+    }
+    g_status[dev] = p;
+  }
+  return g_status[dev];
+}
+
 // ---- in-situ profiler ---------------------------------------------------------------------------
 struct ProfRec {
   hipEvent_t a, b;
@@ -77,6 +125,34 @@ extern "C" int ddpm_prof_report(char *buf, size_t cap) {
   }
   memcpy(buf, out.c_str(), out.size() + 1);
   return (int)out.size();
+}
+
+extern "C" int ddpm_reload_env(void) {
+  load_switches();
+  return 0;
+}
+
+extern "C" int ddpm_set_split_f16(int on) {
+  (void)sw();
+  const int was = g_sw.split_f16 ? 1 : 0;
+  g_sw.split_f16 = on != 0;
+  return was;
+}
+
+extern "C" int ddpm_get_split_f16(void) { return sw().split_f16 ? 1 : 0; }
+
+extern "C" int ddpm_status_read(unsigned *word, int clear, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(word != nullptr, "status_read: NULL pointer");
+  unsigned *st = status_word();
+  DDPM_CHECK_ARG(st != nullptr, "status_read: no status word on this device");
+  hipError_t e = hipMemcpyAsync(word, st, sizeof(unsigned), hipMemcpyDeviceToHost, as_stream(stream));
+  if (e == hipSuccess && clear) e = hipMemsetAsync(st, 0, sizeof(unsigned), as_stream(stream));
+  if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+  if (e != hipSuccess) {
+    set_error("status_read: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
 }
 
 extern "C" int ddpm_abi_version(void) { return DDPM_ABI_VERSION; }

@@ -757,7 +757,7 @@ int launch_attention(const float *qkv, const float *residual, float *out, int B,
   }
   dim3 grid((N + kQB - 1) / kQB, heads, B);
   ProfScope prof(s, "attention", 4.0 * B * (double)N * N * C, 4.0 * B * C * (double)N * (residual ? 5 : 4));
-  static const bool f16x3 = !(getenv("DDPM_ATTN_F16X3") && atoi(getenv("DDPM_ATTN_F16X3")) == 0);
+  const bool f16x3 = split_f16_on(sw().attn_f16x3);
   // eight-wave form by default (n = 4096: 892 vs 918 us, n = 256: 32.3 vs 34.8 us); DDPM_ATTN_WAVES=4 selects the other
   static const bool waves8 = !(getenv("DDPM_ATTN_WAVES") && atoi(getenv("DDPM_ATTN_WAVES")) == 4);
   const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv) & 15) == 0);

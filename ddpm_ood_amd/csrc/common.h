@@ -32,6 +32,36 @@ inline hipStream_t as_stream(ddpm_stream_t s) { return reinterpret_cast<hipStrea
 
 constexpr int kWave = 64;
 
+// ---- run-time switches (api.hip) ----------------------------------------------------------------
+// The DDPM_* environment switches of DESIGN 4.1 that are looked at per launch, parsed ONCE (ddpm_reload_env() parses them
+// again: the tests flip them inside one process) instead of 3-4 getenv calls per convolution, plus the run-time master
+// switch of the split-f16 kernel families (ddpm_set_split_f16).
+struct Switches {
+  int conv_wino44 = 1;          // DDPM_CONV_WINO44: 0 no F(4x4) kernels, 2 also for launches smaller than the chip
+  bool wino44_f16x3 = true;     // DDPM_WINO44_F16X3
+  int wino44_split = 4;         // DDPM_WINO44_SPLIT
+  int wino44_xmap = -1;         // DDPM_WINO44_XMAP (-1: unset, each kernel has its own default)
+  int w44_abl = 0;              // DDPM_W44_ABL
+  bool up_wino44h = true;       // DDPM_UP_WINO44H
+  int down_s2h = 1;             // DDPM_DOWN_S2H (0 off, 2 / 3 force a form)
+  bool conv1x1_f16x3 = true;    // DDPM_CONV1X1_F16X3
+  bool attn_f16x3 = true;       // DDPM_ATTN_F16X3
+  bool conv_splitk = true;      // DDPM_CONV_SPLITK
+  bool gn_fused = true;         // DDPM_GN_FUSED
+  bool prof_shapes = false;     // DDPM_PROF_SHAPES
+  bool split_f16 = true;        // ddpm_set_split_f16(): false = every split-f16 family runs its fp32-MFMA form
+};
+const Switches &sw();
+inline bool split_f16_on(bool family) { return family && sw().split_f16; }
+
+// ---- device status word (api.hip) ---------------------------------------------------------------
+// One 32-bit word per device, set (atomicOr, only when something is wrong) by the cheap kernels every tensor of the path
+// passes through; read with ddpm_status_read.  A non-finite value here means either a genuine fp32 overflow (the
+// reference would write NaN to its CSV) or an operand beyond the f16 range of a split-f16 kernel -- the caller re-runs
+// the batch with ddpm_set_split_f16(0) to tell the two apart (trainer.py::get_scores).
+unsigned *status_word();  // device pointer of the current device's word (allocated and zeroed on first use; NULL on failure)
+__device__ __forceinline__ bool non_finite(float v) { return !(__builtin_fabsf(v) <= 3.402823466e+38f); }
+
 // ---- in-situ profiler (api.hip) ----------------------------------------------------------------
 extern bool g_prof_on;
 void prof_begin(hipStream_t s, const char *kernel, double flops, double bytes);

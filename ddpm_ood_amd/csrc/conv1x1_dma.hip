@@ -54,8 +54,7 @@ constexpr int kDBuf = kDC * (kDM + kDP);  // floats per LDS buffer (6 144)
 constexpr int kDAff = 4 * 64;             // + the chunk's GroupNorm scale / shift pairs (AFFINE)
 
 static bool conv1x1_f16x3_enabled() {
-  static const bool on = !(getenv("DDPM_CONV1X1_F16X3") && atoi(getenv("DDPM_CONV1X1_F16X3")) == 0);
-  return on;
+  return split_f16_on(sw().conv1x1_f16x3);
 }
 
 bool conv1x1_dma_supported(const ddpm_conv_desc &d) {
@@ -74,9 +73,10 @@ bool conv1x1_dma_supported(const ddpm_conv_desc &d) {
   // smaller launches stay with conv_mfma's 64 / 128-pixel tiles and its split-K (DDPM_CONV1X1_DMA_MIN_WG: A/B of the
   // threshold).  Split-f16: half a chip of workgroups already wins (8x8 skip at B = 256, 128 workgroups: 83 -> 55 us;
   // the `big` UNet's q / k / v at B = 16, 192 workgroups: 115 -> 70 us); the f32 loop needed 1.5 waves of the chip
-  static const long min_wg = getenv("DDPM_CONV1X1_DMA_MIN_WG") ? atol(getenv("DDPM_CONV1X1_DMA_MIN_WG"))
-                             : conv1x1_f16x3_enabled()         ? 64  // (8x8 skip at B = 128, 64 workgroups: 62 -> 50 us)
-                                                               : 384;
+  static const long min_wg_env = getenv("DDPM_CONV1X1_DMA_MIN_WG") ? atol(getenv("DDPM_CONV1X1_DMA_MIN_WG")) : -1;
+  const long min_wg = min_wg_env >= 0 ? min_wg_env
+                      : conv1x1_f16x3_enabled() ? 64  // (8x8 skip at B = 128, 64 workgroups: 62 -> 50 us)
+                                                : 384;
   return tiles * (d.Cout / kDM) >= min_wg;
 }
 

@@ -550,8 +550,7 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g_in, hipStre
   g.pstride = 0;
   ddpm_conv_desc dk = d;
   const size_t out_floats = (size_t)d.B * d.Cout * g.Do * g.HWo;
-  const char *sk_env = getenv("DDPM_CONV_SPLITK");  // 0: off (A/B, tests); read per call
-  const bool sk_on = !(sk_env && atoi(sk_env) == 0);
+  const bool sk_on = sw().conv_splitk;  // DDPM_CONV_SPLITK=0: off (A/B, tests)
   if (sk_on && NTAPS != 4 && g.npar == 1 && d.scratch && d.out_act == DDPM_ACT_NONE && (g.Do * g.HWo) % 4 == 0) {
     const long wgs = (long)g.ntiles * (d.Cout / kConvNT);
     const int cus = mfma_cus();
@@ -592,7 +591,7 @@ static int launch_variant(const ddpm_conv_desc &d, const ConvGeom &g_in, hipStre
                         : (NTAPS == 9 ? (AFFINE ? "conv3x3_mfma_gn_silu_t64" : "conv3x3_mfma_t64")
                                       : (AFFINE ? "conv1x1_mfma_gn_t64" : "conv1x1_mfma_t64"));
   char kshape[160];
-  if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {  // development: one profile row per layer shape
+  if (g_prof_on && sw().prof_shapes) {  // development: one profile row per layer shape
     snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%dx%d m%d t%d", kname, d.C1, d.C2, d.Cout, g.Do, d.Ho, d.Wo, d.mode,
              MT);
     kname = kshape;

@@ -52,7 +52,7 @@ struct S2Geom {
 };
 
 static bool s2h_geom(const ddpm_conv_desc &d, S2Geom &g) {
-  static const bool on = !(getenv("DDPM_DOWN_S2H") && atoi(getenv("DDPM_DOWN_S2H")) == 0);  // (2 / 3: force a kernel form)
+  const bool on = split_f16_on(sw().down_s2h != 0);  // DDPM_DOWN_S2H (2 / 3: force a kernel form)
   if (!on || d.force_direct || !d.w_wino44h) return false;
   if (d.mode != DDPM_CONV_STRIDE2 || d.ksize != 3 || d.dims == 3 || d.Di > 1 || d.Do > 1) return false;
   if (d.gscale || d.act != DDPM_ACT_NONE || d.C2 || d.chan_add || d.residual || d.out_act != DDPM_ACT_NONE) return false;
@@ -525,7 +525,7 @@ int launch_conv_s2h(const ddpm_conv_desc &d, hipStream_t s) {
                  4.0 * ((double)d.B * d.C1 * d.Hi * d.Wi + M * d.Cout) + 2.0 * (double)d.Cout * d.C1 * 18);
   // launches of at least one workgroup per CU in the four-tile form take it (weights resident over four pixel tiles, both
   // cout tiles of a pair on one staged input window); DDPM_DOWN_S2H=2 / 3 force the small / the four-tile form (tests)
-  static const int force = getenv("DDPM_DOWN_S2H") ? atoi(getenv("DDPM_DOWN_S2H")) : 1;
+  const int force = sw().down_s2h;
   int cus = 256;
   {
     int dev = 0;

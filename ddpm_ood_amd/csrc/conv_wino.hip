@@ -1346,7 +1346,7 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
   const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9 * g.nkd);
   const char *kname = d.dims == 3 ? (d.gscale ? "conv3d_wino_gn_silu" : "conv3d_wino") : g.up ? "conv3x3_wino_up" : d.gscale ? "conv3x3_wino_gn_silu" : "conv3x3_wino";
   char kshape[160];
-  if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {
+  if (g_prof_on && sw().prof_shapes) {
     snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);
     kname = kshape;
   }

@@ -228,15 +228,13 @@ static bool w44_geom(const ddpm_conv_desc &d, W44Geom &g, bool sizing = false) {
   const long items = (long)g.KT * g.parts * g.NIT;
   const int cus = w44_cus();
   // small launches: conv_wino.hip (half-size items) and its channel-stream split.  DDPM_CONV_WINO44=2 lifts the rule (tests)
-  const char *sw = getenv("DDPM_CONV_WINO44");  // read per call: tests flip it
-  const bool any_size = sw && atoi(sw) == 2;
+  const bool any_size = sw().conv_wino44 == 2;  // (tests flip it: ddpm_reload_env)
   g.S = 1;
   g.pstride = 0;
   if (items < cus && !any_size) {
     if (is3d) return false;
     // every workgroup of a split walks an even number (>= 4) of chunks; DDPM_WINO44_SPLIT caps S (0 / 1: no split)
-    const char *sp_env = getenv("DDPM_WINO44_SPLIT");
-    const int sp_max = sp_env ? atoi(sp_env) : 4;
+    const int sp_max = sw().wino44_split;
     for (int sp = 4; sp >= 2; sp >>= 1)
       if (sp <= sp_max && items * sp <= cus && g.nchunks % (2 * sp) == 0 && g.nchunks / sp >= 4) { g.S = sp; break; }
     // below three quarters of the chip conv_wino.hip's half-size items (and its own split) are faster -- measured at B = 16:
@@ -250,25 +248,22 @@ static bool w44_geom(const ddpm_conv_desc &d, W44Geom &g, bool sizing = false) {
   g.IPW = (int)((items + cus - 1) / cus);
   g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW) * g.S;
   g.grid = g.KT * ((g.NS + 7) / 8) * 8;
-  g.abl = getenv("DDPM_W44_ABL") ? atoi(getenv("DDPM_W44_ABL")) : 0;
-  const char *xm = getenv("DDPM_WINO44_XMAP");
-  g.xmap = (xm ? atoi(xm) != 0 : 1) && (8 % g.KT == 0);
+  g.abl = sw().w44_abl;
+  g.xmap = (sw().wino44_xmap >= 0 ? sw().wino44_xmap != 0 : 1) && (8 % g.KT == 0);
   if (g.xmap) g.grid = 8 * ((g.NS + 8 / g.KT - 1) / (8 / g.KT));
   return true;
 }
 
 bool conv_wino44_supported(const ddpm_conv_desc &d) {
-  const char *sw = getenv("DDPM_CONV_WINO44");
-  const bool enabled = !(sw && atoi(sw) == 0);
+  const bool enabled = sw().conv_wino44 != 0;
   W44Geom g;
   return enabled && d.w_wino44 != nullptr && !d.force_direct && w44_geom(d, g);
 }
 
 // floats of scratch with which this descriptor runs as a split F(4x4) launch (0: unsplit, or not an F(4x4) shape)
 size_t conv_wino44_scratch_floats(const ddpm_conv_desc &d) {
-  const char *sw = getenv("DDPM_CONV_WINO44");
   W44Geom g;
-  if ((sw && atoi(sw) == 0) || !d.w_wino44 || d.force_direct || !w44_geom(d, g, true) || g.S == 1) return 0;
+  if (sw().conv_wino44 == 0 || !d.w_wino44 || d.force_direct || !w44_geom(d, g, true) || g.S == 1) return 0;
   return (size_t)g.S * d.B * d.Cout * g.HW;
 }
 
@@ -799,7 +794,7 @@ int launch_conv_wino44(const ddpm_conv_desc &d, hipStream_t s) {
   const double bytes = 4.0 * (M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9 * g.nkd);
   const char *kname = d.dims == 3 ? "conv3d_wino44" : d.gscale ? "conv3x3_wino44_gn_silu" : "conv3x3_wino44";
   char kshape[160];
-  if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {
+  if (g_prof_on && sw().prof_shapes) {
     snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);
     kname = kshape;
   }

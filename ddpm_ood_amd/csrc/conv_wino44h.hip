@@ -17,7 +17,11 @@
 // layer's largest transformed weight --, V by 2^3 through the activation that feeds the transform; the product of the two
 // scales is stored behind the packed planes and goes back into the epilogue's fused multiply-add.  Full precision holds for
 // |V| in [2^-6, 8188]; below, the absolute error of an operand is <= 2^-28 (V) / 2^-39 of the layer's largest |U|; above, the
-// high half of V overflows to inf (loud).
+// high half of V overflows to inf.  Behind a GroupNorm the input is bounded and 2^3 centres its range; the forms that read an
+// UN-NORMALISED tensor (Upsample: the raw residual stream; the VQ-VAE's 3-D residual units: ReLU activations) use 2^0 instead
+// -- full precision for |V| in [2^-3, 65504], i.e. patches up to ~650 in the worst case (B^T d B has gain <= 100) and ~5 000
+// for typical data, graceful (absolute error <= 2^-25) below.  An overflow is never silent: the inf / NaN reaches the
+// status word of the PLMS / clamp kernels (ddpm_status_read) and the caller re-runs the batch on the fp32-MFMA kernels.
 //
 // Structure (why it is not the old kernel with other MFMAs).  K = 16 per instruction means 8 channels x 36 positions x
 // (64 + 32) operand rows = 110 KB per K-step: the operand images cannot be double-buffered per chunk any more.  So a chunk
@@ -63,7 +67,8 @@ constexpr int kVB0 = 2 * kUSB;            // byte offset of the V ring
 constexpr int kRINGF = (2 * kUSB + 2 * kVSB) / 4;  // floats of both rings (18432)
 constexpr int kXS = kX * 2 * 64;          // exchange slab of the epilogue: [xi][cout block][lane] (4608 floats)
 static_assert(kRINGF == 4 * kXS, "the operand rings are the epilogue's four exchange slabs");
-constexpr float kVScale = 8.f;            // 2^3 on V (through the activation)
+constexpr float kVScale = 8.f;            // 2^3 on V (through the activation) behind a GroupNorm + SiLU prologue
+constexpr float kVScaleRaw = 1.f;         // 2^0 on V for un-normalised inputs (Upsample, VQ-VAE residual units, plain convs)
 constexpr int kTail = 64;                 // f16 slots behind the packed planes: float [0] = max |U|, float [1] = 1 / (2^3 2^su)
 
 // ---- accumulators.  A wave owns nine 32x32 fp32 tiles.  Eight of them live in a[0:127], addressed BY NAME inside the asm
@@ -236,8 +241,7 @@ static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false)
   // Upsample convolutions (F.interpolate(nearest, x2) + conv3x3 of generative's Upsample, between the up levels): plain
   // convolution of the virtual upsampled image; 64-pixel staging units must be an even number of rows (Wo <= 32)
   if (up) {
-    static const bool up_on = !(getenv("DDPM_UP_WINO44H") && atoi(getenv("DDPM_UP_WINO44H")) == 0);
-    if (!up_on || is3d || d.gscale || d.act != DDPM_ACT_NONE || d.C2 || d.chan_add || d.residual || d.out_act != DDPM_ACT_NONE)
+    if (!sw().up_wino44h || is3d || d.gscale || d.act != DDPM_ACT_NONE || d.C2 || d.chan_add || d.residual || d.out_act != DDPM_ACT_NONE)
       return false;
     if (d.Ho != 2 * d.Hi || d.Wo != 2 * d.Wi || d.Wo > 32) return false;
   }
@@ -307,14 +311,12 @@ static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false)
   g.NIT = (g.NIMG + g.TI - 1) / g.TI;
   const long items = (long)g.KT * g.parts * g.NIT;
   const int cus = w44h_cus();
-  const char *sw = getenv("DDPM_CONV_WINO44");  // 2: any launch size (tests)
-  const bool any_size = sw && atoi(sw) == 2;
+  const bool any_size = sw().conv_wino44 == 2;  // any launch size (tests)
   g.S = 1;
   g.pstride = 0;
   if (items < cus && !any_size) {
     if (is3d) return false;
-    const char *sp_env = getenv("DDPM_WINO44_SPLIT");
-    const int sp_max = sp_env ? atoi(sp_env) : 4;
+    const int sp_max = sw().wino44_split;
     for (int sp = 4; sp >= 2; sp >>= 1)  // every workgroup of a split walks an even number of chunks
       if (sp <= sp_max && items * sp <= cus && g.NCH % (2 * sp) == 0) { g.S = sp; break; }
     if (g.S == 1 || items * g.S * 4 < (long)cus * 3) return false;  // below three quarters of the chip: conv_wino.hip
@@ -325,17 +327,15 @@ static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false)
   g.IPW = (int)((items + cus - 1) / cus);
   g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW) * g.S;
   g.grid = g.KT * ((g.NS + 7) / 8) * 8;
-  const char *xm = getenv("DDPM_WINO44_XMAP");
   // default 0: the cout tiles of a slot are neighbours on ONE XCD, so that the KT re-reads of the slot's input hit that XCD's L2
   // (rocprofv3 FETCH_SIZE / WRITE_SIZE at B = 1 024: 1.14 GB per launch against 1.49 GB with one cout tile per XCD, same time)
-  g.xmap = (xm ? atoi(xm) != 0 : 0) && (8 % g.KT == 0);
+  g.xmap = (sw().wino44_xmap >= 0 ? sw().wino44_xmap != 0 : 0) && (8 % g.KT == 0);
   if (g.xmap) g.grid = 8 * ((g.NS + 8 / g.KT - 1) / (8 / g.KT));
   return true;
 }
 
 static bool w44h_enabled() {
-  const char *sw = getenv("DDPM_CONV_WINO44"), *f = getenv("DDPM_WINO44_F16X3");
-  return !(sw && atoi(sw) == 0) && !(f && atoi(f) == 0);
+  return sw().conv_wino44 != 0 && split_f16_on(sw().wino44_f16x3);
 }
 
 // slices per (image, cout) of the GroupNorm statistics the epilogue writes to desc.stats_out (0: none -- 3-D, split
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
         const float t = __builtin_fmaf(x, -1.44269504088896341f * sa, -1.44269504088896341f * sb);
         y = (kVScale * v) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
       } else {
-        y = kVScale * (silu ? silu_fast(x) : x);
+        y = kVScaleRaw * (silu ? silu_fast(x) : x);
       }
       P[ring * g.HS + pw_of(k)] = y;
     };
@@ -900,6 +900,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     float kOutScale, unused_umax;
     sload2(reinterpret_cast<const float *>(a.w_wino44h + (size_t)kX * a.Cout * g.Cin * 2 * g.nkd_w) + 1, kOutScale, unused_umax);
     (void)unused_umax;
+    if (!AFFINE) kOutScale *= kVScale / kVScaleRaw;  // the packed tail carries 1 / (2^3 2^su)
     // accumulator tile 3 t + i of wave pg holds position s = 3 pg + i of phase t: row (0,5 | 1,2 | 3,4)[s / 6], column s % 6
     const int rsel = pg >> 1, cofs = 3 * (pg & 1);
     const int xb0 = (rsel ? 5 : 0) * 6 + cofs, xb1 = (rsel ? 2 : 1) * 6 + cofs, xb2 = (rsel ? 4 : 3) * 6 + cofs;
@@ -1083,7 +1084,7 @@ int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s) {
   const double bytes = 4.0 * ((g.up ? 0.25 : 1.0) * M * g.Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * g.Cin * 9 * g.nkd);
   const char *kname = d.dims == 3 ? "conv3d_wino44h" : g.up ? "conv3x3_wino44h_up" : d.gscale ? "conv3x3_wino44h_gn_silu" : "conv3x3_wino44h";
   char kshape[160];
-  if (g_prof_on && getenv("DDPM_PROF_SHAPES")) {
+  if (g_prof_on && sw().prof_shapes) {
     snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);
     kname = kshape;
   }

@@ -99,14 +99,17 @@ struct PlmsArgs {
   float sample_coeff, coef_eps, denom, v_a, v_b;
   int v_prediction;
   int64_t numel;
+  unsigned *status;  // device status word (DDPM_STATUS_NONFINITE_EPS) or NULL
 };
 
 template <int KIND>
 __global__ __launch_bounds__(256) void plms_step_kernel(const PlmsArgs a) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;  // every tensor of a UNet forward ends in its eps: a non-finite value anywhere inside shows up here
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.numel; i += stride) {
     const float x = a.sample[i];
     const float e0 = a.e0[i];
+    bad |= non_finite(e0);
     const float e1 = KIND >= 1 ? a.e1[i] : 0.f;
     const float e2 = KIND >= 3 ? a.e2[i] : 0.f;
     const float e3 = KIND >= 4 ? a.e3[i] : 0.f;
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(256) void plms_step_kernel(const PlmsArgs a) {
     if (a.v_prediction) eps = a.v_a * eps + a.v_b * x;
     a.prev[i] = a.sample_coeff * x - (a.coef_eps * eps) / a.denom;
   }
+  if (bad && a.status) atomicOr(a.status, (unsigned)DDPM_STATUS_NONFINITE_EPS);
 }
 
 int launch_plms_step(const PlmsArgs &a, int kind, hipStream_t s) {
@@ -140,27 +144,31 @@ int launch_plms_step(const PlmsArgs &a, int kind, hipStream_t s) {
 
 // ---- x / b_scale, clamp(0, 1) in place, per-image mean squared error --------------------------
 __global__ __launch_bounds__(256) void clamp_mse_kernel(const float *__restrict__ orig, float *__restrict__ recon,
-                                                        float b_scale, float *__restrict__ mse, int64_t chw) {
+                                                        float b_scale, float *__restrict__ mse, int64_t chw,
+                                                        unsigned *__restrict__ status) {
   __shared__ float red[4];
   const int b = blockIdx.x;
   const float *o = orig + (int64_t)b * chw;
   float *r = recon + (int64_t)b * chw;
   float acc = 0.f;
+  bool bad = false;
   for (int64_t i = threadIdx.x; i < chw; i += 256) {
     float v = r[i] / b_scale;
-    v = fminf(fmaxf(v, 0.f), 1.f);
+    bad |= non_finite(v);
+    v = v != v ? v : fminf(fmaxf(v, 0.f), 1.f);  // torch.clamp_ keeps a NaN (fminf / fmaxf would return the bound)
     r[i] = v;
     const float d = o[i] - v;
     acc += d * d;
   }
   const float tot = block_sum_256(acc, red);
   if (threadIdx.x == 0) mse[b] = tot / (float)chw;
+  if (bad && status) atomicOr(status, (unsigned)DDPM_STATUS_NONFINITE_RECON);
 }
 
 int launch_clamp_mse(const float *orig, float *recon, float b_scale, float *mse, int B, int64_t chw, hipStream_t s) {
   DDPM_CHECK_ARG(orig && recon && mse && B > 0 && chw > 0 && b_scale != 0.f, "clamp_mse: bad argument");
   ProfScope prof(s, "clamp_mse", 5.0 * B * chw, 12.0 * B * chw);
-  hipLaunchKernelGGL(clamp_mse_kernel, dim3(B), dim3(256), 0, s, orig, recon, b_scale, mse, chw);
+  hipLaunchKernelGGL(clamp_mse_kernel, dim3(B), dim3(256), 0, s, orig, recon, b_scale, mse, chw, status_word());
   DDPM_CHECK_LAUNCH();
   return 0;
 }
@@ -205,7 +213,7 @@ extern "C" int ddpm_plms_step_f32(const float *sample, const float *e0, const fl
                                   const float *e3, int kind, int v_prediction, float v_a, float v_b,
                                   float sample_coeff, float coef_eps, float denom, float *prev, int64_t numel,
                                   ddpm_stream_t stream) {
-  PlmsArgs a{sample, e0, e1, e2, e3, prev, sample_coeff, coef_eps, denom, v_a, v_b, v_prediction, numel};
+  PlmsArgs a{sample, e0, e1, e2, e3, prev, sample_coeff, coef_eps, denom, v_a, v_b, v_prediction, numel, status_word()};
   return launch_plms_step(a, kind, as_stream(stream));
 }
 

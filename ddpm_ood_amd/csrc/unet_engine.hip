@@ -493,7 +493,7 @@ struct Runner {
   int rc = 0;
   float *temb = nullptr;  // [B, temb_total]
   std::deque<int> spool;  // Act::sparts storage (stable addresses)
-  bool fuse_stats = !(getenv("DDPM_GN_FUSED") && atoi(getenv("DDPM_GN_FUSED")) == 0);  // 0: every GroupNorm reads its input
+  bool fuse_stats = sw().gn_fused;  // 0: every GroupNorm reads its input
   bool eager_stats = false;  // large launches: per-channel slabs for every tensor (a skip connection is reduced once, not twice)
 
   const float *P(size_t off) const { return u->blob + off; }

@@ -16,7 +16,8 @@ namespace ddpm {
 template <int D>
 __global__ __launch_bounds__(256) void vq_nearest_kernel(const float *__restrict__ x, const float *__restrict__ e,
                                                          const float *__restrict__ e2, int *__restrict__ idx,
-                                                         float *__restrict__ out, int S, int K, long npos) {
+                                                         float *__restrict__ out, int S, int K, long npos,
+                                                         unsigned *__restrict__ status) {
   __shared__ float bd[4][64];
   __shared__ int bi[4][64];
   const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
@@ -31,6 +32,8 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float *__restrict
     z[d] = live ? xp[(size_t)d * S] : 0.f;
     z2 += z[d] * z[d];
   }
+  // a non-finite latent picks an arbitrary code: say so
+  if (quarter == 0 && non_finite(z2) && status) atomicOr(status, (unsigned)DDPM_STATUS_NONFINITE_LATENT);
   const int kq = (K + 3) / 4, k0 = quarter * kq, k1 = min(K, k0 + kq);
   float best = INFINITY;
   int besti = k0;
@@ -66,13 +69,15 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float *__restrict
 // any embedding_dim (the built sizes above keep z in registers; this one re-reads it, cached, per code): same arithmetic order
 __global__ __launch_bounds__(256) void vq_nearest_generic_kernel(const float *__restrict__ x, const float *__restrict__ e,
                                                                  const float *__restrict__ e2, int *__restrict__ idx,
-                                                                 float *__restrict__ out, int D, int S, int K, long npos) {
+                                                                 float *__restrict__ out, int D, int S, int K, long npos,
+                                                                 unsigned *__restrict__ status) {
   const long pos = (long)blockIdx.x * 256 + threadIdx.x;
   if (pos >= npos) return;
   const long b = pos / S, p = pos - b * S;
   const float *xp = x + (size_t)b * D * S + p;
   float z2 = 0.f;
   for (int d = 0; d < D; ++d) z2 += xp[(size_t)d * S] * xp[(size_t)d * S];
+  if (non_finite(z2) && status) atomicOr(status, (unsigned)DDPM_STATUS_NONFINITE_LATENT);
   float best = INFINITY;
   int besti = 0;
   for (int k = 0; k < K; ++k) {
@@ -114,7 +119,8 @@ int launch_vq_nearest(const float *x, const float *codebook, float *code_norms, 
   const dim3 grid((unsigned)((npos + 63) / 64));
 #define DDPM_VQ_CASE(DD)                                                                                             \
   case DD:                                                                                                           \
-    hipLaunchKernelGGL(vq_nearest_kernel<DD>, grid, dim3(256), 0, s, x, codebook, code_norms, idx, out, (int)S, K, npos); \
+    hipLaunchKernelGGL(vq_nearest_kernel<DD>, grid, dim3(256), 0, s, x, codebook, code_norms, idx, out, (int)S, K, npos, \
+                       status_word());                                                                                   \
     break;
   switch (D) {
     DDPM_VQ_CASE(8)
@@ -124,7 +130,7 @@ int launch_vq_nearest(const float *x, const float *codebook, float *code_norms, 
     DDPM_VQ_CASE(128)
     default:  // other embedding sizes: the generic kernel (x and out must not alias)
       hipLaunchKernelGGL(vq_nearest_generic_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, s, x, codebook, code_norms,
-                         idx, out, D, (int)S, K, npos);
+                         idx, out, D, (int)S, K, npos, status_word());
       break;
   }
 #undef DDPM_VQ_CASE

@@ -313,72 +313,108 @@ class Reconstruct(BaseTrainer):
         ids_all, names_all, scores_all = [], [], []
         t_values = [int(t) for t in reversed(self.make_scheduler().timesteps)[1::inference_skip_factor]]
         n_recon = n_fwd = 0
+        guard = {"batches_rerun_fp32": 0, "batches_nonfinite": 0}
+        _lib.status_read(clear=True)  # whatever an earlier caller left behind is not this run's
         for batch in loader:
-            sched = self.make_scheduler()  # one per batch: PLMS history leaks across t-starts (Q3)
-            timesteps = sched.timesteps
-            start_points = reversed(timesteps)[1::inference_skip_factor]
-            t_values = [int(t) for t in start_points]
-
-            t1 = time.time()
-            images_original = batch["image"].to(self.device, non_blocking=True).float().contiguous()
-            images = self.vqvae_model.encode_stage_2_inputs(images_original).float().contiguous()
-            if self.do_latent_pad:
-                images = F.pad(input=images, pad=self.latent_pad, mode="constant", value=0)
-            B = images.shape[0]
-            idx = batch["index"]
-            per_t = []
-            for t_start in start_points:
-                if self.reset_scheduler_per_t:
-                    sched.set_timesteps(self.num_inference_steps)
-                start_timesteps = torch.Tensor([t_start] * B).long()
-                noise = batch_noise(self.seed, idx, int(t_start), images.shape).to(self.device, non_blocking=True)
-                x = sched.add_noise(original_samples=images, noise=noise, timesteps=start_timesteps,
-                                    b_scale=self.b_scale)
-                first = self.profile_first_steps
-                for step in timesteps[timesteps <= t_start]:
-                    if first:
-                        _lib.load().ddpm_prof_enable(1)
-                    eps = self.model(x, timesteps=self._timesteps_tensor(int(step), B))
-                    x, _ = sched.step(eps, step, x)
-                    if first:
-                        _lib.load().ddpm_prof_enable(0)
-                        first = False
-                    n_fwd += B
-                if self.do_latent_pad:
-                    x = F.pad(input=x, pad=self.inverse_latent_pad, mode="constant", value=0).contiguous()
-                prof_decode = self.profile_first_steps and not isinstance(self.vqvae_model, PassthroughVQVAE)
-                if prof_decode:
-                    _lib.load().ddpm_prof_enable(1)
-                x = self.vqvae_model.decode_stage_2_outputs(x).contiguous()
-                if prof_decode:
-                    _lib.load().ddpm_prof_enable(0)
-                mse = ops.clamp_mse_(images_original, x, self.b_scale)  # x / b_scale, clamp_(0, 1), MSE
-                if self.spatial_dimension == 2:
-                    if images_original.shape[3] == 28:
-                        pd_ = pl(F.pad(images_original, (2, 2, 2, 2)), F.pad(x, (2, 2, 2, 2)))
-                    else:
-                        pd_ = pl(images_original, x)
-                    pd_ = pd_.reshape(B)
-                else:
-                    pd_ = torch.stack([pl(images_original[b, None, ...], x[b, None, ...]).reshape(())
-                                       for b in range(B)])
-                per_t.append(torch.stack([pd_, mse], dim=1))
-                n_recon += B
-            scores = torch.stack(per_t, dim=1)  # [B, n_t, 2] on the device
+            scores, t_values, n_r, n_f, B, dt = self._score_batch(batch, pl, inference_skip_factor)
+            # numeric guard (include/ddpm_ood_hip.h): a non-finite eps / reconstruction / latent set the device status word.
+            # With the split-f16 kernels on, that may be an operand beyond the f16 range rather than a genuine fp32
+            # overflow: run THIS batch again on the fp32-MFMA kernels; what is still non-finite then is written as NaN,
+            # like the reference would (reconstruct.py:188-204 has no check).
+            word = _lib.status_read(clear=True)
+            if word and _lib.split_f16():
+                print(f"WARNING: {_lib.status_text(word)} in a batch of {B} on the split-f16 kernels: running the batch "
+                      f"again with fp32 MFMA products (ddpm_set_split_f16(0); permanently: DDPM_WINO44_F16X3=0 "
+                      f"DDPM_CONV1X1_F16X3=0 DDPM_ATTN_F16X3=0 DDPM_DOWN_S2H=0)", file=sys.__stderr__, flush=True)
+                _lib.set_split_f16(False)
+                try:
+                    scores, t_values, n_r, n_f, B, dt2 = self._score_batch(batch, pl, inference_skip_factor)
+                    dt += dt2
+                    word = _lib.status_read(clear=True)
+                finally:
+                    _lib.set_split_f16(True)
+                guard["batches_rerun_fp32"] += 1
+            if word:
+                guard["batches_nonfinite"] += 1
+                print(f"WARNING: {_lib.status_text(word)} with fp32 products too: a genuine overflow of this checkpoint on "
+                      f"these inputs; the affected scores are NaN / inf in the CSV, as the reference would write them",
+                      file=sys.__stderr__, flush=True)
+            n_recon += n_r
+            n_fwd += n_f
             scores_all.append(scores)
-            ids_all.append(torch.tensor(idx, dtype=torch.int32))
+            ids_all.append(torch.tensor(batch["index"], dtype=torch.int32))
             names_all.extend(batch["image_meta_dict"]["filename_or_obj"])
-            torch.cuda.current_stream().synchronize()
-            t2 = time.time()
             if quiet:
                 pass
             elif self.ddp:
-                print(f"{self.rank}: Took {t2-t1}s for a batch size of {B}")
+                print(f"{self.rank}: Took {dt}s for a batch size of {B}")
             else:
-                print(f"Took {t2-t1}s for a batch size of {B}")
+                print(f"Took {dt}s for a batch size of {B}")
         self.last_stats = {"reconstructions": n_recon, "unet_forwards": n_fwd,
-                           "lpips_pretrained": bool(pl.perceptual_function.pretrained)}
+                           "lpips_pretrained": bool(pl.perceptual_function.pretrained), **guard}
+        return self._collect(loader, dataset_name, t_values, ids_all, names_all, scores_all, quiet)
 
+    def _score_batch(self, batch, pl, inference_skip_factor):
+        """One batch through reconstruct.py:97-204: every t-start's noise, PLMS trajectory, decode, MSE and LPIPS.
+        Returns (scores [B, n_t, 2] on the device, t values, reconstructions, UNet image-forwards, B, seconds)."""
+        n_recon = n_fwd = 0
+        sched = self.make_scheduler()  # one per batch: PLMS history leaks across t-starts (Q3)
+        timesteps = sched.timesteps
+        start_points = reversed(timesteps)[1::inference_skip_factor]
+        t_values = [int(t) for t in start_points]
+
+        t1 = time.time()
+        images_original = batch["image"].to(self.device, non_blocking=True).float().contiguous()
+        images = self.vqvae_model.encode_stage_2_inputs(images_original).float().contiguous()
+        if self.do_latent_pad:
+            images = F.pad(input=images, pad=self.latent_pad, mode="constant", value=0)
+        B = images.shape[0]
+        idx = batch["index"]
+        per_t = []
+        for t_start in start_points:
+            if self.reset_scheduler_per_t:
+                sched.set_timesteps(self.num_inference_steps)
+            start_timesteps = torch.Tensor([t_start] * B).long()
+            noise = batch_noise(self.seed, idx, int(t_start), images.shape).to(self.device, non_blocking=True)
+            x = sched.add_noise(original_samples=images, noise=noise, timesteps=start_timesteps,
+                                b_scale=self.b_scale)
+            first = self.profile_first_steps
+            for step in timesteps[timesteps <= t_start]:
+                if first:
+                    _lib.load().ddpm_prof_enable(1)
+                eps = self.model(x, timesteps=self._timesteps_tensor(int(step), B))
+                x, _ = sched.step(eps, step, x)
+                if first:
+                    _lib.load().ddpm_prof_enable(0)
+                    first = False
+                n_fwd += B
+            if self.do_latent_pad:
+                x = F.pad(input=x, pad=self.inverse_latent_pad, mode="constant", value=0).contiguous()
+            prof_decode = self.profile_first_steps and not isinstance(self.vqvae_model, PassthroughVQVAE)
+            if prof_decode:
+                _lib.load().ddpm_prof_enable(1)
+            x = self.vqvae_model.decode_stage_2_outputs(x).contiguous()
+            if prof_decode:
+                _lib.load().ddpm_prof_enable(0)
+            mse = ops.clamp_mse_(images_original, x, self.b_scale)  # x / b_scale, clamp_(0, 1), MSE
+            if self.spatial_dimension == 2:
+                if images_original.shape[3] == 28:
+                    pd_ = pl(F.pad(images_original, (2, 2, 2, 2)), F.pad(x, (2, 2, 2, 2)))
+                else:
+                    pd_ = pl(images_original, x)
+                pd_ = pd_.reshape(B)
+            else:
+                pd_ = torch.stack([pl(images_original[b, None, ...], x[b, None, ...]).reshape(())
+                                   for b in range(B)])
+            per_t.append(torch.stack([pd_, mse], dim=1))
+            n_recon += B
+        scores = torch.stack(per_t, dim=1)  # [B, n_t, 2] on the device
+        torch.cuda.current_stream().synchronize()
+        t2 = time.time()
+        return scores, t_values, n_recon, n_fwd, B, t2 - t1
+
+    def _collect(self, loader, dataset_name, t_values, ids_all, names_all, scores_all, quiet):
+        """reconstruct.py:238-250: everyone's rows on every rank, through ONE collective."""
         if not scores_all and not self.ddp:
             return []
         if scores_all:

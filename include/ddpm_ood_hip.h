@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDPM_ABI_VERSION 7
+#define DDPM_ABI_VERSION 8
 
 #define DDPM_EINVAL (-1)      /* bad argument / unsupported shape      */
 #define DDPM_ENOPARAM (-2)    /* unknown or missing parameter name     */
@@ -369,6 +369,32 @@ int ddpm_unet_num_graphs(const ddpm_unet *h);
  * ---------------------------------------------------------------------------------- */
 int ddpm_prof_enable(int on);
 int ddpm_prof_report(char *buf, size_t cap);
+
+/* ------------------------------------------------------------------------------------
+ * Numeric guard of the split-f16 kernel families (ABI 8).
+ *
+ * The reference computes this path in fp32 / fp16-autocast ATen ops (src/trainers/reconstruct.py:129,151-157); a
+ * non-finite value there lands as NaN in its CSV.  Here the MFMA products of the 3x3 / 1x1 convolutions and of
+ * attention are split-f16: exact for operands inside the f16 exponent range, inf beyond it
+ * (F(4x4) input patches above ~80 in the worst case, ~600 typically).  So that an overflow can never reach the CSV
+ * silently, the kernels every tensor of the path ends in -- the PLMS update (reads every eps), clamp + MSE (reads every
+ * reconstruction), the VQ-VAE quantiser (reads every latent) -- OR a bit into a per-device status word when they meet a
+ * non-finite value.  Protocol of the caller (ddpm_ood_amd/trainer.py::get_scores): read + clear after each batch; if set
+ * while the split-f16 kernels are on, run the batch again after ddpm_set_split_f16(0); a word that is still set then is
+ * a genuine fp32 overflow and the NaN is written like the reference would.
+ * ---------------------------------------------------------------------------------- */
+#define DDPM_STATUS_NONFINITE_EPS 1u    /* ddpm_plms_step_f32 read a non-finite model output           */
+#define DDPM_STATUS_NONFINITE_RECON 2u  /* ddpm_clamp_mse_f32 read a non-finite reconstruction          */
+#define DDPM_STATUS_NONFINITE_LATENT 4u /* ddpm_vq_nearest_f32 read a non-finite latent                 */
+/* Copies the current device's status word to *word (host memory), clears it if `clear`, and synchronises `stream`. */
+int ddpm_status_read(unsigned *word, int clear, ddpm_stream_t stream);
+/* on = 0: every split-f16 kernel family runs its fp32-MFMA form (bit-exact fp32 products) whatever the DDPM_*_F16X3
+ * environment switches say; on = 1: back to what the environment selects (default: split-f16).  Returns the previous
+ * setting.  Process-wide; not thread-safe against concurrent launches. */
+int ddpm_set_split_f16(int on);
+int ddpm_get_split_f16(void);
+/* Parses the DDPM_* environment switches again (they are read once per process otherwise). */
+int ddpm_reload_env(void);
 
 #ifdef __cplusplus
 }

@@ -30,3 +30,39 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no ROCm device")
     return torch.device("cuda:0")
+
+
+# The library parses its DDPM_* switches once per process (ddpm_reload_env parses them again): tests that flip a switch through
+# monkeypatch get the reload for free, including the undo at teardown.
+def _reload_switches():
+    try:
+        from ddpm_ood_amd import _lib
+
+        _lib.reload_env()
+    except Exception:
+        pass
+
+
+_setenv, _delenv, _undo = pytest.MonkeyPatch.setenv, pytest.MonkeyPatch.delenv, pytest.MonkeyPatch.undo
+
+
+def _setenv_reload(self, name, value, prepend=None):
+    _setenv(self, name, value, prepend)
+    if name.startswith("DDPM_"):
+        _reload_switches()
+
+
+def _delenv_reload(self, name, raising=True):
+    _delenv(self, name, raising)
+    if name.startswith("DDPM_"):
+        _reload_switches()
+
+
+def _undo_reload(self):
+    _undo(self)
+    _reload_switches()
+
+
+pytest.MonkeyPatch.setenv = _setenv_reload
+pytest.MonkeyPatch.delenv = _delenv_reload
+pytest.MonkeyPatch.undo = _undo_reload

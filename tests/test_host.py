@@ -120,7 +120,8 @@ def test_ood_scoring_matches_oracle_and_handles_duplicates(tmp_path):
     dup = pd.concat([inn, inn.iloc[:3].assign(mse=99.0)])  # DDP padding duplicates: keep-first (Q21)
     d1, m1, a1 = ood.score(val, dup, out)
     d2, m2, a2 = oracle.z_scores_and_auroc(val, inn, out)
-    assert a1 == a2 and np.allclose(d1["z_score_mse"], d2["z_score_mse"])
+    assert abs(a1 - a2) < 1e-12 and np.allclose(d1["z_score_mse"], d2["z_score_mse"], rtol=0, atol=1e-9)
+    assert np.allclose(d1["z_score_perceptual_difference"], d2["z_score_perceptual_difference"], rtol=0, atol=1e-9)
     gold = json.load(open(G / "ood_scores.json"))
     assert np.allclose(d1["z_score_mse"], gold["z_score_mse"], atol=1e-9)
     # strict t window (ood_detection.py:59-61)
@@ -532,3 +533,13 @@ def test_png_and_pnm_ingest(tmp_path):
     (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff")
     with pytest.raises(NotImplementedError, match="JPEG"):
         read_image(str(tmp_path / "x.jpg"))
+
+
+def test_product_lpips_refuses_cpu_tensors():
+    """The product's PerceptualLoss has no CPU arithmetic left (the CPU restatement is oracle/lpips.py): host tensors raise,
+    like every other op of the path."""
+    from ddpm_ood_amd.perceptual import PerceptualLoss
+
+    pl = PerceptualLoss(dimensions=2, include_pixel_loss=False, is_fake_3d=False, lpips_normalize=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pl(torch.rand(2, 1, 32, 32), torch.rand(2, 1, 32, 32))
