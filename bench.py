@@ -30,16 +30,29 @@ and the per-rank device list gathered over that group.
     cfg5  128^3 volumes, README VQ-VAE (4 x stride 2, 256 ch, 2 048 codes) -> [128, 8, 8, 8] latents -> 3-D
           `small` UNet -> re-quantise + decode -> 2.5-D LPIPS  (batch 64, k = 4)
 
-One JSON line on rank 0.  `roofline` describes the kernel class with the most time in the sampled launches
-(first UNet step -- and, for the LDM, the decode -- of each t-start of the LAST timed step, hipEvent-bracketed on
-the launch stream by the library): `achieved` = MFMA FLOPs actually EXECUTED per launch / launch time, `frac`
-= achieved / the 157.3 TFLOP/s dense f32 MFMA peak.  Winograd kernels execute 16/36 (9/36 for the upsample
-form) of the direct convolution's multiplies: the direct-conv-equivalent rate is reported separately as
-`algorithmic_equiv_tflops` and is NOT a roofline fraction.  `rooflines` lists every MFMA kernel class the same
-way (cfg4: the attention kernel; cfg5: the 3-D convolutions).  `cpu_baseline` = the CPU oracle timed on this
-box's host cores on a bounded sample of the same workload (rank 0, N = 1, default config only).
+One JSON line on rank 0.
+`dtype`     "f32 (split-f16 MFMA products, fp32 accumulate)": storage, transforms, reductions and accumulation are fp32;
+            the MFMA products of the 3x3 / 1x1 convolutions and of attention are rebuilt from exact f16 partial products
+            (`arithmetic` spells it out).  `value_fp32_products` (N = 1, cfg2) is the same workload with every split-f16
+            family switched to its fp32-MFMA form (ddpm_set_split_f16(0): bit-exact fp32 products), one timed step after
+            the main timed region -- so the line carries both arithmetics.
+`roofline`  the kernel class with the most time in the sampled launches (first UNet step -- and, for the LDM, the decode
+            -- of each t-start of the LAST timed step, hipEvent-bracketed on the launch stream by the library).
+            `achieved` = MFMA FLOPs actually EXECUTED per launch / launch time.  Pricing per class (MFMA_KERNELS below):
+            split-f16 kernels against the 2 500 TFLOP/s dense f16 MFMA peak with 4 (F(4x4), Downsample) or 3 (attention)
+            executed f16 products per fp32 product; fp32-MFMA kernels against the 157.3 TFLOP/s dense f32 MFMA peak; the
+            DMA-fed 1x1 against 8 TB/s of HBM (algorithmic bytes / time).  Winograd kernels execute 36/144 (F(4x4)), 16/36
+            (F(2x2)) or 9/36 (F(2x2) upsample form) of the direct convolution's multiplies: the direct-conv-equivalent
+            rate is reported separately as `algorithmic_equiv_tflops` and is NOT a roofline fraction.  `traffic` = HBM
+            bytes per launch from a separate builder-side `rocprofv3 --pmc` pass at the same batch (profiles/
+            pmc_traffic.json; counters cannot be collected inside this process), null if there is none for that batch.
+`rooflines` every MFMA kernel class the same way (cfg4: the attention kernel; cfg5: the 3-D convolutions).
+`cpu_baseline`  the CPU oracle timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1,
+            default config only).
 `value_batch256` (N = 1, cfg2 only): the same workload at the reference's default batch of 256 images
-(/root/reference/reconstruct.py:91), two timed steps after the main timed region.
+            (/root/reference/reconstruct.py:91), two timed steps after the main timed region.
+`numeric_guard`  batches the trainer had to run again on fp32 products / batches whose scores stayed non-finite (0 / 0 on
+            the synthetic workload; include/ddpm_ood_hip.h, "Numeric guard").
 """
 
 import argparse
@@ -315,6 +328,8 @@ def main():
     ap.add_argument("--images", type=int, default=None,
                     help="--scaling strong: size of the fixed image set (default: one batch of the config)")
     ap.add_argument("--no-batch256", action="store_true", help="skip the extra batch-256 measurement (cfg2, N = 1)")
+    ap.add_argument("--no-fp32-products", action="store_true",
+                    help="skip the extra step on the fp32-MFMA kernels (`value_fp32_products`; cfg2, N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
@@ -377,6 +392,14 @@ def main():
             return rows
 
         log(f"setup done ({a.config}: model on device, {per_rank[rank]} images resident on rank 0)")
+        # per-rank start-up (weight upload + packing into the engine blob, workspace allocation, code-object loading, LPIPS
+        # weight packing) happens on first use: do it here, outside the timed region, whatever --warmup says -- the first
+        # t-start only (2 UNet forwards per image)
+        rec.max_t_start = 10
+        step()
+        rec.max_t_start = None
+        torch.cuda.synchronize()
+        log("start-up done (weights packed, workspace allocated, kernels loaded: t_start = 10 only, untimed)")
         for i in range(a.warmup):
             step()
             log(f"warmup step {i} done")
@@ -398,6 +421,10 @@ def main():
     finally:
         sys.stdout = out_stream
 
+    main_stats = dict(rec.last_stats)  # of the timed workload: the extra legs below overwrite rec.last_stats
+    forwards_per_image = main_stats["unet_forwards"] // max(per_rank[rank], 1)
+    if a.config in ("cfg2", "cfg3"):
+        assert forwards_per_image == 1250, forwards_per_image  # 25 t-starts, sum over t of (t / 10 + 1): nothing skipped
     devices = [f"rank {rank}: {socket.gethostname()} cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"]
     if world > 1:  # what the RCCL group actually spans: every rank reports its device through the group itself
         gathered = [None] * world
@@ -424,6 +451,29 @@ def main():
         b256 = {"value": round(2 * len(r256) / dt256, 3), "steps": 2, "ms_per_step": round(dt256 / 2 * 1e3, 2)}
         log(f"batch-256 measurement done: {b256}")
 
+    # the same workload with bit-exact fp32 MFMA products everywhere (the run-time switch of the numeric guard): one timed step
+    fp32p = None
+    if world == 1 and a.config == "cfg2" and not a.no_fp32_products:
+        from ddpm_ood_amd import _lib as L
+
+        sys.stdout = open(os.devnull, "w")
+        L.set_split_f16(False)
+        try:
+            rec.get_scores(loader, "val", 64)  # warm-up of the other kernels (2 t-starts)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r32 = rec.get_scores(loader, "val", cfg["skip"])
+            torch.cuda.synchronize()
+            dt32 = time.perf_counter() - t0
+        finally:
+            L.set_split_f16(True)
+            sys.stdout = out_stream
+        fp32p = {"value": round(len(r32) / dt32, 3), "steps": 1, "ms_per_step": round(dt32 * 1e3, 2),
+                 "arithmetic": "every MFMA product bit-exact fp32 (ddpm_set_split_f16(0) = DDPM_WINO44_F16X3=0 "
+                               "DDPM_CONV1X1_F16X3=0 DDPM_ATTN_F16X3=0 DDPM_DOWN_S2H=0): conv_wino44_kernel / "
+                               "conv_wino_up_kernel / conv_mfma_kernel / f32 attention loops"}
+        log(f"fp32-products measurement done: {fp32p}")
+
     n_t = len({r["t"] for r in rows})
     assert len(rows) == n_images * n_t, (len(rows), n_images, n_t)  # every rank's scores came back through the gather
     recon_per_step = n_images * n_t
@@ -439,14 +489,14 @@ def main():
         "metric": f"reconstructions/sec (whole node), {cfg['metric_tag']}", "value": round(value, 3),
         "unit": "reconstructions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": a.scaling,
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (split-f16 MFMA products, fp32 accumulate)", "data": "synthetic",
         "arithmetic": ARITHMETIC, "rccl_world_size": dist.get_world_size() if world > 1 else 1,
         **({"dist_backend": backend} if backend != "nccl" else {}), "devices": devices,
         "config": {"workload": cfg["workload"], "name": a.config, "images_per_gpu_per_batch": batch,
                    "images_per_step": n_images, "reconstructions_per_step": recon_per_step,
-                   "unet_forwards_per_image": rec.last_stats["unet_forwards"] // max(per_rank[rank], 1),
+                   "unet_forwards_per_image": forwards_per_image,
                    "sharding": f"images x{world} ({a.scaling})",
-                   "lpips_weights": "pretrained" if rec.last_stats.get("lpips_pretrained") else "seeded random",
+                   "lpips_weights": "pretrained" if main_stats.get("lpips_pretrained") else "seeded random",
                    **({"lpips_2p5d_views_computed": "all 3 (DDPM_LPIPS_ALL_VIEWS=1)"
                        if os.environ.get("DDPM_LPIPS_ALL_VIEWS", "0") == "1" else
                        "last of 3 (the reference's loop overwrites the other two: same scores)"}
@@ -460,9 +510,13 @@ def main():
                         "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
                     for k, v in prof.items()},
     }
+    line["numeric_guard"] = {k: main_stats.get(k, 0) for k in ("batches_rerun_fp32", "batches_nonfinite")}
     if b256:
         line["value_batch256"] = b256["value"]
         line["batch256"] = b256
+    if fp32p:
+        line["value_fp32_products"] = fp32p["value"]
+        line["fp32_products"] = fp32p
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
         line["cpu_baseline"] = cpu_baseline()
         log(f"cpu baseline done: {line['cpu_baseline']}")

@@ -1283,6 +1283,7 @@ int launch_conv_wino(const ddpm_conv_desc &d, hipStream_t s) {
     g.grid = g.KT * ((g.NS + 7) / 8) * 8;
   }
   ddpm_conv_desc dk = d;  // the descriptor the kernel sees
+  if (conv_wino_stats_parts(d) == 0) dk.stats_out = nullptr;  // the ABI's promise: parts = 0 -> stats_out is ignored
   if (g.S > 1) {  // partial sums go to the scratch slabs, the addends to the reduce pass
     g.pstride = (long long)out_floats;
     dk.out = d.scratch;

@@ -1047,6 +1047,9 @@ int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s) {
     attr_done = true;
   }
   ddpm_conv_desc dk = d;
+  // the ABI's promise: stats_out is ignored whenever ddpm_conv_stats_parts() is 0 for this descriptor (a split launch's
+  // statistics come from its reduce pass, which is handed `d`, not `dk`)
+  if (g.S > 1 || conv_wino44h_stats_parts(d) == 0) dk.stats_out = nullptr;
   if (g.S > 1) {  // partial sums go to the scratch slabs, the addends to the reduce pass
     dk.out = d.scratch;
     dk.bias = nullptr;

@@ -247,6 +247,9 @@ class Reconstruct(BaseTrainer):
                                        and args.num_inference_steps) or 100  # Q1: 100 is hard-coded
         self.reset_scheduler_per_t = bool(getattr(args, "reset_scheduler_per_t", 0))
         self.timestep_list = getattr(args, "timestep_list", "monai")
+        # test hook (not a CLI flag): only the t-starts <= max_t_start of the reference's list are run -- a PREFIX of the
+        # chained list, so the trajectories that do run are exactly the reference's (tests price the CPU oracle per forward)
+        self.max_t_start = getattr(args, "max_t_start", None)
         self.lpips_weights = getattr(args, "lpips_weights", None)
         self._loader_args = dict(batch_size=args.batch_size, is_grayscale=bool(args.is_grayscale),
                                  image_size=self.image_size, drop_last=bool(args.drop_last),
@@ -311,7 +314,8 @@ class Reconstruct(BaseTrainer):
         pl = self._perceptual()
         self.model.eval()
         ids_all, names_all, scores_all = [], [], []
-        t_values = [int(t) for t in reversed(self.make_scheduler().timesteps)[1::inference_skip_factor]]
+        t_values = [int(t) for t in reversed(self.make_scheduler().timesteps)[1::inference_skip_factor]
+                    if self.max_t_start is None or int(t) <= int(self.max_t_start)]
         n_recon = n_fwd = 0
         guard = {"batches_rerun_fp32": 0, "batches_nonfinite": 0}
         _lib.status_read(clear=True)  # whatever an earlier caller left behind is not this run's
@@ -361,6 +365,8 @@ class Reconstruct(BaseTrainer):
         sched = self.make_scheduler()  # one per batch: PLMS history leaks across t-starts (Q3)
         timesteps = sched.timesteps
         start_points = reversed(timesteps)[1::inference_skip_factor]
+        if self.max_t_start is not None:
+            start_points = start_points[start_points <= int(self.max_t_start)]
         t_values = [int(t) for t in start_points]
 
         t1 = time.time()

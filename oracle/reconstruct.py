@@ -46,7 +46,7 @@ def get_scores(loader, dataset_name: str, inference_skip_factor: int, *, model, 
                beta_start: float = 1e-4, beta_end: float = 2e-2, b_scale: float = 1.0,
                snr_shift: float = 1.0, latent_pad=None, num_inference_steps: int = 100,
                reset_scheduler_per_t: bool = False, timestep_list: str = "monai",
-               return_reconstructions: bool = False):
+               return_reconstructions: bool = False, max_t_start: int = None):
     results = []
     recons = []
     model.eval()
@@ -59,6 +59,8 @@ def get_scores(loader, dataset_name: str, inference_skip_factor: int, *, model, 
         sched.set_timesteps(num_inference_steps)
         timesteps = sched.timesteps
         start_points = reversed(timesteps)[1::inference_skip_factor]
+        if max_t_start is not None:  # test hook: a prefix of the chained t-start list (same trajectories, fewer of them)
+            start_points = start_points[start_points <= int(max_t_start)]
 
         images_original = batch["image"].float()
         images = vqvae.encode_stage_2_inputs(images_original)

@@ -58,7 +58,8 @@ def oracle_scores(args, rec, ids, name, *, model, vqvae=None, loader_kw=None):
         noise_fn=lambda batch, t, shape: batch_noise(args.seed, batch["index"], t, shape),
         prediction_type=args.prediction_type, beta_schedule=args.beta_schedule, beta_start=args.beta_start,
         beta_end=args.beta_end, b_scale=args.b_scale, snr_shift=args.snr_shift, latent_pad=args.latent_pad,
-        num_inference_steps=rec.num_inference_steps, timestep_list=rec.timestep_list))
+        num_inference_steps=rec.num_inference_steps, timestep_list=rec.timestep_list,
+        max_t_start=getattr(rec, "max_t_start", None)))
 
 
 def hip_scores(args, rec, ids, name, loader_kw=None):

@@ -47,14 +47,14 @@ def _report():
     return json.loads(buf.value.decode()) if n > 0 else {}
 
 
-def _models(device, sd, channels=1):
+def _models(device, sd, channels=1, model_type="small"):
     import oracle
     from ddpm_ood_amd import DiffusionModelUNet
     from ddpm_ood_amd.trainer import MODEL_CONFIGS
 
-    ref = oracle.DiffusionModelUNet(2, channels, channels, **MODEL_CONFIGS["small"]).eval()
+    ref = oracle.DiffusionModelUNet(2, channels, channels, **MODEL_CONFIGS[model_type]).eval()
     ref.load_state_dict(sd)
-    hip = DiffusionModelUNet(2, channels, channels, **MODEL_CONFIGS["small"])
+    hip = DiffusionModelUNet(2, channels, channels, **MODEL_CONFIGS[model_type])
     hip.load_state_dict(sd)
     return ref, hip.to(device).eval()
 
@@ -172,3 +172,90 @@ def test_trained_weights_forward_and_trajectory_vs_oracle(device, tmp_path):
         assert_rows_close(rows_h[n], rows_o[n], 2e-4, n)
     worst, auc_h, auc_o = assert_z_close(rows_h, rows_o)
     print(f"trained weights, k = 64: max |dZ| = {worst:.2e}, AUROC hip {auc_h:.4f} / oracle {auc_o:.4f}")
+
+
+# ---- cfg4 / cfg5 at the batches bench.py times (parity there was only tested at B = 2 / B = 1) --------------------
+
+def test_big_forward_at_benchmarked_batch_vs_oracle(device):
+    """BASELINE configs[3] (`big` UNet, /root/reference/src/trainers/base.py:77-86, 64x64x3) at bench.py's cfg4 batch of 16:
+    one forward against the CPU oracle (5.4 TFLOP of oracle), and the profiler shows the launches bench.py times there --
+    split-f16 F(4x4) ResnetBlock convolutions, the eight-wave attention over 4096 / 1024 / 256 tokens, the GroupNorm-ed q / k / v
+    projection and the skip 1x1s on the DMA-fed kernel, the Upsample convolutions, the Downsample convolutions."""
+    from ddpm_ood_amd.synthetic import random_state_dict
+
+    ref, hip = _models(device, random_state_dict("big", 3, seed=1), channels=3, model_type="big")
+    g = torch.Generator().manual_seed(404)
+    x = torch.randn(16, 3, 64, 64, generator=g)
+    t = torch.randint(0, 1000, (16,), generator=g)
+    with torch.no_grad():
+        yr = ref(x, timesteps=t)
+    yh, prof = _profiled(lambda: hip(x.to(device), timesteps=t.to(device)).cpu())
+    err, scale = (yh - yr).abs().max().item(), yr.abs().max().item()
+    print(f"big, B = 16: max |eps_hip - eps_oracle| = {err:.3e} (max |eps| = {scale:.3f})")
+    assert math.isfinite(err) and err <= 2e-5 * (1 + scale), err
+    assert scale > 0.05
+    # 2 ResnetBlocks x 3 levels down, 2 in the middle, 3 x 3 up = 17 blocks = 34 convolutions, all on the split-f16 F(4x4) kernel
+    assert prof["conv3x3_wino44h_gn_silu"]["launches"] == 34, prof.get("conv3x3_wino44h_gn_silu")
+    assert "conv3x3_wino44_gn_silu" not in prof and "conv3x3_wino_gn_silu" not in prof and "conv3x3_mfma_gn_silu" not in prof, sorted(prof)
+    assert prof["attention"]["launches"] == 16 and prof["conv1x1_dma_gn"]["launches"] == 16, (prof["attention"], prof.get("conv1x1_dma_gn"))
+    assert prof["conv3x3_s2h"]["launches"] == 2 and prof["conv1x1_dma"]["launches"] >= 1, sorted(prof)
+    ups = prof.get("conv3x3_wino44h_up", {"launches": 0})["launches"] + prof.get("conv3x3_wino_up", {"launches": 0})["launches"]
+    assert ups == 2, sorted(prof)
+
+
+def test_cfg4_trajectories_on_the_reference_t_list(device, tmp_path):
+    """cfg4 on the reference's hard-coded 100-step schedule (reconstruct.py:118; inference_skip_factor = 2 -> t_start = 10, 30,
+    50, ...): the first three chained t-starts (2 + 4 + 6 forwards per image; the `max_t_start` test hook cuts the list, not the
+    schedule), val / in / out sets of two 64x64x3 images -> raw scores, Z-scores, AUROC."""
+    import oracle
+    from ddpm_ood_amd import synthetic
+    from ddpm_ood_amd.trainer import MODEL_CONFIGS, Reconstruct
+
+    sets = {"val": "synthetic:blobs:n=2:channels=3:size=64:seed=30", "in": "synthetic:blobs:n=2:channels=3:size=64:seed=31",
+            "out": "synthetic:speckle:n=2:channels=3:size=64:seed=32:mix=10"}
+    args = make_args(tmp_path, model_type="big", is_grayscale=0, inference_skip_factor=2, batch_size=2,
+                     validation_ids=sets["val"], in_ids=sets["in"])
+    sd = synthetic.random_state_dict("big", 3, seed=1)
+    write_checkpoint(tmp_path, args, sd)
+    rec = Reconstruct(args)
+    rec.quiet = True
+    rec.max_t_start = 50
+    assert rec.num_inference_steps == 100
+    ref = oracle.DiffusionModelUNet(2, 3, 3, **MODEL_CONFIGS["big"]).eval()
+    ref.load_state_dict(sd)
+    rows_h, rows_o = {}, {}
+    for name, ids in sets.items():
+        rows_h[name] = hip_scores(args, rec, ids, name)
+        assert sorted(set(rows_h[name]["t"])) == [10, 30, 50] and rec.last_stats["unet_forwards"] == 2 * 12
+        rows_o[name] = oracle_scores(args, rec, ids, name, model=ref)
+        assert_rows_close(rows_h[name], rows_o[name], 2e-4, name)
+    worst, auc_h, auc_o = assert_z_close(rows_h, rows_o)
+    print(f"cfg4, 100-step list, t <= 50: max |dZ| = {worst:.2e}, AUROC hip {auc_h:.4f} / oracle {auc_o:.4f}")
+
+
+def test_cfg5_decode_two_volumes_in_one_call_vs_oracle(device):
+    """cfg5: re-quantise + decode (reconstruct.py:166 -> VQVAE.decode_stage_2_outputs) of TWO [128, 8, 8, 8] latents -> two
+    128^3 volumes in one call, README VQ-VAE shape: every 3-D split-f16 F(4x4) launch fills the chip several times over (what
+    bench.py's cfg5 times), against the CPU oracle's decoder on the same weights; codes identical."""
+    from oracle.vqvae import VQVAE as OracleVQVAE
+    from ddpm_ood_amd.vqvae import VQVAE
+
+    from test_gpu_configs import VQ_README
+
+    torch.manual_seed(3)
+    ovq = OracleVQVAE(**VQ_README).eval()
+    with torch.no_grad():
+        ovq.quantizer.quantizer.embedding.weight.mul_(3.0)
+    vq = VQVAE(**VQ_README).eval()
+    vq.load_state_dict(ovq.state_dict())
+    vq = vq.to(device)
+    z = torch.randn(2, 128, 8, 8, 8, generator=torch.Generator().manual_seed(8)) * 2.0
+    with torch.no_grad():
+        xo = ovq.decode_stage_2_outputs(z)
+    xh, prof = _profiled(lambda: vq.decode_stage_2_outputs(z.to(device)).cpu())
+    assert xh.shape == xo.shape == (2, 1, 128, 128, 128)
+    err, scale = (xh - xo).abs().max().item(), xo.abs().max().item()
+    print(f"decode of 2 volumes: max |x_hip - x_oracle| = {err:.3e} (max |x| = {scale:.3f})")
+    assert math.isfinite(err) and err <= 2e-5 * (1 + scale), err
+    assert prof["conv3d_wino44h"]["launches"] >= 12 and "conv3d_wino44" not in prof, sorted(prof)
+    assert "conv3d_transpose_k4s2" in prof and "convT3d_k4s2_cout1" in prof and "vq_nearest" in prof, sorted(prof)

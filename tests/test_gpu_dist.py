@@ -165,6 +165,32 @@ def test_two_rank_training_starts_and_stays_in_step(device, tmp_path):
     assert recs[0][2] == recs[1][2] == "2" and {recs[0][3], recs[1][3]} == {"5", "4"}
 
 
+def test_bench_self_launches_eight_ranks_on_one_gpu(device):
+    """The driver's 8-GPU command line -- `python bench.py --gpus 8` -- with all eight ranks on the one GPU of this box (gloo
+    transport, shared device): self-launch, rendezvous on 127.0.0.1, eight strong-scaling shards of 8 images, barriers, MAX over
+    ranks, one collective per step, ONE JSON line that lists eight ranks and 64 x 25 rows; and every rank's start-up (weights
+    packed, workspace allocated) is logged BEFORE the timed region starts although --warmup is 0.  What an 8-GPU node adds is
+    the RCCL transport under the same calls (reference launch model /root/reference/src/trainers/base.py:22-33, gather
+    /root/reference/src/trainers/reconstruct.py:238-248)."""
+    import json
+
+    env = dict(os.environ, DDPM_DIST_BACKEND="gloo", DDPM_DIST_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--images", "64",
+                          "--batch", "8", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl_world_size"] == 8 and d["scaling"] == "strong" and d["dist_backend"] == "gloo"
+    assert d["config"]["images_per_step"] == 64 and d["config"]["reconstructions_per_step"] == 64 * 25
+    assert d["config"]["unet_forwards_per_image"] == 1250
+    assert [x.split(":")[0] for x in d["devices"]] == [f"rank {r}" for r in range(8)]
+    assert d["value"] > 0 and d["numeric_guard"] == {"batches_rerun_fp32": 0, "batches_nonfinite": 0}
+    err = out.stderr
+    assert 0 <= err.find("start-up done") < err.find("timed region done"), err[-2000:]
+
+
 def test_bench_self_launches_two_ranks_on_one_gpu(device):
     """`python bench.py --gpus 2` as the driver runs it (no launcher): bench.py starts its own ranks through
     torch.distributed.run, shards the fixed image set (strong scaling is the default for N > 1), brackets the timed region
