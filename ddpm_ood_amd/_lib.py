@@ -89,6 +89,9 @@ SIGNATURES = {
     "ddpm_channel_stats_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_float, C.c_void_p]),
+    "ddpm_attention_scratch_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ddpm_attention_ws_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddpm_timestep_embedding_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_add_noise_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
                                      C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),

@@ -38,6 +38,7 @@ static void load_switches() {
   n.down_s2h = env_int("DDPM_DOWN_S2H", 1);
   n.conv1x1_f16x3 = env_int("DDPM_CONV1X1_F16X3", 1) != 0;
   n.attn_f16x3 = env_int("DDPM_ATTN_F16X3", 1) != 0;
+  n.attn_fa = env_int("DDPM_ATTN_FA", 1);
   n.conv_splitk = env_int("DDPM_CONV_SPLITK", 1) != 0;
   n.gn_fused = env_int("DDPM_GN_FUSED", 1) != 0;
   n.prof_shapes = getenv("DDPM_PROF_SHAPES") != nullptr;
@@ -301,4 +302,13 @@ extern "C" int ddpm_gn_scale_shift_f32(const float *in1, const float *in2, int C
 extern "C" int ddpm_attention_f32(const float *qkv, const float *residual, float *out, int B, int C, int N,
                                   int num_heads, float scale, ddpm_stream_t stream) {
   return launch_attention(qkv, residual, out, B, C, N, num_heads, scale, as_stream(stream));
+}
+
+extern "C" size_t ddpm_attention_scratch_floats(int B, int C, int N, int num_heads) {
+  return attention_fa_scratch_floats(B, C, N, num_heads);
+}
+
+extern "C" int ddpm_attention_ws_f32(const float *qkv, const float *residual, float *out, int B, int C, int N, int num_heads,
+                                     float scale, float *scratch, size_t scratch_floats, ddpm_stream_t stream) {
+  return launch_attention(qkv, residual, out, B, C, N, num_heads, scale, as_stream(stream), scratch, scratch_floats);
 }

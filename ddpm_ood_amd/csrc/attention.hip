@@ -739,7 +739,7 @@ __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict
 }
 
 int launch_attention(const float *qkv, const float *residual, float *out, int B, int C, int N, int heads, float scale,
-                     hipStream_t s) {
+                     hipStream_t s, float *scratch, size_t scratch_floats) {
   DDPM_CHECK_ARG(qkv && out && B > 0 && N > 0 && heads > 0, "attention: null pointer or empty shape");
   DDPM_CHECK_ARG(C == heads * kDH, "attention: only head dim 256 is built (C = %d, heads = %d)", C, heads);
   DDPM_CHECK_ARG(B <= 65535 && heads <= 65535, "attention: grid too large");
@@ -756,8 +756,13 @@ int launch_attention(const float *qkv, const float *residual, float *out, int B,
     attr_done = true;
   }
   dim3 grid((N + kQB - 1) / kQB, heads, B);
-  ProfScope prof(s, "attention", 4.0 * B * (double)N * N * C, 4.0 * B * C * (double)N * (residual ? 5 : 4));
   const bool f16x3 = split_f16_on(sw().attn_f16x3);
+  // register-resident form (attention_fa.hip) whenever the caller gave scratch for the f16 planes and N is a multiple of 64
+  if (f16x3 && sw().attn_fa && attention_fa_supported(B, C, N, heads, scratch, scratch_floats)) {
+    ProfScope prof(s, "attention_fa", 4.0 * B * (double)N * N * C, 4.0 * B * C * (double)N * (residual ? 5 : 4));
+    return launch_attention_fa(qkv, residual, out, B, C, N, heads, scale, scratch, s);
+  }
+  ProfScope prof(s, "attention", 4.0 * B * (double)N * N * C, 4.0 * B * C * (double)N * (residual ? 5 : 4));
   // eight-wave form by default (n = 4096: 892 vs 918 us, n = 256: 32.3 vs 34.8 us); DDPM_ATTN_WAVES=4 selects the other
   static const bool waves8 = !(getenv("DDPM_ATTN_WAVES") && atoi(getenv("DDPM_ATTN_WAVES")) == 4);
   const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv) & 15) == 0);

@@ -46,6 +46,8 @@ struct Switches {
   int down_s2h = 1;             // DDPM_DOWN_S2H (0 off, 2 / 3 force a form)
   bool conv1x1_f16x3 = true;    // DDPM_CONV1X1_F16X3
   bool attn_f16x3 = true;       // DDPM_ATTN_F16X3
+  int attn_fa = 1;              // DDPM_ATTN_FA (0: the LDS-exchange kernels of attention.hip also when scratch is given; 2: the
+                                // register-resident kernel for every multiple of 64 tokens, not only from 1 024)
   bool conv_splitk = true;      // DDPM_CONV_SPLITK
   bool gn_fused = true;         // DDPM_GN_FUSED
   bool prof_shapes = false;     // DDPM_PROF_SHAPES
@@ -214,7 +216,11 @@ int launch_gn_finalize(const float *st1, int parts1, int C1, const float *st2, i
                        const float *beta, float *scale, float *shift, int B, int HW, int groups, float eps, hipStream_t s);
 int launch_channel_stats(const float *in, float *stats, int B, int C, int HW, hipStream_t s);
 int launch_attention(const float *qkv, const float *residual, float *out, int B, int C, int N, int heads, float scale,
-                     hipStream_t s);
+                     hipStream_t s, float *scratch = nullptr, size_t scratch_floats = 0);
+size_t attention_fa_scratch_floats(int B, int C, int N, int heads);
+bool attention_fa_supported(int B, int C, int N, int heads, const float *scratch, size_t scratch_floats);
+int launch_attention_fa(const float *qkv, const float *residual, float *out, int B, int C, int N, int heads, float scale,
+                        float *scratch, hipStream_t s);
 int launch_timestep_embedding(const int64_t *t, const float *freqs, float *out, int B, int dim, hipStream_t s);
 int launch_copy_f32(const float *src, float *dst, int64_t n, hipStream_t s);
 

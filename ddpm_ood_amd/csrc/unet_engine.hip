@@ -607,11 +607,13 @@ struct Runner {
     float *qkv = ws.get((size_t)B * 3 * a.C * N);
     conv(a.qkv, x, nullptr, sc, sh, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, nullptr, qkv, x.H, x.W, x.D);
     const float scale = 1.0f / sqrtf((float)a.C / (float)a.heads);
+    const size_t nplanes = attention_fa_scratch_floats(B, a.C, N, a.heads);  // f16 planes of q / k / v (attention_fa.hip)
+    float *planes = nplanes ? ws.get(nplanes) : nullptr;
     if (!u->cfg.use_proj_attn) {
-      if (!ws.dry && !rc) rc = launch_attention(qkv, x.p, out.p, B, a.C, N, a.heads, scale, s);
+      if (!ws.dry && !rc) rc = launch_attention(qkv, x.p, out.p, B, a.C, N, a.heads, scale, s, planes, nplanes);
     } else {
       Act o{ws.get((size_t)B * a.C * N), a.C, x.H, x.W, x.D};
-      if (!ws.dry && !rc) rc = launch_attention(qkv, nullptr, o.p, B, a.C, N, a.heads, scale, s);
+      if (!ws.dry && !rc) rc = launch_attention(qkv, nullptr, o.p, B, a.C, N, a.heads, scale, s, planes, nplanes);
       conv(a.proj, o, nullptr, nullptr, nullptr, DDPM_ACT_NONE, DDPM_CONV_NORMAL, nullptr, 0, x.p, out.p, x.H, x.W,
            x.D);
     }

@@ -452,8 +452,9 @@ def channel_stats(x):
     return stats
 
 
-def attention(qkv, residual, num_heads: int, scale: float):
-    """qkv: [B, 3C, N] -> [B, C, N] = softmax(scale q^T k) v (+ residual)."""
+def attention(qkv, residual, num_heads: int, scale: float, use_scratch: bool = True):
+    """qkv: [B, 3C, N] -> [B, C, N] = softmax(scale q^T k) v (+ residual).  use_scratch: give the library the scratch its
+    register-resident kernel (csrc/attention_fa.hip) wants for the f16 planes of q / k / v, as the UNet engine does."""
     lib = _lib.load()
     qkv = require_device_f32(qkv, "qkv")
     B, C3, N = qkv.shape
@@ -461,8 +462,14 @@ def attention(qkv, residual, num_heads: int, scale: float):
     if residual is not None:
         residual = require_device_f32(residual, "residual")
     out = torch.empty((B, Cc, N), dtype=torch.float32, device=qkv.device)
-    check(lib.ddpm_attention_f32(ptr(qkv), ptr(residual), ptr(out), B, Cc, N, num_heads, scale, stream_ptr()),
-          "attention")
+    nscr = lib.ddpm_attention_scratch_floats(B, Cc, N, num_heads) if use_scratch else 0
+    if nscr:
+        scratch = torch.empty(nscr, dtype=torch.float32, device=qkv.device)
+        check(lib.ddpm_attention_ws_f32(ptr(qkv), ptr(residual), ptr(out), B, Cc, N, num_heads, scale, ptr(scratch), nscr,
+                                        stream_ptr()), "attention")
+    else:
+        check(lib.ddpm_attention_f32(ptr(qkv), ptr(residual), ptr(out), B, Cc, N, num_heads, scale, stream_ptr()),
+              "attention")
     return out
 
 

@@ -371,6 +371,18 @@ int ddpm_prof_enable(int on);
 int ddpm_prof_report(char *buf, size_t cap);
 
 /* ------------------------------------------------------------------------------------
+ * Attention with caller scratch (ABI 8).  Same op as ddpm_attention_f32 -- generative's AttentionBlock inside
+ * DiffusionModelUNet.forward, call site src/trainers/reconstruct.py:151-153: softmax(q k^T * scale) v (+ residual) over
+ * qkv [B, 3 C, N], head dim 256 --; with `scratch` of at least ddpm_attention_scratch_floats(B, C, N, heads) floats (16-byte
+ * aligned; 0 = this shape has no such form: N must be a multiple of 64) q, k and v are first split into MFMA-ready f16
+ * planes there and the register-resident kernel of csrc/attention_fa.hip runs (one barrier per 32-key block, K / V by
+ * LDS-DMA, scores and output never leave registers).  scratch = NULL: exactly ddpm_attention_f32.
+ * ---------------------------------------------------------------------------------- */
+size_t ddpm_attention_scratch_floats(int B, int C, int N, int num_heads);
+int ddpm_attention_ws_f32(const float *qkv, const float *residual, float *out, int B, int C, int N, int num_heads,
+                          float scale, float *scratch, size_t scratch_floats, ddpm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Numeric guard of the split-f16 kernel families (ABI 8).
  *
  * The reference computes this path in fp32 / fp16-autocast ATen ops (src/trainers/reconstruct.py:129,151-157); a

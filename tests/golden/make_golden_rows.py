@@ -1,0 +1,121 @@
+"""Generate the ORACLE side of the expensive workload-level parity tests as committed fixtures.
+
+    python tests/golden/make_golden_rows.py [case ...]        (build container, CPU only; ~10 min for all cases)
+
+The `-m gpu` suite used to spend two thirds of its time waiting for the CPU oracle to price hundreds of image
+trajectories (one test: 384 images x 68 UNet forwards = 206 TFLOP of oneDNN on the GPU box's host).  The oracle side of
+those tests is a pure function of seeds -- weights `random_state_dict(seed)`, images `synthetic:...:seed=`, per-image noise
+`batch_noise(seed, index, t)`, LPIPS weights `LPIPS(seed)` -- so it is computed once here and committed as rows
+(`rows_<case>.csv`, one line per (set, image, t): what /root/reference/src/trainers/reconstruct.py:192-204 appends), with the
+specification and the digests of the regenerated weights in `rows_<case>.json`.  The tests
+
+  * compare the HIP path with the committed rows (all images), and
+  * run the oracle LIVE on the first few images of every set and hold it to the committed rows (1e-5) and to the HIP rows,
+    so a stale or foreign fixture cannot pass: the fixture is pinned to the oracle code of the day.
+
+The per-image result does not depend on the batch it rides in (noise is a function of the image index, the PLMS history
+is per element), which is what makes "first few images" a valid sample of the same computation.
+"""
+
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import pandas as pd
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(HERE))
+
+from make_golden import state_dict_digest  # noqa: E402
+
+CASES = {
+    # tests/test_gpu_dispatch.py::test_k64_trajectories_at_batch_128_absolute_z
+    "k64_b128": dict(channels=1, model_type="small", skip=64, batch=128, live=4,
+                     sets={"val": "synthetic:blobs:n=128:seed=10", "in": "synthetic:blobs:n=128:seed=11",
+                           "out": "synthetic:speckle:n=128:seed=12:mix=10"}),
+    # tests/test_gpu_configs.py::test_cfg2_all_25_chained_t_starts
+    "cfg2_25t": dict(channels=1, model_type="small", skip=4, batch=3, live=1,
+                     sets={"val": "synthetic:blobs:n=2:seed=10", "in": "synthetic:blobs:n=2:seed=11",
+                           "out": "synthetic:speckle:n=1:seed=12:mix=10"}),
+    # tests/test_gpu_configs.py::test_cfg3_three_channel_two_ood_sets_and_sensitive_auroc
+    "cfg3": dict(channels=3, model_type="small", skip=64, batch=32, live=2,
+                 sets={"val": "synthetic:blobs:n=16:channels=3:seed=10", "in": "synthetic:blobs:n=32:channels=3:seed=11",
+                       "SVHN": "synthetic:speckle:n=32:channels=3:seed=13:mix=5:name=SVHN",
+                       "CelebA": "synthetic:blobs:n=32:channels=3:seed=12:name=CelebA"}),
+}
+
+
+def set_type(name: str) -> str:
+    return name if name in ("val", "in") else "out"
+
+
+def oracle_rows(case: dict, name: str, ids: str, first_n=None) -> pd.DataFrame:
+    """The oracle's rows for one set (optionally only its first images), inputs exactly as tests/parity_util.oracle_scores."""
+    import oracle
+    from ddpm_ood_amd.data import get_data_loader
+    from ddpm_ood_amd.perceptual import LPIPS
+    from ddpm_ood_amd.synthetic import random_state_dict
+    from ddpm_ood_amd.trainer import MODEL_CONFIGS, batch_noise
+    from parity_util import SCHED
+
+    c = case["channels"]
+    key = (c, case["model_type"])
+    if key not in _MODELS:
+        sd = random_state_dict(case["model_type"], c, seed=1)
+        m = oracle.DiffusionModelUNet(2, c, c, **MODEL_CONFIGS[case["model_type"]]).eval()
+        m.load_state_dict(sd)
+        pl = oracle.PerceptualLoss(dimensions=2, include_pixel_loss=False, is_fake_3d=False, lpips_normalize=True)
+        lp = LPIPS().state_dict()  # the product's default (seeded) LPIPS weights: a CPU-side constant
+        pl.perceptual_function.load_state_dict(lp)
+        _MODELS[key] = (m, pl, state_dict_digest(sd), state_dict_digest(lp))
+    m, pl, _, _ = _MODELS[key]
+    loader = get_data_loader(ids, batch_size=case["batch"], is_grayscale=c == 1, spatial_dimension=2, first_n=first_n)
+    return pd.DataFrame(oracle.get_scores(
+        loader, set_type(name), case["skip"], model=m, vqvae=oracle.PassthroughVQVAE(), perceptual=pl,
+        noise_fn=lambda batch, t, shape: batch_noise(2, batch["index"], t, shape), **SCHED))
+
+
+_MODELS = {}
+
+
+def digests(case: dict):
+    key = (case["channels"], case["model_type"])
+    return {"state_dict_sha256": _MODELS[key][2], "lpips_sha256": _MODELS[key][3]}
+
+
+def load(case_name: str):
+    """(spec, {set name: rows}) of a committed case."""
+    spec = json.load(open(HERE / f"rows_{case_name}.json"))
+    df = pd.read_csv(HERE / f"rows_{case_name}.csv", index_col=0)
+    return spec, {n: df[df["set"] == n].drop(columns="set").reset_index(drop=True) for n in spec["sets"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cases", nargs="*", default=sorted(CASES))
+    a = ap.parse_args()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    for name in a.cases:
+        case = CASES[name]
+        frames = []
+        t0 = time.time()
+        for sname, ids in case["sets"].items():
+            with torch.no_grad():
+                df = oracle_rows(case, sname, ids)
+            df.insert(0, "set", sname)
+            frames.append(df)
+            print(f"{name}/{sname}: {len(df)} rows, {time.time() - t0:.0f} s", flush=True)
+        pd.concat(frames, ignore_index=True).to_csv(HERE / f"rows_{name}.csv", float_format="%.9e")
+        json.dump({**{k: v for k, v in case.items()}, **digests(case), "noise_seed": 2, "weight_seed": 1,
+                   "generator": "tests/golden/make_golden_rows.py (CPU fp32 oracle, build container)"},
+                  open(HERE / f"rows_{name}.json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -179,7 +179,11 @@ def test_gn_scale_shift(device, B, C1, C2, HW):
 
 @pytest.mark.parametrize("B,heads,N", [(3, 1, 64), (2, 2, 256), (1, 3, 100), (2, 1, 8), (1, 1, 1024)])
 @pytest.mark.parametrize("with_res", [True, False])
-def test_attention(device, B, heads, N, with_res):
+@pytest.mark.parametrize("use_scratch", [True, False])
+def test_attention(device, B, heads, N, with_res, use_scratch, monkeypatch):
+    """use_scratch: with caller scratch the multiples of 64 take the register-resident kernel (attention_fa.hip; by default only
+    from 1 024 tokens, DDPM_ATTN_FA=2 lifts that), without it (and for every other N) the LDS-exchange kernels of attention.hip."""
+    monkeypatch.setenv("DDPM_ATTN_FA", "2")
     from ddpm_ood_amd import ops
 
     C = 256 * heads
@@ -188,11 +192,49 @@ def test_attention(device, B, heads, N, with_res):
     qkv[:, :C] *= 1.5  # make the softmax peaky enough to exercise the running max
     res = torch.randn(B, C, N, generator=g) if with_res else None
     scale = 1 / math.sqrt(C / heads)
-    out = ops.attention(qkv.to(device), None if res is None else res.to(device), heads, scale)
+    out = ops.attention(qkv.to(device), None if res is None else res.to(device), heads, scale, use_scratch=use_scratch)
     q, k, v = (t.reshape(B, heads, 256, N) for t in qkv.split(C, dim=1))
     s = torch.einsum("bhdi,bhdj->bhij", q, k) * scale
     o = torch.einsum("bhij,bhdj->bhdi", s.softmax(-1), v).reshape(B, C, N)
     _close(out, o + res if with_res else o, tol=1e-5)
+
+
+@pytest.mark.parametrize("B,heads,N,qs,vs", [(3, 1, 64, 1.0, 1.0), (2, 3, 256, 0.05, 20.0), (2, 2, 1024, 3.0, 0.01),
+                                             (32, 1, 1024, 1.0, 1.0), (8, 1, 4096, 1.5, 1.0)])
+def test_attention_register_resident_vs_float64(device, B, heads, N, qs, vs, monkeypatch):
+    """attention_fa.hip (f16 planes of q / k / v from a pre-pass, S^T and O^T in registers, 16-query waves; the last two
+    shapes fill the chip with the eight-wave 128-query workgroups, the others run the four-wave form) against a float64
+    attention on the first images: the error stays of the order of an fp32 attention's own from flat to peaky softmaxes, and
+    the result differs from the LDS-exchange kernel's only in the last bits."""
+    monkeypatch.setenv("DDPM_ATTN_FA", "2")  # (by default the small token counts stay on attention.hip: they are faster there)
+    from ddpm_ood_amd import ops
+
+    C = 256 * heads
+    g = torch.Generator().manual_seed(21 + N)
+    qkv = torch.randn(B, 3 * C, N, generator=g)
+    qkv[:, :2 * C] *= qs
+    qkv[:, 2 * C:] *= vs
+    res = torch.randn(B, C, N, generator=g)
+    scale = 1 / 16.0
+    out = ops.attention(qkv.to(device), res.to(device), heads, scale)
+    old = ops.attention(qkv.to(device), res.to(device), heads, scale, use_scratch=False)
+    assert not torch.equal(out, old)  # (another kernel ran)
+    n = min(B, 2 if N < 4096 else 1)
+
+    def ref(t, r):
+        q, k, v = (x.reshape(n, heads, 256, N) for x in t.split(C, dim=1))
+        s = torch.einsum("bhdi,bhdj->bhij", q, k) * scale
+        return torch.einsum("bhij,bhdj->bhdi", s.softmax(-1), v).reshape(n, C, N) + r
+
+    r64 = ref(qkv[:n].double(), res[:n].double())
+    norm = r64.abs().max().item()
+    err = (out[:n].cpu().double() - r64).abs().max().item() / norm
+    err_old = (old[:n].cpu().double() - r64).abs().max().item() / norm
+    err32 = (ref(qkv[:n], res[:n]).double() - r64).abs().max().item() / norm
+    print(f"N = {N}: register-resident {err:.2e}, LDS-exchange {err_old:.2e}, fp32 on the host {err32:.2e}")
+    assert math.isfinite(err) and err <= max(4 * err32, 2e-6), (err, err32)
+    # every image, not only the ones priced in float64: the two kernels agree
+    assert (out - old).abs().max().item() <= 1e-5 * (1 + old.abs().max().item())
 
 
 def test_attention_online_softmax_rescale(device):
