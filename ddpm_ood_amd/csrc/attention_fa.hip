@@ -202,21 +202,40 @@ __global__ __launch_bounds__(64 * NW) void attention_fa_kernel(const f16x8 *__re
   float m_run = -INFINITY, l_part = 0.f;
   const float sscale = scale_log2e * (1.f / (kPre * kPre));  // the scores carry 2^8 from the q / k pre-scales
 
-  // S^T = K Q^T of one block, two 16-key tiles
+  // S^T = K Q^T of one block, two 16-key tiles.  Operands come through a three-deep register ring (the reads of k-step
+  // ks + 2 are issued before the MFMAs of k-step ks: left alone, hipcc emits "2 reads, s_waitcnt lgkmcnt(0), 3 MFMAs" per step
+  // and the matrix pipe idles for an LDS round trip 16 times per block), and the six MFMAs of a k-step alternate between four
+  // accumulators -- cross terms (kh ql + kl qh) and main terms (kh qh) of the two tiles -- so that no MFMA waits for its
+  // predecessor's result; the small cross terms are summed separately and added once.
   auto scores = [&](const f16x8 *Ks, f32x4 (&sacc)[2]) {
-    sacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    sacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    f32x4 cr[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 mn_[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f16x8 kh[3][2], kl[3][2];
+    auto rd = [&](int ks, int slot) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const f16x8 kh = Ks[(4 * ks + g) * kKBk + 16 * t + c];
-        const f16x8 kl = Ks[(kD / 8) * kKBk + (4 * ks + g) * kKBk + 16 * t + c];
-        FA_MFMA(sacc[t], kh, ql[ks]);
-        FA_MFMA(sacc[t], kl, qh[ks]);
-        FA_MFMA(sacc[t], kh, qh[ks]);
+        kh[slot][t] = Ks[(4 * ks + g) * kKBk + 16 * t + c];
+        kl[slot][t] = Ks[(kD / 8) * kKBk + (4 * ks + g) * kKBk + 16 * t + c];
       }
+    };
+    rd(0, 0);
+    rd(1, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int sl = ks % 3;
+      if (ks + 2 < 8) rd(ks + 2, (ks + 2) % 3);
+      FA_MFMA(cr[0], kh[sl][0], ql[ks]);
+      FA_MFMA(cr[1], kh[sl][1], ql[ks]);
+      FA_MFMA(mn_[0], kh[sl][0], qh[ks]);
+      FA_MFMA(mn_[1], kh[sl][1], qh[ks]);
+      FA_MFMA(cr[0], kl[sl][0], qh[ks]);
+      FA_MFMA(cr[1], kl[sl][1], qh[ks]);
+      if (ks + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
     }
+    sacc[0] = mn_[0] + cr[0];
+    sacc[1] = mn_[1] + cr[1];
   };
 
   f32x4 scur[2];
@@ -231,9 +250,16 @@ __global__ __launch_bounds__(64 * NW) void attention_fa_kernel(const f16x8 *__re
     f32x4 snext[2];
     if (PIPE) {
       // K(jb) was read in the previous iteration (or the prologue): its slot takes K(jb + 2); V(jb - 1)'s slot takes V(jb + 1)
+#ifndef FA_NO_DMA  // (static ablations for tools/fa_abl.sh: timing only, wrong results)
       if (jb + 2 < nblk) dma_planes(Kp + (size_t)(jb + 2) * kKUnits, Kring + stage * kKUnits);
       if (jb + 1 < nblk) dma_planes(Vp + (size_t)(jb + 1) * kKUnits, Vring + (stage ^ 1) * kKUnits);
+#endif
+#ifndef FA_NO_S
       if (jb + 1 < nblk) scores(Kring + (stage ^ 1) * kKUnits, snext);
+#else
+      snext[0] = scur[0] * 1.0001f;
+      snext[1] = scur[1] * 0.9999f;
+#endif
     } else {
       if (jb + 1 < nblk) {
         dma_planes(Kp + (size_t)(jb + 1) * kKUnits, Kring + (stage ^ 1) * kKUnits);
@@ -253,7 +279,9 @@ __global__ __launch_bounds__(64 * NW) void attention_fa_kernel(const f16x8 *__re
         x[4 * t + r] = scur[t][r] * sscale;
         bm = fmaxf(bm, x[4 * t + r]);
       }
+#ifndef FA_NO_SOFTMAX
     bm = quad_max(bm);
+#endif
     const float mn = fmaxf(m_run, bm);
     const float alpha = __builtin_amdgcn_exp2f(m_run - mn);  // exp2(-inf) = 0 on the first block
     m_run = mn;
@@ -261,7 +289,11 @@ __global__ __launch_bounds__(64 * NW) void attention_fa_kernel(const f16x8 *__re
     f16x8 ph, pl;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+#ifndef FA_NO_SOFTMAX
       const float p = __builtin_amdgcn_exp2f(x[k] - mn);
+#else
+      const float p = x[k] - mn;
+#endif
       sum += p;
       const float ps = p * kPScale;
       const _Float16 h = (_Float16)ps;
@@ -274,14 +306,38 @@ __global__ __launch_bounds__(64 * NW) void attention_fa_kernel(const f16x8 *__re
       for (int dt = 0; dt < 16; ++dt) o[dt] *= alpha;
     }
 
-    // ---- O^T += V P^T over the block's 32 keys (one k-step) -----------------------------------------------------------
+    // ---- O^T += V P^T over the block's 32 keys (one k-step per 16-row tile of d): tiles in pairs, operands through a
+    // three-deep ring, the six MFMAs of a pair alternating between its two accumulators ------------------------------------
+    {
+      f16x8 vh[3][2], vl[3][2];
+      auto rd = [&](int pr, int slot) {
 #pragma unroll
-    for (int dt = 0; dt < 16; ++dt) {
-      const f16x8 vh = Vs[g * kD + 16 * dt + c];
-      const f16x8 vl = Vs[(kKBk / 8) * kD + g * kD + 16 * dt + c];
-      FA_MFMA(o[dt], vh, pl);
-      FA_MFMA(o[dt], vl, ph);
-      FA_MFMA(o[dt], vh, ph);
+        for (int u = 0; u < 2; ++u) {
+          vh[slot][u] = Vs[g * kD + 16 * (2 * pr + u) + c];
+          vl[slot][u] = Vs[(kKBk / 8) * kD + g * kD + 16 * (2 * pr + u) + c];
+        }
+      };
+      rd(0, 0);
+      rd(1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        const int sl = pr % 3;
+        if (pr + 2 < 8) rd(pr + 2, (pr + 2) % 3);
+#ifndef FA_NO_PV
+        FA_MFMA(o[2 * pr], vh[sl][0], pl);
+        FA_MFMA(o[2 * pr + 1], vh[sl][1], pl);
+        FA_MFMA(o[2 * pr], vl[sl][0], ph);
+        FA_MFMA(o[2 * pr + 1], vl[sl][1], ph);
+        FA_MFMA(o[2 * pr], vh[sl][0], ph);
+        FA_MFMA(o[2 * pr + 1], vh[sl][1], ph);
+#else
+        o[2 * pr] += f32x4{(float)vh[sl][0][0], (float)vl[sl][0][1], (float)pl[0], (float)ph[1]};
+        o[2 * pr + 1] += f32x4{(float)vh[sl][1][0], (float)vl[sl][1][1], (float)pl[2], (float)ph[3]};
+#endif
+        if (pr + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      }
     }
     if (PIPE) {
       scur[0] = snext[0];
