@@ -99,3 +99,51 @@ def assert_z_close(rows_h: dict, rows_o: dict, tol: float = 1e-4, auc_tol: float
         worst = max(worst, err)
     assert abs(auc_h - auc_o) <= auc_tol, (auc_h, auc_o)
     return worst, auc_h, auc_o
+
+
+# ---- committed oracle rows (tests/golden/make_golden_rows.py) ---------------------------------------------------------------
+
+def golden_rows(case: str):
+    """(spec, {set: rows}) of a committed oracle fixture, after checking that the weights the test is about to regenerate are
+    the ones the fixture was computed with (RNG drift would otherwise look like a parity failure)."""
+    import sys
+    from pathlib import Path
+
+    g = Path(__file__).resolve().parent / "golden"
+    if str(g) not in sys.path:
+        sys.path.insert(0, str(g))
+    import make_golden_rows as mg
+    from make_golden import state_dict_digest
+    from ddpm_ood_amd.perceptual import LPIPS
+    from ddpm_ood_amd.synthetic import random_state_dict
+
+    spec, rows = mg.load(case)
+    assert state_dict_digest(random_state_dict(spec["model_type"], spec["channels"], seed=1)) == spec["state_dict_sha256"]
+    assert state_dict_digest(LPIPS().state_dict()) == spec["lpips_sha256"]
+    return spec, rows
+
+
+def live_oracle_pins_fixture(case: str, spec, rows, hip_rows=None, tol_fixture=1e-5, tol_hip=2e-4):
+    """The oracle, LIVE, on the first `spec["live"]` images of every set of a committed case: it must reproduce the committed
+    rows (so the fixture is this oracle's output, not a stale or foreign file) and, when given, agree with the HIP rows of the
+    same images.  The per-image result does not depend on the batch an image rides in (noise is a function of the image
+    index, the PLMS history is per element)."""
+    import sys
+    from pathlib import Path
+
+    g = Path(__file__).resolve().parent / "golden"
+    if str(g) not in sys.path:
+        sys.path.insert(0, str(g))
+    import make_golden_rows as mg
+    import torch
+
+    for name, ids in spec["sets"].items():
+        with torch.no_grad():
+            live = mg.oracle_rows(spec, name, ids, first_n=spec["live"])
+        names = set(live["filename"])
+        assert len(names) == spec["live"]
+        fix = rows[name][rows[name]["filename"].isin(names)].reset_index(drop=True)
+        assert_rows_close(live, fix, tol_fixture, f"{case}/{name}: live oracle vs committed rows")
+        if hip_rows is not None:
+            h = hip_rows[name][hip_rows[name]["filename"].isin(names)].reset_index(drop=True)
+            assert_rows_close(h, live, tol_hip, f"{case}/{name}: HIP vs live oracle")

@@ -5,7 +5,7 @@ the HIP path, and the option branches of the reconstruction loop.
           carried from every trajectory into the next, reference loop reconstruct.py:128-157)
     cfg3  CIFAR-shaped 32x32x3: trajectories, 3-channel LPIPS, two OOD sets through the CLI-level scorer, with a
           32 / 32 split whose oracle AUROC is neither 0.5-by-construction nor saturated
-    cfg4  CelebA-shaped 64x64x3 `big` UNet (attention at every level), skip factor 2, B = 2
+    cfg4  CelebA-shaped 64x64x3 `big` UNet: tests/test_gpu_dispatch.py (B = 16 forward; t-starts 10, 30, 50 of the 100-step list)
     cfg5  LDM path at the README VQ-VAE shape (4 stride-2 levels, 256 channels, 2 048 codes x 128;
           /root/reference/README.md:153-158) -> 3-D `small` UNet -> re-quantise + decode -> 2.5-D LPIPS
 
@@ -115,18 +115,21 @@ def test_golden_trajectory_rows_and_ood_scores_vs_hip(device, tmp_path):
 def test_cfg2_all_25_chained_t_starts(device, tmp_path):
     """BASELINE configs[1]: inference_skip_factor = 4 -> t_start = 10, 50, ..., 970; 1 250 UNet forwards per image.
     One scheduler per batch, so each of the 25 trajectories starts with the PLMS history the previous one left
-    behind (reconstruct.py:98-157).  val / in / out sets -> Z-scores <= 1e-4."""
-    args, rec, ref = _setup(tmp_path, 1, inference_skip_factor=4, batch_size=3)
-    sets = {"val": "synthetic:blobs:n=2:seed=10", "in": "synthetic:blobs:n=2:seed=11",
-            "out": "synthetic:speckle:n=1:seed=12:mix=10"}  # 5 images x 1 250 forwards: ~1.5 min of CPU oracle
-    rows_h, rows_o = {}, {}
-    for name, ids in sets.items():
+    behind (reconstruct.py:98-157).  val / in / out sets -> Z-scores <= 1e-4.
+    Oracle side: the committed rows of all 5 images x 25 t-starts (tests/golden/rows_cfg2_25t.csv, 6 250 CPU forwards);
+    live: the first image of every set, all 25 t-starts, against the fixture and against the HIP rows."""
+    from parity_util import golden_rows, live_oracle_pins_fixture
+
+    spec, rows_o = golden_rows("cfg2_25t")
+    args, rec, _ = _setup(tmp_path, 1, inference_skip_factor=spec["skip"], batch_size=spec["batch"])
+    rows_h = {}
+    for name, ids in spec["sets"].items():
         rows_h[name] = hip_scores(args, rec, ids, name)
-        rows_o[name] = oracle_scores(args, rec, ids, name, model=ref)
         assert sorted(set(rows_h[name]["t"])) == list(range(10, 1000, 40))
         assert_rows_close(rows_h[name], rows_o[name], 2e-4, name)
     assert rec.last_stats["unet_forwards"] == 1 * 1250
     assert_z_close(rows_h, rows_o)
+    live_oracle_pins_fixture("cfg2_25t", spec, rows_o, rows_h)
 
 
 def test_cfg2_trajectories_through_the_f4x4_winograd_kernel(device, tmp_path, monkeypatch):
@@ -155,22 +158,20 @@ def test_cfg2_trajectories_through_the_f4x4_winograd_kernel(device, tmp_path, mo
 def test_cfg3_three_channel_two_ood_sets_and_sensitive_auroc(device, tmp_path):
     """BASELINE configs[2]: 3-channel images (3-channel conv_in / conv_out, 3-channel LPIPS), CIFAR10-named run so
     that ood_detection picks SVHN / CelebA (+ flips; ood_detection.py:91-135).  16 val / 32 in / 32 + 32 out
-    images: the AUROCs land strictly inside (0.2, 0.8), where one swapped pair moves them by 1e-3."""
+    images: the AUROCs land strictly inside (0.2, 0.8), where one swapped pair moves them by 1e-3.
+    Oracle side: committed rows of all 112 images (tests/golden/rows_cfg3.csv); live: the first two images of every set."""
     import argparse
 
-    import oracle
+    from parity_util import golden_rows, live_oracle_pins_fixture
     from ddpm_ood_amd import ood
 
-    sets = {"val": "synthetic:blobs:n=16:channels=3:seed=10", "in": "synthetic:blobs:n=32:channels=3:seed=11",
-            "SVHN": "synthetic:speckle:n=32:channels=3:seed=13:mix=5:name=SVHN",
-            "CelebA": "synthetic:blobs:n=32:channels=3:seed=12:name=CelebA"}
-    args, rec, ref = _setup(tmp_path, 3, model_name="cifar10_synth", batch_size=32, validation_ids=sets["val"],
-                            in_ids=sets["in"], out_ids=",".join([sets["SVHN"], sets["CelebA"]]))
+    spec, rows_o = golden_rows("cfg3")
+    sets = spec["sets"]
+    args, rec, _ = _setup(tmp_path, 3, model_name="cifar10_synth", batch_size=spec["batch"], validation_ids=sets["val"],
+                          in_ids=sets["in"], out_ids=",".join([sets["SVHN"], sets["CelebA"]]))
     rec.reconstruct(args)  # the CLI-level driver: results_{val,in,SVHN,CelebA}.csv
     out_dir = tmp_path / args.model_name / "ood"
     rows_h = {n: pd.read_csv(out_dir / f"results_{n}.csv", index_col=0) for n in sets}
-    rows_o = {n: oracle_scores(args, rec, ids, "val" if n == "val" else "in" if n == "in" else "out", model=ref)
-              for n, ids in sets.items()}
     for n in sets:
         assert sorted(set(rows_h[n]["t"])) == [10, 650]
         assert_rows_close(rows_h[n], rows_o[n], 2e-4, n)
@@ -184,30 +185,14 @@ def test_cfg3_three_channel_two_ood_sets_and_sensitive_auroc(device, tmp_path):
         assert abs(aucs[n] - auc_o) <= 1e-3, (n, aucs[n], auc_o)  # product scorer on product CSVs vs oracle on oracle rows
         _, auc_hp, auc_op = assert_z_close(hs, os_, plot_target="perceptual_difference")
         assert 0.2 < auc_op < 0.8
+    live_oracle_pins_fixture("cfg3", spec, rows_o, rows_h)
 
 
 # ---- cfg4 --------------------------------------------------------------------------------------------------------
 
-def test_cfg4_big_unet_trajectory(device, tmp_path):
-    """BASELINE configs[3]: `big` UNet (172.6 M parameters; attention over 4096 / 1024 / 256 tokens, 1 / 2 / 3
-    heads) at 64x64x3, inference_skip_factor = 2, B = 2.  The t-start list is shortened the only way the CLI offers
-    (--honour_num_inference_steps=1 --num_inference_steps=10 -> t_start = 100, 300, 500, 700, 900: five chained
-    trajectories, 30 UNet forwards per image) so that the CPU oracle finishes in about a minute; val / in / out sets of
-    two images each -> Z-scores and AUROC."""
-    args, rec, ref = _setup(tmp_path, 3, model_type="big", inference_skip_factor=2, batch_size=2,
-                            honour_num_inference_steps=1, num_inference_steps=10)
-    assert rec.num_inference_steps == 10
-    sets = {"val": "synthetic:blobs:n=2:channels=3:size=64:seed=30", "in": "synthetic:blobs:n=2:channels=3:size=64:seed=31",
-            "out": "synthetic:speckle:n=2:channels=3:size=64:seed=32:mix=10"}
-    rows_h, rows_o = {}, {}
-    for name, ids in sets.items():
-        rows_h[name] = hip_scores(args, rec, ids, name)
-        rows_o[name] = oracle_scores(args, rec, ids, name, model=ref)
-        assert sorted(set(rows_h[name]["t"])) == [100, 300, 500, 700, 900]
-        assert rec.last_stats["unet_forwards"] == 2 * 30
-        assert_rows_close(rows_h[name], rows_o[name], 2e-4, name)
-    worst, auc_h, auc_o = assert_z_close(rows_h, rows_o)  # |dZ| <= 1e-4 absolute, AUROC +-1e-3
-    print(f"cfg4: max |dZ| = {worst:.2e}, AUROC hip {auc_h:.4f} / oracle {auc_o:.4f}")
+# (the `big` UNet's trajectories on the reference's own 100-step t list and its B = 16 forward at the benchmarked dispatch live in
+# tests/test_gpu_dispatch.py::test_cfg4_trajectories_on_the_reference_t_list / test_big_forward_at_benchmarked_batch_vs_oracle;
+# the 10-inference-step surrogate this file carried until round 3 is gone)
 
 
 # ---- cfg5 --------------------------------------------------------------------------------------------------------

@@ -102,21 +102,23 @@ def test_small_forward_at_benchmarked_batch_vs_oracle(device, B):
 
 def test_k64_trajectories_at_batch_128_absolute_z(device, tmp_path):
     """BASELINE configs[0]'s t-start list (k = 64: t in {10, 650}, 68 forwards per image) at a chip-filling batch:
-    128 val / 128 in / 128 out images, one batch each.  |dZ| <= 1e-4 ABSOLUTE (north_star), AUROC +-1e-3."""
-    import oracle
+    128 val / 128 in / 128 out images, one batch each.  |dZ| <= 1e-4 ABSOLUTE (north_star), AUROC +-1e-3.
+    The oracle side of all 384 images (206 TFLOP of CPU convolutions: 5.5 minutes of this suite until round 3) is the committed
+    fixture tests/golden/rows_k64_b128.csv; the oracle runs live on the first images of every set and has to reproduce the
+    fixture and match the HIP rows (parity_util.live_oracle_pins_fixture)."""
+    from parity_util import golden_rows, live_oracle_pins_fixture
     from ddpm_ood_amd import synthetic
-    from ddpm_ood_amd.trainer import MODEL_CONFIGS, Reconstruct
+    from ddpm_ood_amd.trainer import Reconstruct
 
-    sets = {"val": "synthetic:blobs:n=128:seed=10", "in": "synthetic:blobs:n=128:seed=11",
-            "out": "synthetic:speckle:n=128:seed=12:mix=10"}
-    args = make_args(tmp_path, inference_skip_factor=64, batch_size=128, validation_ids=sets["val"], in_ids=sets["in"])
+    spec, rows_o = golden_rows("k64_b128")
+    sets = spec["sets"]
+    args = make_args(tmp_path, inference_skip_factor=spec["skip"], batch_size=spec["batch"], validation_ids=sets["val"],
+                     in_ids=sets["in"])
     sd = synthetic.random_state_dict("small", 1, seed=1)
     write_checkpoint(tmp_path, args, sd)
     rec = Reconstruct(args)
     rec.quiet = True
-    ref = oracle.DiffusionModelUNet(2, 1, 1, **MODEL_CONFIGS["small"]).eval()
-    ref.load_state_dict(sd)
-    rows_h, rows_o = {}, {}
+    rows_h = {}
     for name, ids in sets.items():
         rec.profile_first_steps = name == "val"  # hipEvent-bracket the first UNet step of each t-start
         rows_h[name] = hip_scores(args, rec, ids, name)
@@ -125,10 +127,10 @@ def test_k64_trajectories_at_batch_128_absolute_z(device, tmp_path):
             prof = _report()
             missing = [k for k in BENCH_KEYS if k not in prof]
             assert not missing, (missing, sorted(prof))
-        rows_o[name] = oracle_scores(args, rec, ids, name, model=ref)
         assert_rows_close(rows_h[name], rows_o[name], 2e-4, name)
     worst, auc_h, auc_o = assert_z_close(rows_h, rows_o)
     print(f"B = 128, k = 64: max |dZ| = {worst:.2e}, AUROC hip {auc_h:.4f} / oracle {auc_o:.4f}")
+    live_oracle_pins_fixture("k64_b128", spec, rows_o, rows_h)
 
 
 def test_trained_weights_forward_and_trajectory_vs_oracle(device, tmp_path):

@@ -152,3 +152,17 @@ def test_golden_ood_scores_via_independent_numpy():
     si, so = score(inn), score(out)
     pairs = [(a > b) + 0.5 * (a == b) for b in si.values() for a in so.values()]
     assert abs(np.mean(pairs) - auc) < 1e-12  # AUROC = P(score_out > score_in)
+
+
+@pytest.mark.parametrize("case", ["k64_b128", "cfg3"])
+def test_committed_oracle_rows_are_this_oracles_output(case):
+    """tests/golden/rows_<case>.csv (the oracle side of the expensive -m gpu parity tests, make_golden_rows.py) against the
+    oracle run live on the first image of every set: a stale fixture -- or an oracle that changed without the fixture being
+    regenerated -- fails here, on the CPU, before any GPU test trusts the file."""
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from parity_util import golden_rows, live_oracle_pins_fixture
+
+    spec, rows = golden_rows(case)
+    live_oracle_pins_fixture(case, dict(spec, live=1), rows)
