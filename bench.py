@@ -204,6 +204,9 @@ MFMA_KERNELS = [
                     "fp32 products from three f16 MFMAs (hi / lo split, fp32 accumulate)", "hbm"),
     ("conv1x1_mfma", "conv_mfma_kernel<1>: 1x1 conv / Linear (fused QKV, time MLP), fp32 MFMA", 1.0),
     ("lpips_conv_mfma", "lpips_conv_mfma_kernel: AlexNet 5x5 layer of the 2.5-D LPIPS as an implicit GEMM, fp32 MFMA", 1.0),
+    ("attention_fa", "attention_fa_kernel: register-resident flash attention on v_mfma_f32_16x16x32_f16 (q tile, scores and output in "
+                     "registers; K / V f16 planes from a pre-pass through LDS-DMA; fp32 products from three f16 MFMAs, fp32 "
+                     "accumulate); launch time includes the pre-pass", ("f16", 3.0)),
     # split-f16: executed MFMA work = 3 f16 MFMAs per fp32 product, priced against the dense f16 peak
     ("attention", "attention_kernel: QK^T, online softmax, AV (+ residual); fp32 products from three f16 MFMAs "
                   "(hi / lo split, fp32 accumulate)", ("f16", 3.0)),

@@ -36,6 +36,14 @@
 // ABSOLUTE error <= 2^-30 (x) / 2^-36 (w) -- it degrades gracefully, like fp32 flush-to-zero does much further
 // down -- and above them the high half overflows to inf (loud; nothing a GroupNorm-ed UNet produces).
 //
+// Tried in round 4 and dropped (same-box A/B, tools/conv1x1_ab.py at B = 1 024): ONE eight-wave workgroup multiplying both
+// 128-cout tiles of a 256-cout pair against one staged input tile, so that the input is read once instead of once per cout
+// tile (the PMC pass had shown 878 MB per launch against 0.5 GB algorithmic on those layers).  256+256->256 @16x16 375 -> 379 us,
+// 256+128->256 @16x16 282 -> 290 us, the q / k / v projections 158 -> 158 / 144 -> 171 / 129 -> 128 us: no gain -- the second
+// read hits L2 and the 256-cout layers are bound by the operand SPLIT (VALU), not by bytes: per chunk a wave splits 16 weight
+// and 32 input values per lane for 24 MFMAs, and both cout halves split the same input.  What would help is weights pre-split
+// at pack time plus waves that own disjoint pixels (halves the split work); not built.
+//
 // GroupNorm prologue (split-f16 form only): the operands pass through registers for the split anyway, so the
 // per-(image, channel) affine of a GroupNorm-ed input (the attention blocks' q / k / v projections) is applied
 // there; its scale / shift pairs for the chunk ride the DMA ring (one global_load_lds_dword per wave and chunk:

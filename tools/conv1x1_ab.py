@@ -47,8 +47,9 @@ def child(batch):
               f"{byts / ms / 1e9:6.2f} TB/s  max rel err vs f64 {err:.2e}")
         tot += ms
     print(f"  sum {tot:.3f} ms")
-    for C, Cout, H in [(256, 768, 8), (512, 1536, 16)]:  # fused q / k / v behind GroupNorm: small @8x8, big @16x16
-        b_ = batch if C == 256 else max(batch // 16, 1)
+    # fused q / k / v behind GroupNorm: small @8x8, big @64x64 / 32x32 / 16x16 (B = batch / 64: cfg4's 16 at --batch 1024)
+    for C, Cout, H in [(256, 768, 8), (256, 768, 64), (512, 1536, 32), (768, 2304, 16)]:
+        b_ = batch if H == 8 else max(batch // 64, 1)
         x = torch.randn(b_, C, H, H, device=dev)
         w = torch.randn(Cout, C, 1, 1, device=dev) / C ** 0.5
         b = torch.randn(Cout, device=dev)
@@ -73,7 +74,7 @@ if __name__ == "__main__":
     if a.child:
         child(a.batch)
     else:
-        for v, wg in (("0", "384"), ("1", "384"), ("1", "128")):
-            print(f"DDPM_CONV1X1_F16X3={v} DDPM_CONV1X1_DMA_MIN_WG={wg}", flush=True)
-            env = dict(os.environ, DDPM_CONV1X1_F16X3=v, DDPM_CONV1X1_DMA_MIN_WG=wg)
+        for v in ("0", "1"):
+            print(f"DDPM_CONV1X1_F16X3={v}", flush=True)
+            env = dict(os.environ, DDPM_CONV1X1_F16X3=v)
             subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--batch", str(a.batch)], env=env, check=True)
