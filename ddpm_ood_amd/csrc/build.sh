@@ -29,4 +29,11 @@ for p in "${pids[@]}"; do wait "$p"; done
 objs=()
 for f in "${srcs[@]}"; do objs+=("${obj}/${f}.o"); done
 "${HIPCC}" --offload-arch=gfx950 -fPIC -shared "${objs[@]}" -o "${out}"
+# every kernel's host stub must be defined in the library itself (a toolchain quirk once dropped them silently: the library
+# linked, and only dlopen failed)
+if nm -C "${out}" | grep -q " U .*ddpm::"; then
+  echo "undefined ddpm:: symbols in ${out}:" >&2
+  nm -C "${out}" | grep " U .*ddpm::" | head >&2
+  exit 1
+fi
 echo "built ${out}"
