@@ -60,6 +60,8 @@ SIGNATURES = {
     "ddpm_conv_stats_parts": (C.c_int, [C.POINTER(ConvDesc)]),
     "ddpm_conv_s2h_weight_halves": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_conv_s2h_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_conv1x1_h_weight_halves": (C.c_size_t, [C.c_int, C.c_int]),
+    "ddpm_pack_conv1x1_h_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_packed_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ddpm_pack_conv_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p]),

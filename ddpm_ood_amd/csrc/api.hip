@@ -175,6 +175,12 @@ extern "C" int ddpm_pack_conv_s2h_weight(const float *w_raw, uint16_t *dst, int 
   return launch_pack_conv_s2h_weight(w_raw, dst, Cout, Cin, as_stream(stream));
 }
 
+extern "C" size_t ddpm_conv1x1_h_weight_halves(int Cout, int Cin) { return conv1x1_h_weight_halves(Cout, Cin); }
+
+extern "C" int ddpm_pack_conv1x1_h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, ddpm_stream_t stream) {
+  return launch_pack_conv1x1_h_weight(w_raw, dst, Cout, Cin, 0, Cout, as_stream(stream));
+}
+
 extern "C" int ddpm_conv_stats_parts(const ddpm_conv_desc *d) {
   if (!d) return 0;
   return conv_stats_parts(*d);

@@ -170,6 +170,9 @@ size_t packed_conv_weight_floats(int Cout, int Cin, int ksize);
 size_t folded_upsample_weight_floats(int Cout, int Cin);
 bool conv1x1_dma_supported(const ddpm_conv_desc &d);
 int launch_conv1x1_dma(const ddpm_conv_desc &d, hipStream_t s);
+size_t conv1x1_h_weight_halves(int Cout, int Cin);
+int launch_pack_conv1x1_h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, int cout_offset, int Cout_total,
+                                 hipStream_t s);
 bool linear_skinny_supported(const ddpm_conv_desc &d);
 int launch_linear_skinny(const ddpm_conv_desc &d, hipStream_t s);
 bool conv_wino_supported(const ddpm_conv_desc &d);

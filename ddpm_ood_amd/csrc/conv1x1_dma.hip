@@ -88,14 +88,23 @@ bool conv1x1_dma_supported(const ddpm_conv_desc &d) {
   return tiles * (d.Cout / kDM) >= min_wg;
 }
 
-template <bool F16X3, bool AFFINE>
+// PRE (round 4): the weights arrive PRE-SPLIT -- ddpm_pack_conv1x1_h_weight stores, per (cout tile, chunk), the two f16 planes
+// hi = f16(2^6 w), lo = f16((2^6 w - hi) 2^5) as [plane][k group of 8][cout 128] units of eight k (the same 8 KB per chunk as
+// the fp32 image, so the DMA ring is unchanged), i.e. exactly the registers split_f16x8 produced from the fp32 weights: the A
+// operand of a cout block is one ds_read_b128 per plane and no VALU.  With the weight split gone the input split is what is
+// left, so the waves own DISJOINT pixels (4 waves x (128 couts x 64 pixels) instead of 2 x 2 x (64 x 128)): each input value
+// is split once per workgroup instead of twice.  Per chunk and wave: 16 instead of 48 values through split_f16x8 for the same
+// 24 MFMAs.  Same products in the same order -> bit-identical to the non-PRE form (tests/test_gpu_ops.py).
+template <bool F16X3, bool AFFINE, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_desc a) {
+  static_assert(!PRE || F16X3, "pre-split weights are the split-f16 form's");
+  constexpr int NI = PRE ? 4 : 2, NJ = PRE ? 2 : 4;  // cout blocks x pixel tiles (32 x 32) of a wave
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][ A [16][128] | B [16][256] | affine [4][64] ]
   constexpr int kBuf = kDBuf + (AFFINE ? kDAff : 0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int wco = (wave & 1) * 64, wpx = (wave >> 1) * 128;  // 4 waves: 2 x 2
+  const int wco = PRE ? 0 : (wave & 1) * 64, wpx = PRE ? wave * 64 : (wave >> 1) * 128;  // 4 waves: 2 x 2 (PRE: 1 x 4)
   const int HW = a.Ho * a.Wo, Cin = a.C1 + a.C2, nchunks = Cin / kDC;
   // Workgroup -> (pixel tile, cout tile).  The cout tiles of one pixel tile read the same input; workgroups are dealt
   // round-robin to the 8 XCDs (id % 8), each with its own L2, so the cout tiles of a pixel tile take consecutive slots
@@ -122,7 +131,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_des
   // ---- DMA roles.  A: the chunk's 16 x 128 weights are 8 KB contiguous -> pieces 2 wave, 2 wave + 1 of 8.
   // B: one piece per channel (256 pixels = 1 KB); this wave copies channels 4 wave .. 4 wave + 3.  A lane copies 4
   // consecutive pixels (16 B) of its channel row; pixels past the end re-read the last group.
-  const float *wsrc = a.w_packed + (size_t)nt * nchunks * kDC * kDM + wave * 512 + lane * 4;
+  const float *wsrc = (PRE ? reinterpret_cast<const float *>(a.w_wino44h) : a.w_packed) + (size_t)nt * nchunks * kDC * kDM +
+                      wave * 512 + lane * 4;
   size_t boff1, boff2;  // element offset of (image, channel 0, pixel) in in1 / in2
   {
     long t = t0 + lane * 4;
@@ -155,11 +165,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_des
     if constexpr (AFFINE) __builtin_amdgcn_global_load_lds(gsrc + q * kDC, dstA + kDBuf + wave * 64, 4, 0, 0);
   };
 
-  f32x16 acc[2][4];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -181,21 +191,31 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_des
       const float *A = smem + (q % 3) * kBuf + 8 * lhi * kDM + wco + l31;
       const float *Bm = smem + (q % 3) * kBuf + kDC * kDM + 8 * lhi * kDP + wpx + l31;
       const float *G = smem + (q % 3) * kBuf + kDBuf + (wpx >> 6) * 64 + 8 * lhi;
-      f16x8 ah[2], al[2], as[2];
+      f16x8 ah[NI], al[NI], as[NI];
+      if constexpr (PRE) {
+        const f16x8 *Ah = reinterpret_cast<const f16x8 *>(smem + (q % 3) * kBuf) + lhi * kDM + l31, *Al = Ah + 2 * kDM;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float v[8];
+        for (int i = 0; i < NI; ++i) {
+          ah[i] = Ah[32 * i];
+          al[i] = Al[32 * i];
+          as[i] = ah[i] * (_Float16)(1.f / kF16LoScale);
+        }
+      } else {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = A[t * kDM + 32 * i] * kF16WScale;
-        split_f16x8(v, ah[i], al[i], as[i]);
+        for (int i = 0; i < NI; ++i) {
+          float v[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) v[t] = A[t * kDM + 32 * i] * kF16WScale;
+          split_f16x8(v, ah[i], al[i], as[i]);
+        }
       }
       float bq[2][8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) bq[0][t] = Bm[t * kDP];
       float sc[8], sh[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j + 1 < 4) {
+      for (int j = 0; j < NJ; ++j) {
+        if (j + 1 < NJ) {
 #pragma unroll
           for (int t = 0; t < 8; ++t) bq[(j + 1) & 1][t] = Bm[t * kDP + 32 * (j + 1)];
         }
@@ -214,11 +234,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_des
         split_f16x8(bq[j & 1], bh, bl, bs);
         // the two cross terms first, the two cout tiles interleaved (no MFMA waits on the one before it)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[i], bl, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[i], bl, acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bs, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bs, acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][j], 0, 0, 0);
       }
     } else {
       const float *A = smem + (q % 3) * kBuf + lhi * kDM + wco + l31;
@@ -250,13 +270,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_des
   // ---- epilogue: D[row = cout][col = pixel] -> NCHW, 128 B contiguous per (register, half-wave) -------------
   const int co_base = nt * kDM + wco + 4 * lhi;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const long t = t0 + wpx + 32 * j + l31;
     if (t < npix) {
       const long n = t / HW, p = t - n * HW;
       const size_t obase = ((size_t)n * a.Cout + co_base) * HW + p;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NI; ++i) {
         float add[16], rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -280,6 +300,40 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ddpm_conv_des
   }
 }
 
+// ---- pre-split weights: torch [Cout][Cin] rows [cout_offset, cout_offset + Cout) of a (possibly fused) 1x1 weight ->
+//   [cout tile 128][chunk 16][plane hi | lo][k group 2][cout 128][8 k] f16, values as split_f16x8 makes them from 2^6 w
+__global__ void conv1x1_h_pack_kernel(const float *__restrict__ src, _Float16 *__restrict__ dst, int Cout, int Cin, int cout_offset,
+                                      int Cout_total) {
+  const int64_t total = (int64_t)Cout * Cin;
+  const int nchunks = Cin / kDC;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin), co = (int)(i / Cin) + cout_offset;
+    const float v = src[i] * kF16WScale;
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)((v - (float)h) * kF16LoScale);
+    const int tile = co / kDM, c128 = co % kDM, chunk = ci / kDC, kk = ci % kDC;
+    const size_t unit = (((size_t)tile * nchunks + chunk) * 2 * 2 + (kk >> 3)) * kDM + c128;  // plane 0
+    dst[unit * 8 + (kk & 7)] = h;
+    dst[(unit + 2 * kDM) * 8 + (kk & 7)] = l;
+  }
+  (void)Cout_total;
+}
+
+size_t conv1x1_h_weight_halves(int Cout, int Cin) {
+  return (Cout % kDM == 0 && Cin % kDC == 0) ? (size_t)Cout * Cin * 2 : 0;
+}
+
+int launch_pack_conv1x1_h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, int cout_offset, int Cout_total,
+                                 hipStream_t s) {
+  DDPM_CHECK_ARG(w_raw && dst && conv1x1_h_weight_halves(Cout_total, Cin) != 0 && cout_offset >= 0 && cout_offset + Cout <= Cout_total,
+                 "conv1x1 pre-split pack: Cout_total %% 128 or Cin %% 16 != 0, or rows out of range");
+  const int64_t total = (int64_t)Cout * Cin;
+  hipLaunchKernelGGL(conv1x1_h_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_raw,
+                     reinterpret_cast<_Float16 *>(dst), Cout, Cin, cout_offset, Cout_total);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
 int launch_conv1x1_dma(const ddpm_conv_desc &d, hipStream_t s) {
   if (!conv1x1_dma_supported(d)) {
     set_error("conv1x1_dma: unsupported shape");
@@ -291,7 +345,9 @@ int launch_conv1x1_dma(const ddpm_conv_desc &d, hipStream_t s) {
   if (!attr_done) {
     for (const void *f : {reinterpret_cast<const void *>(&conv1x1_dma_kernel<false, false>),
                           reinterpret_cast<const void *>(&conv1x1_dma_kernel<true, false>),
-                          reinterpret_cast<const void *>(&conv1x1_dma_kernel<true, true>)})
+                          reinterpret_cast<const void *>(&conv1x1_dma_kernel<true, true>),
+                          reinterpret_cast<const void *>(&conv1x1_dma_kernel<true, false, true>),
+                          reinterpret_cast<const void *>(&conv1x1_dma_kernel<true, true, true>)})
       (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
@@ -302,7 +358,13 @@ int launch_conv1x1_dma(const ddpm_conv_desc &d, hipStream_t s) {
   static const bool xcd_order = !(getenv("DDPM_CONV1X1_XCD") && atoi(getenv("DDPM_CONV1X1_XCD")) == 0);
   const unsigned PT = (unsigned)((npix + kDP - 1) / kDP), CT = d.Cout / kDM;
   const dim3 grid = xcd_order ? dim3(8 * ((PT + 7) / 8) * CT) : dim3(PT, CT);
-  if (aff)
+  static const bool pre_on = !(getenv("DDPM_CONV1X1_PRESPLIT") && atoi(getenv("DDPM_CONV1X1_PRESPLIT")) == 0);  // A/B
+  const bool pre = f16x3 && pre_on && d.w_wino44h != nullptr;  // weights pre-split by ddpm_pack_conv1x1_h_weight
+  if (pre && aff)
+    hipLaunchKernelGGL((conv1x1_dma_kernel<true, true, true>), grid, dim3(256), lds, s, d);
+  else if (pre)
+    hipLaunchKernelGGL((conv1x1_dma_kernel<true, false, true>), grid, dim3(256), lds, s, d);
+  else if (aff)
     hipLaunchKernelGGL((conv1x1_dma_kernel<true, true>), grid, dim3(256), lds, s, d);
   else if (f16x3)
     hipLaunchKernelGGL((conv1x1_dma_kernel<true, false>), grid, dim3(256), lds, s, d);

@@ -38,6 +38,7 @@ struct ParamSlot {
   bool has_wino44h = false;     // ... and its split-f16 form (conv_wino44h.hip); base in floats, 2 f16 per float
   size_t wino44h_base = 0;
   bool has_s2h = false;         // Downsample conv: split-f16 planes of the direct stride-2 kernel (conv_s2h.hip), in wino44h_base
+  bool has_h1 = false;          // 1x1 conv: pre-split f16 planes of the DMA-fed kernel (conv1x1_dma.hip), in wino44h_base
   int Cout = 0, Cin = 0, ksize = 1, cout_offset = 0, Cout_total = 0;
   int dims = 2;                 // 3: [Cout, Cin, k, k, k] packed as k slabs of 2-D taps (one per depth tap)
   bool optional = false;
@@ -155,10 +156,17 @@ struct ddpm_unet {
     r.w_raw = alloc(n);
     r.has_packed = packed_conv_weight_floats(Cout, Cin, k) != 0;
     if (r.has_packed) r.w_packed = alloc(n);
+    const bool h1 = k == 1 && r.has_packed && conv1x1_h_weight_halves(Cout, Cin) != 0;  // skip connections, proj_attn
+    if (h1) {
+      r.has_wino44h = true;
+      r.w_wino44h = alloc(n);  // 2 f16 per weight
+    }
     r.bias = alloc(Cout);
     const int wi = add_raw(prefix + ".weight", (int64_t)n, r.w_raw, optional);
     params[wi].is_conv = r.has_packed;
     params[wi].packed_base = r.w_packed;
+    params[wi].has_h1 = h1;
+    params[wi].wino44h_base = r.w_wino44h;
     params[wi].Cout = Cout; params[wi].Cin = Cin; params[wi].ksize = k;
     params[wi].cout_offset = 0; params[wi].Cout_total = Cout; params[wi].dims = dims;
     add_raw(prefix + ".bias", Cout, r.bias, optional);
@@ -171,6 +179,8 @@ struct ddpm_unet {
                            shared.w_raw + (size_t)cout_offset * shared.Cin * shared.ksize * shared.ksize);
     params[wi].is_conv = shared.has_packed;
     params[wi].packed_base = shared.w_packed;
+    params[wi].has_h1 = shared.ksize == 1 && shared.has_wino44h;
+    params[wi].wino44h_base = shared.w_wino44h;
     params[wi].Cout = Cout; params[wi].Cin = shared.Cin; params[wi].ksize = shared.ksize;
     params[wi].cout_offset = cout_offset; params[wi].Cout_total = shared.Cout;
     add_raw(prefix + ".bias", Cout, shared.bias + cout_offset);
@@ -182,6 +192,10 @@ struct ddpm_unet {
     r.w_raw = alloc(n);
     r.has_packed = packed_conv_weight_floats(Cout_total, Cin, k) != 0;
     if (r.has_packed) r.w_packed = alloc(n);
+    if (k == 1 && r.has_packed && conv1x1_h_weight_halves(Cout_total, Cin) != 0) {  // fused q / k / v (and the temb projections)
+      r.has_wino44h = true;
+      r.w_wino44h = alloc(n);
+    }
     r.bias = alloc(Cout_total);
     return r;
   }
@@ -445,6 +459,11 @@ extern "C" int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *
   }
   if (p.has_s2h) {
     rc = launch_pack_conv_s2h_weight(src, reinterpret_cast<uint16_t *>(h->blob + p.wino44h_base), p.Cout, p.Cin, s);
+    if (rc) return rc;
+  }
+  if (p.has_h1) {
+    rc = launch_pack_conv1x1_h_weight(src, reinterpret_cast<uint16_t *>(h->blob + p.wino44h_base), p.Cout, p.Cin, p.cout_offset,
+                                      p.Cout_total, s);
     if (rc) return rc;
   }
   if (p.has_folded) {

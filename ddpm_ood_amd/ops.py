@@ -89,6 +89,21 @@ def pack_wino44h_weight(weight: torch.Tensor) -> torch.Tensor | None:
     return out
 
 
+def pack_conv1x1_h_weight(w):
+    """[Cout, Cin(, 1, 1)] -> the pre-split f16 planes of the DMA-fed 1x1 kernel (conv1x1_dma.hip), or None if Cout % 128 or
+    Cin % 16.  Pass it as conv(..., wino44h=...) of a 1x1 convolution."""
+    lib = _lib.load()
+    w = require_device_f32(w, "weight")
+    if w.ndim == 4 and (w.shape[2] != 1 or w.shape[3] != 1):
+        return None
+    n = lib.ddpm_conv1x1_h_weight_halves(w.shape[0], w.shape[1])
+    if n == 0:
+        return None
+    out = torch.empty(n, dtype=torch.float16, device=w.device)
+    check(lib.ddpm_pack_conv1x1_h_weight(ptr(w), out.data_ptr(), w.shape[0], w.shape[1], stream_ptr()), "pack_conv1x1_h_weight")
+    return out
+
+
 def pack_conv_s2h_weight(w):
     """[Cout, Cin, 3, 3] -> split-f16 planes of the direct stride-2 kernel (conv_s2h.hip), or None if the shape has no tiling.
     Pass it as conv(..., mode=CONV_STRIDE2, wino44h=...)."""

@@ -133,6 +133,14 @@ typedef struct ddpm_conv_desc {
 int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream);
 /* Floats of scratch this descriptor can use (0: none); device- and shape-dependent, constant for a given process.  */
 size_t ddpm_conv_scratch_floats(const ddpm_conv_desc *d);
+/* Optional, 1x1 convolutions (ResnetBlock.skip_connection, the fused q / k / v projection; ABI 8): the weights pre-split into
+ * the two f16 planes the DMA-fed split-f16 kernel multiplies (hi = f16(2^6 w), lo = f16((2^6 w - hi) 2^5), laid out
+ * [cout tile 128][chunk of 16 channels][plane][k group][cout][8 k]), handed over in ddpm_conv_desc.w_wino44h.  Halves needed:
+ * ddpm_conv1x1_h_weight_halves(Cout, Cin) (0: Cout % 128 or Cin % 16 != 0).  With them the kernel reads its A operand
+ * straight from LDS and splits every input value once per workgroup instead of twice -- same products, same order,
+ * bit-identical results; without them it splits the fp32 packed weights in registers as before. */
+size_t ddpm_conv1x1_h_weight_halves(int Cout, int Cin);
+int ddpm_pack_conv1x1_h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, ddpm_stream_t stream);
 /* Slices per (image, channel) of the statistics ddpm_conv_f32 writes to d->stats_out for this descriptor (1 .. 8), or 0
  * when the kernel it dispatches to does not emit them (the caller then runs ddpm_gn_scale_shift_f32 on the tensor).  */
 int ddpm_conv_stats_parts(const ddpm_conv_desc *d);

@@ -1025,6 +1025,11 @@ def test_conv1x1_dma(device, case):
     y = ops.conv(d(x), d(w), d(b), x2=d(x2), chan_add=d(chan_add), residual=d(residual))
     torch.cuda.synchronize()
     _close(y, ref, tol=2e-5)
+    # weights pre-split at pack time (what the UNet engine hands over): same products in the same order -> the same bits
+    wh = ops.pack_conv1x1_h_weight(d(w))
+    if wh is not None:
+        y2 = ops.conv(d(x), d(w), d(b), x2=d(x2), chan_add=d(chan_add), residual=d(residual), wino44h=wh)
+        assert torch.equal(y, y2)
 
 
 @pytest.mark.parametrize("case", CONV1X1_DMA_GN_CASES)
@@ -1045,6 +1050,8 @@ def test_conv1x1_dma_groupnorm_prologue(device, case):
     y = ops.conv(d(x), d(w), d(b), gscale=gs, gshift=gh)
     torch.cuda.synchronize()
     _close(y, ref, tol=2e-5)
+    y2 = ops.conv(d(x), d(w), d(b), gscale=gs, gshift=gh, wino44h=ops.pack_conv1x1_h_weight(d(w)))  # pre-split weights
+    assert torch.equal(y, y2)
 
 
 @pytest.mark.parametrize("xs,ws,floor", [(1.0, 1.0, 1e-6), (1e-2, 30.0, 1e-6), (50.0, 1e-2, 1e-6), (1e-3, 1.0, 4e-6),

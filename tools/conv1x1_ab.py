@@ -29,12 +29,14 @@ def child(batch):
         w = torch.randn(Cout, C1 + C2, 1, 1, device=dev) / (C1 + C2) ** 0.5
         b = torch.randn(Cout, device=dev)
         r = torch.randn(batch, Cout, H, H, device=dev)
+        wh = ops.pack_conv1x1_h_weight(w) if os.environ.get("AB_PRESPLIT", "1") == "1" else None
+        pk = ops.pack_conv_weight(w)
         for _ in range(5):
-            y = ops.conv(x, w, b, x2=x2, residual=r)
+            y = ops.conv(x, w, b, x2=x2, residual=r, packed=pk, wino44h=wh)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(50):
-            y = ops.conv(x, w, b, x2=x2, residual=r)
+            y = ops.conv(x, w, b, x2=x2, residual=r, packed=pk, wino44h=wh)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 50
@@ -54,12 +56,14 @@ def child(batch):
         w = torch.randn(Cout, C, 1, 1, device=dev) / C ** 0.5
         b = torch.randn(Cout, device=dev)
         gs, gh = ops.gn_scale_shift(x, torch.ones(C, device=dev), torch.zeros(C, device=dev), 32, 1e-6)
+        wh = ops.pack_conv1x1_h_weight(w) if os.environ.get("AB_PRESPLIT", "1") == "1" else None
+        pk = ops.pack_conv_weight(w)
         for _ in range(5):
-            y = ops.conv(x, w, b, gscale=gs, gshift=gh)
+            y = ops.conv(x, w, b, gscale=gs, gshift=gh, packed=pk, wino44h=wh)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(50):
-            y = ops.conv(x, w, b, gscale=gs, gshift=gh)
+            y = ops.conv(x, w, b, gscale=gs, gshift=gh, packed=pk, wino44h=wh)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 50
@@ -74,7 +78,7 @@ if __name__ == "__main__":
     if a.child:
         child(a.batch)
     else:
-        for v in ("0", "1"):
-            print(f"DDPM_CONV1X1_F16X3={v}", flush=True)
-            env = dict(os.environ, DDPM_CONV1X1_F16X3=v)
+        for v, pre in (("0", "0"), ("1", "0"), ("1", "1")):
+            print(f"DDPM_CONV1X1_F16X3={v} pre-split weights={pre}", flush=True)
+            env = dict(os.environ, DDPM_CONV1X1_F16X3=v, AB_PRESPLIT=pre)
             subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--batch", str(a.batch)], env=env, check=True)
