@@ -205,35 +205,46 @@ def transform_image(a: torch.Tensor, image_roi=None, image_size=None, add_vflip=
 
 
 def _png_unfilter(raw: bytes, height: int, stride: int, bpp: int) -> np.ndarray:
-    """PNG scanline filters 0..4 (None, Sub, Up, Average, Paeth; PNG specification section 9) -> [height, stride] uint8."""
+    """PNG scanline filters 0..4 (None, Sub, Up, Average, Paeth; PNG specification section 9) -> [height, stride] uint8.
+    None / Up are whole-row numpy operations, Sub is a per-channel running sum (mod 256); Average and Paeth depend on the
+    reconstructed left neighbour and run per byte -- over Python ints of a bytearray (about ten times faster than indexing
+    numpy scalars: 0.03 s instead of 0.3-1 s for a 256 x 256 RGB image)."""
     out = np.zeros((height, stride), dtype=np.uint8)
-    prev = np.zeros(stride, dtype=np.int32)
+    prev = bytes(stride)
     pos = 0
     for y in range(height):
         ft = raw[pos]
-        line = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=pos + 1).astype(np.int32)
+        line = raw[pos + 1:pos + 1 + stride]
         pos += stride + 1
         if ft == 0:
-            cur = line
+            cur = bytes(line)
         elif ft == 2:
-            cur = (line + prev) & 255
-        elif ft in (1, 3, 4):
-            cur = line.copy()
-            for x in range(stride):  # sequential by definition (left neighbour of the RECONSTRUCTED line)
-                a = cur[x - bpp] if x >= bpp else 0
-                b = prev[x]
-                if ft == 1:
-                    pred = a
-                elif ft == 3:
-                    pred = (a + b) >> 1
-                else:
-                    c = prev[x - bpp] if x >= bpp else 0
-                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
-                    pred = a if pa <= pb and pa <= pc else b if pb <= pc else c
-                cur[x] = (cur[x] + pred) & 255
+            cur = ((np.frombuffer(line, dtype=np.uint8).astype(np.uint16) + np.frombuffer(prev, dtype=np.uint8)) & 255) \
+                .astype(np.uint8).tobytes()
+        elif ft == 1:
+            px = np.frombuffer(line, dtype=np.uint8).astype(np.uint32)
+            n = stride // bpp
+            head = np.cumsum(px[:n * bpp].reshape(n, bpp), axis=0, dtype=np.uint32) & 255
+            cur = head.astype(np.uint8).tobytes()
+            if n * bpp != stride:  # (never for the colour types read_png accepts: stride = width x bpp)
+                raise ValueError("PNG: row length is not a multiple of the pixel size")
+        elif ft in (3, 4):
+            c = bytearray(line)
+            if ft == 3:
+                for x in range(stride):
+                    left = c[x - bpp] if x >= bpp else 0
+                    c[x] = (c[x] + ((left + prev[x]) >> 1)) & 255
+            else:
+                for x in range(stride):
+                    left = c[x - bpp] if x >= bpp else 0
+                    up = prev[x]
+                    ul = prev[x - bpp] if x >= bpp else 0
+                    pa, pb, pc = abs(up - ul), abs(left - ul), abs(left + up - 2 * ul)
+                    c[x] = (c[x] + (left if pa <= pb and pa <= pc else up if pb <= pc else ul)) & 255
+            cur = bytes(c)
         else:
             raise ValueError(f"PNG: unknown filter type {ft}")
-        out[y] = cur
+        out[y] = np.frombuffer(cur, dtype=np.uint8)
         prev = cur
     return out
 
@@ -265,6 +276,11 @@ def read_png(path: str) -> np.ndarray:
     if channels is None or depth not in (8, 16) or interlace:
         raise NotImplementedError(f"{path}: PNG colour type {ctype} / bit depth {depth} / interlace {interlace} is not read "
                                   "(greyscale, greyscale + alpha, RGB, RGBA at 8 or 16 bits, non-interlaced are)")
+    if depth == 16 and channels >= 3:
+        # PIL (what MONAI's LoadImage sees, reference src/data/get_train_and_val_dataloader.py:60-76) converts 16-bit RGB(A)
+        # files to 8 bits per channel on open; returning the 16-bit values here would silently differ from the reference
+        raise NotImplementedError(f"{path}: 16-bit RGB / RGBA PNG -- PIL truncates these to 8 bits per channel; convert the file "
+                                  "to 8-bit (or to .npy) so that both pipelines see the same numbers")
     bpp = channels * depth // 8
     rows = _png_unfilter(zlib.decompress(b"".join(idat)), h, w * bpp, bpp)
     a = rows.reshape(h, w, channels, depth // 8)

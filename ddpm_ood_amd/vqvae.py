@@ -81,9 +81,12 @@ class _Convolution(nn.Module):
         self._packed = None
 
     def _hip_kind(self, x):
-        """Which HIP kernel computes this layer for input x (None: PyTorch-ROCm fallback)."""
+        """Which specialised HIP kernel computes this layer for input x (None: the generic HIP convolution)."""
         sd, k, s, dil, pad, opad = self.geom
         w = self.conv.weight
+        if x.is_cuda and sd == 2 and not self.is_transposed and (k, s, dil, pad) == (3, 1, 1, 1) and \
+                w.shape[0] % 128 == 0 and w.shape[1] % 4 == 0:
+            return "conv2d"  # 2-D VQ-VAEs: the stride-1 3x3 layers with an MFMA tiling on the UNet's convolution (ADVICE r3)
         if not x.is_cuda or sd != 3 or dil != 1 or pad != 1 or opad != 0:
             return None
         even = all(e % 2 == 0 and e >= 2 for e in x.shape[2:])
@@ -105,6 +108,12 @@ class _Convolution(nn.Module):
         w, b = self.conv.weight, self.conv.bias
         kind = self._hip_kind(x)
         out_act = ops.ACT_NONE if self.conv_only else ops.ACT_RELU
+        if kind == "conv2d":
+            key = (w.data_ptr(), w._version)
+            if self._packed is None or self._packed[0] != key:
+                self._packed = (key, ops.pack_conv_weight(w.detach()), ops.pack_wino_weight(w.detach()))
+            return ops.conv(x.float().contiguous(), w.detach(), b.detach(), packed=self._packed[1], wino=self._packed[2],
+                            out_act=out_act)
         if kind in ("conv", "convT"):
             key = (w.data_ptr(), w._version)
             if self._packed is None or self._packed[0] != key:
@@ -166,9 +175,16 @@ class _ResidualUnit(nn.Module):
                               packed=p2, wino=u2, wino44=v2, wino44h=h2)
         _require_device(x)
         x = x.float().contiguous()
-        h = self.conv1(x)  # generic kernel, ReLU fused
+        h = self.conv1(x)  # generic kernel (2-D layers with an MFMA tiling: the UNet's convolution), ReLU fused
         c2 = self.conv2
         sd, k, s, dil, pad, opad = c2.geom
+        if c2._hip_kind(h) == "conv2d":  # relu(x + conv2(h)): residual and ReLU in the MFMA kernel's epilogue
+            w2 = c2.conv.weight
+            key = (w2.data_ptr(), w2._version)
+            if c2._packed is None or c2._packed[0] != key:
+                c2._packed = (key, ops.pack_conv_weight(w2.detach()), ops.pack_wino_weight(w2.detach()))
+            return ops.conv(h, w2.detach(), c2.conv.bias.detach() if c2.conv.bias is not None else None, packed=c2._packed[1],
+                            wino=c2._packed[2], residual=x, out_act=ops.ACT_RELU)
         return ops.convnd_generic(h, c2.conv.weight.detach(), c2.conv.bias.detach() if c2.conv.bias is not None else None,
                                   stride=s, padding=pad, residual=x, relu=True)
 
@@ -211,6 +227,13 @@ class _VectorQuantizer(nn.Module):
 
 
 class VQVAE(nn.Module):
+    """MONAI-Generative's VQVAE as the reconstruction path uses it (reference: /root/reference/src/trainers/base.py:44-61,
+    /root/reference/src/trainers/reconstruct.py:124,166): inference only, on the device only -- every layer runs on a HIP kernel
+    of libddpm_ood_hip (CPU tensors raise; parameters are read detached, so nothing here is differentiable: VQ-VAE TRAINING is
+    off the path).  3-D README shapes take the MFMA kernels; 2-D stride-1 3x3 layers with Cout % 128 == 0 and
+    Cin % 4 == 0 the UNet's MFMA / Winograd convolution; everything else the generic kernel ddpm_convnd_generic_f32 (correct,
+    slow: one thread per output), announced once per layer shape on stderr."""
+
     def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, num_channels=(96, 96, 192),
                  num_res_layers: int = 3, num_res_channels=(96, 96, 192),
                  downsample_parameters=((2, 4, 1, 1), (2, 4, 1, 1), (2, 4, 1, 1)),
