@@ -543,6 +543,33 @@ def test_vqvae_residual_units_on_hip_match_torch(device):
         _close(p.decode_stage_2_outputs(zp), o.decode_stage_2_outputs(zo), tol=2e-5)
 
 
+def test_vqvae_2d_mfma_friendly_layers_match_oracle(device):
+    """a 2-D VQ-VAE whose stride-1 3x3 layers have an MFMA tiling (128 channels) runs them -- residual units included --
+    on the UNet's convolution kernels instead of the one-thread-per-output generic kernel; the k4-s2 down / up layers stay
+    generic.  Encode + decode vs the CPU oracle."""
+    from oracle.vqvae import VQVAE as OV
+    from ddpm_ood_amd.vqvae import VQVAE as PV, _Convolution
+
+    cfg = dict(spatial_dims=2, in_channels=1, out_channels=1, num_channels=(128, 128), num_res_layers=2,
+               num_res_channels=(128, 128), downsample_parameters=((2, 4, 1, 1), (2, 4, 1, 1)),
+               upsample_parameters=((2, 4, 1, 1, 0), (2, 4, 1, 1, 0)), num_embeddings=32, embedding_dim=128)
+    torch.manual_seed(1)
+    o = OV(**cfg).eval()
+    with torch.no_grad():
+        o.quantizer.quantizer.embedding.weight.mul_(3.0)
+    p = PV(**cfg)
+    p.load_state_dict(o.state_dict())
+    p = p.to(device).eval()
+    x = torch.rand(3, 1, 32, 32, generator=torch.Generator().manual_seed(2))
+    kinds = {m._hip_kind(torch.zeros(1, m.conv.weight.shape[1], 8, 8, device=device)) for m in p.modules() if isinstance(m, _Convolution)}
+    assert "conv2d" in kinds
+    with torch.no_grad():
+        zo = o.encode_stage_2_inputs(x)
+        zp = p.encode_stage_2_inputs(x.to(device))
+        _close(zp, zo, tol=1e-5)
+        _close(p.decode_stage_2_outputs(zp), o.decode_stage_2_outputs(zo), tol=2e-5)
+
+
 WINO_CASES = [
     # B, C1, C2, Cout, H, gn, chan_add, residual
     (2, 128, 0, 128, 32, True, True, False),
