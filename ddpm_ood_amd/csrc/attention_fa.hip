@@ -240,13 +240,19 @@ __global__ __launch_bounds__(64 * NW) void attention_fa_kernel(const f16x8 *__re
 
   f32x4 scur[2];
   if (PIPE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // K(0) (and K(1), V(0)) have landed
     scores(Kring, scur);
   }
 
   for (int jb = 0; jb < nblk; ++jb) {
     const int stage = jb & 1;
-    __syncthreads();  // every piece issued so far has landed (a wave waits for its own first); last iteration's reads are done
+    // every piece issued so far has landed -- a wave waits for ITS OWN pieces explicitly: hipcc's __syncthreads() does not put an
+    // s_waitcnt vmcnt in front of the barrier for LDS-DMA writes issued in the previous iteration of a loop (it did in the
+    // prologue); without it a block could be multiplied before it had arrived -- errors of 1e-3 that came and went with the
+    // timing (found by test_big_forward_at_benchmarked_batch_vs_oracle) -- and last iteration's reads are done
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     f32x4 snext[2];
     if (PIPE) {
       // K(jb) was read in the previous iteration (or the prologue): its slot takes K(jb + 2); V(jb - 1)'s slot takes V(jb + 1)

@@ -251,6 +251,29 @@ def test_attention_online_softmax_rescale(device):
     _close(out, torch.einsum("bij,bdj->bdi", s.softmax(-1), v), tol=1e-5)
 
 
+def test_attention_register_resident_is_bit_reproducible_under_load(device):
+    """Race detector for the LDS-DMA ring of attention_fa.hip: the cfg4 launch (B = 16, n = 4096: two waves of workgroups over the
+    chip) repeated back to back with other work in flight must return the same bits every time -- a K / V block multiplied before
+    its DMA has landed shows up as run-to-run differences (round 4: hipcc's __syncthreads() does not wait for LDS-DMA writes
+    issued in the previous loop iteration; the kernel waits with an explicit s_waitcnt vmcnt(0))."""
+    from ddpm_ood_amd import ops
+
+    B, C, N = 16, 256, 4096
+    g = torch.Generator(device=device).manual_seed(5)
+    qkv = torch.randn(B, 3 * C, N, device=device, generator=g)
+    res = torch.randn(B, C, N, device=device, generator=g)
+    junk = torch.randn(4096, 4096, device=device)
+    first = ops.attention(qkv, res, 1, 1 / 16.0)
+    for i in range(6):
+        if i & 1:
+            junk = junk @ junk * 1e-4  # other kernels between the launches: different arrival times
+        again = ops.attention(qkv, res, 1, 1 / 16.0)
+        assert torch.equal(first, again), i
+    q, k, v = (t.reshape(1, 1, 256, N) for t in qkv[3:4].split(C, dim=1))
+    ref = torch.einsum("bhij,bhdj->bhdi", (torch.einsum("bhdi,bhdj->bhij", q, k) / 16.0).softmax(-1), v).reshape(1, C, N) + res[3:4]
+    assert (first[3:4] - ref).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("qs,vs", [(1.0, 1.0), (0.05, 20.0), (3.0, 0.01)])
 def test_attention_split_f16_error(device, qs, vs):
     """Both contractions run as split-f16 MFMA products (22-bit products, fp32 accumulate): against a float64
