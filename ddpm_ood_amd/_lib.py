@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
         ("Di", C.c_int), ("Do", C.c_int), ("dims", C.c_int), ("reserved0", C.c_int),
         ("w_folded", C.c_void_p), ("out_act", C.c_int), ("reserved", C.c_int), ("w_wino", C.c_void_p),
         ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t), ("w_wino44", C.c_void_p),
-        ("w_wino44h", C.c_void_p), ("stats_out", C.c_void_p),
+        ("w_wino44h", C.c_void_p), ("stats_out", C.c_void_p), ("w_d3h", C.c_void_p),
     ]
 
 
@@ -60,6 +60,8 @@ SIGNATURES = {
     "ddpm_conv_stats_parts": (C.c_int, [C.POINTER(ConvDesc)]),
     "ddpm_conv_s2h_weight_halves": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_conv_s2h_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_conv_d3h_weight_halves": (C.c_size_t, [C.c_int, C.c_int]),
+    "ddpm_pack_conv_d3h_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_conv1x1_h_weight_halves": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_conv1x1_h_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_packed_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -39,6 +39,7 @@ static void load_switches() {
   n.conv1x1_f16x3 = env_int("DDPM_CONV1X1_F16X3", 1) != 0;
   n.attn_f16x3 = env_int("DDPM_ATTN_F16X3", 1) != 0;
   n.attn_fa = env_int("DDPM_ATTN_FA", 1);
+  n.conv_d3h = env_int("DDPM_CONV_D3H", 0);
   n.conv_splitk = env_int("DDPM_CONV_SPLITK", 1) != 0;
   n.gn_fused = env_int("DDPM_GN_FUSED", 1) != 0;
   n.prof_shapes = getenv("DDPM_PROF_SHAPES") != nullptr;
@@ -173,6 +174,12 @@ extern "C" size_t ddpm_conv_s2h_weight_halves(int Cout, int Cin) { return conv_s
 
 extern "C" int ddpm_pack_conv_s2h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, ddpm_stream_t stream) {
   return launch_pack_conv_s2h_weight(w_raw, dst, Cout, Cin, as_stream(stream));
+}
+
+extern "C" size_t ddpm_conv_d3h_weight_halves(int Cout, int Cin) { return conv_d3h_weight_halves(Cout, Cin); }
+
+extern "C" int ddpm_pack_conv_d3h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, ddpm_stream_t stream) {
+  return launch_pack_conv_d3h_weight(w_raw, dst, Cout, Cin, as_stream(stream));
 }
 
 extern "C" size_t ddpm_conv1x1_h_weight_halves(int Cout, int Cin) { return conv1x1_h_weight_halves(Cout, Cin); }

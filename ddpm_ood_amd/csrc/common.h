@@ -46,6 +46,8 @@ struct Switches {
   int down_s2h = 1;             // DDPM_DOWN_S2H (0 off, 2 / 3 force a form)
   bool conv1x1_f16x3 = true;    // DDPM_CONV1X1_F16X3
   bool attn_f16x3 = true;       // DDPM_ATTN_F16X3
+  int conv_d3h = 0;             // DDPM_CONV_D3H: 1 the direct split-f16 3x3 kernel (conv_d3h.hip; experimental, 20 % slower than the F(4x4)
+                                // form) where a launch fills the chip, 2 also for smaller launches (tests)
   int attn_fa = 1;              // DDPM_ATTN_FA (0: the LDS-exchange kernels of attention.hip also when scratch is given; 2: the
                                 // register-resident kernel for every multiple of 64 tokens, not only from 1 024)
   bool conv_splitk = true;      // DDPM_CONV_SPLITK
@@ -190,6 +192,10 @@ size_t wino44_weight_floats(int Cout, int Cin);
 bool conv_wino44h_supported(const ddpm_conv_desc &d);
 int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_wino44h_scratch_floats(const ddpm_conv_desc &d);
+bool conv_d3h_supported(const ddpm_conv_desc &d);
+int launch_conv_d3h(const ddpm_conv_desc &d, hipStream_t s);
+size_t conv_d3h_weight_halves(int Cout, int Cin);
+int launch_pack_conv_d3h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, hipStream_t s);
 bool conv_s2h_supported(const ddpm_conv_desc &d);
 int launch_conv_s2h(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_s2h_weight_halves(int Cout, int Cin);

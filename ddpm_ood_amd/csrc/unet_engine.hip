@@ -38,6 +38,8 @@ struct ParamSlot {
   bool has_wino44h = false;     // ... and its split-f16 form (conv_wino44h.hip); base in floats, 2 f16 per float
   size_t wino44h_base = 0;
   bool has_s2h = false;         // Downsample conv: split-f16 planes of the direct stride-2 kernel (conv_s2h.hip), in wino44h_base
+  bool has_d3h = false;         // stride-1 3x3 conv: split-f16 planes of the direct kernel (conv_d3h.hip)
+  size_t d3h_base = 0;
   bool has_h1 = false;          // 1x1 conv: pre-split f16 planes of the DMA-fed kernel (conv1x1_dma.hip), in wino44h_base
   int Cout = 0, Cin = 0, ksize = 1, cout_offset = 0, Cout_total = 0;
   int dims = 2;                 // 3: [Cout, Cin, k, k, k] packed as k slabs of 2-D taps (one per depth tap)
@@ -46,8 +48,8 @@ struct ParamSlot {
 };
 
 struct ConvRef {  // a conv-like op: weight (raw + packed) and bias locations in the blob
-  size_t w_raw = 0, w_packed = 0, bias = 0, w_folded = 0, w_wino = 0, w_wino44 = 0, w_wino44h = 0;
-  bool has_packed = false, has_folded = false, has_wino = false, has_wino44 = false, has_wino44h = false;
+  size_t w_raw = 0, w_packed = 0, bias = 0, w_folded = 0, w_wino = 0, w_wino44 = 0, w_wino44h = 0, w_d3h = 0;
+  bool has_packed = false, has_folded = false, has_wino = false, has_wino44 = false, has_wino44h = false, has_d3h = false;
   int Cin = 0, Cout = 0, ksize = 1;
   int dims = 2;
 };
@@ -247,6 +249,13 @@ static ResRef build_res(ddpm_unet *u, const std::string &prefix, int Cin, int Co
         cr[i]->w_wino44h = u->alloc(nh / 2);
         ps.has_wino44h = true;
         ps.wino44h_base = cr[i]->w_wino44h;
+      }
+      // direct split-f16 form (conv_d3h.hip): opt-in (slower than the F(4x4) form) -- no planes unless switched on
+      if (const size_t nd = sw().conv_d3h ? conv_d3h_weight_halves(cr[i]->Cout, cr[i]->Cin) : 0) {
+        cr[i]->has_d3h = true;
+        cr[i]->w_d3h = u->alloc((nd + 1) / 2);
+        ps.has_d3h = true;
+        ps.d3h_base = cr[i]->w_d3h;
       }
     }
   }
@@ -457,6 +466,10 @@ extern "C" int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *
     rc = launch_pack_wino44h_weight(src, reinterpret_cast<uint16_t *>(h->blob + p.wino44h_base), p.Cout, p.Cin, s);
     if (rc) return rc;
   }
+  if (p.has_d3h) {
+    rc = launch_pack_conv_d3h_weight(src, reinterpret_cast<uint16_t *>(h->blob + p.d3h_base), p.Cout, p.Cin, s);
+    if (rc) return rc;
+  }
   if (p.has_s2h) {
     rc = launch_pack_conv_s2h_weight(src, reinterpret_cast<uint16_t *>(h->blob + p.wino44h_base), p.Cout, p.Cin, s);
     if (rc) return rc;
@@ -538,6 +551,7 @@ struct Runner {
     if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino && c.dims == 2)
       d.w_wino = P(c.w_wino);
     if (mode == DDPM_CONV_NORMAL && c.has_wino44 && c.dims == 2) d.w_wino44 = P(c.w_wino44);
+    if (mode == DDPM_CONV_NORMAL && c.has_d3h && c.dims == 2) d.w_d3h = reinterpret_cast<const uint16_t *>(P(c.w_d3h));
     if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2 || mode == DDPM_CONV_STRIDE2) && c.has_wino44h && c.dims == 2)
       d.w_wino44h = reinterpret_cast<const uint16_t *>(P(c.w_wino44h));
     if (c.dims == 3 && c.ksize == 3 && mode == DDPM_CONV_NORMAL && c.has_wino) d.w_wino = P(c.w_wino);  // F(2x2) per depth tap

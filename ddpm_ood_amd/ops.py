@@ -104,6 +104,21 @@ def pack_conv1x1_h_weight(w):
     return out
 
 
+def pack_conv_d3h_weight(w):
+    """[Cout, Cin, 3, 3] -> split-f16 planes of the direct 3x3 kernel (conv_d3h.hip), or None (Cout % 128, Cin % 8).  Pass it as
+    conv(..., d3h=...)."""
+    lib = _lib.load()
+    w = require_device_f32(w, "weight")
+    if w.ndim != 4 or w.shape[2] != 3 or w.shape[3] != 3:
+        return None
+    n = lib.ddpm_conv_d3h_weight_halves(w.shape[0], w.shape[1])
+    if n == 0:
+        return None
+    out = torch.empty(n, dtype=torch.float16, device=w.device)
+    check(lib.ddpm_pack_conv_d3h_weight(ptr(w), out.data_ptr(), w.shape[0], w.shape[1], stream_ptr()), "pack_conv_d3h_weight")
+    return out
+
+
 def pack_conv_s2h_weight(w):
     """[Cout, Cin, 3, 3] -> split-f16 planes of the direct stride-2 kernel (conv_s2h.hip), or None if the shape has no tiling.
     Pass it as conv(..., mode=CONV_STRIDE2, wino44h=...)."""
@@ -121,7 +136,7 @@ def pack_conv_s2h_weight(w):
 
 def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NONE, mode=CONV_NORMAL,
          chan_add=None, chan_add_offset=0, residual=None, packed=None, force_direct=False, folded=None,
-         wino=None, out_act=ACT_NONE, wino44=None, wino44h=None, want_stats=False):
+         wino=None, out_act=ACT_NONE, wino44=None, wino44h=None, want_stats=False, d3h=None):
     """Fused conv / linear.  x: [B, C1, H, W]; x2: optional second source of a virtual concat.
     want_stats: return (out, stats) with the produced tensor's per-channel GroupNorm statistics (ddpm_conv_desc.stats_out)."""
     lib = _lib.load()
@@ -175,6 +190,7 @@ def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NON
     d.w_wino = ptr(wino)
     d.w_wino44 = ptr(wino44)
     d.w_wino44h = wino44h.data_ptr() if wino44h is not None else None
+    d.w_d3h = d3h.data_ptr() if d3h is not None else None
     d.out_act = out_act
     need = lib.ddpm_conv_scratch_floats(C.byref(d))  # small batches: split-K partial slabs (0 otherwise)
     if need:

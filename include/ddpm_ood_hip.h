@@ -128,6 +128,13 @@ typedef struct ddpm_conv_desc {
    * (parts = ddpm_conv_stats_parts(d); 0 = this dispatch does not emit them and stats_out is ignored).  Merged pairwise
    * in a fixed order (no atomics): bit-reproducible.  ddpm_gn_finalize_f32 turns them into scale / shift.  */
   float *stats_out;
+  /* Optional, 2-D 3x3 DDPM_CONV_NORMAL only (ABI 8): the weights as split-f16 planes of the DIRECT convolution kernel
+   * (csrc/conv_d3h.hip), packed by ddpm_pack_conv_d3h_weight (ddpm_conv_d3h_weight_halves(Cout, Cin) halves; 0: Cout % 128 or
+   * Cin % 8 != 0).  When present, W in {16, 32, 64}, 256-pixel tiles of whole rows and the launch fills the chip, the
+   * convolution runs as nine taps on v_mfma_f32_32x32x16_f16 with three exact f16 partial products per fp32 product (fp32
+   * accumulate; GroupNorm + SiLU prologue, concat, bias / temb / residual epilogue) instead of the Winograd forms; it emits no
+   * statistics (ddpm_conv_stats_parts = 0).  Takes precedence over w_wino44h; DDPM_CONV_D3H=0 switches it off.  */
+  const uint16_t *w_d3h;
 } ddpm_conv_desc;
 
 int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream);
@@ -139,6 +146,8 @@ size_t ddpm_conv_scratch_floats(const ddpm_conv_desc *d);
  * ddpm_conv1x1_h_weight_halves(Cout, Cin) (0: Cout % 128 or Cin % 16 != 0).  With them the kernel reads its A operand
  * straight from LDS and splits every input value once per workgroup instead of twice -- same products, same order,
  * bit-identical results; without them it splits the fp32 packed weights in registers as before. */
+size_t ddpm_conv_d3h_weight_halves(int Cout, int Cin);
+int ddpm_pack_conv_d3h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, ddpm_stream_t stream);
 size_t ddpm_conv1x1_h_weight_halves(int Cout, int Cin);
 int ddpm_pack_conv1x1_h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, ddpm_stream_t stream);
 /* Slices per (image, channel) of the statistics ddpm_conv_f32 writes to d->stats_out for this descriptor (1 .. 8), or 0

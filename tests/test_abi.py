@@ -41,7 +41,7 @@ def test_struct_layouts_match_header(lib):
     from ddpm_ood_amd._lib import ConvDesc, UNetConfig
 
     # field order of the C structs (pointers 8 B, ints 4 B): sizes computed by hand from the header
-    assert C.sizeof(ConvDesc) == 8 + 8 + 4 + 4 + 8 * 5 + 8 + 8 + 8 + 8 + 4 * 10 + 4 * 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # incl. padding after stride; + scratch, scratch_floats, w_wino44, w_wino44h, stats_out
+    assert C.sizeof(ConvDesc) == 8 + 8 + 4 + 4 + 8 * 5 + 8 + 8 + 8 + 8 + 4 * 10 + 4 * 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # incl. padding after stride; + scratch, scratch_floats, w_wino44, w_wino44h, stats_out, w_d3h
     assert C.sizeof(UNetConfig) == 4 * 4 + 4 * 8 * 4 + 4 + 4 + 4
 
 
