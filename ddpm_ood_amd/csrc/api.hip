@@ -32,6 +32,7 @@ static void load_switches() {
   n.conv_wino44 = env_int("DDPM_CONV_WINO44", 1);
   n.wino44_f16x3 = env_int("DDPM_WINO44_F16X3", 1) != 0;
   n.wino44_split = env_int("DDPM_WINO44_SPLIT", 4);
+  n.wino_split = env_int("DDPM_WINO_SPLIT", 8);
   n.wino44_xmap = env_int("DDPM_WINO44_XMAP", -1);
   n.w44_abl = env_int("DDPM_W44_ABL", 0);
   n.up_wino44h = env_int("DDPM_UP_WINO44H", 1) != 0;

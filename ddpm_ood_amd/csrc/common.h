@@ -40,6 +40,7 @@ struct Switches {
   int conv_wino44 = 1;          // DDPM_CONV_WINO44: 0 no F(4x4) kernels, 2 also for launches smaller than the chip
   bool wino44_f16x3 = true;     // DDPM_WINO44_F16X3
   int wino44_split = 4;         // DDPM_WINO44_SPLIT
+  int wino_split = 8;           // DDPM_WINO_SPLIT: most channel-stream splits of a conv_wino.hip launch smaller than half the chip (power of two)
   int wino44_xmap = -1;         // DDPM_WINO44_XMAP (-1: unset, each kernel has its own default)
   int w44_abl = 0;              // DDPM_W44_ABL
   bool up_wino44h = true;       // DDPM_UP_WINO44H

@@ -371,12 +371,18 @@ __global__ __launch_bounds__(512, 1) void conv_d3h_kernel(const ddpm_conv_desc a
           // ---- the staging work dealt out behind MFMA number `slot` of the chunk (0 .. 119): every wave's VALU / memory
           // instructions issue while the SIMD's other wave has the matrix pipe
           const int slot = 24 * j + 12 * half + m;
+#ifdef D3H_DMA_SPREAD
           if (slot % 24 == 1) {  // weights of chunk q + 1: one 1 KB piece per K-step
+            const int pc = j;
+#else
+          if (slot >= 1 && slot <= 9 && (slot & 1)) {  // weights of chunk q + 1: the five 1 KB pieces right behind the barrier (a whole
+            const int pc = slot >> 1;                    // chunk to land: the next barrier waits for them)
+#endif
 #ifdef D3H_NO_DMA
             if (q < 0)
 #endif
-            __builtin_amdgcn_global_load_lds(wsrc + (size_t)cq1 * kAUnits + (wave * 5 + j) * 64 + lane,
-                                             lds + (PAR ^ 1) * kAUnits + (wave * 5 + j) * 64, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(wsrc + (size_t)cq1 * kAUnits + (wave * 5 + pc) * 64 + lane,
+                                             lds + (PAR ^ 1) * kAUnits + (wave * 5 + pc) * 64, 16, 0, 0);
           }
 #ifndef D3H_NO_XSTORE
           if (slot >= 40 && slot < 120 && (slot - 40) % 5 == 0) {  // value (pixel px, channel c) of X(q + 1): slots 40, 45, .., 115

@@ -175,7 +175,7 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   g.S = 1;
   g.pstride = 0;
   if (!is3d && !g.up && items * 2 <= cus) {  // launch would leave more than half of the chip idle
-    for (int sp = 4; sp >= 2; sp >>= 1)
+    for (int sp = sw().wino_split; sp >= 2; sp >>= 1)
       if (items * sp <= cus && g.nchunks % sp == 0 && g.nchunks / sp >= 4) { g.S = sp; break; }
   }
   g.grid = g.KT * ((g.NS * g.S + 7) / 8) * 8;
