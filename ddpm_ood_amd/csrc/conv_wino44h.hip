@@ -206,6 +206,7 @@ struct W44HGeom {
   int NRT;          // staging rounds per pixel wave and half-chunk: TI * UI
   int KT, NIT, IPW, NS, grid;
   int xmap;
+  int xitem;        // 1: the pixel waves' staging stream runs on across item boundaries (DDPM_W44H_XITEM, A/B)
   int up, HWin;     // 1: DDPM_CONV_UPSAMPLE2 -- the pixel waves read the nearest-x2 image from the stored low-res one (HWin pixels)
   int S;            // channel-stream splits per item (1: none)
   long long pstride;
@@ -327,6 +328,7 @@ static bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false)
   g.IPW = (int)((items + cus - 1) / cus);
   g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW) * g.S;
   g.grid = g.KT * ((g.NS + 7) / 8) * 8;
+  g.xitem = sw().w44h_xitem;
   // default 0: the cout tiles of a slot are neighbours on ONE XCD, so that the KT re-reads of the slot's input hit that XCD's L2
   // (rocprofv3 FETCH_SIZE / WRITE_SIZE at B = 1 024: 1.14 GB per launch against 1.49 GB with one cout tile per XCD, same time)
   g.xmap = (sw().wino44_xmap >= 0 ? sw().wino44_xmap != 0 : 0) && (8 % g.KT == 0);
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
   // ================================================================================================ PRODUCER waves
   // lane = (tile of 16, channel pair j of 4); wave & 1 = tile half; (wave >> 1) = group: group G runs the first half (channel
   // 2 j) of the task of phase m + 2 when m + G is even and the second half (channel 2 j + 1, pack, store) of phase m + 1 else.
-  auto producer_item = [&](auto grpc) {
+  auto producer_item = [&](auto grpc, bool first_item) {
     constexpr int GRP = decltype(grpc)::value;  // waves 0, 1: group 0; waves 2, 3: group 1
     const int st = (wave & 1) * 16 + (lane & 15), j = lane >> 4;
     int tb0;  // pixel-ring offset of this lane's patch origin in channel 2 j (half-chunk j >> 1, plane 2 (j & 1))
@@ -701,10 +703,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     };
     for (int m = -6; m < NPH; m += 6) {
       if (m == 0) zero_accumulators();
-      body(std::integral_constant<int, 0>{}, m);
-      body(std::integral_constant<int, 1>{}, m + 1);
-      body(std::integral_constant<int, 2>{}, m + 2);
-      body(std::integral_constant<int, 3>{}, m + 3);
+      if (m >= 0 || first_item) {  // (a later item's fill is its last two phases: see the item loop)
+        body(std::integral_constant<int, 0>{}, m);
+        body(std::integral_constant<int, 1>{}, m + 1);
+        body(std::integral_constant<int, 2>{}, m + 2);
+        body(std::integral_constant<int, 3>{}, m + 3);
+      }
       body(std::integral_constant<int, 4>{}, m + 4);
       body(std::integral_constant<int, 5>{}, m + 5);
     }
@@ -717,8 +721,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
   //   phase m = 3 c + 2: activation (set 0) of half 0 of chunk c + 2
   // i.e. every load has two phases to land, and a half-tile is rewritten one phase after its last reader (the second half of
   // the task of the last phase of chunk c - 2) has passed its barrier.
-  auto pixel_item = [&](int n_cur) {
+  auto pixel_item = [&](int n_cur, bool first_item) {
     const int sc = wave - 4;
+    const bool has_next = g.xitem && n_cur + g.TI < n_end;  // the item's last two chunks of staging fetch the NEXT item's chunks 0, 1
     const int row_lo = max(0, 4 * r0 - 1), row_hi = min(a.Ho, 4 * (r0 + g.TR) + 1);
     const int npx = (row_hi - row_lo) * a.Wo;
     const int dump = 4 * g.PCH + 1 + lane;  // relative to the half-tile
@@ -762,14 +767,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
 
     auto load_stage = [&](auto setc, int c, int half) {
       constexpr int S = decltype(setc)::value;
-      const int cl = min(max(c, 0), NCHs - 1);  // past the item's last chunk: a harmless repeat (uniform vmcnt bookkeeping)
+      // past the item's last chunk: the next item's first chunks (the stream of half-tiles runs on across the output transform,
+      // which does not touch the pixel ring); behind the last item a harmless repeat (uniform vmcnt bookkeeping)
+      const bool nxt = c >= NCHs && has_next;
+      const int cl = nxt ? c - NCHs : min(max(c, 0), NCHs - 1);
+      const int n_it = nxt ? n_cur + g.TI : n_cur;
       int cg = (ch_lo + cl) * kC + half * 4 + sc;
       int soff3 = 0;
       bool dok = true;  // D3: the depth tap's slice lies inside the volume
       if (D3) {  // stream chunk -> (depth tap, channel chunk); image -> (batch item, slice); one image per item
         const int kdi = cl / g.NCHc;
         cg = (cl - kdi * g.NCHc) * kC + half * 4 + sc;
-        const int ni = min(n_cur, g.NIMG - 1);
+        const int ni = min(n_it, g.NIMG - 1);
         const int nb = ni / g.D, dsl = ni - nb * g.D + g.kd0 + kdi - 1;
         dok = dsl >= 0 && dsl < g.D;
         soff3 = ((nb * a.C1 + cg) * g.D + (dok ? dsl : 0)) * g.HW * 4;
@@ -780,7 +789,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       const int cx = first ? a.C1 : a.C2, cgl = first ? cg : cg - a.C1;
 #pragma unroll
       for (int k = 0; k < NRT; ++k) {
-        const int ni = min(n_cur + (ONEIMG ? 0 : k / GD), g.NIMG - 1);
+        const int ni = min(n_it + (ONEIMG ? 0 : k / GD), g.NIMG - 1);
         // D3: a depth tap outside the volume reads zeros -- the range check of a raw buffer load is on the VGPR offset, and
         // 0x80000000 is past every resource (as for the out-of-image lanes in pix0)
         const int soff = D3 ? soff3 : (ni * cx + cgl) * (UP ? g.HWin : g.HW) * 4;
@@ -790,11 +799,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     };
     auto load_affine = [&](int c, int half) {
       if (!AFFINE) return;
-      const int cl = min(max(c, 0), NCHs - 1);
+      const bool nxt = c >= NCHs && has_next;
+      const int cl = nxt ? c - NCHs : min(max(c, 0), NCHs - 1);
       const int cg = (ch_lo + cl) * kC + half * 4 + sc;
 #pragma unroll
       for (int i = 0; i < NGS; ++i) {
-        const int ni = min(n_cur + i, g.NIMG - 1);
+        const int ni = min((nxt ? n_cur + g.TI : n_cur) + i, g.NIMG - 1);
         const int goff = (ni * g.Cin + cg) * 4;
         gs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
         gh[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
@@ -814,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
       }
       P[ring * g.HS + pw_of(k)] = y;
     };
-    auto body = [&](auto qc, int c) {  // c = chunk of the phase (floor(m / 3); -2, -1 in the fill phases)
+    auto body = [&](auto qc, int c, bool mini = false) {  // c = chunk of the phase (floor(m / 3); -2, -1 in the fill phases)
       constexpr int Q = decltype(qc)::value;
       const int m = 3 * c + Q % 3;
 #ifdef W44H_PROBE
@@ -848,7 +858,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
 #pragma unroll
           for (int kk = 3 * (k - 1); kk < 3 * k && kk < NRT; ++kk) {  // three rounds per slice: done by slice 4
             if (R == 0) activate(I1{}, kk, ringB);
-            if (R == 2) activate(I0{}, kk, ringA);
+            if (R == 2 && !mini) activate(I0{}, kk, ringA);  // (mini: that half-tile was written during the previous item)
           }
           if (R == 2 && k == 5) load_affine(c + 2, 1);  // for the next phase's activation (half 1 of the same chunk)
         }
@@ -863,12 +873,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     int c = -2;
     for (int m = -6; m < NPH; m += 6, c += 2) {
       if (m == 0) zero_accumulators();
-      body(std::integral_constant<int, 0>{}, c);
-      body(std::integral_constant<int, 1>{}, c);
-      body(std::integral_constant<int, 2>{}, c);
-      body(std::integral_constant<int, 3>{}, c + 1);
+      const bool mini = m < 0 && !first_item;
+      if (!mini) {
+        body(std::integral_constant<int, 0>{}, c);
+        body(std::integral_constant<int, 1>{}, c);
+        body(std::integral_constant<int, 2>{}, c);
+        body(std::integral_constant<int, 3>{}, c + 1);
+      }
+      // a later item's fill: chunk 0 and half 0 of chunk 1 are in the pixel ring already (staged during the previous item's
+      // last two chunks); what is left is the half in flight at the boundary -- loads of half 1 of chunk 1 (phase -2), its
+      // scale / shift pairs (phase -1) -- and the producers' task halves + U slots of phases 0 and 1
       body(std::integral_constant<int, 4>{}, c + 1);
-      body(std::integral_constant<int, 5>{}, c + 1);
+      body(std::integral_constant<int, 5>{}, c + 1, mini);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the repeats past the last chunk: nothing may land after the item
   };
@@ -877,9 +893,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
   if (wave < 4) asm volatile("s_setprio 1");
 #endif
   for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
-    if (wave < 2) producer_item(I0{});
-    else if (wave < 4) producer_item(I1{});
-    else pixel_item(n_cur);
+    // Items after the first skip four of the six fill phases: the pixel waves' stream of half-tiles (loads, GroupNorm + SiLU,
+    // pixel ring) does not stop at an item's last chunk but goes on into the next item's chunks 0 and 1, and the pixel ring
+    // survives the output transform (which owns only the operand rings).  (Round 4: -4 phases of ~0.8 us per item.)
+    const bool first_item = n_cur == n_first || !g.xitem;
+    if (wave < 2) producer_item(I0{}, first_item);
+    else if (wave < 4) producer_item(I1{}, first_item);
+    else pixel_item(n_cur, first_item);
 
     // ---- end of an item: Y = A^T M A through four exchange slabs [xi][cout block][lane] (the operand rings: every stage of
     // the item has finished).  Pass q moves accumulator registers 4 q .. 4 q + 3 of all 36 positions; wave (cb, pg) then

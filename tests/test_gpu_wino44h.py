@@ -233,6 +233,56 @@ def test_conv3d_wino44h_vs_conv3d(device, case, monkeypatch):
         assert err.pow(2).mean().sqrt().item() < 1e-5 * (1 + ref.pow(2).mean().sqrt().item())
     assert torch.equal(y, ops.conv3d(d(x), d(w), d(b), wino44h=wh, **kw))
 
+XITEM_CASES = [
+    (300, 128, 0, 128, 16, True, True, True),     # two images per item, 2 x 150 items
+    (70, 64, 64, 128, 32, True, True, True),      # one image per two items, 280 items, concat
+    (520, 64, 64, 256, 8, True, True, False),     # eight images per item: 4 x 65 items
+    (66, 128, 0, 128, 32, False, True, True),     # no prologue
+    (1, 64, 0, 64, 64, True, False, False),       # 8 items
+]
+
+
+@pytest.mark.parametrize("case", XITEM_CASES)
+def test_conv_wino44h_stream_across_items_is_bit_identical(device, case, monkeypatch):
+    """Round 4: a workgroup's pixel waves keep staging across item boundaries (the next item's chunks 0 and 1 enter the pixel
+    ring during the current item's last chunks; DDPM_W44H_XITEM).  Same arithmetic in the same order: the output must not
+    change by a bit against the per-item refill, on launches where workgroups own SEVERAL items (more items than CUs)."""
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, Cout, H, gn, chan, res = case
+    t = _inputs(case)
+    wh = ops.pack_wino44h_weight(t[2].to(device))
+    monkeypatch.setenv("DDPM_CONV_WINO44", "2")
+    y1 = _run(device, case, t, wino44h=wh)
+    assert torch.equal(y1, _run(device, case, t, wino44h=wh))
+    monkeypatch.setenv("DDPM_W44H_XITEM", "0")
+    y0 = _run(device, case, t, wino44h=wh)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    x, x2, w, b, gamma, beta, chan_add, residual = t
+    ref = _ref_conv(x, x2, w, b, (gamma, beta) if gn else None, chan_add[:, 32:32 + Cout] if chan else None, residual)
+    assert (y1.cpu() - ref).abs().max().item() < 2e-4 * (1 + ref.abs().max().item())
+
+
+def test_conv3d_wino44h_stream_across_items_is_bit_identical(device, monkeypatch):
+    """The 3-D form of the same: 2 x 40 slices of 32 x 32 = 320 items (depth taps in the chunk stream, out-of-volume taps zero)."""
+    from ddpm_ood_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 40, 32, 32, generator=g).to(device)
+    w = (torch.randn(128, 64, 3, 3, 3, generator=g) / math.sqrt(27 * 64)).to(device)
+    b = torch.randn(128, generator=g).to(device)
+    r = torch.randn(2, 128, 40, 32, 32, generator=g).to(device)
+    wh = ops.pack_wino44h_3d_weight(w)
+    kw = dict(residual=r, out_act=ops.ACT_RELU)
+    y1 = ops.conv3d(x, w, b, wino44h=wh, **kw)
+    monkeypatch.setenv("DDPM_W44H_XITEM", "0")
+    y0 = ops.conv3d(x, w, b, wino44h=wh, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    ref = F.relu(F.conv3d(x, w, b, padding=1) + r)
+    assert (y1 - ref).abs().max().item() < 2e-4 * (1 + ref.abs().max().item())
+
 
 # ---- GroupNorm statistics from the epilogue (ddpm_conv_desc.stats_out, ABI 7) ------------------------------------------
 
