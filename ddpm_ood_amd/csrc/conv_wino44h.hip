@@ -36,8 +36,10 @@
 //   all 8 waves: 3 jobs x 2 MFMAs per phase (job = one position x one cout block: A, B_h, B_l by ds_read_b128).
 // Waves w and w + 4 share a SIMD: one producer and one pixel wave each.  The two roles run separate instruction streams
 // (same barrier sequence), so that neither pays for the other's registers.
-// Per item the pipeline is filled (six MFMA-free phases) and drained; the epilogue (output transform through four LDS
-// exchange slabs, as conv_wino44.hip) then owns the operand rings.
+// Per item the pipeline is filled and drained; the epilogue (output transform through four LDS exchange slabs, as
+// conv_wino44.hip) then owns the operand rings -- but not the pixel ring: a workgroup's first item fills in six MFMA-free phases,
+// every later one in two, because the pixel waves stage the next item's chunks 0 and 1 during the current item's last chunks
+// (round 4, DDPM_W44H_XITEM).
 //
 // LDS: U ring 2 x 24 KB + V ring 2 x 12 KB (= the four 18 KB exchange slabs of the epilogue) + pixel ring.
 #include <stdint.h>
