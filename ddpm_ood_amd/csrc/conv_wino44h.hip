@@ -162,6 +162,26 @@ __device__ __forceinline__ void sload2(const float *p, float &x0, float &x1) {
                : "=&s"(x0), "=&s"(x1) : "s"(p) : "memory");
 }
 
+// eight floats at byte offsets 32 q + {0, 16} (q = 0..3) from each of two wave-uniform pointers, ONE wait: the epilogue's bias /
+// temb addends.  (As four + four sload2 calls an item paid eight serialized scalar-cache round trips before its first pass.)
+__device__ __forceinline__ void sload8(const float *p, float (&x)[8]) {
+  asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x10\n\ts_load_dword %2, %8, 0x20\n\ts_load_dword %3, %8, 0x30\n\t"
+               "s_load_dword %4, %8, 0x40\n\ts_load_dword %5, %8, 0x50\n\ts_load_dword %6, %8, 0x60\n\ts_load_dword %7, %8, 0x70\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(x[0]), "=&s"(x[1]), "=&s"(x[2]), "=&s"(x[3]), "=&s"(x[4]), "=&s"(x[5]), "=&s"(x[6]), "=&s"(x[7])
+               : "s"(p) : "memory");
+}
+__device__ __forceinline__ void sload8x2(const float *p, const float *r, float (&x)[8], float (&y)[8]) {
+  asm volatile("s_load_dword %0, %16, 0x0\n\ts_load_dword %1, %16, 0x10\n\ts_load_dword %2, %16, 0x20\n\ts_load_dword %3, %16, 0x30\n\t"
+               "s_load_dword %4, %16, 0x40\n\ts_load_dword %5, %16, 0x50\n\ts_load_dword %6, %16, 0x60\n\ts_load_dword %7, %16, 0x70\n\t"
+               "s_load_dword %8, %17, 0x0\n\ts_load_dword %9, %17, 0x10\n\ts_load_dword %10, %17, 0x20\n\ts_load_dword %11, %17, 0x30\n\t"
+               "s_load_dword %12, %17, 0x40\n\ts_load_dword %13, %17, 0x50\n\ts_load_dword %14, %17, 0x60\n\ts_load_dword %15, %17, 0x70\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(x[0]), "=&s"(x[1]), "=&s"(x[2]), "=&s"(x[3]), "=&s"(x[4]), "=&s"(x[5]), "=&s"(x[6]), "=&s"(x[7]),
+                 "=&s"(y[0]), "=&s"(y[1]), "=&s"(y[2]), "=&s"(y[3]), "=&s"(y[4]), "=&s"(y[5]), "=&s"(y[6]), "=&s"(y[7])
+               : "s"(p), "s"(r) : "memory");
+}
+
 // 1-D input transform B^T w (as conv_wino44.hip)
 __device__ __forceinline__ void bt6(const float (&w)[6], float (&t)[6]) {
   const float p = __builtin_fmaf(-4.f, w[2], w[4]), q = __builtin_fmaf(-4.f, w[1], w[3]);
@@ -928,14 +948,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino44h_kernel(const ddpm_conv_de
     const int xb0 = (rsel ? 5 : 0) * 6 + cofs, xb1 = (rsel ? 2 : 1) * 6 + cofs, xb2 = (rsel ? 4 : 3) * 6 + cofs;
     float addv[4];
     if (ONEIMG) {
+      // pass q, lanes 0..31: cout co0 + 8 q, lanes 32..63: co0 + 8 q + 4 -- floats 8 q and 8 q + 4 behind co0
+      const int co0 = kt * kK + cb * 32 + pg;
+      float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ts[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float *const tp = a.chan_add ? a.chan_add + (size_t)min(n_cur, g.NIMG - 1) * a.chan_add_stride + co0 : nullptr;
+      if (a.bias && tp) sload8x2(a.bias + co0, tp, bs, ts);
+      else if (a.bias) sload8(a.bias + co0, bs);
+      else if (tp) sload8(tp, ts);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co0 = kt * kK + cb * 32 + 8 * q + pg;  // lanes 0..31; lanes 32..63 hold co0 + 4
-        float b0 = 0.f, b1 = 0.f, t0v = 0.f, t1v = 0.f;
-        if (a.bias) sload2(a.bias + co0, b0, b1);
-        if (a.chan_add) sload2(a.chan_add + (size_t)min(n_cur, g.NIMG - 1) * a.chan_add_stride + co0, t0v, t1v);
-        addv[q] = elhi ? b1 + t1v : b0 + t0v;
-      }
+      for (int q = 0; q < 4; ++q) addv[q] = elhi ? bs[2 * q + 1] + ts[2 * q + 1] : bs[2 * q] + ts[2 * q];
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
