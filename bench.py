@@ -198,6 +198,13 @@ MFMA_KERNELS = [
     # split-f16 direct convolution: four exact f16 partial products per fp32 product (two K = 16 MFMAs per 8 channels and tap)
     ("conv3x3_s2h", "conv_s2h_kernel: Downsample 3x3 stride-2 conv, direct form on v_mfma_f32_32x32x16_f16 with split-f16 operands "
                     "(hi + lo, four exact partial products per fp32 product, fp32 accumulate)", ("f16", 4.0)),
+    # split-f16 direct convolution of small launches: three f16 partial products per fp32 product x 10 / 9 taps (one zero tap pads
+    # the fifth two-tap K-step); launch time includes the reduce pass over the channel slices
+    ("conv3x3_d3s", "conv_d3s_kernel: one-shot direct 3x3 conv of launches far smaller than the chip (8x8 / 16x16 levels of a few "
+                    "images) on v_mfma_f32_32x32x16_f16 with split-f16 operands (three partial products per fp32 product, fp32 "
+                    "accumulate), channel slices of 32 reduced in a fixed order", ("f16", 3.0 * 10.0 / 9.0)),
+    ("conv3x3_d3h", "conv_d3h_kernel: direct 3x3 conv on v_mfma_f32_32x32x16_f16, split-f16 operands (opt-in, DDPM_CONV_D3H)",
+     ("f16", 3.0 * 10.0 / 9.0)),
     ("conv3x3_mfma", "conv_mfma_kernel<9>: direct 3x3 conv (stride 2, ragged extents, 3-D depth-tap launches), fp32 MFMA", 1.0),
     # split-f16: three v_mfma_f32_32x32x16_f16 per fp32 product, 16x the f32 MFMA rate -> the layer is HBM-bound
     ("conv1x1_dma", "conv1x1_dma_kernel: LDS-DMA-fed 1x1 conv (skip connections; with GroupNorm prologue: q / k / v), "

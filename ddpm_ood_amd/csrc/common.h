@@ -50,6 +50,7 @@ struct Switches {
   bool attn_f16x3 = true;       // DDPM_ATTN_F16X3
   int conv_d3h = 0;             // DDPM_CONV_D3H: 1 the direct split-f16 3x3 kernel (conv_d3h.hip; experimental, 20 % slower than the F(4x4)
                                 // form) where a launch fills the chip, 2 also for smaller launches (tests)
+  int conv_d3s = 1;             // DDPM_CONV_D3S: 0 never the one-shot small-launch 3x3 kernel (conv_d3s.hip), 2 for any launch size (tests)
   int attn_fa = 1;              // DDPM_ATTN_FA (0: the LDS-exchange kernels of attention.hip also when scratch is given; 2: the
                                 // register-resident kernel for every multiple of 64 tokens, not only from 1 024)
   bool conv_splitk = true;      // DDPM_CONV_SPLITK
@@ -194,6 +195,11 @@ size_t wino44_weight_floats(int Cout, int Cin);
 bool conv_wino44h_supported(const ddpm_conv_desc &d);
 int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_wino44h_scratch_floats(const ddpm_conv_desc &d);
+bool conv_d3s_supported(const ddpm_conv_desc &d);
+int launch_conv_d3s(const ddpm_conv_desc &d, hipStream_t s);
+size_t conv_d3s_scratch_floats(const ddpm_conv_desc &d);
+int conv_d3s_stats_parts(const ddpm_conv_desc &d);
+int device_cus();
 bool conv_d3h_supported(const ddpm_conv_desc &d);
 int launch_conv_d3h(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_d3h_weight_halves(int Cout, int Cin);

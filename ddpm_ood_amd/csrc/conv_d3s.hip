@@ -1,0 +1,306 @@
+// conv_d3s.hip -- the ResnetBlock 3x3 convolution (stride 1, padding 1) of SMALL launches: the 8x8 / 16x16 levels of a UNet forward
+// at a batch of a few images (BASELINE configs[0]: first_n = 16; generative's ResnetBlock.conv1 / conv2 inside
+// DiffusionModelUNet.forward, reference call site /root/reference/src/trainers/reconstruct.py:151-153).  Round 4.
+//
+// Why another kernel.  At B = 16 a 256 -> 256 convolution over 8x8 images is 1.2 GFLOP -- 0.5 us of the chip -- yet every kernel
+// built for throughput takes 25-40 us on it (rocprofv3, profiles/r04_b16_kernel_trace.csv): their chunk streams are software
+// pipelines three to six stages deep (pixel loads, activation, transform, operand rings), so a stream of four chunks is all fill
+// and drain, a chain of eight to ten dependent global-memory round trips.  This kernel has NO pipeline: a workgroup owns
+// 64 couts x 128 pixels x 32 input channels, requests everything it needs at once (80 KB of weights by LDS-DMA, 16 KB of pixels
+// into registers), stages the pixels, multiplies, stores: one memory round trip, one barrier before and one behind the staging.
+// The channel slices (Cin / 32 of them) go to scratch slabs and conv_wino.hip's fixed-order reduce pass adds them up together with
+// bias / temb / residual and emits the GroupNorm statistics: bit-reproducible, no atomics.
+//
+// Arithmetic: conv_d3h.hip's -- direct convolution on v_mfma_f32_32x32x16_f16, operands split into f16 hi / lo planes,
+//     x' w' ~= wh xh + wh xl + wl xh,   x' = 2^3 act(x) (2^0 without prologue),  w' = 2^su w  (ddpm_pack_conv_d3h_weight)
+// (three of the four partial products: 22 mantissa bits per product, fp32 accumulate); one K-step = 8 channels x two taps.
+//
+// Layout.  Weights in LDS [chunk 4][tap 10][plane 2][cout 64] units of 8 channels (the packed planes' 64-cout halves are 1 KB
+// contiguous: 80 LDS-DMA pieces).  Pixels as [chunk][plane][haloed window] units: W = 8: two whole images per workgroup (4 waves,
+// 128 pixels), rows of 10 units; W = 16: one whole image (8 waves, 256 pixels: half the weight traffic of 128-pixel tiles, which
+// made 1 024 workgroups of 80 KB each), rows of 18 units; the halo is zeros written before the staging.
+// Wave w owns pixel block w (32 pixels: 4 rows of an 8x8 image / 2 rows of a 16x16 one) x both 32-cout blocks.
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace ddpm {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+constexpr int kSM = 64;                   // couts per workgroup
+constexpr int kSCh = 8;                   // input channels per chunk
+constexpr int kSNC = 4;                   // chunks per workgroup (one channel slice = 32 channels)
+constexpr int kSTaps = 10;                // nine taps + a zero tap (conv_d3h.hip's packed planes)
+constexpr int kSWU = kSNC * kSTaps * 2 * kSM;  // weight units in LDS (5 120 = 80 KB)
+constexpr int kPackM = 128;               // couts per tile of the packed planes
+constexpr float kXScale = 8.f;
+
+struct D3SGeom {
+  int W, HW;
+  int TI;        // images per tile: 2 (8x8) or 1 (16x16)
+  int RS, IS;    // units per haloed row, per image window (W + 2 rows)
+  int XU;        // units per (chunk, plane): TI * IS
+  int PT, CT, S; // pixel tiles, cout tiles (64), channel slices
+  int nch;
+  long long pstride;
+};
+
+bool d3s_geom(const ddpm_conv_desc &d, D3SGeom &g) {
+  const int Cin = d.C1 + d.C2;
+  if (d.ksize != 3 || d.mode != DDPM_CONV_NORMAL || d.dims == 3 || d.Di > 1 || d.Do > 1 || d.force_direct) return false;
+  if (d.Hi != d.Ho || d.Wi != d.Wo || d.Ho != d.Wo) return false;
+  if (d.out_act != DDPM_ACT_NONE || d.act == DDPM_ACT_RELU) return false;
+  if (d.gscale && (d.act != DDPM_ACT_SILU || !d.gshift)) return false;
+  if (!d.gscale && d.act != DDPM_ACT_NONE) return false;
+  if (Cin % (kSCh * kSNC) || (d.C2 > 0 && d.C1 % kSCh) || d.Cout % kPackM) return false;
+  if (d.Wo != 8 && d.Wo != 16) return false;
+  g.W = d.Wo;
+  g.HW = d.Ho * d.Wo;
+  g.TI = g.W == 8 ? 2 : 1;
+  g.RS = g.W + 2;
+  g.IS = (g.W + 2) * g.RS;
+  g.XU = g.TI * g.IS;
+  g.PT = (d.B + g.TI - 1) / g.TI;
+  g.CT = d.Cout / kSM;
+  g.nch = Cin / kSCh;
+  g.S = g.nch / kSNC;
+  g.pstride = (long long)d.B * d.Cout * g.HW;
+  if ((reinterpret_cast<uintptr_t>(d.in1) | reinterpret_cast<uintptr_t>(d.in2) | reinterpret_cast<uintptr_t>(d.gscale) |
+       reinterpret_cast<uintptr_t>(d.gshift)) & 15)
+    return false;  // 16-byte loads
+  return true;
+}
+
+size_t d3s_lds_bytes(const D3SGeom &g) { return ((size_t)kSWU + (size_t)kSNC * 2 * g.XU + 1) * 16; }
+
+// (conv_d3h.hip) lanes 2 k / 2 k + 1 hold channels 0-3 / 4-7 of the same four pixels: they swap halves by DPP, the even lane
+// assembles the whole units of pixels 0, 1, the odd lane those of pixels 2, 3
+__device__ __forceinline__ v4i_t d3s_pair_unit(h4_t p, h4_t p2, bool odd) {
+  const v2i_t a = __builtin_bit_cast(v2i_t, p), b = __builtin_bit_cast(v2i_t, p2);
+  v2i_t own, got;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int send = odd ? a[d] : b[d];
+    own[d] = odd ? b[d] : a[d];
+    got[d] = __builtin_amdgcn_mov_dpp(send, 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, true);
+  }
+  return odd ? v4i_t{got[0], got[1], own[0], own[1]} : v4i_t{own[0], own[1], got[0], got[1]};
+}
+
+// NW waves = 32 NW pixels: 4 (W = 8) or 8 (W = 16)
+template <bool AFFINE, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void conv_d3s_kernel(const ddpm_conv_desc a, const D3SGeom g, const uint16_t *__restrict__ wq) {
+  extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  constexpr int W = NW == 4 ? 8 : 16, HW = W * W, TI = NW == 4 ? 2 : 1, NT = 64 * NW;
+  // staging items per chunk: TI images x (W + 2) window rows x (W / 4) pixel groups x 2 channel halves: 80 / 144 -- two rounds
+  constexpr int kItemsPerChunk = TI * (W + 2) * (W / 4) * 2, kItems = kSNC * kItemsPerChunk;
+  static_assert(kItems <= 2 * NT, "two staging rounds");
+  const int Cin = a.C1 + a.C2;
+  f16x8 *const Xb = lds + kSWU;
+
+  // workgroup -> (channel slice, cout tile, pixel tile): the slices of one output tile are neighbours
+  const int split = blockIdx.x % g.S, ct = (blockIdx.x / g.S) % g.CT, pt = blockIdx.x / (g.S * g.CT);
+  const int n0 = pt * TI;
+  const int ch0 = split * kSNC * kSCh;  // first input channel of the slice
+
+  // ---- 1. the slice's weights: chunk q, tap t, plane p -> 64 units (1 KB) of the packed planes
+  {
+    const f16x8 *const wsrc = reinterpret_cast<const f16x8 *>(wq) +
+                              ((size_t)(ct >> 1) * g.nch + (size_t)split * kSNC) * (kSTaps * 2 * kPackM) + (ct & 1) * kSM;
+#pragma unroll
+    for (int p = 0; p < kSNC * kSTaps * 2 / NW; ++p) {
+      const int piece = p * NW + wave;  // (chunk, tap, plane) = piece / 20, (piece / 2) % 10, piece & 1
+      __builtin_amdgcn_global_load_lds(wsrc + (size_t)piece * kPackM + lane, lds + piece * kSM, 16, 0, 0);
+    }
+  }
+
+  // ---- 2. this thread's staging items (two rounds): item = chunk x (four consecutive pixels of a window row) x (channels 4 h .. 4 h + 3)
+  v4f_t raw[2][4], gsa[2], gsb[2];
+  int sbyte[2];  // byte offset of the first unit this lane stores inside the X region; -1: nothing to stage
+  const bool odd = lane & 1;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int e = tid + NT * r;
+    const int q = e / kItemsPerChunk, rem = e - q * kItemsPerChunk;
+    constexpr int W4 = W >> 2;
+    const int hsel = rem & 1, pg = rem >> 1;
+    const int ti = pg / ((W + 2) * W4), rem2 = pg - ti * ((W + 2) * W4);
+    const int srow = rem2 / W4, scol = (rem2 - srow * W4) * 4;  // window row 0 .. W + 1 <-> image row srow - 1
+    const int yin = srow - 1, n = n0 + ti;
+    const bool own = e < kItems && yin >= 0 && yin < W && n < a.B;
+    sbyte[r] = own ? (((q * 2) * g.XU + ti * g.IS + srow * g.RS + scol + 1) + 2 * hsel) * 16 : -1;
+    const int cg = ch0 + q * kSCh + 4 * hsel;  // first of the item's four channels
+    const bool first = cg < a.C1;               // (C1 % 8 == 0: a chunk never straddles the concat seam)
+    if (own) {
+      const float *src = first ? a.in1 + ((size_t)n * a.C1 + cg) * HW : a.in2 + ((size_t)n * a.C2 + (cg - a.C1)) * HW;
+      src += yin * W + scol;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) raw[r][c] = *reinterpret_cast<const v4f_t *>(src + (size_t)c * HW);
+      if (AFFINE) {
+        gsa[r] = *reinterpret_cast<const v4f_t *>(a.gscale + (size_t)n * Cin + cg);
+        gsb[r] = *reinterpret_cast<const v4f_t *>(a.gshift + (size_t)n * Cin + cg);
+      }
+    }
+  }
+
+  // ---- 3. zeros under the window (halo columns, rows outside the image, images past the batch)
+  {
+    v4i_t z = {0, 0, 0, 0};
+    for (int e = tid; e < kSNC * 2 * g.XU + 1; e += NT) *reinterpret_cast<v4i_t *>(Xb + e) = z;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the loads stay in flight)
+
+  // ---- 4. activation, split, store
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (sbyte[r] < 0) continue;  // (lane pairs share their pixels: both lanes of a pair take the same way)
+    h4_t hi[4], lo[4];
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float y = raw[r][c][px];
+        if (AFFINE) {
+          const float v = __builtin_fmaf(y, gsa[r][c], gsb[r][c]);
+          const float t = __builtin_fmaf(y, -1.44269504088896341f * gsa[r][c], -1.44269504088896341f * gsb[r][c]);
+          y = (kXScale * v) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+        }
+        const _Float16 h = (_Float16)y;
+        hi[px][c] = h;
+        lo[px][c] = (_Float16)(y - (float)h);
+      }
+    }
+    char *Xw = reinterpret_cast<char *>(Xb) + sbyte[r];
+    const int slo = g.XU * 16;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      *reinterpret_cast<v4i_t *>(Xw + p * 16) = d3s_pair_unit(hi[p], hi[p + 2], odd);
+      *reinterpret_cast<v4i_t *>(Xw + p * 16 + slo) = d3s_pair_unit(lo[p], lo[p + 2], odd);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // weights landed, window complete
+
+  // ---- 5. 4 chunks x 5 K-steps x (2 cout blocks x 3 products)
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  int xb;  // this lane's pixel in window units (tap (0, 0))
+  {
+    const int pp = wave * 32 + l31;
+    if (TI == 2) {
+      const int ti = pp >> 6, rem = pp & 63;
+      xb = ti * g.IS + (rem >> 3) * g.RS + (rem & 7);
+    } else {
+      xb = (pp >> 4) * g.RS + (pp & 15);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kSNC; ++q) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int tap = min(2 * j + lhi, 8);  // (the tenth tap's weights are zeros: it re-reads tap 8's pixels)
+      const int dy = tap / 3, dx = tap - 3 * dy;
+      const f16x8 *A = lds + ((q * kSTaps + 2 * j + lhi) * 2) * kSM + l31;
+      const f16x8 *X = Xb + (q * 2) * g.XU + xb + dy * g.RS + dx;
+      const f16x8 bh = X[0], bl = X[g.XU];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f16x8 ah = A[32 * i], al = A[kSM + 32 * i];
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- 6. the slice's partial sums -> its scratch slab (NCHW; D[row = cout][col = pixel]: a 32-pixel block is 128 contiguous bytes)
+  const float oscale = reinterpret_cast<const float *>(wq + (size_t)a.Cout * Cin * kSTaps * 2)[1] * (AFFINE ? 1.f : kXScale);
+  const int pp = wave * 32 + l31;
+  const int n = TI == 2 ? n0 + (pp >> 6) : n0;
+  const int pix = TI == 2 ? (pp & 63) : pp;
+  if (n < a.B) {
+    float *const dst = a.scratch + (size_t)split * g.pstride + ((size_t)n * a.Cout + ct * kSM + 4 * lhi) * HW + pix;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * HW] = acc[i][r] * oscale;
+  }
+}
+
+}  // namespace
+
+static bool d3s_take(const ddpm_conv_desc &d, D3SGeom &g, bool sizing) {
+  if (!sw().conv_d3s || !split_f16_on(true) || !d.w_d3h || !d3s_geom(d, g)) return false;
+  if (g.S < 2) return false;
+  // small launches only: where the throughput kernels' pipelines are all fill and drain.  Upper bound: four workgroups per CU
+  // (beyond that the F(4x4) kernel's 2.25-4x fewer multiplies win); `2`: any size (tests)
+  const long wgs = (long)g.PT * g.CT * g.S;
+  if (sw().conv_d3s != 2 && (wgs > 4L * device_cus() || (long)g.PT * g.CT > device_cus() / 2 || (long)d.B * g.HW > 4096)) return false;
+  if (!sizing && (!d.scratch || d.scratch_floats < (size_t)g.S * (size_t)g.pstride)) return false;
+  return true;
+}
+
+bool conv_d3s_supported(const ddpm_conv_desc &d) {
+  D3SGeom g;
+  return d3s_take(d, g, false);
+}
+
+size_t conv_d3s_scratch_floats(const ddpm_conv_desc &d) {
+  D3SGeom g;
+  return d3s_take(d, g, true) ? (size_t)g.S * (size_t)g.pstride : 0;
+}
+
+int conv_d3s_stats_parts(const ddpm_conv_desc &d) { return wino_split_reduce_stats_parts(d.Ho * d.Wo); }
+
+int launch_conv_d3s(const ddpm_conv_desc &d, hipStream_t s) {
+  D3SGeom g;
+  if (!d3s_take(d, g, false)) {
+    set_error("conv_d3s: unsupported shape");
+    return DDPM_EINVAL;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    for (const void *f : {reinterpret_cast<const void *>(&conv_d3s_kernel<false, 4>), reinterpret_cast<const void *>(&conv_d3s_kernel<true, 4>),
+                          reinterpret_cast<const void *>(&conv_d3s_kernel<false, 8>), reinterpret_cast<const void *>(&conv_d3s_kernel<true, 8>)})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int Cin = d.C1 + d.C2;
+  const double M = (double)d.B * g.HW;
+  char kshape[160];
+  const char *kname = d.gscale ? "conv3x3_d3s_gn_silu" : "conv3x3_d3s";
+  if (g_prof_on && sw().prof_shapes) {
+    snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);
+    kname = kshape;
+  }
+  ProfScope prof(s, kname, 2.0 * M * d.Cout * Cin * 9,
+                 4.0 * (M * Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * Cin * 9));
+  const dim3 grid((unsigned)(g.PT * g.CT * g.S));
+  const size_t lds = d3s_lds_bytes(g);
+  if (g.W == 8) {
+    if (d.gscale) hipLaunchKernelGGL((conv_d3s_kernel<true, 4>), grid, dim3(256), lds, s, d, g, d.w_d3h);
+    else hipLaunchKernelGGL((conv_d3s_kernel<false, 4>), grid, dim3(256), lds, s, d, g, d.w_d3h);
+  } else {
+    if (d.gscale) hipLaunchKernelGGL((conv_d3s_kernel<true, 8>), grid, dim3(512), lds, s, d, g, d.w_d3h);
+    else hipLaunchKernelGGL((conv_d3s_kernel<false, 8>), grid, dim3(512), lds, s, d, g, d.w_d3h);
+  }
+  DDPM_CHECK_LAUNCH();
+  ddpm_conv_desc dr = d;
+  if (conv_d3s_stats_parts(d) == 0) dr.stats_out = nullptr;
+  return launch_wino_split_reduce(dr, g.S, g.pstride, g.HW, s);
+}
+
+}  // namespace ddpm

@@ -100,7 +100,7 @@ struct WinoGeom {
   long long pstride;  // floats between two partial-output slabs (0 when S == 1)
 };
 
-static int device_cus() {
+int device_cus() {
   static int cus = 0;
   if (!cus) {
     int dev = 0;

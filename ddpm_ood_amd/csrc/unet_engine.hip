@@ -250,8 +250,9 @@ static ResRef build_res(ddpm_unet *u, const std::string &prefix, int Cin, int Co
         ps.has_wino44h = true;
         ps.wino44h_base = cr[i]->w_wino44h;
       }
-      // direct split-f16 form (conv_d3h.hip): opt-in (slower than the F(4x4) form) -- no planes unless switched on
-      if (const size_t nd = sw().conv_d3h ? conv_d3h_weight_halves(cr[i]->Cout, cr[i]->Cin) : 0) {
+      // direct split-f16 planes: read by the small-launch kernel (conv_d3s.hip: 8x8 / 16x16 layers of a few images) and by the
+      // opt-in conv_d3h.hip
+      if (const size_t nd = (sw().conv_d3h || sw().conv_d3s) ? conv_d3h_weight_halves(cr[i]->Cout, cr[i]->Cin) : 0) {
         cr[i]->has_d3h = true;
         cr[i]->w_d3h = u->alloc((nd + 1) / 2);
         ps.has_d3h = true;

@@ -1355,6 +1355,60 @@ def test_conv_stride2_split_f16_operand_range(device):
         assert err <= (4e-6 if sx < 1e-2 else 2e-6), (sx, sw, err)  # (inputs below 2^-9: their lo halves go subnormal)
 
 
+D3S_CASES = [
+    # B, C1, C2, Cout, H, gn, chan_add, residual
+    (16, 256, 0, 256, 8, True, True, False),      # the benchmark's 8x8 layers at first_n = 16: 8 x 4 x 8 workgroups
+    (5, 256, 256, 256, 8, True, False, True),     # virtual concat, ragged last tile (one image), 16 slices
+    (3, 128, 0, 128, 16, True, True, True),       # 16x16: two tiles per image
+    (4, 256, 128, 256, 16, True, False, False),   # concat seam inside a slice's chunks
+    (2, 64, 0, 128, 8, False, False, True),       # no prologue (raw input, 2^0)
+    (1, 32, 32, 128, 16, False, True, False),
+]
+
+
+@pytest.mark.parametrize("case", D3S_CASES)
+def test_conv_small_launch_split_f16_vs_conv2d(device, case, monkeypatch):
+    """conv_d3s.hip: the one-shot 3x3 convolution of launches far smaller than the chip (cfg1: 8x8 / 16x16 levels at 16 images):
+    channel slices of 32 into scratch slabs + the fixed-order reduce pass, against F.conv2d in float64; bit-reproducible."""
+    monkeypatch.setenv("DDPM_CONV_D3S", "2")
+    from ddpm_ood_amd import ops
+
+    B, C1, C2, Cout, H, gn, chan, res = case
+    g = torch.Generator().manual_seed(B * 13 + C1 + H)
+    Cin = C1 + C2
+    x = torch.randn(B, C1, H, H, generator=g) * 1.3 + 0.2
+    x2 = torch.randn(B, C2, H, H, generator=g) if C2 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    gamma, beta = (torch.randn(Cin, generator=g), torch.randn(Cin, generator=g)) if gn else (None, None)
+    chan_add = torch.randn(B, Cout, generator=g) if chan else None
+    residual = torch.randn(B, Cout, H, H, generator=g) if res else None
+    xin = (x if x2 is None else torch.cat([x, x2], 1)).double()
+    if gn:
+        xin = F.silu(F.group_norm(xin, 32, gamma.double(), beta.double(), 1e-6))
+    ref = F.conv2d(xin, w.double(), b.double(), padding=1)
+    if chan:
+        ref = ref + chan_add.double()[:, :, None, None]
+    if res:
+        ref = ref + residual.double()
+    d = lambda t: None if t is None else t.to(device)
+    gs = gh = None
+    if gn:
+        gs, gh = ops.gn_scale_shift(d(x), d(gamma), d(beta), 32, 1e-6, x2=d(x2))
+    kw = dict(x2=d(x2), gscale=gs, gshift=gh, act=ops.ACT_SILU if gn else ops.ACT_NONE, chan_add=d(chan_add), residual=d(residual))
+    planes = ops.pack_conv_d3h_weight(d(w))
+    y = ops.conv(d(x), d(w), d(b), d3h=planes, **kw)
+    y0 = ops.conv(d(x), d(w), d(b), **kw)  # without the planes: the fp32 MFMA kernels
+    torch.cuda.synchronize()
+    assert not torch.equal(y, y0)  # (the small-launch kernel ran)
+    assert torch.equal(y, ops.conv(d(x), d(w), d(b), d3h=planes, **kw))
+    scale = ref.abs().max().item()
+    err = (y.cpu().double() - ref).abs().max().item() / scale
+    err0 = (y0.cpu().double() - ref).abs().max().item() / scale
+    print(f"{case}: small-launch split-f16 {err:.2e}, fp32 MFMA kernel {err0:.2e} (max relative to max |y|)")
+    assert math.isfinite(err) and err < 3e-6, (err, err0)
+
+
 D3H_CASES = [
     # B, C1, C2, Cout, H, gn, chan_add, residual
     (2, 128, 0, 128, 32, True, True, False),      # 32x32: eight tile rows per 256-pixel tile, four tiles per image
