@@ -62,6 +62,8 @@ SIGNATURES = {
     "ddpm_pack_conv_s2h_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_conv_d3h_weight_halves": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_conv_d3h_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_conv_d1s_weight_halves": (C.c_size_t, [C.c_int, C.c_int]),
+    "ddpm_pack_conv_d1s_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_conv1x1_h_weight_halves": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_conv1x1_h_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_packed_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

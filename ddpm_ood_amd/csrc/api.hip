@@ -181,6 +181,13 @@ extern "C" int ddpm_pack_conv_s2h_weight(const float *w_raw, uint16_t *dst, int 
 
 extern "C" size_t ddpm_conv_d3h_weight_halves(int Cout, int Cin) { return conv_d3h_weight_halves(Cout, Cin); }
 
+extern "C" size_t ddpm_conv_d1s_weight_halves(int Cout, int Cin) { return conv_d1s_weight_halves(Cout, Cin); }
+
+extern "C" int ddpm_pack_conv_d1s_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, int cout_offset, int Cout_total,
+                                         ddpm_stream_t stream) {
+  return launch_pack_conv_d1s_weight(w_raw, dst, Cout, Cin, cout_offset, Cout_total, as_stream(stream));
+}
+
 extern "C" int ddpm_pack_conv_d3h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, ddpm_stream_t stream) {
   return launch_pack_conv_d3h_weight(w_raw, dst, Cout, Cin, as_stream(stream));
 }

@@ -195,6 +195,11 @@ size_t wino44_weight_floats(int Cout, int Cin);
 bool conv_wino44h_supported(const ddpm_conv_desc &d);
 int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_wino44h_scratch_floats(const ddpm_conv_desc &d);
+bool conv_d1s_supported(const ddpm_conv_desc &d);
+int launch_conv_d1s(const ddpm_conv_desc &d, hipStream_t s);
+size_t conv_d1s_scratch_floats(const ddpm_conv_desc &d);
+size_t conv_d1s_weight_halves(int Cout, int Cin);
+int launch_pack_conv_d1s_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, int cout_offset, int Cout_total, hipStream_t s);
 bool conv_d3s_supported(const ddpm_conv_desc &d);
 int launch_conv_d3s(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_d3s_scratch_floats(const ddpm_conv_desc &d);

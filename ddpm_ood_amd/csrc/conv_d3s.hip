@@ -240,6 +240,160 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_d3s_kernel(const ddpm_conv_de
   }
 }
 
+
+// ============================================================================================================================
+// The 1x1 convolutions of small launches (skip connections, the GroupNorm-ed fused q / k / v projection; generative's
+// ResnetBlock.skip_connection / AttentionBlock.to_q, to_k, to_v, reference call site /root/reference/src/trainers/reconstruct.py:
+// 151-153): the same one-shot scheme.  Workgroup = 64 couts x 128 consecutive pixels of the flattened (image, pixel) space x a
+// slice of 128 input channels: 32 KB of weight planes by LDS-DMA, 64 KB of pixels through registers (GroupNorm affine, 2^3 /
+// 2^0 pre-scale, hi / lo split) into [chunk][plane][pixel] units, 8 K-steps of 16 channels x 3 products x 2 cout blocks per wave.
+// Weights: ddpm_pack_conv_d1s_weight -- [cout tile 64][chunk 8 ch][plane 2][cout 64] units of 2^su w, su PER 64-COUT TILE RANGE
+// of one parameter tensor (the members of a fused q / k / v weight are packed one by one); behind the planes the tiles' epilogue
+// scales 1 / (2^3 2^su) and the maxima they came from.
+constexpr int kD1KC = 16;                       // chunks per channel slice (128 channels)
+constexpr int kD1WU = kD1KC * 2 * kSM;          // weight units in LDS (2 048 = 32 KB)
+constexpr int kD1XU = kD1KC * 2 * 128;          // pixel units in LDS (4 096 = 64 KB)
+
+template <bool AFFINE>
+__global__ __launch_bounds__(256, 1) void conv_d1s_kernel(const ddpm_conv_desc a, const int S, const long long pstride,
+                                                          const uint16_t *__restrict__ wq) {
+  extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int HW = a.Ho * a.Wo, Cin = a.C1 + a.C2, nch = Cin / kSCh, CT = a.Cout / kSM;
+  const long long npix = (long long)a.B * HW;
+  f16x8 *const Xb = lds + kD1WU;
+  const int split = blockIdx.x % S, ct = (blockIdx.x / S) % CT, pt = blockIdx.x / (S * CT);
+  const int ch0 = split * kD1KC * kSCh;
+  const long long p0 = (long long)pt * 128;
+
+  // ---- 1. the slice's weights: 16 chunks x 2 planes x 64 units = 32 pieces of 1 KB, contiguous in the packed planes
+  {
+    const f16x8 *const wsrc = reinterpret_cast<const f16x8 *>(wq) + ((size_t)ct * nch + (size_t)split * kD1KC) * (2 * kSM);
+#pragma unroll
+    for (int p = 0; p < kD1KC * 2 / 4; ++p) {
+      const int piece = p * 4 + wave;
+      __builtin_amdgcn_global_load_lds(wsrc + (size_t)piece * kSM + lane, lds + piece * kSM, 16, 0, 0);
+    }
+  }
+  // ---- 2. staging items: (chunk, four consecutive pixels, channels 4 h .. 4 h + 3): 16 x 32 x 2 = 1 024 = four per thread
+  const bool odd = lane & 1;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {  // (two rounds of two items: 2 x 2 x 6 loads in flight)
+    v4f_t raw[2][4], gsa[2], gsb[2];
+    int sunit[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int e = tid + 256 * (2 * half + r);
+      const int hsel = e & 1, g4 = (e >> 1) & 31, q = e >> 6;
+      const long long p = p0 + 4 * g4;
+      const bool own = p < npix;
+      const int n = own ? (int)(p / HW) : 0, off = own ? (int)(p - (long long)n * HW) : 0;
+      sunit[r] = own ? (q * 2) * 128 + 4 * g4 + 2 * hsel : -1;
+      const int cg = ch0 + q * kSCh + 4 * hsel;
+      const bool first = cg < a.C1;
+      if (own) {
+        const float *src = (first ? a.in1 + ((size_t)n * a.C1 + cg) * HW : a.in2 + ((size_t)n * a.C2 + (cg - a.C1)) * HW) + off;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) raw[r][c] = *reinterpret_cast<const v4f_t *>(src + (size_t)c * HW);
+        if (AFFINE) {
+          gsa[r] = *reinterpret_cast<const v4f_t *>(a.gscale + (size_t)n * Cin + cg);
+          gsb[r] = *reinterpret_cast<const v4f_t *>(a.gshift + (size_t)n * Cin + cg);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      h4_t hi[4], lo[4];
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float y = sunit[r] >= 0 ? raw[r][c][px] : 0.f;  // (pixels past the batch: zeros)
+          if (AFFINE) y = sunit[r] >= 0 ? kXScale * __builtin_fmaf(y, gsa[r][c], gsb[r][c]) : 0.f;
+          const _Float16 h = (_Float16)y;
+          hi[px][c] = h;
+          lo[px][c] = (_Float16)(y - (float)h);
+        }
+      }
+      // (every unit of the tile is written, also for pixels past the batch: no zero fill)
+      const int e = tid + 256 * (2 * half + r);
+      const int u = ((e >> 6) * 2) * 128 + 4 * ((e >> 1) & 31) + 2 * (e & 1);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        *reinterpret_cast<v4i_t *>(Xb + u + p) = d3s_pair_unit(hi[p], hi[p + 2], odd);
+        *reinterpret_cast<v4i_t *>(Xb + u + p + 128) = d3s_pair_unit(lo[p], lo[p + 2], odd);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // ---- 3. 8 K-steps (lanes 0-31: chunk 2 j, lanes 32-63: chunk 2 j + 1) x 2 cout blocks x 3 products
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < kD1KC / 2; ++j) {
+    const f16x8 *A = lds + ((2 * j + lhi) * 2) * kSM + l31;
+    const f16x8 *X = Xb + ((2 * j + lhi) * 2) * 128 + wave * 32 + l31;
+    const f16x8 bh = X[0], bl = X[128];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f16x8 ah = A[32 * i], al = A[kSM + 32 * i];
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
+    }
+  }
+
+  // ---- 4. partial sums -> the slice's slab
+  const float oscale = reinterpret_cast<const float *>(wq + (size_t)a.Cout * Cin * 2)[ct] * (AFFINE ? 1.f : kXScale);
+  const long long p = p0 + wave * 32 + l31;
+  if (p < npix) {
+    const int n = (int)(p / HW), off = (int)(p - (long long)n * HW);
+    float *const dst = a.scratch + (size_t)split * pstride + ((size_t)n * a.Cout + ct * kSM + 4 * lhi) * HW + off;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * HW] = acc[i][r] * oscale;
+  }
+}
+
+__global__ void d1s_max_kernel(const float *__restrict__ src, unsigned *__restrict__ maxes, int Cin, int64_t total) {
+  // one maximum per 64-cout tile of the member: rows are Cin floats
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    atomicMax(maxes + (i / Cin) / kSM, __builtin_bit_cast(unsigned, fabsf(src[i])));  // (non-negative floats order like their bits)
+}
+
+// member rows [cout_offset, cout_offset + Cout) of a [Cout_total][Cin] weight
+__global__ void d1s_pack_kernel(const float *__restrict__ src, _Float16 *__restrict__ dst, int Cout, int Cin, int cout_offset, int Cout_total) {
+  float *const scales = reinterpret_cast<float *>(dst + (size_t)Cout_total * Cin * 2);
+  const float *const maxes = scales + Cout_total / kSM;
+  const int nch = Cin / kSCh;
+  const int64_t total = (int64_t)Cout * Cin;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin), co = cout_offset + (int)(i / Cin);
+    const int tile = co / kSM, c64 = co % kSM;
+    // every tile of the member carries the member's scale: su from the largest of its tiles' maxima
+    float umax = 0.f;
+    for (int t = cout_offset / kSM; t < (cout_offset + Cout) / kSM; ++t) umax = fmaxf(umax, maxes[t]);
+    int e = 0;
+    (void)frexpf(umax, &e);
+    const int su = umax > 0.f ? 15 - e : 0;
+    if (ci == 0 && c64 == 0) scales[tile] = ldexpf(1.f / kXScale, -su);
+    const float w = ldexpf(src[i], su);
+    const _Float16 h = (_Float16)w;
+    const _Float16 l = (_Float16)(w - (float)h);
+    const int chunk = ci / kSCh, cc = ci % kSCh;
+    const size_t unit = ((size_t)tile * nch + chunk) * 2 * kSM + c64;
+    dst[unit * 8 + cc] = h;
+    dst[(unit + kSM) * 8 + cc] = l;
+  }
+}
+
 }  // namespace
 
 static bool d3s_take(const ddpm_conv_desc &d, D3SGeom &g, bool sizing) {
@@ -301,6 +455,96 @@ int launch_conv_d3s(const ddpm_conv_desc &d, hipStream_t s) {
   ddpm_conv_desc dr = d;
   if (conv_d3s_stats_parts(d) == 0) dr.stats_out = nullptr;
   return launch_wino_split_reduce(dr, g.S, g.pstride, g.HW, s);
+}
+
+// ---- 1x1
+size_t conv_d1s_weight_halves(int Cout, int Cin) {
+  return (Cout % kSM == 0 && Cin % (kD1KC * kSCh) == 0) ? (size_t)Cout * Cin * 2 + 4 * (size_t)(Cout / kSM) + 64 : 0;
+}
+
+int launch_pack_conv_d1s_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, int cout_offset, int Cout_total, hipStream_t s) {
+  DDPM_CHECK_ARG(w_raw && dst && conv_d1s_weight_halves(Cout_total, Cin) != 0 && Cout % kSM == 0 && cout_offset % kSM == 0 &&
+                     cout_offset + Cout <= Cout_total,
+                 "conv_d1s pack: Cout %% 64, Cin %% 128 or the member's rows are not whole 64-cout tiles");
+  float *scales = reinterpret_cast<float *>(dst + (size_t)Cout_total * Cin * 2);
+  unsigned *maxes = reinterpret_cast<unsigned *>(scales + Cout_total / kSM) + cout_offset / kSM;
+  hipError_t e = hipMemsetAsync(maxes, 0, (size_t)(Cout / kSM) * 4, s);
+  if (e != hipSuccess) {
+    set_error("conv_d1s pack: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  const int64_t n = (int64_t)Cout * Cin;
+  const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(d1s_max_kernel, dim3(blocks), dim3(256), 0, s, w_raw, maxes, Cin, n);
+  DDPM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(d1s_pack_kernel, dim3(blocks), dim3(256), 0, s, w_raw, reinterpret_cast<_Float16 *>(dst), Cout, Cin, cout_offset,
+                     Cout_total);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+static bool d1s_take(const ddpm_conv_desc &d, int &S, long long &pstride, bool sizing) {
+  const int Cin = d.C1 + d.C2;
+  if (!sw().conv_d3s || !split_f16_on(true) || !d.w_d3h) return false;
+  if (d.ksize != 1 || d.mode != DDPM_CONV_NORMAL || d.dims == 3 || d.Di > 1 || d.Do > 1 || d.force_direct) return false;
+  if (d.act != DDPM_ACT_NONE || d.out_act != DDPM_ACT_NONE || (d.gscale && !d.gshift)) return false;
+  if (conv_d1s_weight_halves(d.Cout, Cin) == 0 || (d.C2 > 0 && d.C1 % kSCh)) return false;
+  const int HW = d.Ho * d.Wo;
+  if (HW % 32 || d.Hi != d.Ho || d.Wi != d.Wo) return false;
+  if ((reinterpret_cast<uintptr_t>(d.in1) | reinterpret_cast<uintptr_t>(d.in2) | reinterpret_cast<uintptr_t>(d.gscale) |
+       reinterpret_cast<uintptr_t>(d.gshift)) & 15)
+    return false;
+  S = Cin / (kD1KC * kSCh);
+  pstride = (long long)d.B * d.Cout * HW;
+  const long long npix = (long long)d.B * HW;
+  const long wgs = (long)((npix + 127) / 128) * (d.Cout / kSM) * S;
+  if (sw().conv_d3s != 2 && (wgs > 4L * device_cus() || npix > 16384)) return false;
+  if (!sizing && (!d.scratch || d.scratch_floats < (size_t)S * (size_t)pstride)) return false;
+  return true;
+}
+
+bool conv_d1s_supported(const ddpm_conv_desc &d) {
+  int S;
+  long long ps;
+  return d1s_take(d, S, ps, false);
+}
+
+size_t conv_d1s_scratch_floats(const ddpm_conv_desc &d) {
+  int S;
+  long long ps;
+  return d1s_take(d, S, ps, true) ? (size_t)S * (size_t)ps : 0;
+}
+
+int launch_conv_d1s(const ddpm_conv_desc &d, hipStream_t s) {
+  int S;
+  long long pstride;
+  if (!d1s_take(d, S, pstride, false)) {
+    set_error("conv_d1s: unsupported shape");
+    return DDPM_EINVAL;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    for (const void *f : {reinterpret_cast<const void *>(&conv_d1s_kernel<false>), reinterpret_cast<const void *>(&conv_d1s_kernel<true>)})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int Cin = d.C1 + d.C2, HW = d.Ho * d.Wo;
+  const double M = (double)d.B * HW;
+  char kshape[160];
+  const char *kname = d.gscale ? "conv1x1_d1s_gn" : "conv1x1_d1s";
+  if (g_prof_on && sw().prof_shapes) {
+    snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);
+    kname = kshape;
+  }
+  ProfScope prof(s, kname, 2.0 * M * d.Cout * Cin, 4.0 * (M * Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * Cin));
+  const dim3 grid((unsigned)(((long long)M + 127) / 128 * (d.Cout / kSM) * S));
+  const size_t lds = ((size_t)kD1WU + kD1XU) * 16;
+  if (d.gscale) hipLaunchKernelGGL(conv_d1s_kernel<true>, grid, dim3(256), lds, s, d, S, pstride, d.w_d3h);
+  else hipLaunchKernelGGL(conv_d1s_kernel<false>, grid, dim3(256), lds, s, d, S, pstride, d.w_d3h);
+  DDPM_CHECK_LAUNCH();
+  ddpm_conv_desc dr = d;
+  dr.stats_out = nullptr;
+  return launch_wino_split_reduce(dr, S, pstride, HW, s);
 }
 
 }  // namespace ddpm

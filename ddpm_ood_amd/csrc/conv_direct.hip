@@ -412,7 +412,8 @@ size_t conv_scratch_floats(const ddpm_conv_desc &d) {
   const size_t c = linear_skinny_supported(d) ? 0 : conv_mfma_scratch_floats(d);
   const size_t h = vol ? 0 : conv_wino44h_scratch_floats(d);
   const size_t ab = (a > b ? a : b) > h ? (a > b ? a : b) : h;
-  const size_t e = vol ? 0 : conv_d3s_scratch_floats(d);
+  const size_t e1 = vol ? 0 : conv_d3s_scratch_floats(d), e2 = vol ? 0 : conv_d1s_scratch_floats(d);
+  const size_t e = e1 > e2 ? e1 : e2;
   const size_t abc = ab > c ? ab : c;
   return abc > e ? abc : e;
 }
@@ -465,6 +466,7 @@ int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
   if (conv_wino44_supported(d)) return launch_conv_wino44(d, s);
   if (conv_wino_supported(d)) return launch_conv_wino(d, s);
   if (conv_s2h_supported(d)) return launch_conv_s2h(d, s);  // Downsample: direct 3x3 stride 2 on the f16 MFMA, split-f16 operands
+  if (conv_d1s_supported(d)) return launch_conv_d1s(d, s);  // small launches: one-shot 1x1, split-f16 (round 4)
   if (conv1x1_dma_supported(d) && conv_mfma_supported(d)) return launch_conv1x1_dma(d, s);
   if (conv_mfma_supported(d)) return launch_conv_mfma(d, s);
   return launch_conv_direct(d, s);

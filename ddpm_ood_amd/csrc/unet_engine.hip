@@ -38,7 +38,8 @@ struct ParamSlot {
   bool has_wino44h = false;     // ... and its split-f16 form (conv_wino44h.hip); base in floats, 2 f16 per float
   size_t wino44h_base = 0;
   bool has_s2h = false;         // Downsample conv: split-f16 planes of the direct stride-2 kernel (conv_s2h.hip), in wino44h_base
-  bool has_d3h = false;         // stride-1 3x3 conv: split-f16 planes of the direct kernel (conv_d3h.hip)
+  bool has_d3h = false;         // stride-1 3x3 conv: split-f16 planes of the direct kernels (conv_d3h.hip, conv_d3s.hip)
+  bool has_d1s = false;         // 1x1 conv: split-f16 planes of the small-launch kernel (conv_d3s.hip), in d3h_base
   size_t d3h_base = 0;
   bool has_h1 = false;          // 1x1 conv: pre-split f16 planes of the DMA-fed kernel (conv1x1_dma.hip), in wino44h_base
   int Cout = 0, Cin = 0, ksize = 1, cout_offset = 0, Cout_total = 0;
@@ -163,8 +164,15 @@ struct ddpm_unet {
       r.has_wino44h = true;
       r.w_wino44h = alloc(n);  // 2 f16 per weight
     }
+    const size_t n1 = (k == 1 && sw().conv_d3s) ? conv_d1s_weight_halves(Cout, Cin) : 0;  // small-launch planes (conv_d3s.hip)
+    if (n1) {
+      r.has_d3h = true;
+      r.w_d3h = alloc((n1 + 1) / 2);
+    }
     r.bias = alloc(Cout);
     const int wi = add_raw(prefix + ".weight", (int64_t)n, r.w_raw, optional);
+    params[wi].has_d1s = n1 != 0;
+    params[wi].d3h_base = r.w_d3h;
     params[wi].is_conv = r.has_packed;
     params[wi].packed_base = r.w_packed;
     params[wi].has_h1 = h1;
@@ -183,6 +191,8 @@ struct ddpm_unet {
     params[wi].packed_base = shared.w_packed;
     params[wi].has_h1 = shared.ksize == 1 && shared.has_wino44h;
     params[wi].wino44h_base = shared.w_wino44h;
+    params[wi].has_d1s = shared.ksize == 1 && shared.has_d3h && Cout % 64 == 0 && cout_offset % 64 == 0;
+    params[wi].d3h_base = shared.w_d3h;
     params[wi].Cout = Cout; params[wi].Cin = shared.Cin; params[wi].ksize = shared.ksize;
     params[wi].cout_offset = cout_offset; params[wi].Cout_total = shared.Cout;
     add_raw(prefix + ".bias", Cout, shared.bias + cout_offset);
@@ -197,6 +207,10 @@ struct ddpm_unet {
     if (k == 1 && r.has_packed && conv1x1_h_weight_halves(Cout_total, Cin) != 0) {  // fused q / k / v (and the temb projections)
       r.has_wino44h = true;
       r.w_wino44h = alloc(n);
+    }
+    if (const size_t n1 = (k == 1 && sw().conv_d3s) ? conv_d1s_weight_halves(Cout_total, Cin) : 0) {
+      r.has_d3h = true;
+      r.w_d3h = alloc((n1 + 1) / 2);
     }
     r.bias = alloc(Cout_total);
     return r;
@@ -469,6 +483,11 @@ extern "C" int ddpm_unet_set_param(ddpm_unet *h, const char *name, const float *
   }
   if (p.has_d3h) {
     rc = launch_pack_conv_d3h_weight(src, reinterpret_cast<uint16_t *>(h->blob + p.d3h_base), p.Cout, p.Cin, s);
+    if (rc) return rc;
+  }
+  if (p.has_d1s) {
+    rc = launch_pack_conv_d1s_weight(src, reinterpret_cast<uint16_t *>(h->blob + p.d3h_base), p.Cout, p.Cin, p.cout_offset,
+                                     p.Cout_total, s);
     if (rc) return rc;
   }
   if (p.has_s2h) {

@@ -119,6 +119,22 @@ def pack_conv_d3h_weight(w):
     return out
 
 
+def pack_conv_d1s_weight(w):
+    """[Cout, Cin, 1, 1] (or [Cout, Cin]) -> split-f16 planes of the small-launch 1x1 kernel (conv_d3s.hip), or None (Cout % 64,
+    Cin % 128).  Pass it as conv(..., d3h=...) of a 1x1 convolution."""
+    lib = _lib.load()
+    w = require_device_f32(w, "weight")
+    if w.ndim == 4 and (w.shape[2] != 1 or w.shape[3] != 1):
+        return None
+    n = lib.ddpm_conv_d1s_weight_halves(w.shape[0], w.shape[1])
+    if n == 0:
+        return None
+    out = torch.zeros(n, dtype=torch.float16, device=w.device)
+    check(lib.ddpm_pack_conv_d1s_weight(ptr(w), out.data_ptr(), w.shape[0], w.shape[1], 0, w.shape[0], stream_ptr()),
+          "pack_conv_d1s_weight")
+    return out
+
+
 def pack_conv_s2h_weight(w):
     """[Cout, Cin, 3, 3] -> split-f16 planes of the direct stride-2 kernel (conv_s2h.hip), or None if the shape has no tiling.
     Pass it as conv(..., mode=CONV_STRIDE2, wino44h=...)."""

@@ -133,7 +133,12 @@ typedef struct ddpm_conv_desc {
    * Cin % 8 != 0).  When present, W in {16, 32, 64}, 256-pixel tiles of whole rows and the launch fills the chip, the
    * convolution runs as nine taps on v_mfma_f32_32x32x16_f16 with three exact f16 partial products per fp32 product (fp32
    * accumulate; GroupNorm + SiLU prologue, concat, bias / temb / residual epilogue) instead of the Winograd forms; it emits no
-   * statistics (ddpm_conv_stats_parts = 0).  Takes precedence over w_wino44h; DDPM_CONV_D3H=0 switches it off.  */
+   * statistics (ddpm_conv_stats_parts = 0).  Takes precedence over w_wino44h; opt-in: DDPM_CONV_D3H=1 (measured slower than the
+   * Winograd form).  The SAME planes feed the one-shot kernel of launches far smaller than the chip (csrc/conv_d3s.hip: 8x8 /
+   * 16x16 images, at most 4 096 pixels per launch, Cin % 32 == 0; DDPM_CONV_D3S=0 switches it off): channel slices of 32 into
+   * desc.scratch + the fixed-order reduce pass, which also emits stats_out.
+   * For a 1x1 DDPM_CONV_NORMAL convolution the field carries the planes of ddpm_pack_conv_d1s_weight instead (the 1x1 form of
+   * the small-launch kernel: at most 16 384 pixels per launch, Cout % 64 == 0, Cin % 128 == 0, act = none).  */
   const uint16_t *w_d3h;
 } ddpm_conv_desc;
 
@@ -148,6 +153,13 @@ size_t ddpm_conv_scratch_floats(const ddpm_conv_desc *d);
  * bit-identical results; without them it splits the fp32 packed weights in registers as before. */
 size_t ddpm_conv_d3h_weight_halves(int Cout, int Cin);
 int ddpm_pack_conv_d3h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, ddpm_stream_t stream);
+/* 1x1 planes of the small-launch kernel (ddpm_conv_desc.w_d3h of a ksize = 1 descriptor): [cout tile 64][chunk of 8 channels]
+ * [plane hi | lo][cout 64][8] f16 of 2^su w, su per packed member; rows [cout_offset, cout_offset + Cout) of a
+ * [Cout_total][Cin] weight are packed per call (the members of a fused q / k / v weight one by one; whole 64-cout tiles).
+ * Halves needed for the whole weight: ddpm_conv_d1s_weight_halves(Cout_total, Cin) (0: Cout % 64 or Cin % 128 != 0).  */
+size_t ddpm_conv_d1s_weight_halves(int Cout, int Cin);
+int ddpm_pack_conv_d1s_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, int cout_offset, int Cout_total,
+                              ddpm_stream_t stream);
 size_t ddpm_conv1x1_h_weight_halves(int Cout, int Cin);
 int ddpm_pack_conv1x1_h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, ddpm_stream_t stream);
 /* Slices per (image, channel) of the statistics ddpm_conv_f32 writes to d->stats_out for this descriptor (1 .. 8), or 0

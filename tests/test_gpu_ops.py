@@ -1409,6 +1409,73 @@ def test_conv_small_launch_split_f16_vs_conv2d(device, case, monkeypatch):
     assert math.isfinite(err) and err < 3e-6, (err, err0)
 
 
+D1S_CASES = [
+    # B, C1, C2, Cout, H, gn, residual
+    (16, 256, 0, 768, 8, True, False),     # the fused q / k / v projection at first_n = 16 (GroupNorm prologue, no activation)
+    (16, 256, 256, 256, 8, False, False),  # skip connection over a virtual concat: four channel slices
+    (5, 256, 128, 256, 8, False, True),    # ragged last pixel tile (320 pixels), three slices, residual
+    (3, 128, 0, 256, 16, False, False),    # a single slice
+    (2, 256, 128, 128, 32, False, False),  # 32x32: sixteen tiles per image pair
+]
+
+
+@pytest.mark.parametrize("case", D1S_CASES)
+def test_conv1x1_small_launch_split_f16_vs_conv2d(device, case, monkeypatch):
+    """conv_d3s.hip's 1x1 form (skip connections, q / k / v at a few images): channel slices of 128 + the reduce pass against
+    F.conv2d in float64; the planes of a fused weight packed member by member equal the planes packed at once."""
+    monkeypatch.setenv("DDPM_CONV_D3S", "2")
+    from ddpm_ood_amd import _lib, ops
+
+    B, C1, C2, Cout, H, gn, res = case
+    g = torch.Generator().manual_seed(B * 17 + C1 + H)
+    Cin = C1 + C2
+    x = torch.randn(B, C1, H, H, generator=g) * 1.7 - 0.3
+    x2 = torch.randn(B, C2, H, H, generator=g) * 3 if C2 else None
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    w[: Cout // 2] *= 0.05  # members of very different magnitude: the scale is per packed member
+    b = torch.randn(Cout, generator=g)
+    gamma, beta = (torch.randn(Cin, generator=g), torch.randn(Cin, generator=g)) if gn else (None, None)
+    residual = torch.randn(B, Cout, H, H, generator=g) if res else None
+    xin = (x if x2 is None else torch.cat([x, x2], 1)).double()
+    if gn:
+        xin = F.group_norm(xin, 32, gamma.double(), beta.double(), 1e-6)
+    ref = F.conv2d(xin, w.double(), b.double())
+    if res:
+        ref = ref + residual.double()
+    d = lambda t: None if t is None else t.to(device)
+    gs = gh = None
+    if gn:
+        gs, gh = ops.gn_scale_shift(d(x), d(gamma), d(beta), 32, 1e-6, x2=d(x2))
+    kw = dict(x2=d(x2), gscale=gs, gshift=gh, act=ops.ACT_NONE, residual=d(residual))
+    planes = ops.pack_conv_d1s_weight(d(w))
+    assert planes is not None
+    y = ops.conv(d(x), d(w), d(b), d3h=planes, **kw)
+    y0 = ops.conv(d(x), d(w), d(b), **kw)  # without the planes: the library's other 1x1 kernels
+    torch.cuda.synchronize()
+    assert not torch.equal(y, y0)
+    assert torch.equal(y, ops.conv(d(x), d(w), d(b), d3h=planes, **kw))
+    scale = ref.abs().max().item()
+    err = (y.cpu().double() - ref).abs().max().item() / scale
+    err0 = (y0.cpu().double() - ref).abs().max().item() / scale
+    print(f"{case}: small-launch 1x1 {err:.2e}, other kernel {err0:.2e} (max relative to max |y|)")
+    assert math.isfinite(err) and err < 3e-6, (err, err0)
+    # member-wise packing (what the UNet engine does for the fused q / k / v weight): two halves, each with its own scale
+    lib = _lib.load()
+    halves = torch.zeros_like(planes)
+    wd = d(w).contiguous()
+    for off in (0, Cout // 2):
+        part = wd[off:off + Cout // 2].contiguous()
+        ops.check(lib.ddpm_pack_conv_d1s_weight(part.data_ptr(), halves.data_ptr(), Cout // 2, Cin, off, Cout, ops.stream_ptr()), "pack")
+    y2 = ops.conv(d(x), d(w), d(b), d3h=halves, **kw)
+    torch.cuda.synchronize()
+    err2 = (y2.cpu().double() - ref).abs().max().item() / scale
+    assert err2 < 3e-6, err2
+    # the small half keeps full precision only with its own scale: relative to ITS outputs
+    sub = ref[:, : Cout // 2]
+    rel_small = (y2.cpu().double()[:, : Cout // 2] - sub).abs().max().item() / (sub - (residual.double()[:, : Cout // 2] if res else 0)).abs().max().item()
+    assert rel_small < 2e-5, rel_small
+
+
 D3H_CASES = [
     # B, C1, C2, Cout, H, gn, chan_add, residual
     (2, 128, 0, 128, 32, True, True, False),      # 32x32: eight tile rows per 256-pixel tile, four tiles per image
