@@ -514,11 +514,17 @@ struct Bump {
   char *base;
   size_t cap, off = 0, peak = 0;
   bool dry;
+  bool over = false;  // a real run asked for more than the dry run had sized: its decisions differed (a bug -- fail loudly)
   float *get(size_t floats) {
     const size_t bytes = (floats * sizeof(float) + 255) & ~size_t(255);
-    float *p = dry ? nullptr : reinterpret_cast<float *>(base + off);
+    // The dry run hands out NON-NULL, 256-byte aligned fake addresses (never dereferenced: every launch is skipped): the kernels'
+    // supported() / scratch_floats() predicates look at which optional pointers are present and how they are aligned, and the
+    // dry run must take the decisions of the real one.  (With NULL here a GroupNorm-ed convolution looked like "SiLU without
+    // scale / shift" to the sizing pass; a kernel that requires the pair was sized out and then taken by the real run.)
+    float *p = dry ? reinterpret_cast<float *>((uintptr_t(1) << 40) + off) : reinterpret_cast<float *>(base + off);
     off += bytes;
     if (off > peak) peak = off;
+    if (!dry && off > cap) over = true;
     return p;
   }
   size_t mark() const { return off; }
@@ -592,6 +598,11 @@ struct Runner {
       d.scratch_floats = need;
     }
     if (ws.dry) return;
+    if (ws.over && !rc) {
+      set_error("unet_forward: workspace overflow (%zu of %zu bytes): the sizing pass took other decisions than the run", ws.off, ws.cap);
+      rc = DDPM_EINVAL;
+    }
+    if (rc) return;
     if (outact && outact->stats && fuse_stats) {  // the epilogue leaves the next GroupNorm's statistics behind
       const int sp = conv_stats_parts(d);
       if (sp > 0 && sp <= kMaxStatParts) {

@@ -43,6 +43,44 @@ def test_unet_forward_small(device, channels, B, H):
     assert yr.abs().max() > 0.05  # not vacuous (finding 12)
 
 
+@pytest.mark.parametrize("B,mode", [(16, "1"), (7, "1"), (20, "2"), (33, "2")])
+def test_unet_forward_small_launch_kernels_vs_oracle(device, B, mode, monkeypatch):
+    """The one-shot kernels of launches far smaller than the chip (conv_d3s.hip: 3x3 at the 8x8 / 16x16 levels, 1x1 skip
+    connections and q / k / v; BASELINE configs[0] runs 16 images) inside a whole forward: the profiler must see them, the
+    forward must agree with the same forward without them (DDPM_CONV_D3S=0) and with the CPU oracle.  Mode 2 forces them onto
+    launches beyond their size gate -- larger scratch than any other kernel asks for: the engine's sizing pass has to take the
+    decisions of the run (a NULL scale / shift in the dry run once sized them out: out-of-bounds scratch)."""
+    import ctypes
+    import json
+
+    from ddpm_ood_amd import _lib
+
+    monkeypatch.setenv("DDPM_CONV_D3S", mode)
+    ref, hip = _pair(device, 1)
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, 1, 32, 32, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    lib = _lib.load()
+    lib.ddpm_prof_enable(1)
+    y = hip(x.to(device), timesteps=t.to(device)).cpu()
+    torch.cuda.synchronize()
+    lib.ddpm_prof_enable(0)
+    buf = ctypes.create_string_buffer(1 << 18)
+    prof = json.loads(buf.value.decode()) if lib.ddpm_prof_report(buf, len(buf)) > 0 else {}
+    assert any(k.startswith("conv3x3_d3s") for k in prof) and any(k.startswith("conv1x1_d1s") for k in prof), sorted(prof)
+    assert torch.equal(y, hip(x.to(device), timesteps=t.to(device)).cpu())  # fixed-order slices: bit-reproducible
+    monkeypatch.setenv("DDPM_CONV_D3S", "0")
+    hip0 = _pair(device, 1)[1]  # (a new engine: the switch decides which planes it packs)
+    y0 = hip0(x.to(device), timesteps=t.to(device)).cpu()
+    scale = y0.abs().max().item()
+    assert scale > 0.05 and not torch.equal(y, y0)
+    assert (y - y0).abs().max().item() <= 2e-5 * (1 + scale)
+    n = min(B, 6)
+    with torch.no_grad():
+        yr = ref(x[:n], timesteps=t[:n])
+    assert (y[:n] - yr).abs().max().item() <= 1e-4 * (1 + yr.abs().max().item())
+
+
 @pytest.mark.parametrize("channels,B,H", [(1, 96, 32), (3, 70, 32), (1, 300, 16), (1, 20, 64), (1, 90, 28)])
 def test_unet_forward_fused_groupnorm_statistics_vs_reading_groupnorm(device, channels, B, H, monkeypatch):
     """Launch sets of >= 64 K pixels take the GroupNorm statistics from the producers' epilogues: the forward
