@@ -61,14 +61,14 @@ bool d3s_geom(const ddpm_conv_desc &d, D3SGeom &g) {
   if (d.gscale && (d.act != DDPM_ACT_SILU || !d.gshift)) return false;
   if (!d.gscale && d.act != DDPM_ACT_NONE) return false;
   if (Cin % (kSCh * kSNC) || (d.C2 > 0 && d.C1 % kSCh) || d.Cout % kPackM) return false;
-  if (d.Wo != 8 && d.Wo != 16) return false;
+  if (d.Wo != 8 && d.Wo != 16 && d.Wo != 32) return false;
   g.W = d.Wo;
   g.HW = d.Ho * d.Wo;
   g.TI = g.W == 8 ? 2 : 1;
   g.RS = g.W + 2;
-  g.IS = (g.W + 2) * g.RS;
+  g.IS = (g.W == 32 ? 10 : g.W + 2) * g.RS;  // 32x32: eight rows of an image per workgroup
   g.XU = g.TI * g.IS;
-  g.PT = (d.B + g.TI - 1) / g.TI;
+  g.PT = g.W == 32 ? d.B * 4 : (d.B + g.TI - 1) / g.TI;
   g.CT = d.Cout / kSM;
   g.nch = Cin / kSCh;
   g.S = g.nch / kSNC;
@@ -95,23 +95,27 @@ __device__ __forceinline__ v4i_t d3s_pair_unit(h4_t p, h4_t p2, bool odd) {
   return odd ? v4i_t{got[0], got[1], own[0], own[1]} : v4i_t{own[0], own[1], got[0], got[1]};
 }
 
-// NW waves = 32 NW pixels: 4 (W = 8) or 8 (W = 16)
-template <bool AFFINE, int NW>
+// NW waves = 32 NW pixels: 4 (W = 8: two images), 8 (W = 16: one image; W = 32: eight rows of an image)
+template <bool AFFINE, int NW, int W>
 __global__ __launch_bounds__(64 * NW, 1) void conv_d3s_kernel(const ddpm_conv_desc a, const D3SGeom g, const uint16_t *__restrict__ wq) {
   extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  constexpr int W = NW == 4 ? 8 : 16, HW = W * W, TI = NW == 4 ? 2 : 1, NT = 64 * NW;
-  // staging items per chunk: TI images x (W + 2) window rows x (W / 4) pixel groups x 2 channel halves: 80 / 144 -- two rounds
-  constexpr int kItemsPerChunk = TI * (W + 2) * (W / 4) * 2, kItems = kSNC * kItemsPerChunk;
+  constexpr int HW = W * W, TI = NW == 4 ? 2 : 1, NT = 64 * NW;
+  constexpr int TR = 32 * NW / (TI * W);  // image rows per tile: 8 / 16 / 8
+  constexpr int WR = TR + 2;              // window rows
+  static_assert(TI * TR * W == 32 * NW && (TR == W || W == 32), "tile = whole images, or eight rows of a 32x32 image");
+  // staging items per chunk: TI images x WR window rows x (W / 4) pixel groups x 2 channel halves: 80 / 144 / 160 -- two rounds
+  constexpr int kItemsPerChunk = TI * WR * (W / 4) * 2, kItems = kSNC * kItemsPerChunk;
   static_assert(kItems <= 2 * NT, "two staging rounds");
   const int Cin = a.C1 + a.C2;
   f16x8 *const Xb = lds + kSWU;
 
   // workgroup -> (channel slice, cout tile, pixel tile): the slices of one output tile are neighbours
   const int split = blockIdx.x % g.S, ct = (blockIdx.x / g.S) % g.CT, pt = blockIdx.x / (g.S * g.CT);
-  const int n0 = pt * TI;
+  const int n0 = W == 32 ? pt >> 2 : pt * TI;
+  const int y0 = W == 32 ? (pt & 3) * TR : 0;
   const int ch0 = split * kSNC * kSCh;  // first input channel of the slice
 
   // ---- 1. the slice's weights: chunk q, tap t, plane p -> 64 units (1 KB) of the packed planes
@@ -135,9 +139,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_d3s_kernel(const ddpm_conv_de
     const int q = e / kItemsPerChunk, rem = e - q * kItemsPerChunk;
     constexpr int W4 = W >> 2;
     const int hsel = rem & 1, pg = rem >> 1;
-    const int ti = pg / ((W + 2) * W4), rem2 = pg - ti * ((W + 2) * W4);
+    const int ti = pg / (WR * W4), rem2 = pg - ti * (WR * W4);
     const int srow = rem2 / W4, scol = (rem2 - srow * W4) * 4;  // window row 0 .. W + 1 <-> image row srow - 1
-    const int yin = srow - 1, n = n0 + ti;
+    const int yin = y0 + srow - 1, n = n0 + ti;
     const bool own = e < kItems && yin >= 0 && yin < W && n < a.B;
     sbyte[r] = own ? (((q * 2) * g.XU + ti * g.IS + srow * g.RS + scol + 1) + 2 * hsel) * 16 : -1;
     const int cg = ch0 + q * kSCh + 4 * hsel;  // first of the item's four channels
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_d3s_kernel(const ddpm_conv_de
       const int ti = pp >> 6, rem = pp & 63;
       xb = ti * g.IS + (rem >> 3) * g.RS + (rem & 7);
     } else {
-      xb = (pp >> 4) * g.RS + (pp & 15);
+      xb = (pp / W) * g.RS + (pp % W);
     }
   }
 #pragma unroll
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_d3s_kernel(const ddpm_conv_de
   const float oscale = reinterpret_cast<const float *>(wq + (size_t)a.Cout * Cin * kSTaps * 2)[1] * (AFFINE ? 1.f : kXScale);
   const int pp = wave * 32 + l31;
   const int n = TI == 2 ? n0 + (pp >> 6) : n0;
-  const int pix = TI == 2 ? (pp & 63) : pp;
+  const int pix = TI == 2 ? (pp & 63) : y0 * W + pp;
   if (n < a.B) {
     float *const dst = a.scratch + (size_t)split * g.pstride + ((size_t)n * a.Cout + ct * kSM + 4 * lhi) * HW + pix;
 #pragma unroll
@@ -402,7 +406,9 @@ static bool d3s_take(const ddpm_conv_desc &d, D3SGeom &g, bool sizing) {
   // small launches only: where the throughput kernels' pipelines are all fill and drain.  Upper bound: four workgroups per CU
   // (beyond that the F(4x4) kernel's 2.25-4x fewer multiplies win); `2`: any size (tests)
   const long wgs = (long)g.PT * g.CT * g.S;
-  if (sw().conv_d3s != 2 && (wgs > 4L * device_cus() || (long)g.PT * g.CT > device_cus() / 2 || (long)d.B * g.HW > 4096)) return false;
+  // (32x32: two workgroups per CU at most -- 1 024 workgroups of a 256 -> 128 layer at 16 images measured 56 us against the F(4x4)
+  // kernel's 52)
+  if (sw().conv_d3s != 2 && (wgs > (g.W == 32 ? 2L : 4L) * device_cus() || (long)g.PT * g.CT > device_cus() / 2 || (long)d.B * g.HW > (g.W == 32 ? 16384 : 4096))) return false;
   if (!sizing && (!d.scratch || d.scratch_floats < (size_t)g.S * (size_t)g.pstride)) return false;
   return true;
 }
@@ -427,8 +433,9 @@ int launch_conv_d3s(const ddpm_conv_desc &d, hipStream_t s) {
   }
   static bool attr_done = false;
   if (!attr_done) {
-    for (const void *f : {reinterpret_cast<const void *>(&conv_d3s_kernel<false, 4>), reinterpret_cast<const void *>(&conv_d3s_kernel<true, 4>),
-                          reinterpret_cast<const void *>(&conv_d3s_kernel<false, 8>), reinterpret_cast<const void *>(&conv_d3s_kernel<true, 8>)})
+    for (const void *f : {reinterpret_cast<const void *>(&conv_d3s_kernel<false, 4, 8>), reinterpret_cast<const void *>(&conv_d3s_kernel<true, 4, 8>),
+                          reinterpret_cast<const void *>(&conv_d3s_kernel<false, 8, 16>), reinterpret_cast<const void *>(&conv_d3s_kernel<true, 8, 16>),
+                          reinterpret_cast<const void *>(&conv_d3s_kernel<false, 8, 32>), reinterpret_cast<const void *>(&conv_d3s_kernel<true, 8, 32>)})
       (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
@@ -445,11 +452,14 @@ int launch_conv_d3s(const ddpm_conv_desc &d, hipStream_t s) {
   const dim3 grid((unsigned)(g.PT * g.CT * g.S));
   const size_t lds = d3s_lds_bytes(g);
   if (g.W == 8) {
-    if (d.gscale) hipLaunchKernelGGL((conv_d3s_kernel<true, 4>), grid, dim3(256), lds, s, d, g, d.w_d3h);
-    else hipLaunchKernelGGL((conv_d3s_kernel<false, 4>), grid, dim3(256), lds, s, d, g, d.w_d3h);
+    if (d.gscale) hipLaunchKernelGGL((conv_d3s_kernel<true, 4, 8>), grid, dim3(256), lds, s, d, g, d.w_d3h);
+    else hipLaunchKernelGGL((conv_d3s_kernel<false, 4, 8>), grid, dim3(256), lds, s, d, g, d.w_d3h);
+  } else if (g.W == 16) {
+    if (d.gscale) hipLaunchKernelGGL((conv_d3s_kernel<true, 8, 16>), grid, dim3(512), lds, s, d, g, d.w_d3h);
+    else hipLaunchKernelGGL((conv_d3s_kernel<false, 8, 16>), grid, dim3(512), lds, s, d, g, d.w_d3h);
   } else {
-    if (d.gscale) hipLaunchKernelGGL((conv_d3s_kernel<true, 8>), grid, dim3(512), lds, s, d, g, d.w_d3h);
-    else hipLaunchKernelGGL((conv_d3s_kernel<false, 8>), grid, dim3(512), lds, s, d, g, d.w_d3h);
+    if (d.gscale) hipLaunchKernelGGL((conv_d3s_kernel<true, 8, 32>), grid, dim3(512), lds, s, d, g, d.w_d3h);
+    else hipLaunchKernelGGL((conv_d3s_kernel<false, 8, 32>), grid, dim3(512), lds, s, d, g, d.w_d3h);
   }
   DDPM_CHECK_LAUNCH();
   ddpm_conv_desc dr = d;

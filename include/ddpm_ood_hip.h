@@ -135,7 +135,8 @@ typedef struct ddpm_conv_desc {
    * accumulate; GroupNorm + SiLU prologue, concat, bias / temb / residual epilogue) instead of the Winograd forms; it emits no
    * statistics (ddpm_conv_stats_parts = 0).  Takes precedence over w_wino44h; opt-in: DDPM_CONV_D3H=1 (measured slower than the
    * Winograd form).  The SAME planes feed the one-shot kernel of launches far smaller than the chip (csrc/conv_d3s.hip: 8x8 /
-   * 16x16 images, at most 4 096 pixels per launch, Cin % 32 == 0; DDPM_CONV_D3S=0 switches it off): channel slices of 32 into
+   * 16x16 images with at most 4 096 pixels per launch, 32x32 images with at most 16 384, Cin % 32 == 0; DDPM_CONV_D3S=0
+   * switches it off): channel slices of 32 into
    * desc.scratch + the fixed-order reduce pass, which also emits stats_out.
    * For a 1x1 DDPM_CONV_NORMAL convolution the field carries the planes of ddpm_pack_conv_d1s_weight instead (the 1x1 form of
    * the small-launch kernel: at most 16 384 pixels per launch, Cout % 64 == 0, Cin % 128 == 0, act = none).  */

@@ -1363,6 +1363,8 @@ D3S_CASES = [
     (4, 256, 128, 256, 16, True, False, False),   # concat seam inside a slice's chunks
     (2, 64, 0, 128, 8, False, False, True),       # no prologue (raw input, 2^0)
     (1, 32, 32, 128, 16, False, True, False),
+    (2, 128, 0, 128, 32, True, True, True),       # 32x32: eight rows of an image per workgroup, four tiles per image
+    (3, 256, 128, 128, 32, True, False, False),   # twelve slices
 ]
 
 
