@@ -43,6 +43,7 @@ static void load_switches() {
   n.attn_fa = env_int("DDPM_ATTN_FA", 1);
   n.conv_d3h = env_int("DDPM_CONV_D3H", 0);
   n.conv_d3s = env_int("DDPM_CONV_D3S", 1);
+  n.d1s_maxpx = env_int("DDPM_D1S_MAXPX", 16384);
   n.conv_splitk = env_int("DDPM_CONV_SPLITK", 1) != 0;
   n.gn_fused = env_int("DDPM_GN_FUSED", 1) != 0;
   n.prof_shapes = getenv("DDPM_PROF_SHAPES") != nullptr;

@@ -50,6 +50,7 @@ struct Switches {
   bool attn_f16x3 = true;       // DDPM_ATTN_F16X3
   int conv_d3h = 0;             // DDPM_CONV_D3H: 1 the direct split-f16 3x3 kernel (conv_d3h.hip; experimental, 20 % slower than the F(4x4)
                                 // form) where a launch fills the chip, 2 also for smaller launches (tests)
+  int d1s_maxpx = 16384;        // DDPM_D1S_MAXPX: pixels per launch up to which a 1x1 takes the one-shot kernel (conv_d3s.hip)
   int conv_d3s = 1;             // DDPM_CONV_D3S: 0 never the one-shot small-launch 3x3 kernel (conv_d3s.hip), 2 for any launch size (tests)
   int attn_fa = 1;              // DDPM_ATTN_FA (0: the LDS-exchange kernels of attention.hip also when scratch is given; 2: the
                                 // register-resident kernel for every multiple of 64 tokens, not only from 1 024)

@@ -508,7 +508,7 @@ static bool d1s_take(const ddpm_conv_desc &d, int &S, long long &pstride, bool s
   pstride = (long long)d.B * d.Cout * HW;
   const long long npix = (long long)d.B * HW;
   const long wgs = (long)((npix + 127) / 128) * (d.Cout / kSM) * S;
-  if (sw().conv_d3s != 2 && (wgs > 4L * device_cus() || npix > 16384)) return false;
+  if (sw().conv_d3s != 2 && (wgs > 4L * device_cus() || npix > sw().d1s_maxpx)) return false;
   if (!sizing && (!d.scratch || d.scratch_floats < (size_t)S * (size_t)pstride)) return false;
   return true;
 }
