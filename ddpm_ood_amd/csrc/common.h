@@ -196,6 +196,9 @@ size_t wino44_weight_floats(int Cout, int Cin);
 bool conv_wino44h_supported(const ddpm_conv_desc &d);
 int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_wino44h_scratch_floats(const ddpm_conv_desc &d);
+bool conv_d3s2_supported(const ddpm_conv_desc &d);
+int launch_conv_d3s2(const ddpm_conv_desc &d, hipStream_t s);
+size_t conv_d3s2_scratch_floats(const ddpm_conv_desc &d);
 bool conv_d1s_supported(const ddpm_conv_desc &d);
 int launch_conv_d1s(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_d1s_scratch_floats(const ddpm_conv_desc &d);

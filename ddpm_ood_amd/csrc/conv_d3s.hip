@@ -366,6 +366,125 @@ __global__ __launch_bounds__(256, 1) void conv_d1s_kernel(const ddpm_conv_desc a
   }
 }
 
+// ============================================================================================================================
+// The Downsample convolutions (3x3, stride 2, padding 1, bias only; generative's Downsample.op, reference call site
+// /root/reference/src/trainers/reconstruct.py:151-153) of small launches: the same one-shot scheme over 64 couts x 128 output
+// pixels (two 8x8 output images, or eight rows of a 16x16 one) x 32 input channels.  The window is the 17 x (2 WO + 1) input
+// patch of the tile's rows; a tap of output pixel (r, c) reads window unit (2 r + dy, 2 c + dx): lanes two units apart (a two-way
+// bank conflict on the B operand, which an LDS pipe that is mostly idle here does not notice).  Eight waves: pixel block w & 3 x
+// cout block w >> 2 (one accumulator tile each), so that the 1 088 staging items are two rounds + a short third.
+template <int WO>
+__global__ __launch_bounds__(512, 1) void conv_d3s2_kernel(const ddpm_conv_desc a, const int S, const long long pstride,
+                                                           const uint16_t *__restrict__ wq) {
+  extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  constexpr int TI = WO == 8 ? 2 : 1, WI = 2 * WO, HWi = WI * WI, HWo = WO * WO;
+  constexpr int WR = 17, RS = WI + 2, IS = WR * RS, XU = TI * IS, W4 = WI / 4;
+  constexpr int kItemsPerChunk = TI * WR * W4 * 2, kItems = kSNC * kItemsPerChunk;  // 272, 1 088
+  const int Cin = a.C1, nch = Cin / kSCh, CT = a.Cout / kSM;
+  f16x8 *const Xb = lds + kSWU;
+  const int split = blockIdx.x % S, ct = (blockIdx.x / S) % CT, pt = blockIdx.x / (S * CT);
+  const int n0 = WO == 8 ? pt * 2 : pt >> 1;
+  const int y0 = WO == 8 ? 0 : (pt & 1) * 8;  // first output row of the tile
+  const int ch0 = split * kSNC * kSCh;
+  {
+    const f16x8 *const wsrc = reinterpret_cast<const f16x8 *>(wq) +
+                              ((size_t)(ct >> 1) * nch + (size_t)split * kSNC) * (kSTaps * 2 * kPackM) + (ct & 1) * kSM;
+#pragma unroll
+    for (int p = 0; p < kSNC * kSTaps * 2 / 8; ++p) {
+      const int piece = p * 8 + wave;
+      __builtin_amdgcn_global_load_lds(wsrc + (size_t)piece * kPackM + lane, lds + piece * kSM, 16, 0, 0);
+    }
+  }
+  const bool odd = lane & 1;
+  auto item = [&](int e, int &sunit, const float *&src) {  // staging item e -> first unit it stores (-1: none), its first pixel
+    const int q = e / kItemsPerChunk, rem = e - q * kItemsPerChunk;
+    const int hsel = rem & 1, pg = rem >> 1;
+    const int ti = pg / (WR * W4), rem2 = pg - ti * (WR * W4);
+    const int srow = rem2 / W4, scol = (rem2 - srow * W4) * 4;  // window row 0..16 <-> input row 2 y0 - 1 + srow
+    const int yin = 2 * y0 - 1 + srow, n = n0 + ti;
+    const bool own = e < kItems && yin >= 0 && yin < WI && n < a.B;
+    sunit = own ? (q * 2) * XU + ti * IS + srow * RS + scol + 1 + 2 * hsel : -1;
+    src = a.in1 + ((size_t)(own ? n : 0) * Cin + ch0 + q * kSCh + 4 * hsel) * HWi + (own ? yin * WI + scol : 0);
+  };
+  v4f_t raw[2][4];
+  int sunit[2];
+  auto request = [&](int r0) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float *src;
+      item(tid + 512 * (r0 + r), sunit[r], src);
+      if (sunit[r] >= 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) raw[r][c] = *reinterpret_cast<const v4f_t *>(src + (size_t)c * HWi);
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (sunit[r] < 0) continue;
+      h4_t hi[4], lo[4];
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float y = raw[r][c][px];
+          const _Float16 h = (_Float16)y;
+          hi[px][c] = h;
+          lo[px][c] = (_Float16)(y - (float)h);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        *reinterpret_cast<v4i_t *>(Xb + sunit[r] + p) = d3s_pair_unit(hi[p], hi[p + 2], odd);
+        *reinterpret_cast<v4i_t *>(Xb + sunit[r] + p + XU) = d3s_pair_unit(lo[p], lo[p + 2], odd);
+      }
+    }
+  };
+  request(0);
+  {
+    v4i_t z = {0, 0, 0, 0};
+    for (int e = tid; e < kSNC * 2 * XU + 1; e += 512) *reinterpret_cast<v4i_t *>(Xb + e) = z;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  stage();
+  request(2);  // (items 1 024 .. 1 087: the first 64 threads)
+  stage();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int pp = (wave & 3) * 32 + l31, cb = wave >> 2;
+  const int ti = WO == 8 ? pp >> 6 : 0, rem = WO == 8 ? pp & 63 : pp;
+  const int pr = rem / WO, pc = rem % WO;
+  const int xb = ti * IS + 2 * pr * RS + 2 * pc;
+#pragma unroll
+  for (int q = 0; q < kSNC; ++q) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int tap = min(2 * j + lhi, 8);
+      const int dy = tap / 3, dx = tap - 3 * dy;
+      const f16x8 *A = lds + ((q * kSTaps + 2 * j + lhi) * 2) * kSM + 32 * cb + l31;
+      const f16x8 *X = Xb + (q * 2) * XU + xb + dy * RS + dx;
+      const f16x8 bh = X[0], bl = X[XU], ah = A[0], al = A[kSM];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+    }
+  }
+  const float oscale = reinterpret_cast<const float *>(wq + (size_t)a.Cout * Cin * kSTaps * 2)[1] * kXScale;
+  const int n = n0 + ti;
+  if (n < a.B) {
+    float *const dst = a.scratch + (size_t)split * pstride + ((size_t)n * a.Cout + ct * kSM + 32 * cb + 4 * lhi) * HWo + (y0 + pr) * WO + pc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2)) * HWo] = acc[r] * oscale;
+  }
+}
+
 __global__ void d1s_max_kernel(const float *__restrict__ src, unsigned *__restrict__ maxes, int Cin, int64_t total) {
   // one maximum per 64-cout tile of the member: rows are Cin floats
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
@@ -555,6 +674,65 @@ int launch_conv_d1s(const ddpm_conv_desc &d, hipStream_t s) {
   ddpm_conv_desc dr = d;
   dr.stats_out = nullptr;
   return launch_wino_split_reduce(dr, S, pstride, HW, s);
+}
+
+// ---- stride 2
+static bool d3s2_take(const ddpm_conv_desc &d, int &S, long long &pstride, bool sizing) {
+  if (!sw().conv_d3s || !split_f16_on(true) || !d.w_d3h) return false;
+  if (d.ksize != 3 || d.mode != DDPM_CONV_STRIDE2 || d.dims == 3 || d.Di > 1 || d.Do > 1 || d.force_direct) return false;
+  if (d.gscale || d.act != DDPM_ACT_NONE || d.out_act != DDPM_ACT_NONE || d.C2 != 0) return false;
+  if ((d.Wo != 8 && d.Wo != 16) || d.Ho != d.Wo || d.Hi != 2 * d.Ho || d.Wi != 2 * d.Wo) return false;
+  if (d.C1 % (kSCh * kSNC) || d.Cout % kPackM) return false;
+  if (reinterpret_cast<uintptr_t>(d.in1) & 15) return false;
+  S = d.C1 / (kSCh * kSNC);
+  if (S < 2) return false;
+  const int HWo = d.Ho * d.Wo;
+  pstride = (long long)d.B * d.Cout * HWo;
+  const long pt = d.Wo == 8 ? (d.B + 1) / 2 : 2L * d.B;
+  const long wgs = pt * (d.Cout / kSM) * S;
+  if (sw().conv_d3s != 2 && (wgs > 4L * device_cus() || (long)d.B * HWo > 4096)) return false;
+  if (!sizing && (!d.scratch || d.scratch_floats < (size_t)S * (size_t)pstride)) return false;
+  return true;
+}
+
+bool conv_d3s2_supported(const ddpm_conv_desc &d) {
+  int S;
+  long long ps;
+  return d3s2_take(d, S, ps, false);
+}
+
+size_t conv_d3s2_scratch_floats(const ddpm_conv_desc &d) {
+  int S;
+  long long ps;
+  return d3s2_take(d, S, ps, true) ? (size_t)S * (size_t)ps : 0;
+}
+
+int launch_conv_d3s2(const ddpm_conv_desc &d, hipStream_t s) {
+  int S;
+  long long pstride;
+  if (!d3s2_take(d, S, pstride, false)) {
+    set_error("conv_d3s2: unsupported shape");
+    return DDPM_EINVAL;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    for (const void *f : {reinterpret_cast<const void *>(&conv_d3s2_kernel<8>), reinterpret_cast<const void *>(&conv_d3s2_kernel<16>)})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int HWo = d.Ho * d.Wo;
+  const double M = (double)d.B * HWo;
+  ProfScope prof(s, "conv3x3_d3s_stride2", 2.0 * M * d.Cout * d.C1 * 9, 4.0 * (4.0 * M * d.C1 + M * d.Cout + (double)d.Cout * d.C1 * 9));
+  const long pt = d.Wo == 8 ? (d.B + 1) / 2 : 2L * d.B;
+  const dim3 grid((unsigned)(pt * (d.Cout / kSM) * S));
+  const int TI = d.Wo == 8 ? 2 : 1;
+  const size_t lds = ((size_t)kSWU + (size_t)kSNC * 2 * TI * 17 * (2 * d.Wo + 2) + 1) * 16;
+  if (d.Wo == 8) hipLaunchKernelGGL(conv_d3s2_kernel<8>, grid, dim3(512), lds, s, d, S, pstride, d.w_d3h);
+  else hipLaunchKernelGGL(conv_d3s2_kernel<16>, grid, dim3(512), lds, s, d, S, pstride, d.w_d3h);
+  DDPM_CHECK_LAUNCH();
+  ddpm_conv_desc dr = d;
+  if (wino_split_reduce_stats_parts(HWo) == 0) dr.stats_out = nullptr;
+  return launch_wino_split_reduce(dr, S, pstride, HWo, s);
 }
 
 }  // namespace ddpm

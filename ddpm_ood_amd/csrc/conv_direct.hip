@@ -419,7 +419,8 @@ size_t conv_scratch_floats(const ddpm_conv_desc &d) {
   const size_t h = vol ? 0 : conv_wino44h_scratch_floats(d);
   const size_t ab = (a > b ? a : b) > h ? (a > b ? a : b) : h;
   const size_t e1 = vol ? 0 : conv_d3s_scratch_floats(d), e2 = vol ? 0 : conv_d1s_scratch_floats(d);
-  const size_t e = e1 > e2 ? e1 : e2;
+  const size_t e3 = vol ? 0 : conv_d3s2_scratch_floats(d);
+  const size_t e = (e1 > e2 ? e1 : e2) > e3 ? (e1 > e2 ? e1 : e2) : e3;
   const size_t abc = ab > c ? ab : c;
   return abc > e ? abc : e;
 }
@@ -428,7 +429,7 @@ size_t conv_scratch_floats(const ddpm_conv_desc &d) {
 int conv_stats_parts(const ddpm_conv_desc &d) {
   const bool is3d = d.dims == 3 && d.ksize != 1;
   if (is3d || d.ksize != 3 || d.Di > 1 || d.Do > 1 || linear_skinny_supported(d)) return 0;
-  if (conv_d3s_supported(d)) return conv_d3s_stats_parts(d);  // (from its reduce pass)
+  if (conv_d3s_supported(d) || conv_d3s2_supported(d)) return conv_d3s_stats_parts(d);  // (from its reduce pass)
   if (conv_d3h_supported(d)) return 0;  // (no statistics epilogue yet: its consumers reduce the tensor per channel once)
   if (conv_wino44h_supported(d)) return conv_wino44h_stats_parts(d);
   if (conv_wino44_supported(d)) return 0;
@@ -471,6 +472,7 @@ int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
   if (conv_wino44h_supported(d)) return launch_conv_wino44h(d, s);  // F(4x4) with split-f16 position GEMMs
   if (conv_wino44_supported(d)) return launch_conv_wino44(d, s);
   if (conv_wino_supported(d)) return launch_conv_wino(d, s);
+  if (conv_d3s2_supported(d)) return launch_conv_d3s2(d, s);  // Downsample of small launches: one-shot, split-f16 (round 4)
   if (conv_s2h_supported(d)) return launch_conv_s2h(d, s);  // Downsample: direct 3x3 stride 2 on the f16 MFMA, split-f16 operands
   if (conv_d1s_supported(d)) return launch_conv_d1s(d, s);  // small launches: one-shot 1x1, split-f16 (round 4)
   if (conv1x1_dma_supported(d) && conv_mfma_supported(d)) return launch_conv1x1_dma(d, s);

@@ -1341,6 +1341,31 @@ def test_conv_stride2_split_f16_vs_conv2d(device, case):
     assert torch.equal(y, ops.conv(d(x), d(w), d(b), mode=ops.CONV_STRIDE2, wino44h=ws))
 
 
+@pytest.mark.parametrize("case", [(16, 128, 128, 32), (16, 256, 256, 16), (5, 256, 256, 16), (3, 64, 128, 32), (1, 64, 128, 16)])
+def test_conv_stride2_small_launch_vs_conv2d(device, case, monkeypatch):
+    """conv_d3s.hip's stride-2 form: the Downsample convolutions of a forward over a few images (32 -> 16, 16 -> 8), channel
+    slices of 32 + the reduce pass, against F.conv2d(stride=2, padding=1) in float64; ragged last tile; bit-reproducible."""
+    monkeypatch.setenv("DDPM_CONV_D3S", "2")
+    from ddpm_ood_amd import ops
+
+    B, Cin, Cout, H = case
+    g = torch.Generator().manual_seed(B + Cin + H)
+    x = torch.randn(B, Cin, H, H, generator=g) * 1.3 + 0.2
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    d = lambda t: t.to(device)
+    planes = ops.pack_conv_d3h_weight(d(w))
+    y = ops.conv(d(x), d(w), d(b), mode=ops.CONV_STRIDE2, d3h=planes)
+    y32 = ops.conv(d(x), d(w), d(b), mode=ops.CONV_STRIDE2)
+    torch.cuda.synchronize()
+    assert not torch.equal(y, y32)  # the one-shot kernel ran
+    scale = ref.abs().max().item()
+    err = (y.cpu().double() - ref).abs().max().item() / scale
+    assert math.isfinite(err) and err < 3e-6, err
+    assert torch.equal(y, ops.conv(d(x), d(w), d(b), mode=ops.CONV_STRIDE2, d3h=planes))
+
+
 def test_conv_stride2_split_f16_operand_range(device):
     """Operand scales over several decades (the per-layer weight scale 2^su and the 2^3 input scale keep the lo halves normal)."""
     from ddpm_ood_amd import ops
