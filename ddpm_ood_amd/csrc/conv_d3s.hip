@@ -55,8 +55,10 @@ struct D3SGeom {
 
 bool d3s_geom(const ddpm_conv_desc &d, D3SGeom &g) {
   const int Cin = d.C1 + d.C2;
-  if (d.ksize != 3 || d.mode != DDPM_CONV_NORMAL || d.dims == 3 || d.Di > 1 || d.Do > 1 || d.force_direct) return false;
-  if (d.Hi != d.Ho || d.Wi != d.Wo || d.Ho != d.Wo) return false;
+  const bool up = d.mode == DDPM_CONV_UPSAMPLE2;  // nearest x2 + 3x3 (generative's Upsample): the staging reads pixel (y >> 1, x >> 1)
+  if (d.ksize != 3 || (d.mode != DDPM_CONV_NORMAL && !up) || d.dims == 3 || d.Di > 1 || d.Do > 1 || d.force_direct) return false;
+  if (up ? (d.Ho != 2 * d.Hi || d.Wo != 2 * d.Wi || d.gscale || d.C2 || d.Wo == 8) : (d.Hi != d.Ho || d.Wi != d.Wo)) return false;
+  if (d.Ho != d.Wo) return false;
   if (d.out_act != DDPM_ACT_NONE || d.act == DDPM_ACT_RELU) return false;
   if (d.gscale && (d.act != DDPM_ACT_SILU || !d.gshift)) return false;
   if (!d.gscale && d.act != DDPM_ACT_NONE) return false;
@@ -96,7 +98,7 @@ __device__ __forceinline__ v4i_t d3s_pair_unit(h4_t p, h4_t p2, bool odd) {
 }
 
 // NW waves = 32 NW pixels: 4 (W = 8: two images), 8 (W = 16: one image; W = 32: eight rows of an image)
-template <bool AFFINE, int NW, int W>
+template <bool AFFINE, int NW, int W, bool UP = false>
 __global__ __launch_bounds__(64 * NW, 1) void conv_d3s_kernel(const ddpm_conv_desc a, const D3SGeom g, const uint16_t *__restrict__ wq) {
   extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
   const int tid = threadIdx.x;
@@ -146,7 +148,15 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_d3s_kernel(const ddpm_conv_de
     sbyte[r] = own ? (((q * 2) * g.XU + ti * g.IS + srow * g.RS + scol + 1) + 2 * hsel) * 16 : -1;
     const int cg = ch0 + q * kSCh + 4 * hsel;  // first of the item's four channels
     const bool first = cg < a.C1;               // (C1 % 8 == 0: a chunk never straddles the concat seam)
-    if (own) {
+    if (own && UP) {  // four pixels of the virtual image = two stored ones, each twice
+      typedef float v2f_t __attribute__((ext_vector_type(2)));
+      const float *src = a.in1 + ((size_t)n * a.C1 + cg) * (HW / 4) + (yin >> 1) * (W / 2) + (scol >> 1);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const v2f_t v = *reinterpret_cast<const v2f_t *>(src + (size_t)c * (HW / 4));
+        raw[r][c] = v4f_t{v[0], v[0], v[1], v[1]};
+      }
+    } else if (own) {
       const float *src = first ? a.in1 + ((size_t)n * a.C1 + cg) * HW : a.in2 + ((size_t)n * a.C2 + (cg - a.C1)) * HW;
       src += yin * W + scol;
 #pragma unroll
@@ -554,14 +564,15 @@ int launch_conv_d3s(const ddpm_conv_desc &d, hipStream_t s) {
   if (!attr_done) {
     for (const void *f : {reinterpret_cast<const void *>(&conv_d3s_kernel<false, 4, 8>), reinterpret_cast<const void *>(&conv_d3s_kernel<true, 4, 8>),
                           reinterpret_cast<const void *>(&conv_d3s_kernel<false, 8, 16>), reinterpret_cast<const void *>(&conv_d3s_kernel<true, 8, 16>),
-                          reinterpret_cast<const void *>(&conv_d3s_kernel<false, 8, 32>), reinterpret_cast<const void *>(&conv_d3s_kernel<true, 8, 32>)})
+                          reinterpret_cast<const void *>(&conv_d3s_kernel<false, 8, 32>), reinterpret_cast<const void *>(&conv_d3s_kernel<true, 8, 32>),
+                          reinterpret_cast<const void *>(&conv_d3s_kernel<false, 8, 16, true>), reinterpret_cast<const void *>(&conv_d3s_kernel<false, 8, 32, true>)})
       (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const int Cin = d.C1 + d.C2;
   const double M = (double)d.B * g.HW;
   char kshape[160];
-  const char *kname = d.gscale ? "conv3x3_d3s_gn_silu" : "conv3x3_d3s";
+  const char *kname = d.mode == DDPM_CONV_UPSAMPLE2 ? "conv3x3_d3s_up" : d.gscale ? "conv3x3_d3s_gn_silu" : "conv3x3_d3s";
   if (g_prof_on && sw().prof_shapes) {
     snprintf(kshape, sizeof(kshape), "%s|%d+%d->%d@%dx%d", kname, d.C1, d.C2, d.Cout, d.Ho, d.Wo);
     kname = kshape;
@@ -570,7 +581,10 @@ int launch_conv_d3s(const ddpm_conv_desc &d, hipStream_t s) {
                  4.0 * (M * Cin + M * d.Cout * (d.residual ? 2 : 1) + (double)d.Cout * Cin * 9));
   const dim3 grid((unsigned)(g.PT * g.CT * g.S));
   const size_t lds = d3s_lds_bytes(g);
-  if (g.W == 8) {
+  if (d.mode == DDPM_CONV_UPSAMPLE2) {
+    if (g.W == 16) hipLaunchKernelGGL((conv_d3s_kernel<false, 8, 16, true>), grid, dim3(512), lds, s, d, g, d.w_d3h);
+    else hipLaunchKernelGGL((conv_d3s_kernel<false, 8, 32, true>), grid, dim3(512), lds, s, d, g, d.w_d3h);
+  } else if (g.W == 8) {
     if (d.gscale) hipLaunchKernelGGL((conv_d3s_kernel<true, 4, 8>), grid, dim3(256), lds, s, d, g, d.w_d3h);
     else hipLaunchKernelGGL((conv_d3s_kernel<false, 4, 8>), grid, dim3(256), lds, s, d, g, d.w_d3h);
   } else if (g.W == 16) {

@@ -410,6 +410,12 @@ extern "C" ddpm_unet *ddpm_unet_create(const ddpm_unet_config *cfg) {
           ps.has_wino44h = true;
           ps.wino44h_base = b.up.w_wino44h;
         }
+        if (const size_t nd = sw().conv_d3s ? conv_d3h_weight_halves(out_c, out_c) : 0) {  // small launches (conv_d3s.hip)
+          b.up.has_d3h = true;
+          b.up.w_d3h = u->alloc((nd + 1) / 2);
+          ps.has_d3h = true;
+          ps.d3h_base = b.up.w_d3h;
+        }
       }
     }
     u->up.push_back(b);
@@ -584,7 +590,7 @@ struct Runner {
     if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2) && c.has_wino && c.dims == 2)
       d.w_wino = P(c.w_wino);
     if (mode == DDPM_CONV_NORMAL && c.has_wino44 && c.dims == 2) d.w_wino44 = P(c.w_wino44);
-    if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_STRIDE2) && c.has_d3h && c.dims == 2) d.w_d3h = reinterpret_cast<const uint16_t *>(P(c.w_d3h));
+    if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_STRIDE2 || mode == DDPM_CONV_UPSAMPLE2) && c.has_d3h && c.dims == 2) d.w_d3h = reinterpret_cast<const uint16_t *>(P(c.w_d3h));
     if ((mode == DDPM_CONV_NORMAL || mode == DDPM_CONV_UPSAMPLE2 || mode == DDPM_CONV_STRIDE2) && c.has_wino44h && c.dims == 2)
       d.w_wino44h = reinterpret_cast<const uint16_t *>(P(c.w_wino44h));
     if (c.dims == 3 && c.ksize == 3 && mode == DDPM_CONV_NORMAL && c.has_wino) d.w_wino = P(c.w_wino);  // F(2x2) per depth tap

@@ -1436,6 +1436,31 @@ def test_conv_small_launch_split_f16_vs_conv2d(device, case, monkeypatch):
     assert math.isfinite(err) and err < 3e-6, (err, err0)
 
 
+@pytest.mark.parametrize("case", [(16, 256, 256, 8), (3, 128, 256, 8), (2, 64, 128, 16), (5, 256, 128, 16)])
+def test_conv_upsample_small_launch_vs_interpolate_conv2d(device, case, monkeypatch):
+    """conv_d3s.hip's upsample-on-load form: F.interpolate(nearest, x2) + conv3x3 (generative's Upsample,
+    /root/reference/src/trainers/reconstruct.py:151-153) of a forward over a few images, against float64; bit-reproducible."""
+    monkeypatch.setenv("DDPM_CONV_D3S", "2")
+    from ddpm_ood_amd import ops
+
+    B, Cin, Cout, H = case
+    g = torch.Generator().manual_seed(B + Cin + H)
+    x = torch.randn(B, Cin, H, H, generator=g) * 2.1 - 0.4
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1)
+    d = lambda t: t.to(device)
+    planes = ops.pack_conv_d3h_weight(d(w))
+    y = ops.conv(d(x), d(w), d(b), mode=ops.CONV_UPSAMPLE2, d3h=planes)
+    y0 = ops.conv(d(x), d(w), d(b), mode=ops.CONV_UPSAMPLE2)
+    torch.cuda.synchronize()
+    assert y.shape == (B, Cout, 2 * H, 2 * H) and not torch.equal(y, y0)  # the one-shot kernel ran
+    scale = ref.abs().max().item()
+    err = (y.cpu().double() - ref).abs().max().item() / scale
+    assert math.isfinite(err) and err < 3e-6, err
+    assert torch.equal(y, ops.conv(d(x), d(w), d(b), mode=ops.CONV_UPSAMPLE2, d3h=planes))
+
+
 D1S_CASES = [
     # B, C1, C2, Cout, H, gn, residual
     (16, 256, 0, 768, 8, True, False),     # the fused q / k / v projection at first_n = 16 (GroupNorm prologue, no activation)
