@@ -183,8 +183,11 @@ __global__ __launch_bounds__(256) void conv_smallco_kernel(const ddpm_conv_desc 
 constexpr int kSW_NJ = 6;   // plane elements per lane: PS <= 384
 constexpr int kSW_PPL = 4;  // output pixels per lane: 256 / 64
 
-__global__ __launch_bounds__(256) void conv_smallco_wave_kernel(const ddpm_conv_desc a, int TH, int RS, int PS) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][2][PS] planes, then [4][256][4] partials
+// NWV waves share the input channels (wave, wave + NWV, ...): 4, or 16 for launches of a few images, whose 64 workgroups x 4 waves
+// each walked 32 channels one after the other (49 us for 16 images; the partial sums are added in wave order either way)
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void conv_smallco_wave_kernel(const ddpm_conv_desc a, int TH, int RS, int PS) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [NWV waves][2][PS] planes, then [NWV][256][4] partials
   const int HW = a.Ho * a.Wo;
   const int Cin = a.C1 + a.C2;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_smallco_wave_kernel(const ddpm_conv_
         pl[r] = v;
       }
     }
-    if (ci + 8 < Cin) fetch(slot, ci + 8);  // refill this register set: the plane two channels ahead
+    if (ci + 2 * NWV < Cin) fetch(slot, ci + 2 * NWV);  // refill this register set: the plane two channels ahead
     // (LDS operations of one wave complete in order: the reads below see the writes above without a barrier)
     float wreg[4][9];
 #pragma unroll
@@ -270,13 +273,13 @@ __global__ __launch_bounds__(256) void conv_smallco_wave_kernel(const ddpm_conv_
     }
   };
   if (wave < Cin) fetch(0, wave);
-  if (wave + 4 < Cin) fetch(1, wave + 4);
-  for (int ci = wave; ci < Cin; ci += 8) {
+  if (wave + NWV < Cin) fetch(1, wave + NWV);
+  for (int ci = wave; ci < Cin; ci += 2 * NWV) {
     consume(0, ci, 0);
-    if (ci + 4 < Cin) consume(1, ci + 4, 1);
+    if (ci + NWV < Cin) consume(1, ci + NWV, 1);
   }
   // ---- four-way reduction of the per-wave partial sums (fixed order: wave 0 + 1 + 2 + 3), epilogue, store ------------
-  float *red = lds + 4 * 2 * PS;
+  float *red = lds + NWV * 2 * PS;
 #pragma unroll
   for (int k = 0; k < kSW_PPL; ++k)
 #pragma unroll
@@ -286,8 +289,9 @@ __global__ __launch_bounds__(256) void conv_smallco_wave_kernel(const ddpm_conv_
     const int th = tid / a.Wo, tw = tid - th * a.Wo;
     const int p = (h0 + th) * a.Wo + tw;
     for (int co = 0; co < a.Cout; ++co) {
-      float v = ((red[(0 * 256 + tid) * 4 + co] + red[(1 * 256 + tid) * 4 + co]) + red[(2 * 256 + tid) * 4 + co]) +
-                red[(3 * 256 + tid) * 4 + co];
+      float v = red[(0 * 256 + tid) * 4 + co];
+#pragma unroll
+      for (int wv = 1; wv < NWV; ++wv) v += red[(wv * 256 + tid) * 4 + co];  // (wave order: ((0 + 1) + 2) + 3 ...)
       const size_t idx = ((size_t)n * a.Cout + co) * HW + p;
       if (a.bias) v += a.bias[co];
       if (a.chan_add) v += a.chan_add[(size_t)n * a.chan_add_stride + co];
@@ -369,8 +373,19 @@ int launch_conv_direct(const ddpm_conv_desc &d, hipStream_t s) {
     dim3 grid(d.Ho / TH, d.B);
     static const bool wave_ok = !(getenv("DDPM_CONVOUT_WAVE") && atoi(getenv("DDPM_CONVOUT_WAVE")) == 0);
     if (wave_ok && PS <= 64 * kSW_NJ && Cin_i >= 16) {
+      if ((long)grid.x * grid.y * 2 <= device_cus() && Cin_i >= 64) {  // a few images: sixteen waves per workgroup
+        const size_t lds_w = ((size_t)16 * 2 * PS + 16 * 256 * 4) * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_smallco_wave_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attr_done = true;
+        }
+        hipLaunchKernelGGL(conv_smallco_wave_kernel<16>, grid, dim3(1024), lds_w, s, d, TH, RS, PS);
+        DDPM_CHECK_LAUNCH();
+        return 0;
+      }
       const size_t lds_w = ((size_t)4 * 2 * PS + 4 * 256 * 4) * sizeof(float);
-      hipLaunchKernelGGL(conv_smallco_wave_kernel, grid, dim3(256), lds_w, s, d, TH, RS, PS);
+      hipLaunchKernelGGL(conv_smallco_wave_kernel<4>, grid, dim3(256), lds_w, s, d, TH, RS, PS);
       DDPM_CHECK_LAUNCH();
       return 0;
     }

@@ -137,6 +137,7 @@ def test_cfg2_trajectories_through_the_f4x4_winograd_kernel(device, tmp_path, mo
     (conv_wino44.hip), whose fp32 rounding is ~10x the direct kernel's.  The small batches of the other tests never reach
     it (a launch has to fill the chip), so this one lifts that rule: seven chained t-starts (350 forwards per image), Z-scores
     still <= 1e-4 against the CPU oracle, and the scores differ in the last bits from the F(2x2) run (the kernel ran)."""
+    monkeypatch.setenv("DDPM_CONV_D3S", "0")  # (batches of three would otherwise take the one-shot small-launch kernels, round 4)
     args, rec, ref = _setup(tmp_path, 1, inference_skip_factor=16, batch_size=3)
     sets = {"val": "synthetic:blobs:n=2:seed=10", "in": "synthetic:blobs:n=2:seed=11",
             "out": "synthetic:speckle:n=1:seed=12:mix=10"}
