@@ -496,9 +496,14 @@ __global__ __launch_bounds__(512, 1) void conv_d3s2_kernel(const ddpm_conv_desc 
 }
 
 __global__ void d1s_max_kernel(const float *__restrict__ src, unsigned *__restrict__ maxes, int Cin, int64_t total) {
-  // one maximum per 64-cout tile of the member: rows are Cin floats
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-    atomicMax(maxes + (i / Cin) / kSM, __builtin_bit_cast(unsigned, fabsf(src[i])));  // (non-negative floats order like their bits)
+  // one maximum per 64-cout tile of the member (blockIdx.y): rows are Cin floats; one atomic per wave (an atomic per element took
+  // 4 ms per call: 0.4 s of start-up for the `big` UNet)
+  const int64_t per_tile = (int64_t)kSM * Cin, base = blockIdx.y * per_tile;
+  float m = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per_tile && base + i < total; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(src[base + i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(maxes + blockIdx.y, __builtin_bit_cast(unsigned, m));  // (non-negative floats order like their bits)
 }
 
 // member rows [cout_offset, cout_offset + Cout) of a [Cout_total][Cin] weight
@@ -618,7 +623,7 @@ int launch_pack_conv_d1s_weight(const float *w_raw, uint16_t *dst, int Cout, int
   }
   const int64_t n = (int64_t)Cout * Cin;
   const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
-  hipLaunchKernelGGL(d1s_max_kernel, dim3(blocks), dim3(256), 0, s, w_raw, maxes, Cin, n);
+  hipLaunchKernelGGL(d1s_max_kernel, dim3(16, (unsigned)(Cout / kSM)), dim3(256), 0, s, w_raw, maxes, Cin, n);
   DDPM_CHECK_LAUNCH();
   hipLaunchKernelGGL(d1s_pack_kernel, dim3(blocks), dim3(256), 0, s, w_raw, reinterpret_cast<_Float16 *>(dst), Cout, Cin, cout_offset,
                      Cout_total);
