@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_smallco_kernel(const ddpm_conv_desc 
 // and a private double-buffered LDS plane: it loads the haloed plane of its next channel (6 loads per lane in
 // flight) while the 3x3 windows of the current one are read back, with no block barrier until the final four-way
 // reduction of the per-wave partial sums.  Same tile (256 pixels = whole rows), one thread-quad of pixels per lane.
-constexpr int kSW_NJ = 6;   // plane elements per lane: PS <= 384
+constexpr int kSW_NJ = 7;   // plane elements per lane: PS <= 448 (64x64 images: four rows + halo = 396)
 constexpr int kSW_PPL = 4;  // output pixels per lane: 256 / 64
 
 // NWV waves share the input channels (wave, wave + NWV, ...): 4, or 16 for launches of a few images, whose 64 workgroups x 4 waves
