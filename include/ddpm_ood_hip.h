@@ -128,7 +128,7 @@ typedef struct ddpm_conv_desc {
    * (parts = ddpm_conv_stats_parts(d); 0 = this dispatch does not emit them and stats_out is ignored).  Merged pairwise
    * in a fixed order (no atomics): bit-reproducible.  ddpm_gn_finalize_f32 turns them into scale / shift.  */
   float *stats_out;
-  /* Optional, 2-D 3x3 DDPM_CONV_NORMAL only (ABI 8): the weights as split-f16 planes of the DIRECT convolution kernel
+  /* Optional, 2-D 3x3 (ABI 8): the weights as split-f16 planes of the DIRECT convolution kernel
    * (csrc/conv_d3h.hip), packed by ddpm_pack_conv_d3h_weight (ddpm_conv_d3h_weight_halves(Cout, Cin) halves; 0: Cout % 128 or
    * Cin % 8 != 0).  When present, W in {16, 32, 64}, 256-pixel tiles of whole rows and the launch fills the chip, the
    * convolution runs as nine taps on v_mfma_f32_32x32x16_f16 with three exact f16 partial products per fp32 product (fp32
@@ -136,7 +136,8 @@ typedef struct ddpm_conv_desc {
    * statistics (ddpm_conv_stats_parts = 0).  Takes precedence over w_wino44h; opt-in: DDPM_CONV_D3H=1 (measured slower than the
    * Winograd form).  The SAME planes feed the one-shot kernel of launches far smaller than the chip (csrc/conv_d3s.hip: 8x8 /
    * 16x16 images with at most 4 096 pixels per launch, 32x32 images with at most 16 384, Cin % 32 == 0; DDPM_CONV_D3S=0
-   * switches it off): channel slices of 32 into
+   * switches it off; also DDPM_CONV_STRIDE2 with 8x8 / 16x16 outputs and DDPM_CONV_UPSAMPLE2 with 16x16 / 32x32 outputs):
+   * channel slices of 32 into
    * desc.scratch + the fixed-order reduce pass, which also emits stats_out.
    * For a 1x1 DDPM_CONV_NORMAL convolution the field carries the planes of ddpm_pack_conv_d1s_weight instead (the 1x1 form of
    * the small-launch kernel: at most 16 384 pixels per launch, Cout % 64 == 0, Cin % 128 == 0, act = none).  */
