@@ -14,7 +14,7 @@ import torch
 
 _LIB = None
 LIB_NAME = "libddpm_ood_hip.so"
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class HipLibraryMissing(RuntimeError):
@@ -116,6 +116,7 @@ SIGNATURES = {
     "ddpm_prof_enable": (C.c_int, [C.c_int]),
     "ddpm_prof_report": (C.c_int, [C.c_char_p, C.c_size_t]),
     "ddpm_status_read": (C.c_int, [C.POINTER(C.c_uint), C.c_int, C.c_void_p]),
+    "ddpm_vq_near_ties_read": (C.c_int, [C.POINTER(C.c_uint), C.c_int, C.c_void_p]),
     "ddpm_set_split_f16": (C.c_int, [C.c_int]),
     "ddpm_get_split_f16": (C.c_int, []),
     "ddpm_reload_env": (C.c_int, []),
@@ -201,6 +202,14 @@ def status_read(clear: bool = True) -> int:
     word = C.c_uint(0)
     check(load().ddpm_status_read(C.byref(word), int(clear), stream_ptr()), "status_read")
     return int(word.value)
+
+
+def vq_near_ties_read(clear: bool = True) -> int:
+    """Latent positions whose two nearest codes were within 1e-5 (relative) of each other since the last clear: how close
+    the quantiser came to a code flip (the one discontinuous op of the path)."""
+    n = C.c_uint(0)
+    check(load().ddpm_vq_near_ties_read(C.byref(n), int(clear), stream_ptr()), "vq_near_ties_read")
+    return int(n.value)
 
 
 def status_text(word: int) -> str:

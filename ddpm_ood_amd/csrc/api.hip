@@ -22,6 +22,8 @@ void set_error(const char *fmt, ...) {
 // ---- run-time switches --------------------------------------------------------------------------
 static Switches g_sw;
 static bool g_sw_loaded = false;
+static unsigned g_sw_epoch = 0;  // bumped whenever a switch may have changed: captured hipGraphs bake the dispatch in
+unsigned switch_epoch() { return g_sw_epoch; }
 static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -41,7 +43,6 @@ static void load_switches() {
   n.conv1x1_f16x3 = env_int("DDPM_CONV1X1_F16X3", 1) != 0;
   n.attn_f16x3 = env_int("DDPM_ATTN_F16X3", 1) != 0;
   n.attn_fa = env_int("DDPM_ATTN_FA", 1);
-  n.conv_d3h = env_int("DDPM_CONV_D3H", 0);
   n.conv_d3s = env_int("DDPM_CONV_D3S", 1);
   n.d1s_maxpx = env_int("DDPM_D1S_MAXPX", 16384);
   n.conv_splitk = env_int("DDPM_CONV_SPLITK", 1) != 0;
@@ -50,6 +51,7 @@ static void load_switches() {
   n.split_f16 = g_sw_loaded ? keep : true;
   g_sw = n;
   g_sw_loaded = true;
+  g_sw_epoch += 1;
 }
 const Switches &sw() {
   if (!g_sw_loaded) load_switches();
@@ -141,11 +143,18 @@ extern "C" int ddpm_reload_env(void) {
 extern "C" int ddpm_set_split_f16(int on) {
   (void)sw();
   const int was = g_sw.split_f16 ? 1 : 0;
+  if ((on != 0) != g_sw.split_f16) g_sw_epoch += 1;
   g_sw.split_f16 = on != 0;
   return was;
 }
 
-extern "C" int ddpm_get_split_f16(void) { return sw().split_f16 ? 1 : 0; }
+// 1 only when the master switch is on AND at least one split-f16 family is enabled: "would ddpm_set_split_f16(0) change
+// which kernels run?" (the trainer's re-run guard asks exactly that)
+extern "C" int ddpm_get_split_f16(void) {
+  const Switches &w = sw();
+  const bool any = w.wino44_f16x3 || w.conv1x1_f16x3 || w.attn_f16x3 || w.down_s2h != 0 || w.conv_d3s != 0 || w.up_wino44h;
+  return w.split_f16 && any ? 1 : 0;
+}
 
 extern "C" int ddpm_status_read(unsigned *word, int clear, ddpm_stream_t stream) {
   DDPM_CHECK_ARG(word != nullptr, "status_read: NULL pointer");

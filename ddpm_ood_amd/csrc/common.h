@@ -48,8 +48,6 @@ struct Switches {
   int down_s2h = 1;             // DDPM_DOWN_S2H (0 off, 2 / 3 force a form)
   bool conv1x1_f16x3 = true;    // DDPM_CONV1X1_F16X3
   bool attn_f16x3 = true;       // DDPM_ATTN_F16X3
-  int conv_d3h = 0;             // DDPM_CONV_D3H: 1 the direct split-f16 3x3 kernel (conv_d3h.hip; experimental, 20 % slower than the F(4x4)
-                                // form) where a launch fills the chip, 2 also for smaller launches (tests)
   int d1s_maxpx = 16384;        // DDPM_D1S_MAXPX: pixels per launch up to which a 1x1 takes the one-shot kernel (conv_d3s.hip)
   int conv_d3s = 1;             // DDPM_CONV_D3S: 0 never the one-shot small-launch 3x3 kernel (conv_d3s.hip), 2 for any launch size (tests)
   int attn_fa = 1;              // DDPM_ATTN_FA (0: the LDS-exchange kernels of attention.hip also when scratch is given; 2: the
@@ -60,6 +58,7 @@ struct Switches {
   bool split_f16 = true;        // ddpm_set_split_f16(): false = every split-f16 family runs its fp32-MFMA form
 };
 const Switches &sw();
+unsigned switch_epoch();  // changes whenever ddpm_reload_env / ddpm_set_split_f16 may have changed the dispatch
 inline bool split_f16_on(bool family) { return family && sw().split_f16; }
 
 // ---- device status word (api.hip) ---------------------------------------------------------------
@@ -209,8 +208,6 @@ int launch_conv_d3s(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_d3s_scratch_floats(const ddpm_conv_desc &d);
 int conv_d3s_stats_parts(const ddpm_conv_desc &d);
 int device_cus();
-bool conv_d3h_supported(const ddpm_conv_desc &d);
-int launch_conv_d3h(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_d3h_weight_halves(int Cout, int Cin);
 int launch_pack_conv_d3h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, hipStream_t s);
 bool conv_s2h_supported(const ddpm_conv_desc &d);

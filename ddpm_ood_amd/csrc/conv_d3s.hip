@@ -11,7 +11,7 @@
 // The channel slices (Cin / 32 of them) go to scratch slabs and conv_wino.hip's fixed-order reduce pass adds them up together with
 // bias / temb / residual and emits the GroupNorm statistics: bit-reproducible, no atomics.
 //
-// Arithmetic: conv_d3h.hip's -- direct convolution on v_mfma_f32_32x32x16_f16, operands split into f16 hi / lo planes,
+// Arithmetic: direct convolution on v_mfma_f32_32x32x16_f16, operands split into f16 hi / lo planes,
 //     x' w' ~= wh xh + wh xl + wl xh,   x' = 2^3 act(x) (2^0 without prologue),  w' = 2^su w  (ddpm_pack_conv_d3h_weight)
 // (three of the four partial products: 22 mantissa bits per product, fp32 accumulate); one K-step = 8 channels x two taps.
 //
@@ -38,7 +38,7 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 constexpr int kSM = 64;                   // couts per workgroup
 constexpr int kSCh = 8;                   // input channels per chunk
 constexpr int kSNC = 4;                   // chunks per workgroup (one channel slice = 32 channels)
-constexpr int kSTaps = 10;                // nine taps + a zero tap (conv_d3h.hip's packed planes)
+constexpr int kSTaps = 10;                // nine taps + a zero tap (the packed planes of ddpm_pack_conv_d3h_weight)
 constexpr int kSWU = kSNC * kSTaps * 2 * kSM;  // weight units in LDS (5 120 = 80 KB)
 constexpr int kPackM = 128;               // couts per tile of the packed planes
 constexpr float kXScale = 8.f;
@@ -83,7 +83,7 @@ bool d3s_geom(const ddpm_conv_desc &d, D3SGeom &g) {
 
 size_t d3s_lds_bytes(const D3SGeom &g) { return ((size_t)kSWU + (size_t)kSNC * 2 * g.XU + 1) * 16; }
 
-// (conv_d3h.hip) lanes 2 k / 2 k + 1 hold channels 0-3 / 4-7 of the same four pixels: they swap halves by DPP, the even lane
+// lanes 2 k / 2 k + 1 hold channels 0-3 / 4-7 of the same four pixels: they swap halves by DPP, the even lane
 // assembles the whole units of pixels 0, 1, the odd lane those of pixels 2, 3
 __device__ __forceinline__ v4i_t d3s_pair_unit(h4_t p, h4_t p2, bool odd) {
   const v2i_t a = __builtin_bit_cast(v2i_t, p), b = __builtin_bit_cast(v2i_t, p2);
@@ -532,7 +532,66 @@ __global__ void d1s_pack_kernel(const float *__restrict__ src, _Float16 *__restr
   }
 }
 
+
+// ---- weights of the 3x3 one-shot kernels (ddpm_pack_conv_d3h_weight; the direct split-f16 kernel these planes were first
+// built for, conv_d3h.hip, measured 17-22 % slower than the F(4x4) form and was removed in round 5): torch [Cout][Cin][3][3] -> [cout tile 128][chunk 8][tap 10][plane hi | lo][cout 128][8 ch] f16 of 2^su w, tap 9 = 0;
+// tail floats {max |w|, 1 / (2^3 2^su)}
+__global__ void d3h_max_kernel(const float *__restrict__ src, unsigned *__restrict__ tail, int64_t total) {
+  float m = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(src[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(tail, __builtin_bit_cast(unsigned, m));  // (non-negative floats order like their bits)
+}
+
+__global__ void d3h_pack_kernel(const float *__restrict__ src, _Float16 *__restrict__ dst, int Cout, int Cin) {
+  float *tail = reinterpret_cast<float *>(dst + (size_t)Cout * Cin * kSTaps * 2);
+  const float umax = tail[0];
+  int e = 0;
+  (void)frexpf(umax, &e);  // umax = m 2^e, m in [0.5, 1)
+  const int su = umax > 0.f ? 15 - e : 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) tail[1] = ldexpf(1.f / kXScale, -su);
+  const int nch = Cin / kSCh;
+  const int64_t total = (int64_t)Cout * Cin * kSTaps;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % kSTaps);
+    const int ci = (int)((i / kSTaps) % Cin), co = (int)(i / ((int64_t)kSTaps * Cin));
+    const float w = tap < 9 ? ldexpf(src[((size_t)co * Cin + ci) * 9 + tap], su) : 0.f;
+    const _Float16 h = (_Float16)w;
+    const _Float16 l = (_Float16)(w - (float)h);
+    const int tile = co / kPackM, c128 = co % kPackM, chunk = ci / kSCh, cc = ci % kSCh;
+    const size_t unit = (((size_t)tile * nch + chunk) * kSTaps + tap) * 2 * kPackM + c128;  // plane 0
+    dst[unit * 8 + cc] = h;
+    dst[(unit + kPackM) * 8 + cc] = l;
+  }
+}
+
+constexpr int kD3TailHalves = 64;  // behind the planes: float [0] = max |w|, float [1] = 1 / (2^3 2^su)
+
 }  // namespace
+
+size_t conv_d3h_weight_halves(int Cout, int Cin) {
+  return (Cout % kPackM == 0 && Cin % kSCh == 0) ? (size_t)Cout * Cin * kSTaps * 2 + kD3TailHalves : 0;
+}
+
+int launch_pack_conv_d3h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, hipStream_t s) {
+  DDPM_CHECK_ARG(w_raw && dst && conv_d3h_weight_halves(Cout, Cin) != 0, "conv_d3h pack: Cout %% 128 or Cin %% 8 != 0");
+  unsigned *tail = reinterpret_cast<unsigned *>(dst + (size_t)Cout * Cin * kSTaps * 2);
+  hipError_t e = hipMemsetAsync(tail, 0, kD3TailHalves * 2, s);
+  if (e != hipSuccess) {
+    set_error("conv_d3h pack: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  const int64_t n9 = (int64_t)Cout * Cin * 9;
+  hipLaunchKernelGGL(d3h_max_kernel, dim3((unsigned)((n9 + 255) / 256 > 1024 ? 1024 : (n9 + 255) / 256)), dim3(256), 0, s, w_raw, tail, n9);
+  DDPM_CHECK_LAUNCH();
+  const int64_t total = (int64_t)Cout * Cin * kSTaps;
+  hipLaunchKernelGGL(d3h_pack_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, s, w_raw,
+                     reinterpret_cast<_Float16 *>(dst), Cout, Cin);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
 
 static bool d3s_take(const ddpm_conv_desc &d, D3SGeom &g, bool sizing) {
   if (!sw().conv_d3s || !split_f16_on(true) || !d.w_d3h || !d3s_geom(d, g)) return false;

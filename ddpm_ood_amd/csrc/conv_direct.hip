@@ -445,7 +445,6 @@ int conv_stats_parts(const ddpm_conv_desc &d) {
   const bool is3d = d.dims == 3 && d.ksize != 1;
   if (is3d || d.ksize != 3 || d.Di > 1 || d.Do > 1 || linear_skinny_supported(d)) return 0;
   if (conv_d3s_supported(d) || conv_d3s2_supported(d)) return conv_d3s_stats_parts(d);  // (from its reduce pass)
-  if (conv_d3h_supported(d)) return 0;  // (no statistics epilogue yet: its consumers reduce the tensor per channel once)
   if (conv_wino44h_supported(d)) return conv_wino44h_stats_parts(d);
   if (conv_wino44_supported(d)) return 0;
   if (conv_wino_supported(d)) return conv_wino_stats_parts(d);  // (the Upsample form only)
@@ -483,7 +482,6 @@ int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
   DDPM_CHECK_ARG(d.Di <= 1 && d.Do <= 1, "conv: Di / Do > 1 needs dims == 3");
   if (linear_skinny_supported(d)) return launch_linear_skinny(d, s);  // Linear over <= 1024 rows: latency, not FLOPs
   if (conv_d3s_supported(d)) return launch_conv_d3s(d, s);          // small launches: one-shot direct 3x3, split-f16 (round 4)
-  if (conv_d3h_supported(d)) return launch_conv_d3h(d, s);          // direct 3x3 on the f16 MFMA, split-f16 operands (round 4)
   if (conv_wino44h_supported(d)) return launch_conv_wino44h(d, s);  // F(4x4) with split-f16 position GEMMs
   if (conv_wino44_supported(d)) return launch_conv_wino44(d, s);
   if (conv_wino_supported(d)) return launch_conv_wino(d, s);

@@ -38,7 +38,7 @@ struct ParamSlot {
   bool has_wino44h = false;     // ... and its split-f16 form (conv_wino44h.hip); base in floats, 2 f16 per float
   size_t wino44h_base = 0;
   bool has_s2h = false;         // Downsample conv: split-f16 planes of the direct stride-2 kernel (conv_s2h.hip), in wino44h_base
-  bool has_d3h = false;         // stride-1 3x3 conv: split-f16 planes of the direct kernels (conv_d3h.hip, conv_d3s.hip)
+  bool has_d3h = false;         // stride-1 3x3 conv: split-f16 planes of the one-shot direct kernels (conv_d3s.hip)
   bool has_d1s = false;         // 1x1 conv: split-f16 planes of the small-launch kernel (conv_d3s.hip), in d3h_base
   size_t d3h_base = 0;
   bool has_h1 = false;          // 1x1 conv: pre-split f16 planes of the DMA-fed kernel (conv1x1_dma.hip), in wino44h_base
@@ -108,6 +108,7 @@ struct ddpm_unet {
   // hipGraph replay (ddpm_unet_forward_graphed): private capture / replay stream + the events that order it
   // against the caller's stream
   std::map<ddpm::GraphKey, ddpm::GraphEntry> graphs;
+  unsigned graph_epoch = 0;  // ddpm::switch_epoch() the captured graphs were taken under
   hipStream_t gstream = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   void drop_graphs() {
@@ -265,8 +266,8 @@ static ResRef build_res(ddpm_unet *u, const std::string &prefix, int Cin, int Co
         ps.wino44h_base = cr[i]->w_wino44h;
       }
       // direct split-f16 planes: read by the small-launch kernel (conv_d3s.hip: 8x8 / 16x16 layers of a few images) and by the
-      // opt-in conv_d3h.hip
-      if (const size_t nd = (sw().conv_d3h || sw().conv_d3s) ? conv_d3h_weight_halves(cr[i]->Cout, cr[i]->Cin) : 0) {
+      // direct split-f16 planes for the one-shot small-launch kernels (conv_d3s.hip)
+      if (const size_t nd = sw().conv_d3s ? conv_d3h_weight_halves(cr[i]->Cout, cr[i]->Cin) : 0) {
         cr[i]->has_d3h = true;
         cr[i]->w_d3h = u->alloc((nd + 1) / 2);
         ps.has_d3h = true;
@@ -528,6 +529,7 @@ struct Bump {
   size_t cap, off = 0, peak = 0;
   bool dry;
   bool over = false;  // a real run asked for more than the dry run had sized: its decisions differed (a bug -- fail loudly)
+  int *rc_out = nullptr;  // the owner's error code, set at the moment of the overflow (Runner::run points it at Runner::rc)
   float *get(size_t floats) {
     const size_t bytes = (floats * sizeof(float) + 255) & ~size_t(255);
     // The dry run hands out NON-NULL, 256-byte aligned fake addresses (never dereferenced: every launch is skipped): the kernels'
@@ -537,7 +539,16 @@ struct Bump {
     float *p = dry ? reinterpret_cast<float *>((uintptr_t(1) << 40) + off) : reinterpret_cast<float *>(base + off);
     off += bytes;
     if (off > peak) peak = off;
-    if (!dry && off > cap) over = true;
+    if (!dry && off > cap) {
+      // never hand out an address past the buffer: the start of the workspace is valid memory, the results are garbage and
+      // `rc_out` (the Runner's rc) stops every later launch -- all of them are gated on it
+      over = true;
+      if (rc_out && !*rc_out) {
+        ddpm::set_error("unet_forward: workspace overflow (%zu of %zu bytes): the sizing pass took other decisions than the run", off, cap);
+        *rc_out = DDPM_EINVAL;
+      }
+      return reinterpret_cast<float *>(base);
+    }
     return p;
   }
   size_t mark() const { return off; }
@@ -710,6 +721,7 @@ struct Runner {
 
   int run(const float *x, const int64_t *timesteps, float *out, int H, int W, int D = 1) {
     const ddpm_unet_config &cfg = u->cfg;
+    ws.rc_out = &rc;  // an overflowing ws.get() stops every launch behind it (conv, GroupNorm, attention, temb alike)
     eager_stats = (size_t)B * H * W >= 64 * 1024;
     // ---- timestep embedding + MLP + all time projections ------------------------------------------
     Act temb0{ws.get((size_t)B * u->ch0), u->ch0, 1, 1};
@@ -858,6 +870,12 @@ extern "C" int ddpm_unet_forward_graphed(ddpm_unet *h, const float *x, const int
   DDPM_CHECK_ARG(h && x && timesteps && out && workspace, "unet_forward_graphed: NULL argument");
   if (g_prof_on)  // per-kernel hipEvents are not graph nodes: profile the eager path
     return ddpm_unet_forward3d(h, x, timesteps, out, B, D, H, W, workspace, workspace_bytes, stream);
+  // a captured graph bakes in WHICH kernels ran: after ddpm_set_split_f16 / ddpm_reload_env the old captures are stale (the
+  // trainer's fp32 re-run of a flagged batch would otherwise replay the split-f16 kernels it is trying to rule out)
+  if (h->graph_epoch != switch_epoch()) {
+    h->drop_graphs();
+    h->graph_epoch = switch_epoch();
+  }
   const GraphKey key(x, timesteps, out, workspace, B, D, H, W);
   GraphEntry &e = h->graphs[key];
   e.calls += 1;

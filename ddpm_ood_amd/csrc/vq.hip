@@ -13,12 +13,14 @@
 
 namespace ddpm {
 
+constexpr float kVqTieRel = 1e-5f;  // relative distance gap below which two codes count as a near-tie (ddpm_vq_near_ties_read)
+
 template <int D>
 __global__ __launch_bounds__(256) void vq_nearest_kernel(const float *__restrict__ x, const float *__restrict__ e,
                                                          const float *__restrict__ e2, int *__restrict__ idx,
                                                          float *__restrict__ out, int S, int K, long npos,
                                                          unsigned *__restrict__ status) {
-  __shared__ float bd[4][64];
+  __shared__ float bd[4][64], bs[4][64];
   __shared__ int bi[4][64];
   const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
   const long pos = (long)blockIdx.x * 64 + lane;
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float *__restrict
   // a non-finite latent picks an arbitrary code: say so
   if (quarter == 0 && non_finite(z2) && status) atomicOr(status, (unsigned)DDPM_STATUS_NONFINITE_LATENT);
   const int kq = (K + 3) / 4, k0 = quarter * kq, k1 = min(K, k0 + kq);
-  float best = INFINITY;
+  float best = INFINITY, second = INFINITY;  // (second: the runner-up distance -- only for the near-tie counter below)
   int besti = k0;
   for (int k = k0; k < k1; ++k) {
     const float *ek = e + (size_t)k * D;  // uniform over the wave
@@ -44,20 +46,31 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float *__restrict
     for (int d = 0; d < D; ++d) dot = fmaf(z[d], ek[d], dot);
     const float dist = (z2 + e2[k]) - 2.f * dot;
     if (dist < best) {
+      second = best;
       best = dist;
       besti = k;
+    } else {
+      second = fminf(second, dist);
     }
   }
   bd[quarter][lane] = best;
   bi[quarter][lane] = besti;
+  bs[quarter][lane] = second;
   __syncthreads();
   if (quarter == 0 && live) {
 #pragma unroll
-    for (int q = 1; q < 4; ++q)
+    for (int q = 1; q < 4; ++q) {
       if (bd[q][lane] < best) {  // strict: the earlier quarter (smaller index) wins a tie
+        second = fminf(best, fminf(second, bs[q][lane]));
         best = bd[q][lane];
         besti = bi[q][lane];
+      } else {
+        second = fminf(second, bd[q][lane]);
       }
+    }
+    // a NEAR-TIE: the two nearest codes within kVqTieRel of each other -- a latent that differs in its 6th digit (another
+    // machine's convolution rounding, the reference's own included) may pick the other one.  Counted, not flagged.
+    if (status && second - best <= kVqTieRel * fabsf(best)) atomicAdd(status + 1, 1u);
     idx[pos] = besti;
     const float *ek = e + (size_t)besti * D;
     float *op = out + (size_t)b * D * S + p;
@@ -78,7 +91,7 @@ __global__ __launch_bounds__(256) void vq_nearest_generic_kernel(const float *__
   float z2 = 0.f;
   for (int d = 0; d < D; ++d) z2 += xp[(size_t)d * S] * xp[(size_t)d * S];
   if (non_finite(z2) && status) atomicOr(status, (unsigned)DDPM_STATUS_NONFINITE_LATENT);
-  float best = INFINITY;
+  float best = INFINITY, second = INFINITY;
   int besti = 0;
   for (int k = 0; k < K; ++k) {
     const float *ek = e + (size_t)k * D;
@@ -86,10 +99,14 @@ __global__ __launch_bounds__(256) void vq_nearest_generic_kernel(const float *__
     for (int d = 0; d < D; ++d) dot = fmaf(xp[(size_t)d * S], ek[d], dot);
     const float dist = (z2 + e2[k]) - 2.f * dot;
     if (dist < best) {
+      second = best;
       best = dist;
       besti = k;
+    } else {
+      second = fminf(second, dist);
     }
   }
+  if (status && second - best <= kVqTieRel * fabsf(best)) atomicAdd(status + 1, 1u);
   idx[pos] = besti;
   const float *ek = e + (size_t)besti * D;
   float *op = out + (size_t)b * D * S + p;
@@ -141,6 +158,20 @@ int launch_vq_nearest(const float *x, const float *codebook, float *code_norms, 
 }  // namespace ddpm
 
 using namespace ddpm;
+
+extern "C" int ddpm_vq_near_ties_read(unsigned *count, int clear, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(count != nullptr, "vq_near_ties_read: NULL pointer");
+  unsigned *st = status_word();
+  DDPM_CHECK_ARG(st != nullptr, "vq_near_ties_read: no status word on this device");
+  hipError_t e = hipMemcpyAsync(count, st + 1, sizeof(unsigned), hipMemcpyDeviceToHost, as_stream(stream));
+  if (e == hipSuccess && clear) e = hipMemsetAsync(st + 1, 0, sizeof(unsigned), as_stream(stream));
+  if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+  if (e != hipSuccess) {
+    set_error("vq_near_ties_read: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
 
 extern "C" int ddpm_vq_nearest_f32(const float *x, const float *codebook, float *code_norms, int *idx, float *out, int B,
                                    int D, int64_t S, int K, ddpm_stream_t stream) {

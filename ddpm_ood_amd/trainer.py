@@ -88,6 +88,8 @@ def gather_scores(ids: torch.Tensor, scores: torch.Tensor, n_max: int = None):
         raise ValueError(f"gather_scores: shard of {ids.shape[0]} rows does not fit the static capacity {n_max}")
     n_t = scores.shape[1]
     # ids travel inside the same fp32 payload (exact for ids < 2^24): one collective, not two
+    if ids.numel() and int(ids.max()) >= 1 << 24:
+        raise ValueError(f"gather_scores: image id {int(ids.max())} is not exact in the fp32 payload (ids must be < 2^24)")
     payload = torch.full((n_max, n_t * 2 + 1), -1.0, dtype=torch.float32, device=scores.device)
     payload[: ids.shape[0], 0] = ids.to(torch.float32)
     payload[: ids.shape[0], 1:] = scores.reshape(ids.shape[0], n_t * 2)  # (an empty shard has 0 rows)
@@ -250,6 +252,8 @@ class Reconstruct(BaseTrainer):
         # test hook (not a CLI flag): only the t-starts <= max_t_start of the reference's list are run -- a PREFIX of the
         # chained list, so the trajectories that do run are exactly the reference's (tests price the CPU oracle per forward)
         self.max_t_start = getattr(args, "max_t_start", None)
+        # test hook: keep only these members of the chained t-start list (in the list's order): long chains at a few start points
+        self.t_start_subset = getattr(args, "t_start_subset", None)
         self.lpips_weights = getattr(args, "lpips_weights", None)
         self._loader_args = dict(batch_size=args.batch_size, is_grayscale=bool(args.is_grayscale),
                                  image_size=self.image_size, drop_last=bool(args.drop_last),
@@ -315,10 +319,15 @@ class Reconstruct(BaseTrainer):
         self.model.eval()
         ids_all, names_all, scores_all = [], [], []
         t_values = [int(t) for t in reversed(self.make_scheduler().timesteps)[1::inference_skip_factor]
-                    if self.max_t_start is None or int(t) <= int(self.max_t_start)]
+                    if (self.max_t_start is None or int(t) <= int(self.max_t_start))
+                    and (self.t_start_subset is None or int(t) in set(self.t_start_subset))]
         n_recon = n_fwd = 0
         guard = {"batches_rerun_fp32": 0, "batches_nonfinite": 0}
         _lib.status_read(clear=True)  # whatever an earlier caller left behind is not this run's
+        quantises = not isinstance(self.vqvae_model, PassthroughVQVAE)
+        if quantises:
+            guard["vq_near_ties"] = 0  # latent positions whose two nearest codes were within 1e-5: candidates for a code flip
+            _lib.vq_near_ties_read(clear=True)
         for batch in loader:
             scores, t_values, n_r, n_f, B, dt = self._score_batch(batch, pl, inference_skip_factor)
             # numeric guard (include/ddpm_ood_hip.h): a non-finite eps / reconstruction / latent set the device status word.
@@ -330,14 +339,16 @@ class Reconstruct(BaseTrainer):
                 print(f"WARNING: {_lib.status_text(word)} in a batch of {B} on the split-f16 kernels: running the batch "
                       f"again with fp32 MFMA products (ddpm_set_split_f16(0); permanently: DDPM_WINO44_F16X3=0 "
                       f"DDPM_CONV1X1_F16X3=0 DDPM_ATTN_F16X3=0 DDPM_DOWN_S2H=0)", file=sys.__stderr__, flush=True)
-                _lib.set_split_f16(False)
+                prev = _lib.set_split_f16(False)
                 try:
                     scores, t_values, n_r, n_f, B, dt2 = self._score_batch(batch, pl, inference_skip_factor)
                     dt += dt2
                     word = _lib.status_read(clear=True)
                 finally:
-                    _lib.set_split_f16(True)
+                    _lib.set_split_f16(prev)
                 guard["batches_rerun_fp32"] += 1
+            if quantises:
+                guard["vq_near_ties"] += _lib.vq_near_ties_read(clear=True)
             if word:
                 guard["batches_nonfinite"] += 1
                 print(f"WARNING: {_lib.status_text(word)} with fp32 products too: a genuine overflow of this checkpoint on "
@@ -367,6 +378,8 @@ class Reconstruct(BaseTrainer):
         start_points = reversed(timesteps)[1::inference_skip_factor]
         if self.max_t_start is not None:
             start_points = start_points[start_points <= int(self.max_t_start)]
+        if self.t_start_subset is not None:
+            start_points = start_points[torch.isin(start_points, torch.as_tensor(list(self.t_start_subset), dtype=start_points.dtype))]
         t_values = [int(t) for t in start_points]
 
         t1 = time.time()
@@ -434,7 +447,13 @@ class Reconstruct(BaseTrainer):
         if self.ddp:
             n_total = len(loader.all_names) if hasattr(loader, "all_names") else None
             n_max = -(-n_total // self.world) if n_total is not None else None
+            if scores.is_cuda:
+                torch.cuda.synchronize()  # (the batch loop already synchronised at its last status read: this prices the collective alone)
+            t_g = time.perf_counter()
             ids, scores, counts = gather_scores(ids, scores, n_max)
+            if scores.is_cuda:
+                torch.cuda.synchronize()
+            self.last_stats["gather_ms"] = round((time.perf_counter() - t_g) * 1e3, 3)  # wait for the slowest rank included
             # every rank can name every image: the id list is the same file on every rank
             name_of = {i: n for i, n in enumerate(loader.all_names)} if hasattr(loader, "all_names") else name_of
             if int(os.environ["LOCAL_RANK"]) != 0 and not quiet:

@@ -111,9 +111,12 @@ class _Convolution(nn.Module):
         if kind == "conv2d":
             key = (w.data_ptr(), w._version)
             if self._packed is None or self._packed[0] != key:
-                self._packed = (key, ops.pack_conv_weight(w.detach()), ops.pack_wino_weight(w.detach()))
-            return ops.conv(x.float().contiguous(), w.detach(), b.detach(), packed=self._packed[1], wino=self._packed[2],
-                            out_act=out_act)
+                # the Winograd kernels take 2-D descriptors only without an output activation (the conv_only layers): a ReLU
+                # layer can only reach conv_mfma, so its Winograd planes would be dead device memory
+                wino = ops.pack_wino_weight(w.detach()) if out_act == ops.ACT_NONE else None
+                self._packed = (key, ops.pack_conv_weight(w.detach()), wino)
+            return ops.conv(x.float().contiguous(), w.detach(), b.detach() if b is not None else None, packed=self._packed[1],
+                            wino=self._packed[2], out_act=out_act)
         if kind in ("conv", "convT"):
             key = (w.data_ptr(), w._version)
             if self._packed is None or self._packed[0] != key:
@@ -182,9 +185,9 @@ class _ResidualUnit(nn.Module):
             w2 = c2.conv.weight
             key = (w2.data_ptr(), w2._version)
             if c2._packed is None or c2._packed[0] != key:
-                c2._packed = (key, ops.pack_conv_weight(w2.detach()), ops.pack_wino_weight(w2.detach()))
+                c2._packed = (key, ops.pack_conv_weight(w2.detach()), None)  # (ReLU epilogue: conv_mfma only, no Winograd planes)
             return ops.conv(h, w2.detach(), c2.conv.bias.detach() if c2.conv.bias is not None else None, packed=c2._packed[1],
-                            wino=c2._packed[2], residual=x, out_act=ops.ACT_RELU)
+                            residual=x, out_act=ops.ACT_RELU)
         return ops.convnd_generic(h, c2.conv.weight.detach(), c2.conv.bias.detach() if c2.conv.bias is not None else None,
                                   stride=s, padding=pad, residual=x, relu=True)
 
@@ -231,7 +234,7 @@ class VQVAE(nn.Module):
     /root/reference/src/trainers/reconstruct.py:124,166): inference only, on the device only -- every layer runs on a HIP kernel
     of libddpm_ood_hip (CPU tensors raise; parameters are read detached, so nothing here is differentiable: VQ-VAE TRAINING is
     off the path).  3-D README shapes take the MFMA kernels; 2-D stride-1 3x3 layers with Cout % 128 == 0 and
-    Cin % 4 == 0 the UNet's MFMA / Winograd convolution; everything else the generic kernel ddpm_convnd_generic_f32 (correct,
+    Cin % 4 == 0 the UNet's MFMA convolution (Winograd forms only for the conv_only layers: they have no output activation); everything else the generic kernel ddpm_convnd_generic_f32 (correct,
     slow: one thread per output), announced once per layer shape on stderr."""
 
     def __init__(self, spatial_dims: int, in_channels: int, out_channels: int, num_channels=(96, 96, 192),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDPM_ABI_VERSION 8
+#define DDPM_ABI_VERSION 9
 
 #define DDPM_EINVAL (-1)      /* bad argument / unsupported shape      */
 #define DDPM_ENOPARAM (-2)    /* unknown or missing parameter name     */
@@ -128,17 +128,14 @@ typedef struct ddpm_conv_desc {
    * (parts = ddpm_conv_stats_parts(d); 0 = this dispatch does not emit them and stats_out is ignored).  Merged pairwise
    * in a fixed order (no atomics): bit-reproducible.  ddpm_gn_finalize_f32 turns them into scale / shift.  */
   float *stats_out;
-  /* Optional, 2-D 3x3 (ABI 8): the weights as split-f16 planes of the DIRECT convolution kernel
-   * (csrc/conv_d3h.hip), packed by ddpm_pack_conv_d3h_weight (ddpm_conv_d3h_weight_halves(Cout, Cin) halves; 0: Cout % 128 or
-   * Cin % 8 != 0).  When present, W in {16, 32, 64}, 256-pixel tiles of whole rows and the launch fills the chip, the
-   * convolution runs as nine taps on v_mfma_f32_32x32x16_f16 with three exact f16 partial products per fp32 product (fp32
-   * accumulate; GroupNorm + SiLU prologue, concat, bias / temb / residual epilogue) instead of the Winograd forms; it emits no
-   * statistics (ddpm_conv_stats_parts = 0).  Takes precedence over w_wino44h; opt-in: DDPM_CONV_D3H=1 (measured slower than the
-   * Winograd form).  The SAME planes feed the one-shot kernel of launches far smaller than the chip (csrc/conv_d3s.hip: 8x8 /
-   * 16x16 images with at most 4 096 pixels per launch, 32x32 images with at most 16 384, Cin % 32 == 0; DDPM_CONV_D3S=0
-   * switches it off; also DDPM_CONV_STRIDE2 with 8x8 / 16x16 outputs and DDPM_CONV_UPSAMPLE2 with 16x16 / 32x32 outputs):
-   * channel slices of 32 into
-   * desc.scratch + the fixed-order reduce pass, which also emits stats_out.
+  /* Optional, 2-D 3x3 (ABI 8): the weights as split-f16 planes of the DIRECT convolution (nine taps on
+   * v_mfma_f32_32x32x16_f16, three exact f16 partial products per fp32 product, fp32 accumulate), packed by
+   * ddpm_pack_conv_d3h_weight (ddpm_conv_d3h_weight_halves(Cout, Cin) halves; 0: Cout % 128 or Cin % 8 != 0).  They feed the
+   * one-shot kernel of launches far smaller than the chip (csrc/conv_d3s.hip: 8x8 / 16x16 images with at most 4 096 pixels
+   * per launch, 32x32 images with at most 16 384, Cin % 32 == 0; DDPM_CONV_D3S=0 switches it off; also DDPM_CONV_STRIDE2
+   * with 8x8 / 16x16 outputs and DDPM_CONV_UPSAMPLE2 with 16x16 / 32x32 outputs): channel slices of 32 into desc.scratch +
+   * the fixed-order reduce pass, which also emits stats_out.  (The chip-filling direct kernel these planes were first built
+   * for, round 4's conv_d3h.hip, measured 17-22 % slower than the Winograd form and was removed in round 5.)
    * For a 1x1 DDPM_CONV_NORMAL convolution the field carries the planes of ddpm_pack_conv_d1s_weight instead (the 1x1 form of
    * the small-launch kernel: at most 16 384 pixels per launch, Cout % 64 == 0, Cin % 128 == 0, act = none).  */
   const uint16_t *w_d3h;
@@ -431,6 +428,13 @@ int ddpm_attention_ws_f32(const float *qkv, const float *residual, float *out, i
 #define DDPM_STATUS_NONFINITE_LATENT 4u /* ddpm_vq_nearest_f32 read a non-finite latent                 */
 /* Copies the current device's status word to *word (host memory), clears it if `clear`, and synchronises `stream`. */
 int ddpm_status_read(unsigned *word, int clear, ddpm_stream_t stream);
+/* ABI 9.  The quantiser is the one discontinuous op of the path (the reference re-quantises the denoised latent in
+ * vqvae.decode_stage_2_outputs, src/trainers/reconstruct.py:166): where the two nearest codes lie within 1e-5 (relative) of
+ * each other, a latent that differs in its 6th digit -- another machine's convolution rounding, the reference's own included --
+ * may pick the other code, an O(1) change of that position's decoded block.  ddpm_vq_nearest_f32 counts such positions in a
+ * per-device counter; this copies it to *count (host memory), clears it if `clear`, and synchronises `stream`.  It never
+ * triggers the fp32 re-run: it tells the caller how close a run came to a flip (trainer.py: last_stats["vq_near_ties"]). */
+int ddpm_vq_near_ties_read(unsigned *count, int clear, ddpm_stream_t stream);
 /* on = 0: every split-f16 kernel family runs its fp32-MFMA form (bit-exact fp32 products) whatever the DDPM_*_F16X3
  * environment switches say; on = 1: back to what the environment selects (default: split-f16).  Returns the previous
  * setting.  Process-wide; not thread-safe against concurrent launches. */

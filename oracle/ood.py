@@ -35,10 +35,19 @@ def _records(df, cols):
     return rows
 
 
+def _nanmean(v) -> float:
+    """groupby(...).mean() of ood_detection.py:174: NaN rows are skipped, an all-NaN group is NaN."""
+    x = np.asarray(v, dtype=np.float64)
+    x = x[~np.isnan(x)]
+    return float(x.sum() / len(x)) if len(x) else float("nan")
+
+
 def _auroc(neg, pos) -> float:
     """P(pos > neg) + P(pos == neg) / 2 by ranks (average rank on ties): the area under the ROC curve."""
     neg, pos = np.asarray(neg, dtype=np.float64), np.asarray(pos, dtype=np.float64)
     both = np.concatenate([neg, pos])
+    if not np.isfinite(both).all():  # sklearn's roc_auc_score (ood_detection.py:206) refuses NaN / inf scores
+        raise ValueError("Input contains NaN or infinity.")
     order = np.argsort(both, kind="mergesort")
     ranks = np.empty(len(both), dtype=np.float64)
     srt = both[order]
@@ -65,7 +74,8 @@ def z_scores_and_auroc(df_val: pd.DataFrame, df_in: pd.DataFrame, df_out: pd.Dat
     for t in t_keep:
         for k, target in enumerate(TARGETS):
             x = np.array([r[3 + k] for r in val if r[2] == t], dtype=np.float64)
-            mean = x.sum() / len(x)
+            x = x[~np.isnan(x)]  # pandas' groupby aggregations skip NaN (ood_detection.py:152-157)
+            mean = x.sum() / len(x) if len(x) else float("nan")
             var = ((x - mean) ** 2).sum() / (len(x) - 1) if len(x) > 1 else float("nan")
             stats[(t, target)] = (mean, np.sqrt(var))
     rows = [r for r in _records(df_in, cols) if r[2] in t_keep] + [r for r in _records(df_out, cols) if r[2] in t_keep]
@@ -84,7 +94,7 @@ def z_scores_and_auroc(df_val: pd.DataFrame, df_in: pd.DataFrame, df_out: pd.Dat
         per_image.setdefault((name, typ), []).append(z)
     keys = sorted(per_image)
     df_mean = pd.DataFrame({"filename": [k[0] for k in keys], "type": [k[1] for k in keys],
-                            target: [float(np.mean(per_image[k])) for k in keys]})
-    s_in = [float(np.mean(v)) for k, v in per_image.items() if k[1] == "in"]
-    s_out = [float(np.mean(v)) for k, v in per_image.items() if k[1] == "out"]
+                            target: [_nanmean(per_image[k]) for k in keys]})
+    s_in = [_nanmean(v) for k, v in per_image.items() if k[1] == "in"]
+    s_out = [_nanmean(v) for k, v in per_image.items() if k[1] == "out"]
     return df, df_mean, _auroc(s_in, s_out)

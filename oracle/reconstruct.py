@@ -46,7 +46,7 @@ def get_scores(loader, dataset_name: str, inference_skip_factor: int, *, model, 
                beta_start: float = 1e-4, beta_end: float = 2e-2, b_scale: float = 1.0,
                snr_shift: float = 1.0, latent_pad=None, num_inference_steps: int = 100,
                reset_scheduler_per_t: bool = False, timestep_list: str = "monai",
-               return_reconstructions: bool = False, max_t_start: int = None):
+               return_reconstructions: bool = False, max_t_start: int = None, t_start_subset=None):
     results = []
     recons = []
     model.eval()
@@ -61,6 +61,9 @@ def get_scores(loader, dataset_name: str, inference_skip_factor: int, *, model, 
         start_points = reversed(timesteps)[1::inference_skip_factor]
         if max_t_start is not None:  # test hook: a prefix of the chained t-start list (same trajectories, fewer of them)
             start_points = start_points[start_points <= int(max_t_start)]
+        if t_start_subset is not None:  # test hook: some members of the chained list, in the list's order (long chains at a
+            # price the CPU oracle can pay; the PLMS history a trajectory inherits is then the previous KEPT one's)
+            start_points = start_points[torch.isin(start_points, torch.as_tensor(list(t_start_subset), dtype=start_points.dtype))]
 
         images_original = batch["image"].float()
         images = vqvae.encode_stage_2_inputs(images_original)

@@ -43,6 +43,18 @@ CASES = {
     "cfg2_25t": dict(channels=1, model_type="small", skip=4, batch=3, live=1,
                      sets={"val": "synthetic:blobs:n=2:seed=10", "in": "synthetic:blobs:n=2:seed=11",
                            "out": "synthetic:speckle:n=1:seed=12:mix=10"}),
+    # tests/test_gpu_dispatch.py::test_cfg2_25_chained_t_starts_at_batch_128_absolute_z -- the workload bench.py times (BASELINE
+    # configs[1]: all 25 chained t-starts, 1 250 forwards per image) at a chip-filling dispatch: the HIP side runs each set's 128
+    # images as ONE batch, the oracle prices the first `oracle_n` of them (a per-image result does not depend on its batch)
+    "cfg2_25t_b128": dict(channels=1, model_type="small", skip=4, batch=128, live=1, live_sets=["val"], oracle_n=16,
+                          sets={"val": "synthetic:blobs:n=128:seed=10", "in": "synthetic:blobs:n=128:seed=11",
+                                "out": "synthetic:speckle:n=128:seed=12:mix=10"}),
+    # tests/test_gpu_dispatch.py::test_cfg4_long_chains_to_t490 -- BASELINE configs[3] (`big` UNet, 64x64x3, k = 2) on LONG chains:
+    # t_start in {10, 250, 490} of the chained k = 2 list (2 + 26 + 50 forwards per image through 16 attention blocks of up to
+    # 4 096 tokens; `t_start_subset` keeps the list's order, the PLMS history a trajectory inherits is the previous kept one's)
+    "cfg4_t490": dict(channels=3, model_type="big", skip=2, batch=2, live=1, live_sets=["val"], t_start_subset=[10, 250, 490],
+                      sets={"val": "synthetic:blobs:n=2:channels=3:size=64:seed=30", "in": "synthetic:blobs:n=1:channels=3:size=64:seed=31",
+                            "out": "synthetic:speckle:n=1:channels=3:size=64:seed=32:mix=10"}),
     # tests/test_gpu_configs.py::test_cfg3_three_channel_two_ood_sets_and_sensitive_auroc
     "cfg3": dict(channels=3, model_type="small", skip=64, batch=32, live=2,
                  sets={"val": "synthetic:blobs:n=16:channels=3:seed=10", "in": "synthetic:blobs:n=32:channels=3:seed=11",
@@ -78,7 +90,8 @@ def oracle_rows(case: dict, name: str, ids: str, first_n=None) -> pd.DataFrame:
     loader = get_data_loader(ids, batch_size=case["batch"], is_grayscale=c == 1, spatial_dimension=2, first_n=first_n)
     return pd.DataFrame(oracle.get_scores(
         loader, set_type(name), case["skip"], model=m, vqvae=oracle.PassthroughVQVAE(), perceptual=pl,
-        noise_fn=lambda batch, t, shape: batch_noise(2, batch["index"], t, shape), **SCHED))
+        noise_fn=lambda batch, t, shape: batch_noise(2, batch["index"], t, shape), t_start_subset=case.get("t_start_subset"),
+        **SCHED))
 
 
 _MODELS = {}
@@ -107,7 +120,7 @@ def main():
         t0 = time.time()
         for sname, ids in case["sets"].items():
             with torch.no_grad():
-                df = oracle_rows(case, sname, ids)
+                df = oracle_rows(case, sname, ids, first_n=case.get("oracle_n"))
             df.insert(0, "set", sname)
             frames.append(df)
             print(f"{name}/{sname}: {len(df)} rows, {time.time() - t0:.0f} s", flush=True)

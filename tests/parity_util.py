@@ -59,7 +59,7 @@ def oracle_scores(args, rec, ids, name, *, model, vqvae=None, loader_kw=None):
         prediction_type=args.prediction_type, beta_schedule=args.beta_schedule, beta_start=args.beta_start,
         beta_end=args.beta_end, b_scale=args.b_scale, snr_shift=args.snr_shift, latent_pad=args.latent_pad,
         num_inference_steps=rec.num_inference_steps, timestep_list=rec.timestep_list,
-        max_t_start=getattr(rec, "max_t_start", None)))
+        max_t_start=getattr(rec, "max_t_start", None), t_start_subset=getattr(rec, "t_start_subset", None)))
 
 
 def hip_scores(args, rec, ids, name, loader_kw=None):
@@ -138,6 +138,8 @@ def live_oracle_pins_fixture(case: str, spec, rows, hip_rows=None, tol_fixture=1
     import torch
 
     for name, ids in spec["sets"].items():
+        if name not in spec.get("live_sets", spec["sets"]):  # (the dearest cases pin one set only)
+            continue
         with torch.no_grad():
             live = mg.oracle_rows(spec, name, ids, first_n=spec["live"])
         names = set(live["filename"])

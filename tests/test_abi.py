@@ -46,7 +46,7 @@ def test_struct_layouts_match_header(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.ddpm_abi_version() == 8
+    assert lib.ddpm_abi_version() == 9
     assert lib.ddpm_set_split_f16(0) == 1 and lib.ddpm_get_split_f16() == 0 and lib.ddpm_set_split_f16(1) == 0
     assert lib.ddpm_reload_env() == 0 and lib.ddpm_get_split_f16() == 1  # a reload keeps the run-time switch
     assert lib.ddpm_packed_conv_weight_floats(128, 128, 3) == 128 * 128 * 9

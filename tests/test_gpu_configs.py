@@ -259,6 +259,105 @@ def test_cfg5_readme_vqvae_ldm_trajectory(device, tmp_path, volume):
     assert_rows_close(h, o, 2e-4, str(volume))
 
 
+def test_cfg5_long_chain_t970_on_the_8cube_latent(device, tmp_path):
+    """cfg5 on its LONGEST trajectory: t_start = 970 (98 PLMS steps of the 3-D latent UNet over a [128, 8, 8, 8] latent), then
+    re-quantise + decode to 128^3, MSE and 2.5-D LPIPS -- against the CPU oracle, live.  (`t_start_subset` keeps t = 970 of the
+    k = 32 list 10, 330, 650, 970.)  The codebook is spread x3 as in the test above, so this
+    test isolates the chain's error growth from nearest-code ties; the ties are the next test's subject."""
+    import oracle
+    from oracle.vqvae import VQVAE as OracleVQVAE
+    from ddpm_ood_amd import synthetic
+    from ddpm_ood_amd.data import ListLoader, synthetic_images
+    from ddpm_ood_amd.trainer import MODEL_CONFIGS, Reconstruct, batch_noise
+
+    torch.manual_seed(3)
+    vq = OracleVQVAE(**VQ_README).eval()
+    with torch.no_grad():
+        vq.quantizer.quantizer.embedding.weight.mul_(3.0)
+    vq_dir = tmp_path / "vqvae"
+    vq_dir.mkdir()
+    torch.save({"model_state_dict": vq.state_dict()}, vq_dir / "checkpoint.pth")
+    json.dump(VQ_README, open(vq_dir / "vqvae_config.json", "w"))
+    args = make_args(tmp_path, model_name="decathlon_synth", spatial_dimension=3, batch_size=1, inference_skip_factor=32,
+                     vqvae_checkpoint=str(vq_dir / "checkpoint.pth"), validation_ids="synthetic:blobs3d:n=1",
+                     in_ids="synthetic:blobs3d:n=1")
+    sd = synthetic.random_state_dict("small", 128, spatial_dims=3, seed=1)
+    write_checkpoint(tmp_path, args, sd)
+    rec = Reconstruct(args)
+    rec.quiet = True
+    rec.t_start_subset = [970]
+    ref = oracle.DiffusionModelUNet(3, 128, 128, **MODEL_CONFIGS["small"]).eval()
+    ref.load_state_dict(sd)
+    vol = synthetic_images("blobs3d", 1, 1, 128, seed=5)
+    mk = lambda: ListLoader(vol, ["vol_000000.npy"], 1)  # noqa: E731
+    h = pd.DataFrame(rec.get_scores(mk(), "in", 32))
+    assert rec.last_stats["unet_forwards"] == 98
+    pl = oracle.PerceptualLoss(dimensions=3, include_pixel_loss=False, is_fake_3d=True, lpips_normalize=True)
+    pl.perceptual_function.load_state_dict(rec._perceptual().perceptual_function.state_dict())
+    o = pd.DataFrame(oracle.get_scores(
+        mk(), "in", 32, model=ref, vqvae=vq, perceptual=pl, spatial_dimension=3, t_start_subset=[970],
+        noise_fn=lambda batch, t, shape: batch_noise(2, batch["index"], t, shape),
+        beta_schedule=args.beta_schedule, beta_start=args.beta_start, beta_end=args.beta_end))
+    assert list(h["t"]) == list(o["t"]) == [970]
+    worst = assert_rows_close(h, o, 2e-4, "cfg5 t = 970")
+    print(f"cfg5, t = 970 (98 steps) on an 8^3 latent: raw scores max relative error {worst}")
+
+
+def test_cfg5_code_flip_sensitivity_on_an_unspread_codebook(device):
+    """The quantiser is the one discontinuous op of the path (reconstruct.py:166 -> decode_stage_2_outputs re-quantises the
+    denoised latent): a trained codebook has near-ties, and a latent that differs from the reference's in the 7th digit can pick
+    another code -- an O(1) change of a 16^3 block of the decoded volume.  This test measures how often, on a codebook that is
+    NOT spread (N(0, 1) rows, `embedding_init="normal"`: 2 048 codes in 128 dimensions):
+      (a) HIP vs oracle nearest-code search on the SAME latents: identical codes except where the two best distances tie within
+          fp32 rounding -- counted, and every differing position must be such a tie (gap <= 1e-4 relative);
+      (b) the same latents perturbed by 1e-6 relative (the size of a long chain's HIP-vs-oracle difference): flipped codes
+          counted and reported together with the gap distribution.
+    Consequence for Z (documented in DESIGN.md): a flip changes the MSE of its volume by the decoded difference of two
+    near-equidistant codes over 1 / 512 of the voxels; the reference itself is exposed to the same flips between any two
+    machines whose convolutions round differently, so the bar "Z within 1e-4" is only meaningful for volumes without a flip --
+    the product counts the near-ties of a run (`last_stats["vq_near_ties"]`, ddpm_vq_near_ties_read) so that a caller can see how
+    close it came."""
+    from oracle.vqvae import VQVAE as OracleVQVAE
+    from ddpm_ood_amd.vqvae import VQVAE
+
+    torch.manual_seed(3)
+    ovq = OracleVQVAE(**VQ_README).eval()  # codebook as initialised: N(0, 1) rows, not spread
+    vq = VQVAE(**VQ_README).eval()
+    vq.load_state_dict(ovq.state_dict())
+    vq = vq.to(device)
+    E = ovq.quantizer.quantizer.embedding.weight.detach().double()  # [2048, 128]
+    g = torch.Generator().manual_seed(17)
+    # latents near the codebook's own scale, 64 volumes of 8^3 positions = 32 768 searches
+    z = torch.randn(64, 128, 8, 8, 8, generator=g)
+    from ddpm_ood_amd import _lib
+
+    with torch.no_grad():
+        co = ovq.quantizer.quantizer.quantize(z)
+        _lib.vq_near_ties_read(clear=True)
+        ch = vq.quantizer.quantizer.quantize(z.to(device)).cpu()
+        near = _lib.vq_near_ties_read(clear=True)  # the product's own counter (ddpm_vq_near_ties_read): gaps <= 1e-5
+        zp = z * (1.0 + 1e-6 * torch.randn(z.shape, generator=g))
+        chp = vq.quantizer.quantizer.quantize(zp.to(device)).cpu()
+    flat = z.permute(0, 2, 3, 4, 1).reshape(-1, 128).double()
+    d = (flat * flat).sum(1, keepdim=True) - 2.0 * flat @ E.t() + (E * E).sum(1)[None]
+    best2 = torch.topk(d, 2, dim=1, largest=False).values
+    gap = ((best2[:, 1] - best2[:, 0]) / best2[:, 0].abs().clamp_min(1e-12)).reshape(co.shape)
+    differ = (ch != co)
+    flipped = (chp != ch)
+    print(f"un-spread codebook, {co.numel()} searches: HIP != oracle at {int(differ.sum())} positions, "
+          f"{int(flipped.sum())} flips under a 1e-6 relative perturbation; relative gap between the two nearest codes: "
+          f"min {gap.min():.2e}, 1st percentile {gap.flatten().kthvalue(max(1, gap.numel() // 100)).values:.2e}, median {gap.median():.2e}")
+    print(f"ddpm_vq_near_ties_read: {near} positions with a relative gap <= 1e-5 (float64 count: {int((gap <= 1e-5).sum())})")
+    # the counter sees what float64 sees, up to the fp32 rounding of the two distances (|d| ~ 256: a gap of 1e-5 is ~40 ulp)
+    assert abs(near - int((gap <= 1e-5).sum())) <= max(3, int((gap <= 2e-5).sum()) - int((gap <= 5e-6).sum()))
+    # a differing / flipped position is a near-tie, never a wrong search
+    assert bool((gap[differ] <= 1e-4).all()) and bool((gap[flipped] <= 1e-4).all())
+    # float64 ground truth: the HIP choice is within rounding of the true minimum everywhere
+    true_best = d.min(dim=1).values.reshape(co.shape)
+    d_h = d.gather(1, ch.reshape(-1, 1).long()).reshape(co.shape)
+    assert bool(((d_h - true_best) <= 1e-4 * true_best.abs().clamp_min(1e-12)).all())
+
+
 # ---- option branches of the loop ---------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("case", ["latent_pad", "v_prediction", "image_size", "diffusers_list", "snr_shift_b_scale",

@@ -133,6 +133,85 @@ def test_k64_trajectories_at_batch_128_absolute_z(device, tmp_path):
     live_oracle_pins_fixture("k64_b128", spec, rows_o, rows_h)
 
 
+def test_cfg2_25_chained_t_starts_at_batch_128_absolute_z(device, tmp_path):
+    """The workload bench.py times (BASELINE configs[1]: inference_skip_factor = 4 -> 25 chained t-starts 10 ... 970, 1 250 UNet
+    forwards per image, the t = 970 trajectory 98 steps long on stale PLMS history) AT A CHIP-FILLING DISPATCH: every set is 128
+    images in ONE batch, so every forward runs on the split-f16 F(4x4) kernel, the DMA-fed 1x1 and the direct stride-2 kernel
+    (profiler-asserted).  The oracle side is the committed rows of the first 16 images of every set
+    (tests/golden/rows_cfg2_25t_b128.csv: 60 000 CPU forwards; a per-image result does not depend on the batch it rides in),
+    pinned by the oracle run live on one image.  Raw scores <= 2e-4 relative, |dZ| <= 1e-4 ABSOLUTE (16 validation images) for
+    both columns, AUROC +-1e-3.  Reference: /root/reference/src/trainers/reconstruct.py:118-120,128-157,166."""
+    from parity_util import golden_rows, live_oracle_pins_fixture
+    from ddpm_ood_amd import synthetic
+    from ddpm_ood_amd.trainer import Reconstruct
+
+    spec, rows_o = golden_rows("cfg2_25t_b128")
+    sets = spec["sets"]
+    args = make_args(tmp_path, inference_skip_factor=spec["skip"], batch_size=spec["batch"], validation_ids=sets["val"],
+                     in_ids=sets["in"])
+    write_checkpoint(tmp_path, args, synthetic.random_state_dict("small", 1, seed=1))
+    rec = Reconstruct(args)
+    rec.quiet = True
+    rows_h = {}
+    for name, ids in sets.items():
+        rec.profile_first_steps = name == "val"
+        full = hip_scores(args, rec, ids, name)
+        rec.profile_first_steps = False
+        if name == "val":
+            prof = _report()
+            missing = [k for k in BENCH_KEYS + ("conv3x3_s2h",) if k not in prof]
+            assert not missing, (missing, sorted(prof))
+            # 25 profiled forwards (the first of each t-start): 22 ResnetBlock + 2 Upsample convolutions on the F(4x4) split-f16 kernel
+            assert prof["conv3x3_wino44h_gn_silu"]["launches"] == 25 * 22 and prof["conv3x3_wino44h_up"]["launches"] == 25 * 2, prof
+            assert "conv3x3_wino44_gn_silu" not in prof and "conv3x3_wino_gn_silu" not in prof and "conv3x3_d3s_gn_silu" not in prof, sorted(prof)
+        assert sorted(set(full["t"])) == list(range(10, 1000, 40))
+        assert rec.last_stats["unet_forwards"] == 128 * 1250 and len(full) == 128 * 25
+        keep = set(rows_o[name]["filename"])
+        assert len(keep) == spec["oracle_n"]
+        rows_h[name] = full[full["filename"].isin(keep)].reset_index(drop=True)
+        worst = assert_rows_close(rows_h[name], rows_o[name], 2e-4, name)
+        print(f"cfg2 25-t chain at B = 128, {name}: raw scores max relative error {worst}")
+    worst, auc_h, auc_o = assert_z_close(rows_h, rows_o)  # 16 validation images: the ABSOLUTE bound
+    assert rows_o["val"]["filename"].nunique() >= 16
+    print(f"cfg2 25-t chain at B = 128: max |dZ| = {worst:.2e} (absolute), AUROC hip {auc_h:.4f} / oracle {auc_o:.4f}")
+    live_oracle_pins_fixture("cfg2_25t_b128", spec, rows_o, rows_h)
+
+
+def test_cfg4_long_chains_to_t490(device, tmp_path):
+    """cfg4 (`big` UNet, 64x64x3, k = 2) on LONG chains: t_start in {10, 250, 490} of the chained list = 2 + 26 + 50 forwards per
+    image, each through 16 attention blocks (10 of them over 4 096 / 1 024 tokens on the register-resident split-f16 kernel) --
+    where a 22-bit product would show if it accumulated.  Oracle side: committed rows (tests/golden/rows_cfg4_t490.csv, 312 `big`
+    CPU forwards), pinned by the live oracle on the first validation image.  Raw scores <= 2e-4, Z (two validation images:
+    relative to max(1, |Z|), parity_util.assert_z_close), AUROC."""
+    from parity_util import golden_rows, live_oracle_pins_fixture
+    from ddpm_ood_amd import synthetic
+    from ddpm_ood_amd.trainer import Reconstruct
+
+    spec, rows_o = golden_rows("cfg4_t490")
+    sets = spec["sets"]
+    args = make_args(tmp_path, model_type="big", is_grayscale=0, inference_skip_factor=spec["skip"], batch_size=spec["batch"],
+                     validation_ids=sets["val"], in_ids=sets["in"])
+    write_checkpoint(tmp_path, args, synthetic.random_state_dict("big", 3, seed=1))
+    rec = Reconstruct(args)
+    rec.quiet = True
+    rec.t_start_subset = spec["t_start_subset"]
+    rows_h = {}
+    for name, ids in sets.items():
+        rec.profile_first_steps = name == "val"
+        rows_h[name] = hip_scores(args, rec, ids, name)
+        rec.profile_first_steps = False
+        if name == "val":
+            prof = _report()
+            assert prof["attention_fa"]["launches"] == 3 * 10, sorted(prof)  # three profiled forwards
+        n = rows_h[name]["filename"].nunique()
+        assert sorted(set(rows_h[name]["t"])) == [10, 250, 490] and rec.last_stats["unet_forwards"] == n * 78
+        worst = assert_rows_close(rows_h[name], rows_o[name], 2e-4, name)
+        print(f"cfg4 long chains, {name}: raw scores max relative error {worst}")
+    worst, auc_h, auc_o = assert_z_close(rows_h, rows_o)
+    print(f"cfg4, t in (10, 250, 490): max |dZ| / max(1, |Z|) = {worst:.2e}, AUROC hip {auc_h:.4f} / oracle {auc_o:.4f}")
+    live_oracle_pins_fixture("cfg4_t490", spec, rows_o, rows_h)
+
+
 def test_trained_weights_forward_and_trajectory_vs_oracle(device, tmp_path):
     """Parity on TRAINED weights: a short run of the product training loop (row f-3) moves the zero-initialised
     convolutions and the GroupNorm affines away from `random_state_dict`'s distribution; the checkpoint it writes is

@@ -177,7 +177,7 @@ def test_bench_self_launches_eight_ranks_on_one_gpu(device):
     env = dict(os.environ, DDPM_DIST_BACKEND="gloo", DDPM_DIST_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--images", "64",
-                          "--batch", "8", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
+                          "--batch", "8", "--no-cpu-baseline", "--dataset-images", "96"], env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -187,6 +187,10 @@ def test_bench_self_launches_eight_ranks_on_one_gpu(device):
     assert d["config"]["unet_forwards_per_image"] == 1250
     assert [x.split(":")[0] for x in d["devices"]] == [f"rank {r}" for r in range(8)]
     assert d["value"] > 0 and d["numeric_guard"] == {"batches_rerun_fp32": 0, "batches_nonfinite": 0}
+    # every rank's own timing is on the line, and the dataset-scale pass (here 96 images: 12 per rank) beside the 64-image one
+    assert [p["rank"] for p in d["per_rank"]] == list(range(8)) and all(p["images"] == 8 and p["timed_s"] > 0 for p in d["per_rank"])
+    assert all(len(p["gather_ms_per_step"]) == 1 and p["startup_s"] > 0 for p in d["per_rank"])
+    assert d["dataset_scale"]["images"] == 96 and d["dataset_scale"]["reconstructions"] == 96 * 25 and d["value_dataset_scale"] > 0
     err = out.stderr
     assert 0 <= err.find("start-up done") < err.find("timed region done"), err[-2000:]
 
@@ -201,7 +205,7 @@ def test_bench_self_launches_two_ranks_on_one_gpu(device):
     env = dict(os.environ, DDPM_DIST_BACKEND="gloo", DDPM_DIST_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "32",
-                          "--images", "64"], env=env, capture_output=True, text=True, timeout=1500)
+                          "--images", "64", "--no-dataset-scale"], env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]

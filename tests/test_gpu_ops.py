@@ -1526,57 +1526,3 @@ def test_conv1x1_small_launch_split_f16_vs_conv2d(device, case, monkeypatch):
     sub = ref[:, : Cout // 2]
     rel_small = (y2.cpu().double()[:, : Cout // 2] - sub).abs().max().item() / (sub - (residual.double()[:, : Cout // 2] if res else 0)).abs().max().item()
     assert rel_small < 2e-5, rel_small
-
-
-D3H_CASES = [
-    # B, C1, C2, Cout, H, gn, chan_add, residual
-    (2, 128, 0, 128, 32, True, True, False),      # 32x32: eight tile rows per 256-pixel tile, four tiles per image
-    (3, 256, 128, 128, 32, True, False, True),    # virtual concat, residual
-    (2, 256, 0, 256, 16, True, True, False),      # 16x16: one image per tile, two cout tiles
-    (3, 256, 256, 256, 16, True, False, True),
-    (1, 128, 0, 128, 64, True, True, True),       # 64x64: four rows per tile
-    (2, 64, 0, 128, 32, False, False, False),     # no prologue (raw input, V pre-scale 2^0), eight chunks
-    (5, 8, 0, 128, 16, False, True, False),       # a single chunk
-]
-
-
-@pytest.mark.parametrize("case", D3H_CASES)
-def test_conv_direct_split_f16_vs_conv2d(device, case, monkeypatch):
-    """conv_d3h.hip: the ResnetBlock 3x3 convolution as nine taps on the f16 MFMA with three exact f16 partial products per fp32
-    product (GroupNorm + SiLU prologue, concat, bias / temb / residual) against F.conv2d in float64: no Winograd transforms, so
-    the error is that of the products alone -- below the fp32 direct kernel's."""
-    monkeypatch.setenv("DDPM_CONV_D3H", "2")  # also for launches smaller than the chip
-    from ddpm_ood_amd import ops
-
-    B, C1, C2, Cout, H, gn, chan, res = case
-    g = torch.Generator().manual_seed(B * 11 + C1 + H)
-    Cin = C1 + C2
-    x = torch.randn(B, C1, H, H, generator=g) * 1.3 + 0.2
-    x2 = torch.randn(B, C2, H, H, generator=g) if C2 else None
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
-    b = torch.randn(Cout, generator=g)
-    gamma, beta = (torch.randn(Cin, generator=g), torch.randn(Cin, generator=g)) if gn else (None, None)
-    chan_add = torch.randn(B, Cout, generator=g) if chan else None
-    residual = torch.randn(B, Cout, H, H, generator=g) if res else None
-    xin = (x if x2 is None else torch.cat([x, x2], 1)).double()
-    if gn:
-        xin = F.silu(F.group_norm(xin, 32, gamma.double(), beta.double(), 1e-6))
-    ref = F.conv2d(xin, w.double(), b.double(), padding=1)
-    if chan:
-        ref = ref + chan_add.double()[:, :, None, None]
-    if res:
-        ref = ref + residual.double()
-    d = lambda t: None if t is None else t.to(device)
-    gs = gh = None
-    if gn:
-        gs, gh = ops.gn_scale_shift(d(x), d(gamma), d(beta), 32, 1e-6, x2=d(x2))
-    kw = dict(x2=d(x2), gscale=gs, gshift=gh, act=ops.ACT_SILU if gn else ops.ACT_NONE, chan_add=d(chan_add), residual=d(residual))
-    y = ops.conv(d(x), d(w), d(b), d3h=ops.pack_conv_d3h_weight(d(w)), **kw)
-    y0 = ops.conv(d(x), d(w), d(b), **kw)  # the fp32 MFMA kernels
-    torch.cuda.synchronize()
-    assert not torch.equal(y, y0)  # (the direct split-f16 kernel ran)
-    scale = ref.abs().max().item()
-    err = (y.cpu().double() - ref).abs().max().item() / scale
-    err0 = (y0.cpu().double() - ref).abs().max().item() / scale
-    print(f"{case}: direct split-f16 {err:.2e}, fp32 MFMA kernel {err0:.2e} (max relative to max |y|)")
-    assert math.isfinite(err) and err < 3e-6, (err, err0)

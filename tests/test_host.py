@@ -142,6 +142,31 @@ def test_ood_scoring_matches_oracle_and_handles_duplicates(tmp_path):
         ood.out_datasets_for("imagenet")
 
 
+def test_ood_scoring_nan_rows_product_and_oracle_agree():
+    """The trainer writes NaN rows on a genuine fp32 overflow (as the reference would).  pandas' groupby mean / std skip them
+    (ood_detection.py:152-174) and roc_auc_score refuses a NaN score (:206): product and oracle follow both."""
+    from ddpm_ood_amd import ood
+
+    df = pd.read_csv(G / "trajectory_rows.csv", index_col=0)
+    val, inn, out = (df[df["type"] == t].copy() for t in ("val", "in", "out"))
+    # one NaN row in val (skipped by the per-t mean / std) and one in `in` (skipped by that image's mean over t)
+    val.iloc[0, val.columns.get_loc("mse")] = np.nan
+    inn.iloc[1, inn.columns.get_loc("mse")] = np.nan
+    d1, m1, a1 = ood.score(val, inn, out)
+    d2, m2, a2 = oracle.z_scores_and_auroc(val, inn, out)
+    assert abs(a1 - a2) < 1e-12
+    z1, z2 = d1["z_score_mse"].to_numpy(), np.asarray(d2["z_score_mse"], dtype=np.float64)
+    assert np.array_equal(np.isnan(z1), np.isnan(z2)) and np.isnan(z1).sum() == 1
+    assert np.allclose(z1[~np.isnan(z1)], z2[~np.isnan(z2)], rtol=0, atol=1e-9)
+    # an image whose every row is NaN has a NaN score: both sides raise, as sklearn does
+    name = inn["filename"].iloc[0]
+    inn.loc[inn["filename"] == name, "mse"] = np.nan
+    with pytest.raises(ValueError):
+        ood.score(val, inn, out)
+    with pytest.raises(ValueError):
+        oracle.z_scores_and_auroc(val, inn, out)
+
+
 def test_reference_exceptions_are_kept(tmp_path):
     """FileNotFoundError / ValueError of the reference's setup (base.py:47-50,87-88; reconstruct.py:31-32)
     -- checked up to the point where a GPU becomes necessary."""

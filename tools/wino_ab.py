@@ -26,9 +26,8 @@ for B, C1, C2, Cout, H in SHAPES:
     b = torch.randn(Cout, device=dev, generator=g)
     temb = torch.randn(B, Cout, device=dev, generator=g)
     pk, wn, w44, w44h = ops.pack_conv_weight(w), ops.pack_wino_weight(w), ops.pack_wino44_weight(w), ops.pack_wino44h_weight(w)
-    d3h = ops.pack_conv_d3h_weight(w) if os.environ.get("AB_D3H", "0") == "1" else None  # the direct split-f16 kernel (conv_d3h.hip)
     gs, gh = ops.gn_scale_shift(x, torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), 32, 1e-6, x2=x2)
-    f = lambda: ops.conv(x, w, b, x2=x2, gscale=gs, gshift=gh, act=ops.ACT_SILU, packed=pk, wino=wn, wino44=w44, wino44h=w44h, chan_add=temb, d3h=d3h)  # noqa: E731
+    f = lambda: ops.conv(x, w, b, x2=x2, gscale=gs, gshift=gh, act=ops.ACT_SILU, packed=pk, wino=wn, wino44=w44, wino44h=w44h, chan_add=temb)  # noqa: E731
     y = f()
     ref = ops.conv(x, w, b, x2=x2, gscale=gs, gshift=gh, act=ops.ACT_SILU, packed=pk, chan_add=temb)
     err = (y - ref).abs().max().item()
@@ -47,4 +46,4 @@ for B, C1, C2, Cout, H in SHAPES:
     fl = 2.0 * B * H * H * Cout * Cin * 9
     print(f"{C1}+{C2}->{Cout}@{H}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.2f} alg TFLOP/s  ({fl / ms / 1e9 * 16 / 36 / 157.3:.3f} of MFMA peak)  "
           f"err vs direct {err:.1e}", flush=True)
-print(f"D3H={os.environ.get('AB_D3H', '0')} F16X3={os.environ.get('DDPM_WINO44_F16X3', '1')} WAVES={os.environ.get('DDPM_WINO_WAVES', '8')} WINO44={os.environ.get('DDPM_CONV_WINO44', '1')} SPLIT44={os.environ.get('DDPM_WINO44_SPLIT', '4')} total {tot * 1e3:.1f} us", flush=True)
+print(f"F16X3={os.environ.get('DDPM_WINO44_F16X3', '1')} WAVES={os.environ.get('DDPM_WINO_WAVES', '8')} WINO44={os.environ.get('DDPM_CONV_WINO44', '1')} SPLIT44={os.environ.get('DDPM_WINO44_SPLIT', '4')} total {tot * 1e3:.1f} us", flush=True)
