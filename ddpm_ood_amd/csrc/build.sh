@@ -8,7 +8,7 @@ obj="${here}/../../build/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 JOBS="${JOBS:-4}"
 mkdir -p "${obj}"
-srcs=(api conv_mfma conv_wino conv_wino44 conv_wino44h conv_d3s conv_s2h conv1x1_dma conv_direct conv3d_edge linear_skinny groupnorm attention attention_fa elementwise lpips vq
+srcs=(api conv_mfma conv_wino conv_wino44 conv_wino44h conv_wino44r conv_d3s conv_s2h conv1x1_dma conv_direct conv3d_edge linear_skinny groupnorm attention attention_fa elementwise lpips vq
       unet_engine)
 common=(--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value)
 # per-file flags: declare an array flags_<source> to add options to one translation unit, e.g.
@@ -16,6 +16,7 @@ common=(--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused
 # conv_wino44h: the SLP vectoriser packs the fp32 transform arithmetic into v_pk_fma_f32 / v_pk_add_f32, which cost more
 # than the scalar forms beside MFMAs (MI355X_MICROARCH.md, price of a filler)
 flags_conv_wino44h=(-fno-slp-vectorize)
+flags_conv_wino44r=(-fno-slp-vectorize)
 pids=()
 for f in "${srcs[@]}"; do
   extra_name="flags_${f}[@]"

@@ -43,6 +43,8 @@ struct Switches {
   int wino_split = 8;           // DDPM_WINO_SPLIT: most channel-stream splits of a conv_wino.hip launch smaller than half the chip (power of two)
   int wino44_xmap = -1;         // DDPM_WINO44_XMAP (-1: unset, each kernel has its own default)
   int w44_abl = 0;              // DDPM_W44_ABL
+  int w44h_reg = 1;             // DDPM_W44H_REG: 0 the LDS-fed form of the split-f16 F(4x4) kernel (conv_wino44h.hip; A/B), 1 the register-fed
+                                // form (conv_wino44r.hip, round 5)
   int w44h_xitem = 1;           // DDPM_W44H_XITEM: 0 every item of conv_wino44h.hip refills its pixel ring from scratch (A/B)
   bool up_wino44h = true;       // DDPM_UP_WINO44H
   int down_s2h = 1;             // DDPM_DOWN_S2H (0 off, 2 / 3 force a form)

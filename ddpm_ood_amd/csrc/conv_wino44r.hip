@@ -1,0 +1,613 @@
+// conv_wino44r.hip -- the split-f16 Winograd F(4x4, 3x3) convolution of conv_wino44h.hip with its chunk pipeline rebuilt.  Round 5.
+//
+// Same fused op (GroupNorm-affine + SiLU prologue, virtual concat, bias / temb / residual epilogue, GroupNorm statistics of the
+// output; reference call site /root/reference/src/trainers/reconstruct.py:151-153, layer list /root/reference/src/trainers/
+// base.py:66-86), same arithmetic (every fp32 product from four exact f16 partial products, fp32 accumulate, fp32 transforms),
+// same work item (64 couts x 32 tiles, nine 32x32 accumulator tiles per wave, eight pinned in a[0:127]), same packed weights,
+// same output transform -- BIT-IDENTICAL results (tests/test_gpu_wino44h.py holds the two kernels to each other).  What changed is
+// how an 8-channel chunk moves through the workgroup.  Two rounds of tuning left conv_wino44h_kernel at ~2 000 cycles per
+// 12-position phase with every pipe under 50 % (MFMA 18 %): three barriers per chunk, each preceded by a drain of the LDS queue and
+// of the U slot's LDS-DMA, each followed by a ~300-cycle wait for nine operand reads before the first MFMA can issue.  Here:
+//
+//   * U never touches LDS.  Wave (cb, pg) is the ONLY reader of its 3 x 3 x 1 KB of transformed weights per chunk (32 couts x
+//     8 channels x {hi, lo} of one position = exactly one MFMA A operand): it loads them straight into registers
+//     (buffer_load_dwordx4, the packed order is already the operand order), six jobs ahead, through a register ring.  No LDS-DMA
+//     issue (100-150 cycles apiece, 24 per phase), no U ring (48 KB), no A-operand ds_read, no vmcnt(0) in front of a barrier.
+//   * ONE barrier per chunk.  The freed LDS holds a V ring of two WHOLE chunks (2 x 36 KB = the epilogue's four exchange slabs),
+//     so everything a chunk interval writes is read in the next one and nothing else orders the waves.
+//   * A wave runs its stages as SEGMENTS, not slices: [pixel loads of chunk c + 2] [the 18 MFMAs of chunk c] [GroupNorm + SiLU
+//     of chunk c + 2 into the pixel ring] [its share of the V transform of chunk c + 1].  Waves 0-3 run the transform segment
+//     last, waves 4-7 (their SIMD partners) first: while one wave of a SIMD sits in its MFMA segment the other one issues VALU
+//     and LDS work -- the pairing MI355X_MICROARCH.md describes ("Two waves per SIMD").
+//   * All eight waves stage pixels (one channel of the chunk each); six of them (0, 1, 2, 4, 5, 6) run one V task per chunk =
+//     the 12 positions of a transform-row pair for 16 tiles x 8 channels (the task conv_wino44h.hip splits in halves over two
+//     phases), waves 3 and 7 none.
+//
+// LDS: V ring 2 x [row pair 3][position 12][plane 2][tile 32][8 ch f16] + pixel ring of four 4-channel half-tiles -- the same
+// bytes as conv_wino44h.hip, so both kernels fit the same shapes (w44h_geom).
+#include "wino44h_common.h"
+
+namespace ddpm {
+
+namespace {
+
+constexpr int kVCB = 3 * kVSB;  // bytes of one V slot: a whole chunk (36 864)
+static_assert(2 * kVCB == kRINGF * 4, "the V ring is the epilogue's four exchange slabs");
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// a wave-uniform pointer the compiler has moved to VGPRs (SGPR pressure) back into SGPRs for the scalar-load asm statements
+template <class T>
+__device__ __forceinline__ const T *uniform_ptr(const T *p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<const T *>(((uint64_t)hi << 32) | lo);
+}
+
+// six positions (O .. O + 5 of a row pair's 12) of a lane's channel pair into the V slot: hi plane at 2 pos, lo plane at 2 pos + 1
+template <int O>
+__device__ __forceinline__ void v_store_row(int vwa, const uint32_t (&hi6)[6], const uint32_t (&lo6)[6]) {
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(hi6[q]), "n"((2 * (O + q)) * (kT * 16)) : "memory");
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(lo6[q]), "n"((2 * (O + q) + 1) * (kT * 16)) : "memory");
+  }
+}
+
+}  // namespace
+
+// NRT = staging rounds of a wave per chunk (one channel); UIT = 0: one image per item, else units per image (4 or 1)
+template <bool AFFINE, int NRT, int UIT, bool RES, bool D3 = false, bool UP = false>
+__global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_desc a, const W44HGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool ONEIMG = UIT == 0;
+  constexpr int NGS = ONEIMG ? 1 : NRT / UIT;        // images per item = GroupNorm scale / shift pairs per channel
+  constexpr int GD = ONEIMG ? NRT : UIT;             // consecutive rounds that belong to one image
+  float *const P = smem + kRINGF;                    // pixel ring: 4 half-tiles of [4 channels][PCH] + 1 + 64 dump floats
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int cb = wave & 1, pg = wave >> 1;  // MFMA role: cout block, position group (positions 3 pg .. 3 pg + 2 of a row pair)
+#ifndef W44R_ROLE
+#define W44R_ROLE 0
+#endif
+  const bool lateprod = W44R_ROLE == 0 ? wave < 4 : W44R_ROLE == 1 ? (wave & 1) == 0 : ((wave >> 1) & 1) == 0;  // waves 0-3: V task at the END of a chunk interval; waves 4-7 (SIMD partners): first
+  const bool silu = a.act == DDPM_ACT_SILU;
+
+  // ---- this workgroup's items (as conv_wino44h.hip)
+  const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3;
+  int kt = wj % g.KT, slot = (wj / g.KT) * 8 + xcd;
+  if (g.xmap) {
+    kt = xcd % g.KT;
+    slot = wj * (8 / g.KT) + xcd / g.KT;
+  }
+  if (slot >= g.NS) return;
+  const int split = slot % g.S;
+  slot /= g.S;
+  const int part = slot % g.parts, it0 = (slot / g.parts) * g.IPW;
+  const int nitems = min(g.IPW, g.NIT - it0);
+  const int r0 = part * g.TR;
+  const int n_first = it0 * g.TI, n_end = n_first + nitems * g.TI;
+  const int NCHs = g.NCH / g.S, ch_lo = split * NCHs;  // this workgroup's chunk range (even length)
+  float *const outp = a.out + (size_t)split * g.pstride;
+
+  f32x16 acc8;  // tiles 0..7: a[0:127] by name (mfma_pin)
+  reserve_agprs();
+
+  // ---- U: wave (cb, pg), job (row pair t, i): position 3 pg + i of the pair, planes {hi, lo} x 32 couts x 8 channels = 1 KB at
+  //   slot (chunk, t) * kUSB + (2 (3 pg + i) + plane) * 1024 + (32 cb + cout) * 16       [packed order = MFMA A operand order]
+  const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(a.w_wino44h), 0, (int)((size_t)kX * a.Cout * g.Cin * g.nkd_w * 4), 0x00020000);
+  const int ukt = ((kt * g.nkd_w + g.kd0) * g.NCHc + ch_lo) * 3;  // U slot index of this workgroup's chunk 0, row pair 0
+  int ua = (3 * pg * 2 + lhi) * (kK * 16) + (cb * 32 + l31) * 16;
+  // ---- V (LDS bytes): slot (chunk & 1) * kVCB + t * kVSB + (2 position + plane) * 512 + tile * 16
+  int va = 3 * pg * (2 * kT * 16) + l31 * 16;
+
+  auto barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto zero_accumulators = [&]() __attribute__((always_inline)) {
+    zero_pinned_tiles();
+    float z;  // (a literal zero vector is materialised THROUGH a0..a15 by hipcc: an opaque zero keeps it in arch VGPRs)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    acc8 = f32x16{z, z, z, z, z, z, z, z, z, z, z, z, z, z, z, z};
+  };
+
+  // ---- zero borders once (pixel writes only ever touch in-image pixels)
+  for (int i = tid; i < 4 * g.HS; i += 512) P[i] = 0.f;
+  __syncthreads();
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+
+  // ================================================================================================ V tasks
+  // Waves 0, 1, 2, 4, 5, 6 = tasks q = 0..5: row pair q / 2, tile half q & 1.  lane = (tile of 16, channel pair j of 4); a task =
+  // the 12 positions of the pair for the lane's two channels: column passes of both channels (12 patch-row reads, 96 VALU), four
+  // row passes (48), twelve pair splits (48), 24 stores.
+  const int ptask = (wave & 3) == 3 ? -1 : wave - (wave >> 2);
+  const int pst = (ptask & 1) * 16 + (lane & 15), pj = lane >> 4;
+  int tb0;  // pixel-ring offset (floats) of this lane's patch origin in channel 2 j of an EVEN chunk (half-tile j >> 1, plane 2 (j & 1))
+  {
+    const int per = g.TR * g.TWc;
+    const int ti = pst / per, rem = pst - ti * per;
+    const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
+    tb0 = (pj >> 1) * g.HS + 2 * (pj & 1) * g.PCH + ti * g.IS + 4 * tr * g.PW + 4 * tc;
+  }
+  int vw0 = pst * 16 + 4 * pj;  // V store (bytes): + slot + t * kVSB + (2 position + plane) * 512
+  auto produce = [&](auto tc_, int cc) __attribute__((always_inline)) {  // V of stream chunk cc (slot cc & 1) from the pixel half-tiles 2 (cc & 1), 2 (cc & 1) + 1
+    constexpr int t = decltype(tc_)::value;
+    constexpr bool t0 = t == 0;
+    constexpr float c1 = t0 ? -5.f : t == 1 ? -2.f : -0.5f, c2 = t0 ? 4.f : c1, bm = t0 ? 0.f : t == 1 ? 1.f : 2.f;
+    asm volatile("" : "+v"(tb0), "+v"(vw0));  // keep the per-lane bases out of LICM's reach
+    const int pb0 = tb0 + (cc & 1) * 2 * g.HS;
+    float cA[2][6], cB[2][6];
+    // column pass of one channel: rows (0, 5): A = d4 - 5 d2 + 4 d0, B = d5 - 5 d3 + 4 d1;  rows (1, 2): p = d4 - 4 d2, q = d3 - 4 d1,
+    // A = p + q, B = p - q;  rows (3, 4): p = d4 - d2, q = d3 - d1, A = p + 2 q, B = p - 2 q   (conv_wino44h.hip's cstep, unsliced)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float *p = P + pb0 + c * g.PCH;
+      float d4[6], d2[6], dx[6], dy[6], dz[6], dw[6];
+      // rows 4, 2, 1 and: pair (0, 5) rows 0, 5, 3; pairs (1, 2), (3, 4) row 3 -- those pairs use rows 2 and 1 twice (same
+      // operation order as conv_wino44h.hip's cstep, which re-reads them: bit-identical)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) d4[q] = p[4 * g.PW + q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) d2[q] = p[2 * g.PW + q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dw[q] = p[1 * g.PW + q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dy[q] = p[(t0 ? 5 : 3) * g.PW + q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dx[q] = t0 ? p[q] : d2[q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dz[q] = t0 ? p[3 * g.PW + q] : dw[q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const float wa = __builtin_fmaf(c2, dx[q], __builtin_fmaf(c1, d2[q], d4[q]));
+        const float qq = __builtin_fmaf(c2, dw[q], __builtin_fmaf(c1, dz[q], dy[q]));
+        cA[c][q] = __builtin_fmaf(bm, qq, wa);
+        cB[c][q] = t0 ? qq : __builtin_fmaf(-bm, qq, wa);
+      }
+    }
+    int vwa = vw0 + (cc & 1) * kVCB + t * kVSB;
+    asm volatile("" : "+v"(vwa));  // ONE address register + immediates
+    float t0r[6], t1r[6];
+    uint32_t hi6[6], lo6[6];
+    bt6(cA[0], t0r);
+    bt6(cA[1], t1r);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) split_pair(t0r[q], t1r[q], hi6[q], lo6[q]);
+    v_store_row<0>(vwa, hi6, lo6);
+    bt6(cB[0], t0r);
+    bt6(cB[1], t1r);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) split_pair(t0r[q], t1r[q], hi6[q], lo6[q]);
+    v_store_row<6>(vwa, hi6, lo6);
+  };
+  auto produce_task = [&](int cc) __attribute__((always_inline)) {
+#ifndef W44R_NO_PROD
+    if (ptask < 0) return;
+    const int t = ptask >> 1;
+    if (t == 0) produce(I0{}, cc);
+    else if (t == 1) produce(I1{}, cc);
+    else produce(I2{}, cc);
+#endif
+  };
+
+  // ================================================================================================ pixel staging
+  // every wave: one channel of the 8-channel chunk (half-chunk wave >> 2, channel wave & 3 of it); round k = 64 pixels
+  const int sc = wave & 3, phalf = wave >> 2;
+  const int row_lo = max(0, 4 * r0 - 1), row_hi = min(a.Ho, 4 * (r0 + g.TR) + 1);
+  const int npx = (row_hi - row_lo) * a.Wo;
+  const int dump = 4 * g.PCH + 1 + lane;  // relative to the half-tile
+  int pix0, pw0, pixL = 0, pwL = 0;
+  {
+    const bool valid = lane < npx;
+    auto src_of = [&](int row, int col) __attribute__((always_inline)) { return UP ? ((row >> 1) * (a.Wo >> 1) + (col >> 1)) * 4 : (row * a.Wo + col) * 4; };
+    pix0 = valid ? src_of(row_lo + lane / a.Wo, lane % a.Wo) : (int)0x80000000;  // out of range: the load returns 0
+    pw0 = valid ? sc * g.PCH + (row_lo + lane / a.Wo - (4 * r0 - 1)) * g.PW + lane % a.Wo + 1 : dump;
+    if (ONEIMG) {
+      const int eL = lane + 64 * (NRT - 1);
+      const bool vL = eL < npx;
+      pixL = vL ? src_of(row_lo + eL / a.Wo, eL % a.Wo) : (int)0x80000000;
+      pwL = vL ? sc * g.PCH + (row_lo + eL / a.Wo - (4 * r0 - 1)) * g.PW + eL % a.Wo + 1 : dump;
+    }
+  }
+  const int prs = (64 / a.Wo) * g.PW;  // pixel-tile floats between a lane's pixels of consecutive rounds of one image
+  constexpr int kRoundBytes = UP ? 64 : 256;
+  auto pix_of = [&](int k) __attribute__((always_inline)) { return ONEIMG ? (k == NRT - 1 ? pixL : pix0 + kRoundBytes * k) : pix0 + kRoundBytes * (k % GD); };
+  auto pw_of = [&](int k) __attribute__((always_inline)) { return ONEIMG ? (k == NRT - 1 ? pwL : pw0 + k * prs) : pw0 + (k % GD) * prs + (k / GD) * g.IS; };
+  const int bytes1 = a.B * a.C1 * (D3 ? g.CS : UP ? g.HWin : g.HW) * 4, bytes2 = a.B * a.C2 * g.HW * 4;
+  const __amdgpu_buffer_rsrc_t rs_sc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gscale), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_sh =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gshift), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
+  int vzero;  // keeps the wave-uniform scale / shift loads on the vector memory path
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  float praw[NRT], gs[NGS], gh[NGS];
+
+  // pixel loads (+ GroupNorm pairs) of stream chunk cc of the item that starts at image n_cur; past the item's last chunk: the
+  // next item's first chunks (the pixel ring survives the output transform), behind the last item a harmless repeat
+  auto load_stage = [&](int cc, int n_cur, bool has_next) __attribute__((always_inline)) {
+#ifndef W44R_NO_PIXEL
+    const bool nxt = cc >= NCHs && has_next;
+    const int cl = nxt ? cc - NCHs : min(max(cc, 0), NCHs - 1);
+    const int n_it = nxt ? n_cur + g.TI : n_cur;
+    int cg = (ch_lo + cl) * kC + phalf * 4 + sc;
+    int soff3 = 0;
+    bool dok = true;  // D3: the depth tap's slice lies inside the volume
+    if (D3) {  // stream chunk -> (depth tap, channel chunk); image -> (batch item, slice); one image per item
+      const int kdi = cl / g.NCHc;
+      cg = (cl - kdi * g.NCHc) * kC + phalf * 4 + sc;
+      const int ni = min(n_it, g.NIMG - 1);
+      const int nb = ni / g.D, dsl = ni - nb * g.D + g.kd0 + kdi - 1;
+      dok = dsl >= 0 && dsl < g.D;
+      soff3 = ((nb * a.C1 + cg) * g.D + (dok ? dsl : 0)) * g.HW * 4;
+    }
+    const bool first = cg < a.C1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
+    const int cx = first ? a.C1 : a.C2, cgl = first ? cg : cg - a.C1;
+#pragma unroll
+    for (int k = 0; k < NRT; ++k) {
+      const int ni = min(n_it + (ONEIMG ? 0 : k / GD), g.NIMG - 1);
+      const int soff = D3 ? soff3 : (ni * cx + cgl) * (UP ? g.HWin : g.HW) * 4;
+      const int voff = D3 && !dok ? (int)0x80000000 : pix_of(k);
+      praw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    }
+    if (AFFINE) {
+      const int cga = (ch_lo + cl) * kC + phalf * 4 + sc;
+#pragma unroll
+      for (int i = 0; i < NGS; ++i) {
+        const int ni = min(n_it + i, g.NIMG - 1);
+        const int goff = (ni * g.Cin + cga) * 4;
+        gs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
+        gh[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
+      }
+    }
+#endif
+  };
+  auto activate_stage = [&](int cc) __attribute__((always_inline)) {  // pixel value x 2^3 (2^0 without prologue): the transform's output is the pre-scaled V
+#ifndef W44R_NO_PIXEL
+    asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL));
+    float *const Pr = P + (2 * (cc & 1) + phalf) * g.HS;
+#pragma unroll
+    for (int k = 0; k < NRT; ++k) {
+      const float x = praw[k];
+      float y;
+      if (AFFINE) {
+        const float sa = gs[k / GD], sb = gh[k / GD];
+        const float v = __builtin_fmaf(x, sa, sb);
+        const float t = __builtin_fmaf(x, -1.44269504088896341f * sa, -1.44269504088896341f * sb);
+        y = (kVScale * v) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+      } else {
+        y = kVScaleRaw * (silu ? silu_fast(x) : x);
+      }
+      Pr[pw_of(k)] = y;
+    }
+#endif
+  };
+
+  // ================================================================================================ MFMA jobs
+  // job jj = 3 t + i of a chunk: accumulator tile jj += U[pair t, position 3 pg + i] (Vh + Vl).  A comes from the register ring
+  // (six jobs ahead; 9 jobs per chunk, ring of 6: the indices repeat every two chunks, hence the two-chunk loop body), Bh / Bl by
+  // ds_read_b128 one job ahead.
+  h8 Ar[6];
+  auto load_a = [&](int cl, int jj) __attribute__((always_inline)) {  // job jj of chunk cl (clamped into the item: behind the last chunk a harmless repeat)
+    const int t = jj / 3, i = jj - 3 * t;
+    const int c2 = min(cl, NCHs - 1);
+    const v4i_t v = __builtin_bit_cast(v4i_t, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ua + i * (2 * kK * 16), (ukt + 3 * c2 + t) * kUSB, 0));
+    return __builtin_bit_cast(h8, v);
+  };
+  auto mfma_chunk = [&](auto parc, int cl) __attribute__((always_inline)) {  // PAR = chunk parity inside the two-chunk body: ring indices are constants
+    constexpr int PAR = decltype(parc)::value;
+    asm volatile("" : "+v"(ua), "+v"(va));
+    const int vb = va + (cl & 1) * kVCB;
+#ifdef W44R_NO_ALOAD
+#define W44R_LOAD_A(ri, cl_, jj_) asm volatile("" : "+v"(Ar[ri]))
+#else
+#define W44R_LOAD_A(ri, cl_, jj_) Ar[ri] = load_a(cl_, jj_)
+#endif
+#ifndef W44R_MFMA_PAIRS
+    // jobs two at a time, so that consecutive MFMAs never share an accumulator (a back-to-back dependent pair stalls the wave for
+    // the first one's full latency): (j, Vh) (j + 1, Vh) (j, Vl) (j + 1, Vl); the next pair's four B reads are issued first
+    auto boff = [&](int jj, int plane) __attribute__((always_inline)) { return (jj / 3) * kVSB + (2 * (jj % 3) + plane) * kT * 16; };
+    h8 Bh[4], Bl[4];
+    Bh[0] = lds_b128(vb, boff(0, 0));
+    Bl[0] = lds_b128(vb, boff(0, 1));
+    Bh[1] = lds_b128(vb, boff(1, 0));
+    Bl[1] = lds_b128(vb, boff(1, 1));
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int j0 = 2 * pp, j1 = j0 + 1, s0 = (pp & 1) * 2, s1 = s0 + 1, n0 = ((pp + 1) & 1) * 2, n1 = n0 + 1;
+      Bh[n0] = lds_b128(vb, boff(j0 + 2, 0));
+      Bl[n0] = lds_b128(vb, boff(j0 + 2, 1));
+      if (pp < 3) {
+        Bh[n1] = lds_b128(vb, boff(j0 + 3, 0));
+        Bl[n1] = lds_b128(vb, boff(j0 + 3, 1));
+      }
+      const int r0i = (PAR * 9 + j0) % 6, r1i = (PAR * 9 + j1) % 6;
+#ifndef W44R_NO_MFMA
+      // outstanding LDS reads, oldest first: Bh(j0) Bl(j0) Bh(j1) Bl(j1) + the next pair's four (two behind the last pair)
+      if (pp < 3) {
+        mfma_pin_wait<7>(j0, Ar[r0i], Bh[s0]);
+        mfma_pin_wait<5>(j1, Ar[r1i], Bh[s1]);
+        mfma_pin(j0, Ar[r0i], Bl[s0]);
+        mfma_pin_wait<4>(j1, Ar[r1i], Bl[s1]);
+      } else {
+        mfma_pin_wait<5>(j0, Ar[r0i], Bh[s0]);
+        mfma_pin_wait<3>(j1, Ar[r1i], Bh[s1]);
+        mfma_pin(j0, Ar[r0i], Bl[s0]);
+        mfma_pin_wait<2>(j1, Ar[r1i], Bl[s1]);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      W44R_LOAD_A(r0i, j0 + 6 < 9 ? cl : cl + 1, (j0 + 6) % 9);
+      W44R_LOAD_A(r1i, j1 + 6 < 9 ? cl : cl + 1, (j1 + 6) % 9);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      const int r8 = (PAR * 9 + 8) % 6;
+#ifndef W44R_NO_MFMA
+      mfma_v_pair_wait0(acc8, Ar[r8], Bh[0], Bl[0]);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      W44R_LOAD_A(r8, cl + 1, 5);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    h8 Bh[2], Bl[2];
+    Bh[0] = lds_b128(vb, 0);
+    Bl[0] = lds_b128(vb, kT * 16);
+#pragma unroll
+    for (int jj = 0; jj < 9; ++jj) {
+      if (jj < 8) {  // next job's B operands: row pair (jj + 1) / 3, position 3 pg + (jj + 1) % 3 (offsets fold to immediates)
+        Bh[(jj + 1) & 1] = lds_b128(vb, ((jj + 1) / 3) * kVSB + 2 * ((jj + 1) % 3) * kT * 16);
+        Bl[(jj + 1) & 1] = lds_b128(vb, ((jj + 1) / 3) * kVSB + (2 * ((jj + 1) % 3) + 1) * kT * 16);
+      }
+      const int ri = (PAR * 9 + jj) % 6;  // ring index of this job's A
+#ifndef W44R_NO_MFMA
+      if (jj == 8) {
+        mfma_v_pair_wait0(acc8, Ar[ri], Bh[jj & 1], Bl[jj & 1]);
+      } else {
+        // outstanding LDS reads, oldest first: Bh(jj), Bl(jj), Bh(jj + 1), Bl(jj + 1)
+        mfma_pin_wait<3>(jj, Ar[ri], Bh[jj & 1]);
+        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        mfma_pin(jj, Ar[ri], Bl[jj & 1]);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      // the A operand six jobs ahead (this ring register is free: the MFMAs above have read it)
+      W44R_LOAD_A(ri, jj + 6 < 9 ? cl : cl + 1, (jj + 6) % 9);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+#undef W44R_LOAD_A
+  };
+
+  for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
+    const bool first_item = n_cur == n_first || !g.xitem;
+    const bool has_next = g.xitem && n_cur + g.TI < n_end;
+    // ---- fill.  A workgroup's first item stages chunks 0 and 1 from scratch; later items find them in the pixel ring (staged
+    // during the previous item's last two chunk intervals: the ring survives the output transform) and only owe V of chunk 0.
+    if (first_item) {
+      load_stage(0, n_cur, has_next);
+      activate_stage(0);
+      load_stage(1, n_cur, has_next);
+      activate_stage(1);
+      barrier();
+    }
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) Ar[jj] = load_a(0, jj);
+    produce_task(0);
+    zero_accumulators();
+    barrier();
+    // ---- chunk intervals.  Interval c of a wave: loads of chunk c + 2, the 18 MFMAs of chunk c, activation of chunk c + 2, and
+    // its V task of chunk c + 1 -- waves 0-3 run that task LAST (before the interval's barrier), waves 4-7 FIRST (behind the
+    // previous interval's barrier: their "interval" is shifted by one segment, so that the two waves of a SIMD are never in their
+    // MFMA segments at the same time).  In program order both are: LMA(c); V task; with the barrier in front of the task (waves
+    // 4-7, task of chunk c + 2) or behind it (waves 0-3, task of chunk c + 1).  Everything an interval writes (V slot, pixel
+    // half-tiles) is read in the next one; the two-slot rings need nothing else.  Chunk NCHs is the next item's chunk 0: its V has
+    // to wait for the output transform, which owns the V ring.
+    const int pahead = lateprod ? 1 : 2;
+    if (!lateprod) produce_task(1);
+    auto interval = [&](auto parc, int cc) __attribute__((always_inline)) {
+      load_stage(cc + 2, n_cur, has_next);
+      mfma_chunk(parc, cc);
+      activate_stage(cc + 2);
+      if (!lateprod) barrier();
+      if (cc + pahead < NCHs) produce_task(cc + pahead);
+      if (lateprod) barrier();
+    };
+    for (int c = 0; c < NCHs; c += 2) {
+      interval(I0{}, c);
+      interval(I1{}, c + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the repeats past the last chunk: nothing may land after the item
+
+    // ---- end of an item: Y = A^T M A through four exchange slabs [xi][cout block][lane] (the V ring: every stage of the item has
+    // finished).  Pass q moves accumulator registers 4 q .. 4 q + 3 of all 36 positions; wave (cb, pg) then finishes register
+    // 4 q + pg of cout block cb: cout = 32 cb + 8 q + 4 lhi + pg, tile = l31 (conv_wino44h.hip's output transform, verbatim).
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' passes
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int el31 = elane & 31, elhi = elane >> 5;
+    const int per = g.TR * g.TWc;
+    const int ti = el31 / per, rem = el31 - ti * per;
+    const int tr = rem / g.TWc, tc = rem - tr * g.TWc;
+    const int n = n_cur + ti, ncl = min(n, g.NIMG - 1);
+    const int nbat = D3 ? ncl / g.D : ncl, dsl_o = D3 ? ncl - nbat * g.D : 0;  // (batch item, slice)
+    const int cstr = D3 ? g.CS : g.HW;                                        // channel stride
+    float *const XS = smem;
+    float kOutScale, unused_umax;
+    sload2(uniform_ptr(reinterpret_cast<const float *>(a.w_wino44h + (size_t)kX * a.Cout * g.Cin * 2 * g.nkd_w) + 1), kOutScale, unused_umax);
+    (void)unused_umax;
+    if (!AFFINE) kOutScale *= kVScale / kVScaleRaw;  // the packed tail carries 1 / (2^3 2^su)
+    // accumulator tile 3 t + i of wave pg holds position s = 3 pg + i of pair t: row (0,5 | 1,2 | 3,4)[s / 6], column s % 6
+    const int rsel = pg >> 1, cofs = 3 * (pg & 1);
+    const int xb0 = (rsel ? 5 : 0) * 6 + cofs, xb1 = (rsel ? 2 : 1) * 6 + cofs, xb2 = (rsel ? 4 : 3) * 6 + cofs;
+    float addv[4];
+    if (ONEIMG) {
+      const int co0 = kt * kK + cb * 32 + pg;
+      float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ts[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float *const tp = a.chan_add ? a.chan_add + (size_t)min(n_cur, g.NIMG - 1) * a.chan_add_stride + co0 : nullptr;
+      if (a.bias && tp) sload8x2(uniform_ptr(a.bias + co0), uniform_ptr(tp), bs, ts);
+      else if (a.bias) sload8(uniform_ptr(a.bias + co0), bs);
+      else if (tp) sload8(uniform_ptr(tp), ts);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) addv[q] = elhi ? bs[2 * q + 1] + ts[2 * q + 1] : bs[2 * q] + ts[2 * q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = kt * kK + cb * 32 + 8 * q + 4 * elhi + pg;
+        addv[q] = (a.bias ? a.bias[co] : 0.f) + (a.chan_add ? a.chan_add[(size_t)ncl * a.chan_add_stride + co] : 0.f);
+      }
+    }
+    const size_t co_e = (size_t)kt * kK + cb * 32 + 4 * elhi + pg;
+    const size_t obase0 = (D3 ? (((size_t)nbat * a.Cout + co_e) * g.D + dsl_o) * g.HW : ((size_t)ncl * a.Cout + co_e) * g.HW) +
+                          (size_t)(4 * (r0 + tr)) * a.Wo + 4 * tc;  // pass q: + 8 q cstr
+    v4f res[4];
+    auto load_res = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        res[k] = *reinterpret_cast<const v4f *>(a.residual + obase0 + (size_t)(8 * q) * cstr + (size_t)k * a.Wo);
+    };
+    if (RES) load_res(0);
+    const bool emit_stats = !D3 && a.stats_out != nullptr && g.S == 1;
+    auto pass = [&](auto qc) __attribute__((always_inline)) {
+      constexpr int q = decltype(qc)::value;
+      const size_t obase = obase0 + (size_t)(8 * q) * cstr;
+      float st_p = 0.f, st_s1 = 0.f, st_s2 = 0.f;  // this lane's 4x4 tile about a pivot (its first value)
+      {
+        float *xw = XS + cb * 64 + elane;
+#pragma unroll
+        for (int x = 0; x < 9; ++x) {
+          const int xi = (x < 3 ? xb0 : x < 6 ? xb1 : xb2) + x % 3;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            xw[rr * kXS + xi * 128] = x == 8 ? acc8[4 * q + rr] : read_pinned(16 * (x & 7) + 4 * q + rr);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const float *xr = XS + pg * kXS + cb * 64 + elane;  // + xi * 128
+      const float ad = addv[q];
+      auto half = [&](auto hc) __attribute__((always_inline)) {
+        constexpr int h = decltype(hc)::value;
+        float w[2][6];
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {  // columns of M through two rows of A^T
+          const float m1 = xr[(1 * 6 + jj) * 128], m2 = xr[(2 * 6 + jj) * 128], m3 = xr[(3 * 6 + jj) * 128],
+                      m4 = xr[(4 * 6 + jj) * 128];
+          if (h == 0) {
+            const float m0 = xr[(0 * 6 + jj) * 128];
+            w[0][jj] = (m0 + (m1 + m2)) + (m3 + m4);
+            w[1][jj] = __builtin_fmaf(2.f, m3 - m4, m1 - m2);
+          } else {
+            const float m5 = xr[(5 * 6 + jj) * 128];
+            w[0][jj] = __builtin_fmaf(4.f, m3 + m4, m1 + m2);
+            w[1][jj] = __builtin_fmaf(8.f, m3 - m4, m1 - m2) + m5;
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int k = 2 * h + kk;
+          float y[4];
+          at4(w[kk][0], w[kk][1], w[kk][2], w[kk][3], w[kk][4], w[kk][5], y);
+          v4f o = v4f{__builtin_fmaf(y[0], kOutScale, ad), __builtin_fmaf(y[1], kOutScale, ad),
+                      __builtin_fmaf(y[2], kOutScale, ad), __builtin_fmaf(y[3], kOutScale, ad)};
+          if (RES) o += res[k];
+          if (D3 && a.out_act == DDPM_ACT_RELU) o = v4f{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)};
+          if (n < g.NIMG) *reinterpret_cast<v4f *>(outp + obase + (size_t)k * a.Wo) = o;
+          if (emit_stats) {
+            if (k == 0) st_p = o[0];
+            const v4f dd = o - st_p;
+            st_s1 += (dd[0] + dd[1]) + (dd[2] + dd[3]);
+            st_s2 += (dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]);
+          }
+        }
+      };
+      half(I0{});
+      v4f r01[2];
+      if (RES && q < 3) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          r01[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * cstr + (size_t)k * a.Wo);
+      }
+      half(I1{});
+      if (RES && q < 3) {
+        res[0] = r01[0];
+        res[1] = r01[1];
+#pragma unroll
+        for (int k = 2; k < 4; ++k)
+          res[k] = *reinterpret_cast<const v4f *>(a.residual + obase + (size_t)8 * cstr + (size_t)k * a.Wo);
+      }
+      if (emit_stats) {
+        float mean = st_p + st_s1 * (1.f / 16.f);
+        float m2 = fmaxf(st_s2 - st_s1 * st_s1 * (1.f / 16.f), 0.f);
+        group_moments_last_lane(mean, m2, 16.f, per);
+        if (rem == per - 1 && n < g.NIMG) {
+          const size_t co = (size_t)kt * kK + cb * 32 + 8 * q + 4 * elhi + pg;
+          *reinterpret_cast<float2 *>(a.stats_out + (((size_t)n * a.Cout + co) * g.parts + part) * 2) = make_float2(mean, m2);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+#ifndef W44R_NO_EPI  // (timing experiment: no output transform / stores -- wrong results)
+    pass(I0{});
+    pass(I1{});
+    pass(I2{});
+    pass(std::integral_constant<int, 3>{});
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+int launch_conv_wino44r(const ddpm_conv_desc &dk, const W44HGeom &g, size_t lds, hipStream_t s) {
+  typedef void (*kern_t)(const ddpm_conv_desc, const W44HGeom);
+  // shapes: one image per item with 9 (32x32) or 10 (64x64) staging units, two 16x16 images, eight 8x8 images
+#define W44R_K(A, N, U) {conv_wino44r_kernel<A, N, U, false>, conv_wino44r_kernel<A, N, U, true>}
+  static const kern_t kerns[2][4][2] = {
+      {W44R_K(false, 9, 0), W44R_K(false, 10, 0), W44R_K(false, 8, 4), W44R_K(false, 8, 1)},
+      {W44R_K(true, 9, 0), W44R_K(true, 10, 0), W44R_K(true, 8, 4), W44R_K(true, 8, 1)}};
+#undef W44R_K
+  static bool attr_done = false;
+  if (!attr_done) {
+    for (int i = 0; i < 16; ++i)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[i / 8][i / 2 % 4][i % 2]),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int shape = g.TI == 1 ? (g.NRT == 9 ? 0 : 1) : g.UI == 4 ? 2 : 3;
+  kern_t kern = kerns[dk.gscale ? 1 : 0][shape][dk.residual ? 1 : 0];
+  if (g.up) {  // no prologue, no residual (w44h_geom)
+    static const kern_t kerns_up[4] = {conv_wino44r_kernel<false, 9, 0, false, false, true>, conv_wino44r_kernel<false, 10, 0, false, false, true>,
+                                       conv_wino44r_kernel<false, 8, 4, false, false, true>, conv_wino44r_kernel<false, 8, 1, false, false, true>};
+    static bool attr_up_done = false;
+    if (!attr_up_done) {
+      for (int i = 0; i < 4; ++i)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns_up[i]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_up_done = true;
+    }
+    kern = kerns_up[shape];
+  }
+  if (dk.dims == 3) {  // only reached without prologue and with whole slices per item (w44h_geom)
+    static const kern_t kerns3d[2][2] = {{conv_wino44r_kernel<false, 9, 0, false, true>, conv_wino44r_kernel<false, 9, 0, true, true>},
+                                         {conv_wino44r_kernel<false, 10, 0, false, true>, conv_wino44r_kernel<false, 10, 0, true, true>}};
+    static bool attr3_done = false;
+    if (!attr3_done) {
+      for (int i = 0; i < 4; ++i)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kerns3d[i / 2][i % 2]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+      attr3_done = true;
+    }
+    kern = kerns3d[g.NRT == 9 ? 0 : 1][dk.residual ? 1 : 0];
+  }
+  hipLaunchKernelGGL(kern, dim3(g.grid), dim3(512), lds, s, dk, g);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace ddpm

@@ -46,4 +46,4 @@ for B, C1, C2, Cout, H in SHAPES:
     fl = 2.0 * B * H * H * Cout * Cin * 9
     print(f"{C1}+{C2}->{Cout}@{H}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.2f} alg TFLOP/s  ({fl / ms / 1e9 * 16 / 36 / 157.3:.3f} of MFMA peak)  "
           f"err vs direct {err:.1e}", flush=True)
-print(f"F16X3={os.environ.get('DDPM_WINO44_F16X3', '1')} WAVES={os.environ.get('DDPM_WINO_WAVES', '8')} WINO44={os.environ.get('DDPM_CONV_WINO44', '1')} SPLIT44={os.environ.get('DDPM_WINO44_SPLIT', '4')} total {tot * 1e3:.1f} us", flush=True)
+print(f"REG={os.environ.get('DDPM_W44H_REG', '1')} F16X3={os.environ.get('DDPM_WINO44_F16X3', '1')} WAVES={os.environ.get('DDPM_WINO_WAVES', '8')} WINO44={os.environ.get('DDPM_CONV_WINO44', '1')} SPLIT44={os.environ.get('DDPM_WINO44_SPLIT', '4')} total {tot * 1e3:.1f} us", flush=True)
