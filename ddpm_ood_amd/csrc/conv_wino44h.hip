@@ -938,7 +938,13 @@ int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s) {
   }
   ProfScope prof(s, kname, flops, bytes);
   if (sw().w44h_reg) {  // the register-fed form (conv_wino44r.hip, round 5): same item, same packed weights, bit-identical results
-    if (const int rc = launch_conv_wino44r(dk, g, lds, s)) return rc;
+    W44HGeom gr = g;
+    w44r_relayout(d, gr);
+    if (w44h_lds_bytes(gr) > 160 * 1024) {
+      set_error("conv_wino44r: pixel-tile layout does not fit");
+      return DDPM_EINVAL;
+    }
+    if (const int rc = launch_conv_wino44r(dk, gr, w44h_lds_bytes(gr), s)) return rc;
   } else {
     hipLaunchKernelGGL(kern, dim3(g.grid), dim3(512), lds, s, dk, g);
     DDPM_CHECK_LAUNCH();

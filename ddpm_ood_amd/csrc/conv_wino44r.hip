@@ -35,6 +35,25 @@ constexpr int kVCB = 3 * kVSB;  // bytes of one V slot: a whole chunk (36 864)
 static_assert(2 * kVCB == kRINGF * 4, "the V ring is the epilogue's four exchange slabs");
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+
+// the same six positions through ds_write_addtid_b32 (address = M0 + offset + 4 lane, no address VGPR, twice the rate of
+// ds_write_b32): with lane = 4 tile + channel pair a position's plane of 16 tiles x 8 channels is 256 lane-linear bytes.  m0base:
+// wave-uniform byte address of the task's block (V slot + row pair + tile half).  (M0 is not otherwise used by this kernel: no
+// LDS-DMA, no movrel; the compiler sets it right before any use of its own.)
+template <int O>
+__device__ __forceinline__ void v_store_row_addtid(int m0base, const uint32_t (&hi6)[6], const uint32_t (&lo6)[6]) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 1" ::"s"(m0base));  // (SALU write of M0 -> add-TID LDS instruction: one wait state)
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+#ifdef W44R_NO_VSTORE  // (timing experiment)
+    asm volatile("" ::"v"(hi6[q]), "v"(lo6[q]));
+#else
+    asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(hi6[q]), "n"((2 * (O + q)) * (kT * 16)) : "memory");
+    asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(lo6[q]), "n"((2 * (O + q) + 1) * (kT * 16)) : "memory");
+#endif
+  }
+}
 
 // a wave-uniform pointer the compiler has moved to VGPRs (SGPR pressure) back into SGPRs for the scalar-load asm statements
 template <class T>
@@ -49,8 +68,12 @@ template <int O>
 __device__ __forceinline__ void v_store_row(int vwa, const uint32_t (&hi6)[6], const uint32_t (&lo6)[6]) {
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
+#ifdef W44R_NO_VSTORE  // (timing experiment)
+    asm volatile("" ::"v"(vwa), "v"(hi6[q]), "v"(lo6[q]));
+#else
     asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(hi6[q]), "n"((2 * (O + q)) * (kT * 16)) : "memory");
     asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(lo6[q]), "n"((2 * (O + q) + 1) * (kT * 16)) : "memory");
+#endif
   }
 }
 
@@ -123,12 +146,23 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
 
+#ifdef W44R_PROBE  // timing experiment: cycle stamps of workgroup 0, every wave, chunk intervals 4..7 of the first item -> desc.scratch
+  int probe_cc = -100;
+#define W44R_STAMP(i)                                                                                                  \
+  if (blockIdx.x == 0 && probe_cc >= 4 && probe_cc < 8 && lane == 0 && a.scratch)                                      \
+    reinterpret_cast<unsigned long long *>(a.scratch)[((wave * 4 + (probe_cc - 4)) * 16 + (i)) & 511] = __builtin_readcyclecounter();
+#else
+#define W44R_STAMP(i)
+#endif
   // ================================================================================================ V tasks
   // Waves 0, 1, 2, 4, 5, 6 = tasks q = 0..5: row pair q / 2, tile half q & 1.  lane = (tile of 16, channel pair j of 4); a task =
   // the 12 positions of the pair for the lane's two channels: column passes of both channels (12 patch-row reads, 96 VALU), four
   // row passes (48), twelve pair splits (48), 24 stores.
+  // NEWLAY (every shape but the eight-images-per-item one): lane = 4 tile + j and the pixel-tile layout of w44r_relayout() -- patch
+  // rows are two conflict-free ds_read_b128, a position's V plane of 16 tiles is lane-linear (ds_write_addtid_b32).
+  constexpr bool NEWLAY = UIT != 1;
   const int ptask = (wave & 3) == 3 ? -1 : wave - (wave >> 2);
-  const int pst = (ptask & 1) * 16 + (lane & 15), pj = lane >> 4;
+  const int pst = (ptask & 1) * 16 + (NEWLAY ? lane >> 2 : lane & 15), pj = NEWLAY ? lane & 3 : lane >> 4;
   int tb0;  // pixel-ring offset (floats) of this lane's patch origin in channel 2 j of an EVEN chunk (half-tile j >> 1, plane 2 (j & 1))
   {
     const int per = g.TR * g.TWc;
@@ -152,18 +186,36 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       float d4[6], d2[6], dx[6], dy[6], dz[6], dw[6];
       // rows 4, 2, 1 and: pair (0, 5) rows 0, 5, 3; pairs (1, 2), (3, 4) row 3 -- those pairs use rows 2 and 1 twice (same
       // operation order as conv_wino44h.hip's cstep, which re-reads them: bit-identical)
+      auto row = [&](int r, float (&dst)[6]) __attribute__((always_inline)) {
+#ifdef W44R_NO_PREAD  // (timing experiment: the patch rows come from nowhere)
+        float fk;
+        asm volatile("v_mov_b32 %0, 1.0" : "=v"(fk));
 #pragma unroll
-      for (int q = 0; q < 6; ++q) d4[q] = p[4 * g.PW + q];
+        for (int q = 0; q < 6; ++q) dst[q] = fk;
+#else
+        if (NEWLAY) {  // 16-byte aligned (w44r_relayout): columns 0-3 conflict-free by ds_read_b128, columns 4-5 by ds_read_b64
+          // (as a second b128 with two dead floats hipcc overlapped the destination registers of consecutive rows and put a
+          // full lgkmcnt(0) between them: eight exposed LDS latencies per task)
+          const v4f lo = *reinterpret_cast<const v4f *>(p + r * g.PW);
+          const v2f_t hi = *reinterpret_cast<const v2f_t *>(p + r * g.PW + 4);
+          dst[0] = lo[0]; dst[1] = lo[1]; dst[2] = lo[2]; dst[3] = lo[3]; dst[4] = hi[0]; dst[5] = hi[1];
+        } else {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) d2[q] = p[2 * g.PW + q];
+          for (int q = 0; q < 6; ++q) dst[q] = p[r * g.PW + q];
+        }
+#endif
+      };
+      row(4, d4);
+      row(2, d2);
+      row(1, dw);
+      row(t0 ? 5 : 3, dy);
+      if (t0) {
+        row(0, dx);
+        row(3, dz);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) dw[q] = p[1 * g.PW + q];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) dy[q] = p[(t0 ? 5 : 3) * g.PW + q];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) dx[q] = t0 ? p[q] : d2[q];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) dz[q] = t0 ? p[3 * g.PW + q] : dw[q];
+        for (int q = 0; q < 6; ++q) dx[q] = d2[q], dz[q] = dw[q];
+      }
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         const float wa = __builtin_fmaf(c2, dx[q], __builtin_fmaf(c1, d2[q], d4[q]));
@@ -171,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
         cA[c][q] = __builtin_fmaf(bm, qq, wa);
         cB[c][q] = t0 ? qq : __builtin_fmaf(-bm, qq, wa);
       }
+      if (c == 0) { W44R_STAMP(8) } else { W44R_STAMP(9) }
     }
     int vwa = vw0 + (cc & 1) * kVCB + t * kVSB;
     asm volatile("" : "+v"(vwa));  // ONE address register + immediates
@@ -180,12 +233,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     bt6(cA[1], t1r);
 #pragma unroll
     for (int q = 0; q < 6; ++q) split_pair(t0r[q], t1r[q], hi6[q], lo6[q]);
-    v_store_row<0>(vwa, hi6, lo6);
+    const int m0base = __builtin_amdgcn_readfirstlane((cc & 1) * kVCB + t * kVSB + (ptask & 1) * 256);
+    W44R_STAMP(10)
+    if (NEWLAY) v_store_row_addtid<0>(m0base, hi6, lo6);
+    else v_store_row<0>(vwa, hi6, lo6);
+    W44R_STAMP(11)
     bt6(cB[0], t0r);
     bt6(cB[1], t1r);
 #pragma unroll
     for (int q = 0; q < 6; ++q) split_pair(t0r[q], t1r[q], hi6[q], lo6[q]);
-    v_store_row<6>(vwa, hi6, lo6);
+    if (NEWLAY) v_store_row_addtid<6>(m0base, hi6, lo6);
+    else v_store_row<6>(vwa, hi6, lo6);
   };
   auto produce_task = [&](int cc) __attribute__((always_inline)) {
 #ifndef W44R_NO_PROD
@@ -415,12 +473,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     const int pahead = lateprod ? 1 : 2;
     if (!lateprod) produce_task(1);
     auto interval = [&](auto parc, int cc) __attribute__((always_inline)) {
+#ifdef W44R_PROBE
+      probe_cc = n_cur == n_first ? cc : -100;
+#endif
+      W44R_STAMP(0)
       load_stage(cc + 2, n_cur, has_next);
+      W44R_STAMP(1)
       mfma_chunk(parc, cc);
+      W44R_STAMP(2)
       activate_stage(cc + 2);
+      W44R_STAMP(3)
       if (!lateprod) barrier();
+      W44R_STAMP(4)
       if (cc + pahead < NCHs) produce_task(cc + pahead);
+      W44R_STAMP(5)
       if (lateprod) barrier();
+      W44R_STAMP(6)
     };
     for (int c = 0; c < NCHs; c += 2) {
       interval(I0{}, c);
@@ -563,6 +631,27 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #endif
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// The pixel-tile layout of the register-fed kernel (every shape but eight images per item).  A V task's lane = (tile of 16,
+// channel pair j of 4) reads, per patch row, columns 0-3 and 4-7 as two ds_read_b128.  ds_read_b128 is served in four groups of 16
+// lanes = 4 tiles x 4 pairs (tiles {0,3,5,6}, {1,2,4,7}, {8,11,13,14}, {9,10,12,15} of the task's 16): conflict-free iff the 16
+// addresses are distinct modulo 256 bytes, i.e. in 16-byte units  U(tile) + O(j)  distinct modulo 16.  With
+//   U(tile) = tile (mod 16):  row length PW = 8 (mod 16) units for 8 tile columns (32x32), 4 (mod 16) for 4 (16x16), anything for 16,
+//   O(j) = 0, 8, 4, 12:       channel-plane stride PCH = 16 (mod 32) floats, half-tile stride HS = 16 (mod 64) floats
+// every group sees {0,3,5,6} + {0,8,4,12} = all 16 residues.  Rows are 16-byte aligned (PW % 4 == 0; pixel (r, c) at r PW + c + 1,
+// so a tile's patch starts at column 4 tc).
+void w44r_relayout(const ddpm_conv_desc &d, W44HGeom &g) {
+  if (g.TI == 8) return;  // 8x8 images: conv_wino44h.hip's layout and its 4-byte patch reads
+  const int w = d.Wo + 2;
+  int pw = (w + 3) & ~3;
+  if (g.TWc == 8) while (pw % 16 != 8) pw += 4;
+  if (g.TWc == 4) while (pw % 16 != 4) pw += 4;
+  g.PW = pw;
+  g.IS = g.prow * g.PW;
+  g.PCH = g.TI * g.IS;
+  while (g.PCH % 32 != 16) g.PCH += 1;
+  g.HS = 4 * g.PCH + 80;  // = 16 (mod 64); the 64 dump floats of out-of-image lanes sit at 4 PCH + 1 ..
 }
 
 int launch_conv_wino44r(const ddpm_conv_desc &dk, const W44HGeom &g, size_t lds, hipStream_t s) {

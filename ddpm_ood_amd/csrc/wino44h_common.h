@@ -208,5 +208,6 @@ bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false);  // c
 inline size_t w44h_lds_bytes(const W44HGeom &g) { return ((size_t)kRINGF + 4 * (size_t)g.HS) * sizeof(float); }
 // conv_wino44r.hip: the same fused convolution, item and packed weights on the register-fed form of the kernel
 int launch_conv_wino44r(const ddpm_conv_desc &dk, const W44HGeom &g, size_t lds, hipStream_t s);
+void w44r_relayout(const ddpm_conv_desc &d, W44HGeom &g);  // its pixel-tile layout (never larger than conv_wino44h.hip's)
 
 }  // namespace ddpm
