@@ -223,7 +223,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
         cA[c][q] = __builtin_fmaf(bm, qq, wa);
         cB[c][q] = t0 ? qq : __builtin_fmaf(-bm, qq, wa);
       }
-      if (c == 0) { W44R_STAMP(8) } else { W44R_STAMP(9) }
     }
     int vwa = vw0 + (cc & 1) * kVCB + t * kVSB;
     asm volatile("" : "+v"(vwa));  // ONE address register + immediates
@@ -234,10 +233,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #pragma unroll
     for (int q = 0; q < 6; ++q) split_pair(t0r[q], t1r[q], hi6[q], lo6[q]);
     const int m0base = __builtin_amdgcn_readfirstlane((cc & 1) * kVCB + t * kVSB + (ptask & 1) * 256);
-    W44R_STAMP(10)
     if (NEWLAY) v_store_row_addtid<0>(m0base, hi6, lo6);
     else v_store_row<0>(vwa, hi6, lo6);
-    W44R_STAMP(11)
     bt6(cB[0], t0r);
     bt6(cB[1], t1r);
 #pragma unroll
@@ -285,68 +282,92 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gshift), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
   int vzero;  // keeps the wave-uniform scale / shift loads on the vector memory path
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-  float praw[NRT], gs[NGS], gh[NGS];
-
-  // pixel loads (+ GroupNorm pairs) of stream chunk cc of the item that starts at image n_cur; past the item's last chunk: the
-  // next item's first chunks (the pixel ring survives the output transform), behind the last item a harmless repeat
-  auto load_stage = [&](int cc, int n_cur, bool has_next) __attribute__((always_inline)) {
-#ifndef W44R_NO_PIXEL
+  // DEEP (every shape but eight images per item, whose 16 scale / shift pairs per set do not fit twice): TWO register sets.
+  // Interval c requests chunk c + 3 into set (c + 1) & 1 and activates chunk c + 2 from set c & 1 (requested an interval earlier),
+  // one round behind each MFMA job: nothing in a wave ever waits for a pixel load, and the loads' issue and the GroupNorm +
+  // SiLU arithmetic hide behind the MFMAs.  Otherwise one set: loads in front of the MFMA segment, activation behind it.
+  constexpr bool DEEP = UIT != 1;
+  constexpr int NSET = DEEP ? 2 : 1;
+  float praw[NSET][NRT], gs[NSET][NGS], gh[NSET][NGS];
+  struct LoadCtx {  // wave-uniform addressing of one stream chunk's loads (SGPRs)
+    __amdgpu_buffer_rsrc_t rs;
+    int n_it, cx, cgl, cga, soff3;
+    bool dok;
+  };
+  // stream chunk cc of the item that starts at image n_cur; past the item's last chunk: the next item's first chunks (the pixel
+  // ring survives the output transform), behind the last item a harmless repeat
+  auto load_prep = [&](int cc, int n_cur, bool has_next) __attribute__((always_inline)) {
+    LoadCtx L;
     const bool nxt = cc >= NCHs && has_next;
     const int cl = nxt ? cc - NCHs : min(max(cc, 0), NCHs - 1);
-    const int n_it = nxt ? n_cur + g.TI : n_cur;
+    L.n_it = nxt ? n_cur + g.TI : n_cur;
     int cg = (ch_lo + cl) * kC + phalf * 4 + sc;
-    int soff3 = 0;
-    bool dok = true;  // D3: the depth tap's slice lies inside the volume
+    L.cga = cg;
+    L.soff3 = 0;
+    L.dok = true;  // D3: the depth tap's slice lies inside the volume
     if (D3) {  // stream chunk -> (depth tap, channel chunk); image -> (batch item, slice); one image per item
       const int kdi = cl / g.NCHc;
       cg = (cl - kdi * g.NCHc) * kC + phalf * 4 + sc;
-      const int ni = min(n_it, g.NIMG - 1);
+      const int ni = min(L.n_it, g.NIMG - 1);
       const int nb = ni / g.D, dsl = ni - nb * g.D + g.kd0 + kdi - 1;
-      dok = dsl >= 0 && dsl < g.D;
-      soff3 = ((nb * a.C1 + cg) * g.D + (dok ? dsl : 0)) * g.HW * 4;
+      L.dok = dsl >= 0 && dsl < g.D;
+      L.soff3 = ((nb * a.C1 + cg) * g.D + (L.dok ? dsl : 0)) * g.HW * 4;
     }
     const bool first = cg < a.C1;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
-    const int cx = first ? a.C1 : a.C2, cgl = first ? cg : cg - a.C1;
-#pragma unroll
-    for (int k = 0; k < NRT; ++k) {
-      const int ni = min(n_it + (ONEIMG ? 0 : k / GD), g.NIMG - 1);
-      const int soff = D3 ? soff3 : (ni * cx + cgl) * (UP ? g.HWin : g.HW) * 4;
-      const int voff = D3 && !dok ? (int)0x80000000 : pix_of(k);
-      praw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
-    }
+    L.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(first ? a.in1 : a.in2), 0, first ? bytes1 : bytes2, 0x00020000);
+    L.cx = first ? a.C1 : a.C2;
+    L.cgl = first ? cg : cg - a.C1;
+    return L;
+  };
+  auto load_round = [&](const LoadCtx &L, auto setc, int k) __attribute__((always_inline)) {
+    constexpr int S = decltype(setc)::value;
+#ifndef W44R_NO_PIXEL
+    const int ni = min(L.n_it + (ONEIMG ? 0 : k / GD), g.NIMG - 1);
+    const int soff = D3 ? L.soff3 : (ni * L.cx + L.cgl) * (UP ? g.HWin : g.HW) * 4;
+    const int voff = D3 && !L.dok ? (int)0x80000000 : pix_of(k);
+    praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(L.rs, voff, soff, 0));
+#endif
+  };
+  auto load_affine = [&](const LoadCtx &L, auto setc, int i) __attribute__((always_inline)) {
+    constexpr int S = decltype(setc)::value;
+#ifndef W44R_NO_PIXEL
     if (AFFINE) {
-      const int cga = (ch_lo + cl) * kC + phalf * 4 + sc;
-#pragma unroll
-      for (int i = 0; i < NGS; ++i) {
-        const int ni = min(n_it + i, g.NIMG - 1);
-        const int goff = (ni * g.Cin + cga) * 4;
-        gs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
-        gh[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
-      }
+      const int ni = min(L.n_it + i, g.NIMG - 1);
+      const int goff = (ni * g.Cin + L.cga) * 4;
+      gs[S][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
+      gh[S][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
     }
 #endif
   };
-  auto activate_stage = [&](int cc) __attribute__((always_inline)) {  // pixel value x 2^3 (2^0 without prologue): the transform's output is the pre-scaled V
-#ifndef W44R_NO_PIXEL
-    asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL));
-    float *const Pr = P + (2 * (cc & 1) + phalf) * g.HS;
+  auto load_stage = [&](auto setc, int cc, int n_cur, bool has_next) __attribute__((always_inline)) {
+    const LoadCtx L = load_prep(cc, n_cur, has_next);
 #pragma unroll
-    for (int k = 0; k < NRT; ++k) {
-      const float x = praw[k];
-      float y;
-      if (AFFINE) {
-        const float sa = gs[k / GD], sb = gh[k / GD];
-        const float v = __builtin_fmaf(x, sa, sb);
-        const float t = __builtin_fmaf(x, -1.44269504088896341f * sa, -1.44269504088896341f * sb);
-        y = (kVScale * v) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
-      } else {
-        y = kVScaleRaw * (silu ? silu_fast(x) : x);
-      }
-      Pr[pw_of(k)] = y;
+    for (int k = 0; k < NRT; ++k) load_round(L, setc, k);
+#pragma unroll
+    for (int i = 0; i < NGS; ++i) load_affine(L, setc, i);
+  };
+  // pixel value x 2^3 (2^0 without prologue): the transform's output is the pre-scaled V
+  auto activate_round = [&](auto setc, int cc, int k) __attribute__((always_inline)) {
+    constexpr int S = decltype(setc)::value;
+#ifndef W44R_NO_PIXEL
+    float *const Pr = P + (2 * (cc & 1) + phalf) * g.HS;
+    const float x = praw[S][k];
+    float y;
+    if (AFFINE) {
+      const float sa = gs[S][k / GD], sb = gh[S][k / GD];
+      const float v = __builtin_fmaf(x, sa, sb);
+      const float t = __builtin_fmaf(x, -1.44269504088896341f * sa, -1.44269504088896341f * sb);
+      y = (kVScale * v) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+    } else {
+      y = kVScaleRaw * (silu ? silu_fast(x) : x);
     }
+    Pr[pw_of(k)] = y;
 #endif
+  };
+  auto activate_stage = [&](auto setc, int cc) __attribute__((always_inline)) {
+    asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL));
+#pragma unroll
+    for (int k = 0; k < NRT; ++k) activate_round(setc, cc, k);
   };
 
   // ================================================================================================ MFMA jobs
@@ -360,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     const v4i_t v = __builtin_bit_cast(v4i_t, __builtin_amdgcn_raw_buffer_load_b128(rs_u, ua + i * (2 * kK * 16), (ukt + 3 * c2 + t) * kUSB, 0));
     return __builtin_bit_cast(h8, v);
   };
-  auto mfma_chunk = [&](auto parc, int cl) __attribute__((always_inline)) {  // PAR = chunk parity inside the two-chunk body: ring indices are constants
+  auto mfma_chunk = [&](auto parc, int cl, auto &&slice) __attribute__((always_inline)) {  // PAR = chunk parity inside the two-chunk body: ring indices are constants
     constexpr int PAR = decltype(parc)::value;
     asm volatile("" : "+v"(ua), "+v"(va));
     const int vb = va + (cl & 1) * kVCB;
@@ -369,54 +390,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #else
 #define W44R_LOAD_A(ri, cl_, jj_) Ar[ri] = load_a(cl_, jj_)
 #endif
-#ifndef W44R_MFMA_PAIRS
-    // jobs two at a time, so that consecutive MFMAs never share an accumulator (a back-to-back dependent pair stalls the wave for
-    // the first one's full latency): (j, Vh) (j + 1, Vh) (j, Vl) (j + 1, Vl); the next pair's four B reads are issued first
-    auto boff = [&](int jj, int plane) __attribute__((always_inline)) { return (jj / 3) * kVSB + (2 * (jj % 3) + plane) * kT * 16; };
-    h8 Bh[4], Bl[4];
-    Bh[0] = lds_b128(vb, boff(0, 0));
-    Bl[0] = lds_b128(vb, boff(0, 1));
-    Bh[1] = lds_b128(vb, boff(1, 0));
-    Bl[1] = lds_b128(vb, boff(1, 1));
-#pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {
-      const int j0 = 2 * pp, j1 = j0 + 1, s0 = (pp & 1) * 2, s1 = s0 + 1, n0 = ((pp + 1) & 1) * 2, n1 = n0 + 1;
-      Bh[n0] = lds_b128(vb, boff(j0 + 2, 0));
-      Bl[n0] = lds_b128(vb, boff(j0 + 2, 1));
-      if (pp < 3) {
-        Bh[n1] = lds_b128(vb, boff(j0 + 3, 0));
-        Bl[n1] = lds_b128(vb, boff(j0 + 3, 1));
-      }
-      const int r0i = (PAR * 9 + j0) % 6, r1i = (PAR * 9 + j1) % 6;
-#ifndef W44R_NO_MFMA
-      // outstanding LDS reads, oldest first: Bh(j0) Bl(j0) Bh(j1) Bl(j1) + the next pair's four (two behind the last pair)
-      if (pp < 3) {
-        mfma_pin_wait<7>(j0, Ar[r0i], Bh[s0]);
-        mfma_pin_wait<5>(j1, Ar[r1i], Bh[s1]);
-        mfma_pin(j0, Ar[r0i], Bl[s0]);
-        mfma_pin_wait<4>(j1, Ar[r1i], Bl[s1]);
-      } else {
-        mfma_pin_wait<5>(j0, Ar[r0i], Bh[s0]);
-        mfma_pin_wait<3>(j1, Ar[r1i], Bh[s1]);
-        mfma_pin(j0, Ar[r0i], Bl[s0]);
-        mfma_pin_wait<2>(j1, Ar[r1i], Bl[s1]);
-      }
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      W44R_LOAD_A(r0i, j0 + 6 < 9 ? cl : cl + 1, (j0 + 6) % 9);
-      W44R_LOAD_A(r1i, j1 + 6 < 9 ? cl : cl + 1, (j1 + 6) % 9);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    {
-      const int r8 = (PAR * 9 + 8) % 6;
-#ifndef W44R_NO_MFMA
-      mfma_v_pair_wait0(acc8, Ar[r8], Bh[0], Bl[0]);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      W44R_LOAD_A(r8, cl + 1, 5);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#else
     h8 Bh[2], Bl[2];
     Bh[0] = lds_b128(vb, 0);
     Bl[0] = lds_b128(vb, kT * 16);
@@ -431,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       if (jj == 8) {
         mfma_v_pair_wait0(acc8, Ar[ri], Bh[jj & 1], Bl[jj & 1]);
       } else {
-        // outstanding LDS reads, oldest first: Bh(jj), Bl(jj), Bh(jj + 1), Bl(jj + 1)
+        // outstanding LDS reads, oldest first: Bh(jj), Bl(jj), Bh(jj + 1), Bl(jj + 1) (+ whatever the slices issued: newer)
         mfma_pin_wait<3>(jj, Ar[ri], Bh[jj & 1]);
         asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
         mfma_pin(jj, Ar[ri], Bl[jj & 1]);
@@ -440,9 +413,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       __builtin_amdgcn_sched_barrier(0);
       // the A operand six jobs ahead (this ring register is free: the MFMAs above have read it)
       W44R_LOAD_A(ri, jj + 6 < 9 ? cl : cl + 1, (jj + 6) % 9);
+      slice(jj);
       __builtin_amdgcn_sched_barrier(0);
     }
-#endif
 #undef W44R_LOAD_A
   };
 
@@ -452,10 +425,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     // ---- fill.  A workgroup's first item stages chunks 0 and 1 from scratch; later items find them in the pixel ring (staged
     // during the previous item's last two chunk intervals: the ring survives the output transform) and only owe V of chunk 0.
     if (first_item) {
-      load_stage(0, n_cur, has_next);
-      activate_stage(0);
-      load_stage(1, n_cur, has_next);
-      activate_stage(1);
+      load_stage(I0{}, 0, n_cur, has_next);
+      activate_stage(I0{}, 0);
+      load_stage(I0{}, 1, n_cur, has_next);
+      activate_stage(I0{}, 1);
+      if (DEEP) load_stage(I0{}, 2, n_cur, has_next);  // (a later item finds these in flight: requested in its predecessor's last interval)
       barrier();
     }
 #pragma unroll
@@ -473,15 +447,35 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     const int pahead = lateprod ? 1 : 2;
     if (!lateprod) produce_task(1);
     auto interval = [&](auto parc, int cc) __attribute__((always_inline)) {
+      constexpr int PAR = decltype(parc)::value;
+      using SA = std::integral_constant<int, DEEP ? PAR : 0>;      // the set activated in this interval
+      using SL = std::integral_constant<int, DEEP ? 1 - PAR : 0>;  // the set requested in this interval
 #ifdef W44R_PROBE
       probe_cc = n_cur == n_first ? cc : -100;
 #endif
       W44R_STAMP(0)
-      load_stage(cc + 2, n_cur, has_next);
+      const LoadCtx L = load_prep(cc + (DEEP ? 3 : 2), n_cur, has_next);
+      if (!DEEP) {
+#pragma unroll
+        for (int k = 0; k < NRT; ++k) load_round(L, SL{}, k);
+#pragma unroll
+        for (int i = 0; i < NGS; ++i) load_affine(L, SL{}, i);
+      }
       W44R_STAMP(1)
-      mfma_chunk(parc, cc);
+      if (DEEP) asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL));
+      mfma_chunk(parc, cc, [&](int jj) __attribute__((always_inline)) {
+        if (!DEEP) return;
+        // behind job jj: activation round(s) jj of chunk cc + 2, then the request(s) of round jj of chunk cc + 3
+#pragma unroll
+        for (int k = 0; k < NRT; ++k)
+          if (k == jj || (jj == 8 && k > 8)) activate_round(SA{}, cc + 2, k);
+#pragma unroll
+        for (int k = 0; k < NRT; ++k)
+          if (k == jj || (jj == 8 && k > 8)) load_round(L, SL{}, k);
+        if (jj < NGS) load_affine(L, SL{}, jj);
+      });
       W44R_STAMP(2)
-      activate_stage(cc + 2);
+      if (!DEEP) activate_stage(SA{}, cc + 2);
       W44R_STAMP(3)
       if (!lateprod) barrier();
       W44R_STAMP(4)

@@ -38,5 +38,5 @@ for wv in range(8):
         r = t[wv * 4 + iv]
         seg = "  ".join(f"{n} {r[i + 1] - r[i]:5d}" for i, n in enumerate(names))
         nxt = f"  (next +{t[wv * 4 + iv + 1][0] - r[6]})" if iv < 3 else ""
-        vt = f"  | vtask: col0 {r[8] - r[4]:5d} col1 {r[9] - r[8]:5d} row+split {r[10] - r[9]:5d} store {r[11] - r[10]:5d} rest {r[5] - r[11]:5d}" if r[8] else ""
+        vt = f"  | vtask: col0 {r[8] - r[4]:5d} col1 {r[9] - r[8]:5d} row+split {r[10] - r[9]:5d} store {r[11] - r[10]:5d} rest {r[5] - r[11]:5d}" if r[8] and r[11] else ""
         print(f"  interval {4 + iv}: {seg}  total {r[6] - r[0]:5d}{nxt}{vt}")
