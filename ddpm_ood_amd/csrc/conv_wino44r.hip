@@ -419,6 +419,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #undef W44R_LOAD_A
   };
 
+  // static priority for the second-dispatched half of the workgroup: at equal priority the older wave of a SIMD wins every VALU
+  // arbitration and waves 4-7 ran every segment ~15 % slower than their partners (MI355X_MICROARCH.md, "Two waves per SIMD", item 4)
+  if (wave >= 4) asm volatile("s_setprio 1");
   for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
     const bool first_item = n_cur == n_first || !g.xitem;
     const bool has_next = g.xitem && n_cur + g.TI < n_end;
@@ -465,14 +468,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       if (DEEP) asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL));
       mfma_chunk(parc, cc, [&](int jj) __attribute__((always_inline)) {
         if (!DEEP) return;
-        // behind job jj: activation round(s) jj of chunk cc + 2, then the request(s) of round jj of chunk cc + 3
+        // behind the EVEN jobs: two activation rounds of chunk cc + 2 at a time (two independent fma -> exp -> rcp chains
+        // interleave; one round per job left each job waiting for a ~100-cycle dependent chain); behind the ODD jobs: the
+        // requests of chunk cc + 3, three rounds at a time (+ the GroupNorm pairs)
+        if ((jj & 1) == 0) {
 #pragma unroll
-        for (int k = 0; k < NRT; ++k)
-          if (k == jj || (jj == 8 && k > 8)) activate_round(SA{}, cc + 2, k);
+          for (int k = 0; k < NRT; ++k)
+            if (k / 2 == jj / 2) activate_round(SA{}, cc + 2, k);
+        } else {
 #pragma unroll
-        for (int k = 0; k < NRT; ++k)
-          if (k == jj || (jj == 8 && k > 8)) load_round(L, SL{}, k);
-        if (jj < NGS) load_affine(L, SL{}, jj);
+          for (int k = 0; k < NRT; ++k)
+            if (k / 3 == jj / 2) load_round(L, SL{}, k);
+#pragma unroll
+          for (int i = 0; i < NGS; ++i)
+            if (i == jj / 2) load_affine(L, SL{}, i);
+        }
       });
       W44R_STAMP(2)
       if (!DEEP) activate_stage(SA{}, cc + 2);

@@ -13,9 +13,14 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def test_wino44h_accumulators_are_never_touched_by_compiler_code():
+import pytest
+
+
+@pytest.mark.parametrize("name", ["conv_wino44h", "conv_wino44r"])
+def test_wino44h_accumulators_are_never_touched_by_compiler_code(name):
+    """Both forms of the split-f16 F(4x4) kernel (LDS-fed conv_wino44h.hip, register-fed conv_wino44r.hip) pin their tiles by name."""
     out = subprocess.run([sys.executable, str(ROOT / "tools" / "check_acc_spills.py"),
-                          str(ROOT / "ddpm_ood_amd" / "csrc" / "conv_wino44h.hip"), "-fno-slp-vectorize"],
+                          str(ROOT / "ddpm_ood_amd" / "csrc" / f"{name}.hip"), "-fno-slp-vectorize"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:]
     assert out.stdout.count(": OK") == 24, out.stdout  # 2 (affine) x 4 (shapes) x 2 (residual) + 4 three-dimensional instantiations
