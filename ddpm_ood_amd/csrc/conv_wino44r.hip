@@ -257,24 +257,35 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   const int sc = wave & 3, phalf = wave >> 2;
   const int row_lo = max(0, 4 * r0 - 1), row_hi = min(a.Ho, 4 * (r0 + g.TR) + 1);
   const int npx = (row_hi - row_lo) * a.Wo;
-  const int dump = 4 * g.PCH + 1 + lane;  // relative to the half-tile
+  // QUAD (every shape but eight images per item and the Upsample form): a lane stages FOUR consecutive pixels of a row per round
+  // (one buffer_load_dwordx4: a round = 256 pixels), a third of the vector-memory instructions of the 64-pixel rounds -- their
+  // issue (~45 cycles apiece in this kernel) was a quarter of the MFMA segment.  NR = rounds per channel and item.
+#ifndef W44R_QUAD
+#define W44R_QUAD 0  // measured: same speed to 1.5 % slower than the 64-pixel rounds (the loads' issue is not what the MFMA segment waits for)
+#endif
+  constexpr bool QUAD = W44R_QUAD && UIT != 1 && !UP;
+  constexpr int NR = QUAD ? (ONEIMG ? 3 : 2) : NRT;
+  constexpr int LP = QUAD ? 4 : 1;                              // pixels per lane and round
+  const int dump = 4 * g.PCH + 1 + LP * lane;  // relative to the half-tile (w44r_relayout keeps 256 dump floats behind the planes)
   int pix0, pw0, pixL = 0, pwL = 0;
   {
-    const bool valid = lane < npx;
+    const int e0 = LP * lane;
+    const bool valid = e0 < npx;
     auto src_of = [&](int row, int col) __attribute__((always_inline)) { return UP ? ((row >> 1) * (a.Wo >> 1) + (col >> 1)) * 4 : (row * a.Wo + col) * 4; };
-    pix0 = valid ? src_of(row_lo + lane / a.Wo, lane % a.Wo) : (int)0x80000000;  // out of range: the load returns 0
-    pw0 = valid ? sc * g.PCH + (row_lo + lane / a.Wo - (4 * r0 - 1)) * g.PW + lane % a.Wo + 1 : dump;
+    pix0 = valid ? src_of(row_lo + e0 / a.Wo, e0 % a.Wo) : (int)0x80000000;  // out of range: the load returns 0
+    pw0 = valid ? sc * g.PCH + (row_lo + e0 / a.Wo - (4 * r0 - 1)) * g.PW + e0 % a.Wo + 1 : dump;
     if (ONEIMG) {
-      const int eL = lane + 64 * (NRT - 1);
+      const int eL = e0 + 64 * LP * (NR - 1);
       const bool vL = eL < npx;
       pixL = vL ? src_of(row_lo + eL / a.Wo, eL % a.Wo) : (int)0x80000000;
       pwL = vL ? sc * g.PCH + (row_lo + eL / a.Wo - (4 * r0 - 1)) * g.PW + eL % a.Wo + 1 : dump;
     }
   }
-  const int prs = (64 / a.Wo) * g.PW;  // pixel-tile floats between a lane's pixels of consecutive rounds of one image
-  constexpr int kRoundBytes = UP ? 64 : 256;
-  auto pix_of = [&](int k) __attribute__((always_inline)) { return ONEIMG ? (k == NRT - 1 ? pixL : pix0 + kRoundBytes * k) : pix0 + kRoundBytes * (k % GD); };
-  auto pw_of = [&](int k) __attribute__((always_inline)) { return ONEIMG ? (k == NRT - 1 ? pwL : pw0 + k * prs) : pw0 + (k % GD) * prs + (k / GD) * g.IS; };
+  const int prs = (64 * LP / a.Wo) * g.PW;  // pixel-tile floats between a lane's pixels of consecutive rounds of one image
+  constexpr int kRoundBytes = UP ? 64 : 256 * LP;
+  constexpr int GDR = QUAD ? (ONEIMG ? NR : 1) : GD;  // consecutive rounds that belong to one image
+  auto pix_of = [&](int k) __attribute__((always_inline)) { return ONEIMG ? (k == NR - 1 ? pixL : pix0 + kRoundBytes * k) : pix0 + kRoundBytes * (k % GDR); };
+  auto pw_of = [&](int k) __attribute__((always_inline)) { return ONEIMG ? (k == NR - 1 ? pwL : pw0 + k * prs) : pw0 + (k % GDR) * prs + (k / GDR) * g.IS; };
   const int bytes1 = a.B * a.C1 * (D3 ? g.CS : UP ? g.HWin : g.HW) * 4, bytes2 = a.B * a.C2 * g.HW * 4;
   const __amdgpu_buffer_rsrc_t rs_sc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gscale), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
@@ -288,7 +299,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   // SiLU arithmetic hide behind the MFMAs.  Otherwise one set: loads in front of the MFMA segment, activation behind it.
   constexpr bool DEEP = UIT != 1;
   constexpr int NSET = DEEP ? 2 : 1;
-  float praw[NSET][NRT], gs[NSET][NGS], gh[NSET][NGS];
+  using praw_t = std::conditional_t<QUAD, v4f, float>;
+  praw_t praw[NSET][NR];
+  float gs[NSET][NGS], gh[NSET][NGS];
   struct LoadCtx {  // wave-uniform addressing of one stream chunk's loads (SGPRs)
     __amdgpu_buffer_rsrc_t rs;
     int n_it, cx, cgl, cga, soff3;
@@ -322,10 +335,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   auto load_round = [&](const LoadCtx &L, auto setc, int k) __attribute__((always_inline)) {
     constexpr int S = decltype(setc)::value;
 #ifndef W44R_NO_PIXEL
-    const int ni = min(L.n_it + (ONEIMG ? 0 : k / GD), g.NIMG - 1);
+    const int ni = min(L.n_it + (ONEIMG ? 0 : k / GDR), g.NIMG - 1);
     const int soff = D3 ? L.soff3 : (ni * L.cx + L.cgl) * (UP ? g.HWin : g.HW) * 4;
     const int voff = D3 && !L.dok ? (int)0x80000000 : pix_of(k);
-    praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(L.rs, voff, soff, 0));
+    if constexpr (QUAD)
+      praw[S][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(L.rs, voff, soff, 0));
+    else
+      praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(L.rs, voff, soff, 0));
 #endif
   };
   auto load_affine = [&](const LoadCtx &L, auto setc, int i) __attribute__((always_inline)) {
@@ -342,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   auto load_stage = [&](auto setc, int cc, int n_cur, bool has_next) __attribute__((always_inline)) {
     const LoadCtx L = load_prep(cc, n_cur, has_next);
 #pragma unroll
-    for (int k = 0; k < NRT; ++k) load_round(L, setc, k);
+    for (int k = 0; k < NR; ++k) load_round(L, setc, k);
 #pragma unroll
     for (int i = 0; i < NGS; ++i) load_affine(L, setc, i);
   };
@@ -350,24 +366,35 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   auto activate_round = [&](auto setc, int cc, int k) __attribute__((always_inline)) {
     constexpr int S = decltype(setc)::value;
 #ifndef W44R_NO_PIXEL
-    float *const Pr = P + (2 * (cc & 1) + phalf) * g.HS;
-    const float x = praw[S][k];
-    float y;
+    float *const Pr = P + (2 * (cc & 1) + phalf) * g.HS + pw_of(k);
+    float sa = 0.f, sb = 0.f, ta = 0.f, tb = 0.f;
     if (AFFINE) {
-      const float sa = gs[S][k / GD], sb = gh[S][k / GD];
-      const float v = __builtin_fmaf(x, sa, sb);
-      const float t = __builtin_fmaf(x, -1.44269504088896341f * sa, -1.44269504088896341f * sb);
-      y = (kVScale * v) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
-    } else {
-      y = kVScaleRaw * (silu ? silu_fast(x) : x);
+      sa = gs[S][k / GDR];
+      sb = gh[S][k / GDR];
+      ta = -1.44269504088896341f * sa;
+      tb = -1.44269504088896341f * sb;
     }
-    Pr[pw_of(k)] = y;
+    auto act = [&](float x) __attribute__((always_inline)) {
+      if (AFFINE) {
+        const float v = __builtin_fmaf(x, sa, sb);
+        const float t = __builtin_fmaf(x, ta, tb);
+        return (kVScale * v) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+      }
+      return kVScaleRaw * (silu ? silu_fast(x) : x);
+    };
+    if constexpr (QUAD) {
+      const v4f x = praw[S][k];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Pr[i] = act(x[i]);
+    } else {
+      Pr[0] = act(praw[S][k]);
+    }
 #endif
   };
   auto activate_stage = [&](auto setc, int cc) __attribute__((always_inline)) {
     asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL));
 #pragma unroll
-    for (int k = 0; k < NRT; ++k) activate_round(setc, cc, k);
+    for (int k = 0; k < NR; ++k) activate_round(setc, cc, k);
   };
 
   // ================================================================================================ MFMA jobs
@@ -406,6 +433,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       } else {
         // outstanding LDS reads, oldest first: Bh(jj), Bl(jj), Bh(jj + 1), Bl(jj + 1) (+ whatever the slices issued: newer)
         mfma_pin_wait<3>(jj, Ar[ri], Bh[jj & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        slice(jj, 0);  // in the shadow of the first MFMA (the second one, on the same tile, cannot issue before it has finished)
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
         mfma_pin(jj, Ar[ri], Bl[jj & 1]);
       }
@@ -413,7 +443,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       __builtin_amdgcn_sched_barrier(0);
       // the A operand six jobs ahead (this ring register is free: the MFMAs above have read it)
       W44R_LOAD_A(ri, jj + 6 < 9 ? cl : cl + 1, (jj + 6) % 9);
-      slice(jj);
+      if (jj == 8) slice(jj, 0);
+      slice(jj, 1);
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef W44R_LOAD_A
@@ -460,28 +491,43 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       const LoadCtx L = load_prep(cc + (DEEP ? 3 : 2), n_cur, has_next);
       if (!DEEP) {
 #pragma unroll
-        for (int k = 0; k < NRT; ++k) load_round(L, SL{}, k);
+        for (int k = 0; k < NR; ++k) load_round(L, SL{}, k);
 #pragma unroll
         for (int i = 0; i < NGS; ++i) load_affine(L, SL{}, i);
       }
       W44R_STAMP(1)
       if (DEEP) asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL));
-      mfma_chunk(parc, cc, [&](int jj) __attribute__((always_inline)) {
+      mfma_chunk(parc, cc, [&](int jj, int part) __attribute__((always_inline)) {
         if (!DEEP) return;
         // behind the EVEN jobs: two activation rounds of chunk cc + 2 at a time (two independent fma -> exp -> rcp chains
         // interleave; one round per job left each job waiting for a ~100-cycle dependent chain); behind the ODD jobs: the
         // requests of chunk cc + 3, three rounds at a time (+ the GroupNorm pairs)
-        if ((jj & 1) == 0) {
+        // part 0 runs between a job's two MFMAs, part 1 behind them.  Even jobs: two activation rounds of chunk cc + 2 (one per
+        // part); odd jobs: the requests of chunk cc + 3 (three rounds: one + two) and the GroupNorm pairs.
+        if (QUAD) {  // (a round = four pixels per lane: round q at job 2 q, its request at job 2 q + 1)
+          if (part == 0) return;
+          if ((jj & 1) == 0 && jj / 2 < NR) activate_round(SA{}, cc + 2, jj / 2);
+          if ((jj & 1) == 1 && jj / 2 < NR) load_round(L, SL{}, jj / 2);
+          if (jj == 7) {
 #pragma unroll
-          for (int k = 0; k < NRT; ++k)
-            if (k / 2 == jj / 2) activate_round(SA{}, cc + 2, k);
+            for (int i = 0; i < NGS; ++i) load_affine(L, SL{}, i);
+          }
+        } else if ((jj & 1) == 0) {
+          const int k = 2 * (jj / 2) + part;
+          if (k < NRT) {
+#pragma unroll
+            for (int kk = 0; kk < NRT; ++kk)
+              if (kk == k) activate_round(SA{}, cc + 2, kk);
+          }
         } else {
 #pragma unroll
           for (int k = 0; k < NRT; ++k)
-            if (k / 3 == jj / 2) load_round(L, SL{}, k);
+            if (k / 3 == jj / 2 && (k % 3 == 0) == (part == 0)) load_round(L, SL{}, k);
+          if (part == 1) {
 #pragma unroll
-          for (int i = 0; i < NGS; ++i)
-            if (i == jj / 2) load_affine(L, SL{}, i);
+            for (int i = 0; i < NGS; ++i)
+              if (i == jj / 2) load_affine(L, SL{}, i);
+          }
         }
       });
       W44R_STAMP(2)
@@ -655,7 +701,7 @@ void w44r_relayout(const ddpm_conv_desc &d, W44HGeom &g) {
   g.IS = g.prow * g.PW;
   g.PCH = g.TI * g.IS;
   while (g.PCH % 32 != 16) g.PCH += 1;
-  g.HS = 4 * g.PCH + 80;  // = 16 (mod 64); the 64 dump floats of out-of-image lanes sit at 4 PCH + 1 ..
+  g.HS = 4 * g.PCH + 272;  // = 16 (mod 64); the 256 dump floats of out-of-image lanes (four per lane) sit at 4 PCH + 1 ..
 }
 
 int launch_conv_wino44r(const ddpm_conv_desc &dk, const W44HGeom &g, size_t lds, hipStream_t s) {
