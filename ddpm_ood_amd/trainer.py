@@ -157,83 +157,90 @@ class BaseTrainer:
         for k, v in vars(args).items():
             print(f"  {k}: {v}")
 
-        # stage-1 model (base.py:44-64)
-        if args.vqvae_checkpoint:
-            vqvae_checkpoint_path = Path(args.vqvae_checkpoint)
-            vqvae_config_path = vqvae_checkpoint_path.parent / "vqvae_config.json"
-            if not vqvae_checkpoint_path.exists():
-                raise FileNotFoundError(f"Cannot find VQ-VAE checkpoint {vqvae_checkpoint_path}")
-            if not vqvae_config_path.exists():
-                raise FileNotFoundError(f"Cannot find VQ-VAE config {vqvae_config_path}")
-            with open(vqvae_config_path, "r") as f:
-                self.vqvae_config = json.load(f)
-            self.vqvae_model = VQVAE(**self.vqvae_config)
-            vqvae_checkpoint = torch.load(vqvae_checkpoint_path, map_location="cpu", weights_only=False)
-            self.vqvae_model.load_state_dict(vqvae_checkpoint["model_state_dict"])
-            self.vqvae_model.to(self.device)
-            self.vqvae_model.eval()
-            print("Loaded vqvae model with config:")
-            for k, v in self.vqvae_config.items():
-                print(f"  {k}: {v}")
-            ddpm_channels = self.vqvae_config["embedding_dim"]
-        else:
+        self._setup_stage1(args)
+        self._setup_unet(args)
+        self._setup_schedule(args)
+        self._setup_geometry(args)
+        self._restore_checkpoint(args)
+        # no optimizer, no GradScaler, no DDP wrap: inference only, every rank reads the same
+        # checkpoint file instead of the reference's DDP parameter broadcast (Q15)
+
+
+    # ---- the pieces of the reference's BaseTrainer.__init__ (base.py:44-158) the reconstruction path needs, one loader each.
+    # Attribute names, printed messages and exception types are the reference's (row a2 of SURVEY 8: a caller that catches
+    # FileNotFoundError / ValueError or reads trainer.vqvae_config keeps working); the structure is not.
+    @staticmethod
+    def _require(path: Path, what: str) -> Path:
+        if not path.exists():
+            raise FileNotFoundError(f"Cannot find {what} {path}")
+        return path
+
+    def _setup_stage1(self, args):
+        """Stage-1 model (base.py:44-64): a VQ-VAE checkpoint + its vqvae_config.json next to it, or the identity."""
+        self.ddpm_channels = 1 if args.is_grayscale else 3
+        if not args.vqvae_checkpoint:
             self.vqvae_model = PassthroughVQVAE()
-            ddpm_channels = 1 if args.is_grayscale else 3
+            return
+        ckpt = self._require(Path(args.vqvae_checkpoint), "VQ-VAE checkpoint")
+        cfg = self._require(ckpt.parent / "vqvae_config.json", "VQ-VAE config")
+        self.vqvae_config = json.loads(cfg.read_text())
+        self.vqvae_model = VQVAE(**self.vqvae_config)
+        state = torch.load(ckpt, map_location="cpu", weights_only=False)["model_state_dict"]
+        self.vqvae_model.load_state_dict(state)
+        self.vqvae_model.to(self.device).eval()
+        print("Loaded vqvae model with config:")
+        for k, v in self.vqvae_config.items():
+            print(f"  {k}: {v}")
+        self.ddpm_channels = self.vqvae_config["embedding_dim"]
+
+    def _setup_unet(self, args):
+        """The denoiser (base.py:65-86): `small` / `big` channel tables, one channel count on both sides."""
         if args.model_type not in MODEL_CONFIGS:
             raise ValueError(f"Do not recognise model type {args.model_type}")
-        self.model = DiffusionModelUNet(spatial_dims=args.spatial_dimension, in_channels=ddpm_channels,
-                                        out_channels=ddpm_channels, with_conditioning=False,
+        self.model = DiffusionModelUNet(spatial_dims=args.spatial_dimension, in_channels=self.ddpm_channels,
+                                        out_channels=self.ddpm_channels, with_conditioning=False,
                                         use_proj_attn=bool(getattr(args, "use_proj_attn", 0)),
                                         **MODEL_CONFIGS[args.model_type]).to(self.device)
         print(f"{sum(p.numel() for p in self.model.parameters()):,} model parameters")
 
-        self.prediction_type = args.prediction_type
-        self.beta_schedule = args.beta_schedule
-        self.beta_start = args.beta_start
-        self.beta_end = args.beta_end
-        self.b_scale = args.b_scale
-        self.snr_shift = args.snr_shift
+    def _setup_schedule(self, args):
+        """Noise schedule attributes + the training scheduler (base.py:88-117); --snr_shift rewrites its tables."""
+        for name in ("prediction_type", "beta_schedule", "beta_start", "beta_end", "b_scale", "snr_shift"):
+            setattr(self, name, getattr(args, name))
         self.scheduler = DDPMScheduler(num_train_timesteps=1000, prediction_type=self.prediction_type,
-                                       schedule=self.beta_schedule, beta_start=self.beta_start,
-                                       beta_end=self.beta_end)
+                                       schedule=self.beta_schedule, beta_start=self.beta_start, beta_end=self.beta_end)
         if self.snr_shift != 1:
             print("Changing scheduler parameters to shift SNR")
             snr_shift_tables(self.scheduler, self.snr_shift)
         self.simplex_noise = bool(args.simplex_noise)
         if self.simplex_noise:
             raise NotImplementedError("--simplex_noise is off the path (default 0, in no BASELINE config)")
+
+    def _setup_geometry(self, args):
+        """Spatial bookkeeping (base.py:118-131): dimension, resize target, latent padding and its inverse."""
         self.spatial_dimension = args.spatial_dimension
         self.image_size = int(args.image_size) if args.image_size else args.image_size
-        if args.latent_pad:
-            self.do_latent_pad = True
+        self.do_latent_pad = bool(args.latent_pad)
+        if self.do_latent_pad:
             self.latent_pad = args.latent_pad
             self.inverse_latent_pad = [-x for x in self.latent_pad]
-        else:
-            self.do_latent_pad = False
 
-        # checkpoint (base.py:133-158; map_location added so a CPU-saved file loads, Q4)
+    def _restore_checkpoint(self, args):
+        """DDPM checkpoint (base.py:133-158; map_location added so a CPU-saved file loads, Q4): counters default to a fresh run."""
         self.run_dir = Path(args.output_dir) / args.model_name
-        if args.ddpm_checkpoint_epoch:
-            checkpoint_path = self.run_dir / f"checkpoint_{int(args.ddpm_checkpoint_epoch)}.pth"
-        else:
-            checkpoint_path = self.run_dir / "checkpoint.pth"
-        if checkpoint_path.exists():
-            checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
-            self.found_checkpoint = True
-            self.start_epoch = checkpoint["epoch"] + 1
-            self.global_step = checkpoint["global_step"]
-            self.model.load_state_dict(checkpoint["model_state_dict"])
-            self.best_loss = checkpoint["best_loss"]
-            self.optimizer_state = checkpoint.get("optimizer_state_dict")  # used by DDPMTrainer only
-            print(f"Resuming training using checkpoint {checkpoint_path} at epoch {self.start_epoch}")
-        else:
-            self.start_epoch = 0
-            self.best_loss = 1000
-            self.global_step = 0
-            self.found_checkpoint = False
-            self.optimizer_state = None
-        # no optimizer, no GradScaler, no DDP wrap: inference only, every rank reads the same
-        # checkpoint file instead of the reference's DDP parameter broadcast (Q15)
+        stem = f"checkpoint_{int(args.ddpm_checkpoint_epoch)}" if args.ddpm_checkpoint_epoch else "checkpoint"
+        checkpoint_path = self.run_dir / f"{stem}.pth"
+        self.start_epoch, self.best_loss, self.global_step, self.optimizer_state = 0, 1000, 0, None
+        self.found_checkpoint = checkpoint_path.exists()
+        if not self.found_checkpoint:
+            return
+        checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        self.model.load_state_dict(checkpoint["model_state_dict"])
+        self.start_epoch = checkpoint["epoch"] + 1
+        self.global_step = checkpoint["global_step"]
+        self.best_loss = checkpoint["best_loss"]
+        self.optimizer_state = checkpoint.get("optimizer_state_dict")  # used by DDPMTrainer only
+        print(f"Resuming training using checkpoint {checkpoint_path} at epoch {self.start_epoch}")
 
 
 class Reconstruct(BaseTrainer):
