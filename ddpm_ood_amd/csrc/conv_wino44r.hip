@@ -180,6 +180,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     float cA[2][6], cB[2][6];
     // column pass of one channel: rows (0, 5): A = d4 - 5 d2 + 4 d0, B = d5 - 5 d3 + 4 d1;  rows (1, 2): p = d4 - 4 d2, q = d3 - 4 d1,
     // A = p + q, B = p - q;  rows (3, 4): p = d4 - d2, q = d3 - d1, A = p + 2 q, B = p - 2 q   (conv_wino44h.hip's cstep, unsliced)
+#ifdef W44R_VREADS_UPFRONT
+    float r4[2][6], r2[2][6], r1[2][6], r3[2][6];
+    if (!t0 && NEWLAY) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float *p = P + pb0 + c * g.PCH;
+        auto rowu = [&](int r, float (&dst)[6]) __attribute__((always_inline)) {
+          const v4f lo = *reinterpret_cast<const v4f *>(p + r * g.PW);
+          const v2f_t hi = *reinterpret_cast<const v2f_t *>(p + r * g.PW + 4);
+          dst[0] = lo[0]; dst[1] = lo[1]; dst[2] = lo[2]; dst[3] = lo[3]; dst[4] = hi[0]; dst[5] = hi[1];
+        };
+        rowu(4, r4[c]); rowu(2, r2[c]); rowu(1, r1[c]); rowu(3, r3[c]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const float *p = P + pb0 + c * g.PCH;
@@ -205,10 +221,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
         }
 #endif
       };
-      row(4, d4);
-      row(2, d2);
-      row(1, dw);
-      row(t0 ? 5 : 3, dy);
+#ifdef W44R_VREADS_UPFRONT
+      if (!t0 && NEWLAY) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) d4[q] = r4[c][q], d2[q] = r2[c][q], dw[q] = r1[c][q], dy[q] = r3[c][q];
+      } else
+#endif
+      {
+        row(4, d4);
+        row(2, d2);
+        row(1, dw);
+        row(t0 ? 5 : 3, dy);
+      }
       if (t0) {
         row(0, dx);
         row(3, dz);
@@ -338,10 +362,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     const int ni = min(L.n_it + (ONEIMG ? 0 : k / GDR), g.NIMG - 1);
     const int soff = D3 ? L.soff3 : (ni * L.cx + L.cgl) * (UP ? g.HWin : g.HW) * 4;
     const int voff = D3 && !L.dok ? (int)0x80000000 : pix_of(k);
+#ifdef W44R_PIX_NOLOAD  // (timing experiment)
+    (void)voff; (void)soff;
+    {
+      float one;
+      asm volatile("v_mov_b32 %0, 1.0" : "=v"(one));
+      if constexpr (QUAD) praw[S][k] = v4f{one, one, one, one};
+      else praw[S][k] = one;
+    }
+#else
     if constexpr (QUAD)
       praw[S][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(L.rs, voff, soff, 0));
     else
       praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(L.rs, voff, soff, 0));
+#endif
 #endif
   };
   auto load_affine = [&](const LoadCtx &L, auto setc, int i) __attribute__((always_inline)) {
@@ -375,6 +409,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       tb = -1.44269504088896341f * sb;
     }
     auto act = [&](float x) __attribute__((always_inline)) {
+#ifdef W44R_PIX_NOMATH  // (timing experiment)
+      return x;
+#endif
       if (AFFINE) {
         const float v = __builtin_fmaf(x, sa, sb);
         const float t = __builtin_fmaf(x, ta, tb);
@@ -382,6 +419,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       }
       return kVScaleRaw * (silu ? silu_fast(x) : x);
     };
+#ifdef W44R_PIX_NOSTORE  // (timing experiment)
+    if constexpr (QUAD) {
+      const v4f x = praw[S][k];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { float y = act(x[i]); asm volatile("" ::"v"(y)); }
+    } else {
+      float y = act(praw[S][k]);
+      asm volatile("" ::"v"(y));
+    }
+    (void)Pr;
+#else
     if constexpr (QUAD) {
       const v4f x = praw[S][k];
 #pragma unroll
@@ -389,6 +437,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     } else {
       Pr[0] = act(praw[S][k]);
     }
+#endif
 #endif
   };
   auto activate_stage = [&](auto setc, int cc) __attribute__((always_inline)) {
@@ -401,7 +450,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   // job jj = 3 t + i of a chunk: accumulator tile jj += U[pair t, position 3 pg + i] (Vh + Vl).  A comes from the register ring
   // (six jobs ahead; 9 jobs per chunk, ring of 6: the indices repeat every two chunks, hence the two-chunk loop body), Bh / Bl by
   // ds_read_b128 one job ahead.
-  h8 Ar[6];
+#ifndef W44R_AR
+#define W44R_AR 6  // A-operand ring depth: a divisor of 18 (static indices over the two-chunk body)
+#endif
+  constexpr int kAR = W44R_AR;
+  h8 Ar[kAR];
   auto load_a = [&](int cl, int jj) __attribute__((always_inline)) {  // job jj of chunk cl (clamped into the item: behind the last chunk a harmless repeat)
     const int t = jj / 3, i = jj - 3 * t;
     const int c2 = min(cl, NCHs - 1);
@@ -426,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
         Bh[(jj + 1) & 1] = lds_b128(vb, ((jj + 1) / 3) * kVSB + 2 * ((jj + 1) % 3) * kT * 16);
         Bl[(jj + 1) & 1] = lds_b128(vb, ((jj + 1) / 3) * kVSB + (2 * ((jj + 1) % 3) + 1) * kT * 16);
       }
-      const int ri = (PAR * 9 + jj) % 6;  // ring index of this job's A
+      const int ri = (PAR * 9 + jj) % kAR;  // ring index of this job's A
 #ifndef W44R_NO_MFMA
       if (jj == 8) {
         mfma_v_pair_wait0(acc8, Ar[ri], Bh[jj & 1], Bl[jj & 1]);
@@ -442,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #endif
       __builtin_amdgcn_sched_barrier(0);
       // the A operand six jobs ahead (this ring register is free: the MFMAs above have read it)
-      W44R_LOAD_A(ri, jj + 6 < 9 ? cl : cl + 1, (jj + 6) % 9);
+      W44R_LOAD_A(ri, jj + kAR < 9 ? cl : cl + 1, (jj + kAR) % 9);
       if (jj == 8) slice(jj, 0);
       slice(jj, 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -467,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       barrier();
     }
 #pragma unroll
-    for (int jj = 0; jj < 6; ++jj) Ar[jj] = load_a(0, jj);
+    for (int jj = 0; jj < kAR; ++jj) Ar[jj] = load_a(0, jj);
     produce_task(0);
     zero_accumulators();
     barrier();
@@ -488,6 +541,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       probe_cc = n_cur == n_first ? cc : -100;
 #endif
       W44R_STAMP(0)
+#ifndef W44R_LOADS_AT_V
+#define W44R_LOADS_AT_V 0  // measured 3 % slower than requesting them behind the odd MFMA jobs (same-box A/B)
+#endif
+      constexpr bool kLoadsAtV = W44R_LOADS_AT_V != 0;
       const LoadCtx L = load_prep(cc + (DEEP ? 3 : 2), n_cur, has_next);
       if (!DEEP) {
 #pragma unroll
@@ -507,10 +564,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
         if (QUAD) {  // (a round = four pixels per lane: round q at job 2 q, its request at job 2 q + 1)
           if (part == 0) return;
           if ((jj & 1) == 0 && jj / 2 < NR) activate_round(SA{}, cc + 2, jj / 2);
-          if ((jj & 1) == 1 && jj / 2 < NR) load_round(L, SL{}, jj / 2);
-          if (jj == 7) {
+          if (!kLoadsAtV) {
+            if ((jj & 1) == 1 && jj / 2 < NR) load_round(L, SL{}, jj / 2);
+            if (jj == 7) {
 #pragma unroll
-            for (int i = 0; i < NGS; ++i) load_affine(L, SL{}, i);
+              for (int i = 0; i < NGS; ++i) load_affine(L, SL{}, i);
+            }
           }
         } else if ((jj & 1) == 0) {
           const int k = 2 * (jj / 2) + part;
@@ -519,7 +578,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
             for (int kk = 0; kk < NRT; ++kk)
               if (kk == k) activate_round(SA{}, cc + 2, kk);
           }
-        } else {
+        } else if (!kLoadsAtV) {
 #pragma unroll
           for (int k = 0; k < NRT; ++k)
             if (k / 3 == jj / 2 && (k % 3 == 0) == (part == 0)) load_round(L, SL{}, k);
@@ -535,6 +594,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       W44R_STAMP(3)
       if (!lateprod) barrier();
       W44R_STAMP(4)
+      if (DEEP && kLoadsAtV) {
+        // the requests of chunk cc + 3, in front of the V task: loads return IN ORDER per wave, so an activation load (HBM, microseconds)
+        // issued among the MFMA jobs held back every later U load (L2, a few hundred cycles) behind it -- the MFMA segment then
+        // waited for HBM although nothing in it needs the pixels.  Here the U ring is full (its six loads are older) and no
+        // further U load is issued until the next MFMA segment, a V task later.
+#pragma unroll
+        for (int k = 0; k < NR; ++k) load_round(L, SL{}, k);
+#pragma unroll
+        for (int i = 0; i < NGS; ++i) load_affine(L, SL{}, i);
+      }
       if (cc + pahead < NCHs) produce_task(cc + pahead);
       W44R_STAMP(5)
       if (lateprod) barrier();
@@ -544,7 +613,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       interval(I0{}, c);
       interval(I1{}, c + 1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the repeats past the last chunk: nothing may land after the item
+    // (no vmcnt(0) here: every vector-memory operation of this kernel is a compiler-visible builtin, so the waitcnt pass orders
+    // the epilogue's register reuse against whatever is still in flight -- the next item's chunk-2 pixels keep landing into their
+    // own register set during the output transform)
 
     // ---- end of an item: Y = A^T M A through four exchange slabs [xi][cout block][lane] (the V ring: every stage of the item has
     // finished).  Pass q moves accumulator registers 4 q .. 4 q + 3 of all 36 positions; wave (cb, pg) then finishes register
