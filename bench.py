@@ -186,14 +186,15 @@ def cpu_baseline():
 MFMA_KERNELS = [
     # split-f16 F(4x4): 36 of 144 multiplies, each as FOUR exact f16 partial products (two K = 16 MFMAs per 8 channels) ->
     # executed f16 MFMA FLOPs = 4 x 36 / 144 = 1.0 x the direct convolution's, priced against the dense f16 peak
-    ("conv3x3_wino44h", "conv_wino44h_kernel: 3x3 conv as Winograd F(4x4,3x3), position GEMMs on v_mfma_f32_32x32x16_f16 with "
-                        "split-f16 operands (hi + lo, four exact partial products per fp32 product, fp32 accumulate), fp32 transforms, "
-                        "GN+SiLU prologue, persistent", ("f16", 4.0 * 36.0 / 144.0)),
+    ("conv3x3_wino44h", "conv_wino44r_kernel (register-fed form of conv_wino44h_kernel; DDPM_W44H_REG=0 selects the LDS-fed one): 3x3 conv "
+                        "as Winograd F(4x4,3x3), position GEMMs on v_mfma_f32_32x32x16_f16 with split-f16 operands (hi + lo, four exact "
+                        "partial products per fp32 product, fp32 accumulate), fp32 transforms, GN+SiLU prologue, persistent",
+     ("f16", 4.0 * 36.0 / 144.0)),
     ("conv3x3_wino44", "conv_wino44_kernel: 3x3 conv as Winograd F(4x4,3x3) (36 of 144 multiplies), persistent, GN+SiLU prologue, fp32 MFMA", 36.0 / 144.0),
     ("conv3x3_wino_up", "conv_wino_up_kernel: nearest-x2 + 3x3 conv in the Winograd domain (9 of 16 positions), fp32 MFMA", 9.0 / 36.0),
     ("conv3x3_wino", "conv_wino_kernel: 3x3 conv as Winograd F(2x2,3x3), persistent, GN+SiLU prologue, fp32 MFMA", 16.0 / 36.0),
     ("conv3x3_mfma_up_folded", "conv_mfma_kernel<4>: nearest-x2 + 3x3 conv folded into four 2x2-tap convs, fp32 MFMA", 16.0 / 36.0),
-    ("conv3d_wino44h", "conv_wino44h_kernel, 3-D: Winograd F(4x4,3x3) per depth tap with split-f16 position GEMMs on "
+    ("conv3d_wino44h", "conv_wino44r_kernel, 3-D: Winograd F(4x4,3x3) per depth tap with split-f16 position GEMMs on "
                        "v_mfma_f32_32x32x16_f16 (four exact partial products per fp32 product, fp32 accumulate), taps accumulated in "
                        "the transform domain", ("f16", 4.0 * 36.0 / 144.0)),
     ("conv3d_wino44", "conv_wino44_kernel, 3-D: Winograd F(4x4,3x3) per depth tap (36 of 144 multiplies), taps accumulated in the transform domain, fp32 MFMA", 36.0 / 144.0),
@@ -207,8 +208,6 @@ MFMA_KERNELS = [
     ("conv3x3_d3s", "conv_d3s_kernel: one-shot direct 3x3 conv of launches far smaller than the chip (8x8 / 16x16 levels of a few "
                     "images) on v_mfma_f32_32x32x16_f16 with split-f16 operands (three partial products per fp32 product, fp32 "
                     "accumulate), channel slices of 32 reduced in a fixed order", ("f16", 3.0 * 10.0 / 9.0)),
-    ("conv3x3_d3h", "conv_d3h_kernel: direct 3x3 conv on v_mfma_f32_32x32x16_f16, split-f16 operands (opt-in, DDPM_CONV_D3H)",
-     ("f16", 3.0 * 10.0 / 9.0)),
     ("conv3x3_mfma", "conv_mfma_kernel<9>: direct 3x3 conv (stride 2, ragged extents, 3-D depth-tap launches), fp32 MFMA", 1.0),
     # split-f16: three v_mfma_f32_32x32x16_f16 per fp32 product, 16x the f32 MFMA rate -> the layer is HBM-bound
     ("conv1x1_dma", "conv1x1_dma_kernel: LDS-DMA-fed 1x1 conv (skip connections; with GroupNorm prologue: q / k / v), "

@@ -60,7 +60,7 @@ def main(root, out_csv, out_json):
                      "over the kernel's launches")
     # profiler key of bench.py's roofline object -> the kernel instantiations behind it
     # (a regular expression on the instantiation name; the last template argument of the Winograd kernels is the 3-D form)
-    for key, pattern in (("conv3x3_wino44h_gn_silu", r"conv_wino44h_kernel<true"),
+    for key, pattern in (("conv3x3_wino44h_gn_silu", r"conv_wino44[hr]_kernel<true"),  # (either form of the split-f16 F(4x4) kernel: same profiler key)
                          ("conv3x3_wino_up", r"conv_wino_up_kernel"),
                          ("conv3x3_wino44_gn_silu", r"conv_wino44_kernel<true, \d, \d, (?:true|false), false>"),
                          ("conv3x3_wino_gn_silu", r"conv_wino_kernel<true, \d, (?:true|false), false>"),
