@@ -471,27 +471,53 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #define W44R_LOAD_A(ri, cl_, jj_) Ar[ri] = load_a(cl_, jj_)
 #endif
     h8 Bh[2], Bl[2];
-    Bh[0] = lds_b128(vb, 0);
-    Bl[0] = lds_b128(vb, kT * 16);
+#ifndef W44R_BVIS
+#define W44R_BVIS 0  // (1: measured equal, 4 808 vs 4 810 us over the six layers; the hand-counted form is the one the full suite validated)
+#endif
+#if W44R_BVIS
+    // B operands as PLAIN LDS loads: the compiler counts them together with the slices' pixel-ring stores and puts the exact
+    // lgkmcnt in front of each MFMA.  (Hand-counted waits were off by the stores: "all but the next job's two reads" also
+    // waited for the next job's FIRST read whenever a slice had stored in between -- one exposed LDS latency per job.)
+    const char *const smbc = reinterpret_cast<const char *>(smem);
+#define W44R_BREAD(off) (*reinterpret_cast<const h8 *>(smbc + vb + (off)))
+#else
+#define W44R_BREAD(off) lds_b128(vb, off)
+#endif
+    Bh[0] = W44R_BREAD(0);
+    Bl[0] = W44R_BREAD(kT * 16);
 #pragma unroll
     for (int jj = 0; jj < 9; ++jj) {
       if (jj < 8) {  // next job's B operands: row pair (jj + 1) / 3, position 3 pg + (jj + 1) % 3 (offsets fold to immediates)
-        Bh[(jj + 1) & 1] = lds_b128(vb, ((jj + 1) / 3) * kVSB + 2 * ((jj + 1) % 3) * kT * 16);
-        Bl[(jj + 1) & 1] = lds_b128(vb, ((jj + 1) / 3) * kVSB + (2 * ((jj + 1) % 3) + 1) * kT * 16);
+        Bh[(jj + 1) & 1] = W44R_BREAD(((jj + 1) / 3) * kVSB + 2 * ((jj + 1) % 3) * kT * 16);
+        Bl[(jj + 1) & 1] = W44R_BREAD(((jj + 1) / 3) * kVSB + (2 * ((jj + 1) % 3) + 1) * kT * 16);
+        __builtin_amdgcn_sched_barrier(0);
       }
       const int ri = (PAR * 9 + jj) % kAR;  // ring index of this job's A
 #ifndef W44R_NO_MFMA
+#if W44R_BVIS
+      if (jj == 8) {  // the ninth tile (arch VGPRs): both MFMAs and their completion in one statement
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\tv_mfma_f32_32x32x16_f16 %0, %1, %3, %0\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7"
+                     : "+v"(acc8) : "v"(Ar[ri]), "v"(Bh[jj & 1]), "v"(Bl[jj & 1]));
+      } else {
+        mfma_pin(jj, Ar[ri], Bh[jj & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        slice(jj, 0);  // in the shadow of the first MFMA (the second one, on the same tile, cannot issue before it has finished)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pin(jj, Ar[ri], Bl[jj & 1]);
+      }
+#else
       if (jj == 8) {
         mfma_v_pair_wait0(acc8, Ar[ri], Bh[jj & 1], Bl[jj & 1]);
       } else {
         // outstanding LDS reads, oldest first: Bh(jj), Bl(jj), Bh(jj + 1), Bl(jj + 1) (+ whatever the slices issued: newer)
         mfma_pin_wait<3>(jj, Ar[ri], Bh[jj & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        slice(jj, 0);  // in the shadow of the first MFMA (the second one, on the same tile, cannot issue before it has finished)
+        slice(jj, 0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
         mfma_pin(jj, Ar[ri], Bl[jj & 1]);
       }
+#endif
 #endif
       __builtin_amdgcn_sched_barrier(0);
       // the A operand six jobs ahead (this ring register is free: the MFMAs above have read it)
@@ -500,6 +526,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       slice(jj, 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+#undef W44R_BREAD
 #undef W44R_LOAD_A
   };
 
