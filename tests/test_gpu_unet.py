@@ -225,6 +225,41 @@ def test_graph_replay_equals_eager(device, monkeypatch):
     assert not m._use_graph(16)  # opt-in: measured no gain (kernel-time-bound even at B = 4)
 
 
+def test_graph_replay_follows_the_split_f16_switch(device, monkeypatch):
+    """a captured forward bakes in WHICH kernels ran.  After ddpm_set_split_f16(0) -- the numeric guard's second pass,
+    bench.py's fp32-products leg -- the replay must come from the fp32-MFMA kernels, not from the graph captured with the split-f16
+    ones (the engine drops its graphs when the switch epoch changes), and flipping back must return the split-f16 result."""
+    from ddpm_ood_amd import DiffusionModelUNet, _lib
+    from ddpm_ood_amd.synthetic import random_state_dict
+
+    m = DiffusionModelUNet(2, 1, 1, **SMALL)
+    m.load_state_dict(random_state_dict("small", 1, seed=1))
+    m = m.to(device).eval()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 1, 32, 32, generator=g).to(device)
+    t = torch.tensor([10, 650, 30, 990], device=device)
+    monkeypatch.setenv("DDPM_UNET_GRAPH", "0")
+    y_split = m(x, timesteps=t).clone()
+    prev = _lib.set_split_f16(False)
+    try:
+        y_fp32 = m(x, timesteps=t).clone()
+    finally:
+        _lib.set_split_f16(prev)
+    assert not torch.equal(y_split, y_fp32)  # (different kernels: different last bits)
+    monkeypatch.setenv("DDPM_UNET_GRAPH", "1")
+    for _ in range(3):  # eager, capture, replay -- with the split-f16 kernels
+        assert torch.equal(m(x, timesteps=t), y_split)
+    assert _lib.load().ddpm_unet_num_graphs(m._engine) == 1
+    prev = _lib.set_split_f16(False)
+    try:
+        for _ in range(3):  # same key (same buffers, same extents): the stale graph must not be replayed
+            assert torch.equal(m(x, timesteps=t), y_fp32)
+    finally:
+        _lib.set_split_f16(prev)
+    for _ in range(3):
+        assert torch.equal(m(x, timesteps=t), y_split)
+
+
 def test_unet_missing_key_and_bad_shape(device):
     from ddpm_ood_amd import DiffusionModelUNet
 
