@@ -15,16 +15,23 @@
 //     issue (100-150 cycles apiece, 24 per phase), no U ring (48 KB), no A-operand ds_read, no vmcnt(0) in front of a barrier.
 //   * ONE barrier per chunk.  The freed LDS holds a V ring of two WHOLE chunks (2 x 36 KB = the epilogue's four exchange slabs),
 //     so everything a chunk interval writes is read in the next one and nothing else orders the waves.
-//   * A wave runs its stages as SEGMENTS, not slices: [pixel loads of chunk c + 2] [the 18 MFMAs of chunk c] [GroupNorm + SiLU
-//     of chunk c + 2 into the pixel ring] [its share of the V transform of chunk c + 1].  Waves 0-3 run the transform segment
-//     last, waves 4-7 (their SIMD partners) first: while one wave of a SIMD sits in its MFMA segment the other one issues VALU
-//     and LDS work -- the pairing MI355X_MICROARCH.md describes ("Two waves per SIMD").
+//   * A wave's chunk interval is two SEGMENTS: [the 18 MFMAs of chunk c, with the pixel staging in their shadow] and [its V task
+//     of chunk c + 1, unsliced].  Waves 0-3 run the V task last, waves 4-7 (their SIMD partners) first: while one wave of a SIMD
+//     sits in its MFMA segment the other one issues VALU and LDS work -- the pairing MI355X_MICROARCH.md describes ("Two waves
+//     per SIMD"); waves 4-7 run at s_setprio 1 (the younger half loses every arbitration otherwise).
 //   * All eight waves stage pixels (one channel of the chunk each); six of them (0, 1, 2, 4, 5, 6) run one V task per chunk =
 //     the 12 positions of a transform-row pair for 16 tiles x 8 channels (the task conv_wino44h.hip splits in halves over two
 //     phases), waves 3 and 7 none.
+//   * Staging runs one interval ahead in a second register set (every shape but eight images per item): interval c requests the
+//     pixels of chunk c + 3 behind its odd MFMA jobs and activates chunk c + 2 (GroupNorm affine + SiLU x 2^3 into the pixel ring)
+//     behind its even ones -- no wave ever waits for a pixel load.
+//   * Pixel-tile layout, patch reads and V stores are conflict-free and wide (w44r_relayout below): a patch row is one
+//     ds_read_b128 + one ds_read_b64, a position's V plane of 16 tiles is 256 lane-linear bytes written by ds_write_addtid_b32.
+// DESIGN.md 3.13 has the measurements (-12.8 % per launch at B = 1 024, -17 % at B = 128 against conv_wino44h.hip, same box),
+// the cycle budget of an interval and everything that was tried and dropped (tools/w44r_abl.sh builds the variants,
+// tools/w44r_probe.py reads the cycle stamps of a -DW44R_PROBE build).
 //
-// LDS: V ring 2 x [row pair 3][position 12][plane 2][tile 32][8 ch f16] + pixel ring of four 4-channel half-tiles -- the same
-// bytes as conv_wino44h.hip, so both kernels fit the same shapes (w44h_geom).
+// LDS: V ring 2 x [row pair 3][position 12][plane 2][tile 32][8 ch f16] + pixel ring of four 4-channel half-tiles.
 #include "wino44h_common.h"
 
 namespace ddpm {
