@@ -329,7 +329,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   // one round behind each MFMA job: nothing in a wave ever waits for a pixel load, and the loads' issue and the GroupNorm +
   // SiLU arithmetic hide behind the MFMAs.  Otherwise one set: loads in front of the MFMA segment, activation behind it.
   constexpr bool DEEP = UIT != 1;
-  constexpr int NSET = DEEP ? 2 : 1;
+#ifndef W44R_SETS
+#define W44R_SETS 2
+#endif
+  // DEEP3 (W44R_SETS=3): THREE sets, requests TWO intervals ahead (interval c requests chunk c + 4): the set of a chunk is its
+  // running index over the workgroup's whole chunk stream modulo 3, so the two-chunk loop body exists in three rotations
+  constexpr bool DEEP3 = DEEP && W44R_SETS == 3;
+  constexpr int NSET = DEEP3 ? 3 : DEEP ? 2 : 1;
+  constexpr int kAhead = DEEP3 ? 4 : DEEP ? 3 : 2;  // interval c requests chunk c + kAhead
   using praw_t = std::conditional_t<QUAD, v4f, float>;
   praw_t praw[NSET][NR];
   float gs[NSET][NGS], gh[NSET][NGS];
@@ -368,7 +375,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #ifndef W44R_NO_PIXEL
     const int ni = min(L.n_it + (ONEIMG ? 0 : k / GDR), g.NIMG - 1);
     const int soff = D3 ? L.soff3 : (ni * L.cx + L.cgl) * (UP ? g.HWin : g.HW) * 4;
+#ifdef W44R_PIX_HITLOAD  // (timing experiment: the same load instructions, always the same 256 bytes -- an L1 / L2 hit)
+    const int voff = (lane & 63) * 4;
+    (void)soff;
+#define soff 0
+#else
     const int voff = D3 && !L.dok ? (int)0x80000000 : pix_of(k);
+#endif
 #ifdef W44R_PIX_NOLOAD  // (timing experiment)
     (void)voff; (void)soff;
     {
@@ -382,6 +395,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       praw[S][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(L.rs, voff, soff, 0));
     else
       praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(L.rs, voff, soff, 0));
+#endif
+#ifdef W44R_PIX_HITLOAD
+#undef soff
 #endif
 #endif
   };
@@ -540,17 +556,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   // static priority for the second-dispatched half of the workgroup: at equal priority the older wave of a SIMD wins every VALU
   // arbitration and waves 4-7 ran every segment ~15 % slower than their partners (MI355X_MICROARCH.md, "Two waves per SIMD", item 4)
   if (wave >= 4) asm volatile("s_setprio 1");
+  int grot = 0;  // DEEP3: running index (over this workgroup's items) of the next interval's chunk, modulo 3
   for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
     const bool first_item = n_cur == n_first || !g.xitem;
     const bool has_next = g.xitem && n_cur + g.TI < n_end;
     // ---- fill.  A workgroup's first item stages chunks 0 and 1 from scratch; later items find them in the pixel ring (staged
     // during the previous item's last two chunk intervals: the ring survives the output transform) and only owe V of chunk 0.
     if (first_item) {
+      grot = 0;
       load_stage(I0{}, 0, n_cur, has_next);
       activate_stage(I0{}, 0);
       load_stage(I0{}, 1, n_cur, has_next);
       activate_stage(I0{}, 1);
-      if (DEEP) load_stage(I0{}, 2, n_cur, has_next);  // (a later item finds these in flight: requested in its predecessor's last interval)
+      // (a later item finds these in flight: requested in its predecessor's last interval(s))
+      if (DEEP3) {  // first item: running index = chunk index
+        load_stage(I2{}, 2, n_cur, has_next);
+        load_stage(I0{}, 3, n_cur, has_next);
+      } else if (DEEP) {
+        load_stage(I0{}, 2, n_cur, has_next);
+      }
       barrier();
     }
 #pragma unroll
@@ -567,10 +591,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     // to wait for the output transform, which owns the V ring.
     const int pahead = lateprod ? 1 : 2;
     if (!lateprod) produce_task(1);
-    auto interval = [&](auto parc, int cc) __attribute__((always_inline)) {
+    auto interval = [&](auto parc, auto rotc, int cc) __attribute__((always_inline)) {
       constexpr int PAR = decltype(parc)::value;
-      using SA = std::integral_constant<int, DEEP ? PAR : 0>;      // the set activated in this interval
-      using SL = std::integral_constant<int, DEEP ? 1 - PAR : 0>;  // the set requested in this interval
+      constexpr int ROT = decltype(rotc)::value;  // DEEP3: running chunk index of chunk cc, modulo 3
+      using SA = std::integral_constant<int, DEEP3 ? (ROT + 2) % 3 : DEEP ? PAR : 0>;      // the set activated in this interval (chunk cc + 2)
+      using SL = std::integral_constant<int, DEEP3 ? (ROT + 1) % 3 : DEEP ? 1 - PAR : 0>;  // the set requested in this interval (chunk cc + kAhead)
 #ifdef W44R_PROBE
       probe_cc = n_cur == n_first ? cc : -100;
 #endif
@@ -579,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #define W44R_LOADS_AT_V 0  // measured 3 % slower than requesting them behind the odd MFMA jobs (same-box A/B)
 #endif
       constexpr bool kLoadsAtV = W44R_LOADS_AT_V != 0;
-      const LoadCtx L = load_prep(cc + (DEEP ? 3 : 2), n_cur, has_next);
+      const LoadCtx L = load_prep(cc + kAhead, n_cur, has_next);
       if (!DEEP) {
 #pragma unroll
         for (int k = 0; k < NR; ++k) load_round(L, SL{}, k);
@@ -643,9 +668,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       if (lateprod) barrier();
       W44R_STAMP(6)
     };
-    for (int c = 0; c < NCHs; c += 2) {
-      interval(I0{}, c);
-      interval(I1{}, c + 1);
+    if constexpr (DEEP3) {
+      for (int c = 0; c < NCHs; c += 2) {
+        if (grot == 0) { interval(I0{}, I0{}, c); interval(I1{}, I1{}, c + 1); }
+        else if (grot == 1) { interval(I0{}, I1{}, c); interval(I1{}, I2{}, c + 1); }
+        else { interval(I0{}, I2{}, c); interval(I1{}, I0{}, c + 1); }
+        grot = grot == 0 ? 2 : grot - 1;  // (+ 2 modulo 3)
+      }
+    } else {
+      for (int c = 0; c < NCHs; c += 2) {
+        interval(I0{}, I0{}, c);
+        interval(I1{}, I0{}, c + 1);
+      }
     }
     // (no vmcnt(0) here: every vector-memory operation of this kernel is a compiler-visible builtin, so the waitcnt pass orders
     // the epilogue's register reuse against whatever is still in flight -- the next item's chunk-2 pixels keep landing into their
