@@ -37,6 +37,7 @@ static void load_switches() {
   n.wino_split = env_int("DDPM_WINO_SPLIT", 8);
   n.w44h_xitem = env_int("DDPM_W44H_XITEM", 1);
   n.w44h_reg = env_int("DDPM_W44H_REG", 1);
+  n.w44r_serp = env_int("DDPM_W44R_SERP", 0);
   n.wino44_xmap = env_int("DDPM_WINO44_XMAP", -1);
   n.w44_abl = env_int("DDPM_W44_ABL", 0);
   n.up_wino44h = env_int("DDPM_UP_WINO44H", 1) != 0;

@@ -45,6 +45,7 @@ struct Switches {
   int w44_abl = 0;              // DDPM_W44_ABL
   int w44h_reg = 1;             // DDPM_W44H_REG: 0 the LDS-fed form of the split-f16 F(4x4) kernel (conv_wino44h.hip; A/B), 1 the register-fed
                                 // form (conv_wino44r.hip, round 5)
+  int w44r_serp = 0;            // DDPM_W44R_SERP: 1 consecutive launches of conv_wino44r.hip walk their items in alternating order (measured: +-0)
   int w44h_xitem = 1;           // DDPM_W44H_XITEM: 0 every item of conv_wino44h.hip refills its pixel ring from scratch (A/B)
   bool up_wino44h = true;       // DDPM_UP_WINO44H
   int down_s2h = 1;             // DDPM_DOWN_S2H (0 off, 2 / 3 force a form)

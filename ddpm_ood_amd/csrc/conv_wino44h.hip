@@ -153,6 +153,7 @@ bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing) {
   g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW) * g.S;
   g.grid = g.KT * ((g.NS + 7) / 8) * 8;
   g.xitem = sw().w44h_xitem;
+  g.rev = 0;
   // default 0: the cout tiles of a slot are neighbours on ONE XCD, so that the KT re-reads of the slot's input hit that XCD's L2
   // (rocprofv3 FETCH_SIZE / WRITE_SIZE at B = 1 024: 1.14 GB per launch against 1.49 GB with one cout tile per XCD, same time)
   g.xmap = (sw().wino44_xmap >= 0 ? sw().wino44_xmap != 0 : 0) && (8 % g.KT == 0);
@@ -940,6 +941,9 @@ int launch_conv_wino44h(const ddpm_conv_desc &d, hipStream_t s) {
   if (sw().w44h_reg) {  // the register-fed form (conv_wino44r.hip, round 5): same item, same packed weights, bit-identical results
     W44HGeom gr = g;
     w44r_relayout(d, gr);
+    // serpentine item order across consecutive launches (DDPM_W44R_SERP=1; measured +-0, default off): results do not depend on it
+    static unsigned launch_parity = 0;
+    gr.rev = sw().w44r_serp ? (int)(launch_parity++ & 1) : 0;
     if (w44h_lds_bytes(gr) > 160 * 1024) {
       set_error("conv_wino44r: pixel-tile layout does not fit");
       return DDPM_EINVAL;

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   const int nitems = min(g.IPW, g.NIT - it0);
   const int r0 = part * g.TR;
   const int n_first = it0 * g.TI, n_end = n_first + nitems * g.TI;
+  const int istep = g.rev ? -g.TI : g.TI;  // images from an item to the next one of this workgroup
   const int NCHs = g.NCH / g.S, ch_lo = split * NCHs;  // this workgroup's chunk range (even length)
   float *const outp = a.out + (size_t)split * g.pstride;
 
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     LoadCtx L;
     const bool nxt = cc >= NCHs && has_next;
     const int cl = nxt ? cc - NCHs : min(max(cc, 0), NCHs - 1);
-    L.n_it = nxt ? n_cur + g.TI : n_cur;
+    L.n_it = nxt ? n_cur + istep : n_cur;
     int cg = (ch_lo + cl) * kC + phalf * 4 + sc;
     L.cga = cg;
     L.soff3 = 0;
@@ -557,9 +558,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   // arbitration and waves 4-7 ran every segment ~15 % slower than their partners (MI355X_MICROARCH.md, "Two waves per SIMD", item 4)
   if (wave >= 4) asm volatile("s_setprio 1");
   int grot = 0;  // DEEP3: running index (over this workgroup's items) of the next interval's chunk, modulo 3
-  for (int n_cur = n_first; n_cur < n_end; n_cur += g.TI) {
-    const bool first_item = n_cur == n_first || !g.xitem;
-    const bool has_next = g.xitem && n_cur + g.TI < n_end;
+  for (int n_idx = 0; n_idx < nitems; ++n_idx) {
+    const int n_cur = g.rev ? n_end - (n_idx + 1) * g.TI : n_first + n_idx * g.TI;
+    const bool first_item = n_idx == 0 || !g.xitem;
+    const bool has_next = g.xitem && n_idx + 1 < nitems;
     // ---- fill.  A workgroup's first item stages chunks 0 and 1 from scratch; later items find them in the pixel ring (staged
     // during the previous item's last two chunk intervals: the ring survives the output transform) and only owe V of chunk 0.
     if (first_item) {
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       using SA = std::integral_constant<int, DEEP3 ? (ROT + 2) % 3 : DEEP ? PAR : 0>;      // the set activated in this interval (chunk cc + 2)
       using SL = std::integral_constant<int, DEEP3 ? (ROT + 1) % 3 : DEEP ? 1 - PAR : 0>;  // the set requested in this interval (chunk cc + kAhead)
 #ifdef W44R_PROBE
-      probe_cc = n_cur == n_first ? cc : -100;
+      probe_cc = n_idx == 0 ? cc : -100;
 #endif
       W44R_STAMP(0)
 #ifndef W44R_LOADS_AT_V

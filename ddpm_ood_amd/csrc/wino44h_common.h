@@ -190,6 +190,8 @@ struct W44HGeom {
   int KT, NIT, IPW, NS, grid;
   int xmap;
   int xitem;        // 1: the pixel waves' staging stream runs on across item boundaries (DDPM_W44H_XITEM, A/B)
+  int rev;          // conv_wino44r.hip: 1 = a workgroup walks its items LAST to first (serpentine across consecutive launches: the
+                    // consumer starts on what its producer wrote last, i.e. on what the 256 MB Infinity Cache still holds)
   int up, HWin;     // 1: DDPM_CONV_UPSAMPLE2 -- the pixel waves read the nearest-x2 image from the stored low-res one (HWin pixels)
   int S;            // channel-stream splits per item (1: none)
   long long pstride;
