@@ -336,8 +336,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   // DEEP3 (W44R_SETS=3): THREE sets, requests TWO intervals ahead (interval c requests chunk c + 4): the set of a chunk is its
   // running index over the workgroup's whole chunk stream modulo 3, so the two-chunk loop body exists in three rotations
   constexpr bool DEEP3 = DEEP && W44R_SETS == 3;
+#ifndef W44R_RELOAD
+#define W44R_RELOAD 0  // measured: 6 % SLOWER (5 152 / 5 196 vs 4 864 / 4 875 us over the six layers, same box)
+#endif
+  // RELOAD (two sets): a round's registers are requested again -- for the chunk TWO intervals on -- right behind the activation that
+  // consumed them, instead of filling the other set one interval ahead: twice the lead for the same registers
+  constexpr bool RELOAD = DEEP && !DEEP3 && W44R_RELOAD;
   constexpr int NSET = DEEP3 ? 3 : DEEP ? 2 : 1;
-  constexpr int kAhead = DEEP3 ? 4 : DEEP ? 3 : 2;  // interval c requests chunk c + kAhead
+  constexpr int kAhead = DEEP3 || RELOAD ? 4 : DEEP ? 3 : 2;  // interval c requests chunk c + kAhead
   using praw_t = std::conditional_t<QUAD, v4f, float>;
   praw_t praw[NSET][NR];
   float gs[NSET][NGS], gh[NSET][NGS];
@@ -574,10 +580,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       if (DEEP3) {  // first item: running index = chunk index
         load_stage(I2{}, 2, n_cur, has_next);
         load_stage(I0{}, 3, n_cur, has_next);
+      } else if (RELOAD) {
+        load_stage(I0{}, 2, n_cur, has_next);
+        load_stage(I1{}, 3, n_cur, has_next);
       } else if (DEEP) {
         load_stage(I0{}, 2, n_cur, has_next);
       }
       barrier();
+    } else if (RELOAD) {
+      load_stage(I1{}, 3, n_cur, has_next);  // (chunk 2 has been in flight since the previous item's last-but-one interval)
     }
 #pragma unroll
     for (int jj = 0; jj < kAR; ++jj) Ar[jj] = load_a(0, jj);
@@ -597,7 +608,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       constexpr int PAR = decltype(parc)::value;
       constexpr int ROT = decltype(rotc)::value;  // DEEP3: running chunk index of chunk cc, modulo 3
       using SA = std::integral_constant<int, DEEP3 ? (ROT + 2) % 3 : DEEP ? PAR : 0>;      // the set activated in this interval (chunk cc + 2)
-      using SL = std::integral_constant<int, DEEP3 ? (ROT + 1) % 3 : DEEP ? 1 - PAR : 0>;  // the set requested in this interval (chunk cc + kAhead)
+      using SL = std::integral_constant<int, DEEP3 ? (ROT + 1) % 3 : RELOAD ? PAR : DEEP ? 1 - PAR : 0>;  // the set requested in this interval (chunk cc + kAhead)
 #ifdef W44R_PROBE
       probe_cc = n_idx == 0 ? cc : -100;
 #endif
@@ -631,6 +642,27 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #pragma unroll
               for (int i = 0; i < NGS; ++i) load_affine(L, SL{}, i);
             }
+          }
+        } else if (RELOAD) {
+          // even jobs: two activation rounds (one per part); odd jobs: the two rounds just consumed are requested again, for chunk cc + 4
+          const int k0 = 2 * (jj / 2) + part;
+          if ((jj & 1) == 0) {
+#pragma unroll
+            for (int kk = 0; kk < NRT; ++kk)
+              if (kk == k0) activate_round(SA{}, cc + 2, kk);
+          } else if (cc + 1 < NCHs) {
+#pragma unroll
+            for (int kk = 0; kk < NRT; ++kk)
+              if (kk == k0) load_round(L, SL{}, kk);
+          }
+          // (an item's LAST interval requests nothing: its chunk cc + 4 is the next item's chunk 3, requested behind the output
+          // transform instead -- only ONE set, the next item's chunk 2, is in flight across the transform, whose residual rows
+          // and exchange temporaries need the registers)
+          if (jj == 8 && part == 1 && cc + 1 < NCHs) {  // rounds 8 (and 9) were activated in this job: their requests and the GroupNorm pairs close the interval
+#pragma unroll
+            for (int kk = 8; kk < NRT; ++kk) load_round(L, SL{}, kk);
+#pragma unroll
+            for (int i = 0; i < NGS; ++i) load_affine(L, SL{}, i);
           }
         } else if ((jj & 1) == 0) {
           const int k = 2 * (jj / 2) + part;
