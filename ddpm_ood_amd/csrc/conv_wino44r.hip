@@ -146,6 +146,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     acc8 = f32x16{z, z, z, z, z, z, z, z, z, z, z, z, z, z, z, z};
   };
 
+#ifdef W44R_PROBE
+  if (blockIdx.x == 0 && lane == 0 && a.scratch) reinterpret_cast<unsigned long long *>(a.scratch)[512 + wave * 32 + 31] = __builtin_readcyclecounter();
+#endif
   // ---- zero borders once (pixel writes only ever touch in-image pixels)
   for (int i = tid; i < 4 * g.HS; i += 512) P[i] = 0.f;
   __syncthreads();
@@ -156,19 +159,29 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 
 #ifdef W44R_PROBE  // timing experiment: cycle stamps of workgroup 0, every wave, chunk intervals 4..7 of the first item -> desc.scratch
   int probe_cc = -100;
+  int n_idx_probe = 0;
 #define W44R_STAMP(i)                                                                                                  \
   if (blockIdx.x == 0 && probe_cc >= 4 && probe_cc < 8 && lane == 0 && a.scratch)                                      \
     reinterpret_cast<unsigned long long *>(a.scratch)[((wave * 4 + (probe_cc - 4)) * 16 + (i)) & 511] = __builtin_readcyclecounter();
+// phase stamps of the first item (fill, first V task, chunk loop, output-transform passes): slot 512 + 32 wave + i
+#define W44R_FSTAMP(i)                                                                                                 \
+  if (blockIdx.x == 0 && n_idx_probe == 0 && lane == 0 && a.scratch)                                                    \
+    reinterpret_cast<unsigned long long *>(a.scratch)[512 + wave * 32 + (i)] = __builtin_readcyclecounter();
 #else
 #define W44R_STAMP(i)
+#define W44R_FSTAMP(i)
 #endif
+  W44R_FSTAMP(0)
   // ================================================================================================ V tasks
   // Waves 0, 1, 2, 4, 5, 6 = tasks q = 0..5: row pair q / 2, tile half q & 1.  lane = (tile of 16, channel pair j of 4); a task =
   // the 12 positions of the pair for the lane's two channels: column passes of both channels (12 patch-row reads, 96 VALU), four
   // row passes (48), twelve pair splits (48), 24 stores.
-  // NEWLAY (every shape but the eight-images-per-item one): lane = 4 tile + j and the pixel-tile layout of w44r_relayout() -- patch
-  // rows are two conflict-free ds_read_b128, a position's V plane of 16 tiles is lane-linear (ds_write_addtid_b32).
-  constexpr bool NEWLAY = UIT != 1;
+  // NEWLAY: lane = 4 tile + j and the pixel-tile layout of w44r_relayout() -- patch rows are a conflict-free ds_read_b128 and a
+  // ds_read_b64, a position's V plane of 16 tiles is lane-linear (ds_write_addtid_b32).
+#ifndef W44R_NEWLAY8
+#define W44R_NEWLAY8 1  // 0: eight 8x8 images per item keep conv_wino44h.hip's layout and its 4-byte patch reads
+#endif
+  constexpr bool NEWLAY = UIT != 1 || W44R_NEWLAY8;
   const int ptask = (wave & 3) == 3 ? -1 : wave - (wave >> 2);
   const int pst = (ptask & 1) * 16 + (NEWLAY ? lane >> 2 : lane & 15), pj = NEWLAY ? lane & 3 : lane >> 4;
   int tb0;  // pixel-ring offset (floats) of this lane's patch origin in channel 2 j of an EVEN chunk (half-tile j >> 1, plane 2 (j & 1))
@@ -325,11 +338,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gshift), 0, AFFINE ? a.B * g.Cin * 4 : 0, 0x00020000);
   int vzero;  // keeps the wave-uniform scale / shift loads on the vector memory path
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-  // DEEP (every shape but eight images per item, whose 16 scale / shift pairs per set do not fit twice): TWO register sets.
+  // PACKED (eight images per item): the item's eight GroupNorm pairs of a channel live in ONE register pair, lane i = image i
+  // (read back with v_readlane at the activation), instead of sixteen wave-uniform registers -- that is what lets this shape hold
+  // two sets as well.
+  constexpr bool PACKED = UIT == 1;
+  constexpr int NGL = PACKED ? 1 : NGS;  // GroupNorm scale / shift registers per set
+#ifndef W44R_DEEP8
+#define W44R_DEEP8 1  // 0: eight images per item stage from ONE set (loads in front of the MFMA segment, activation behind it)
+#endif
+  // DEEP: TWO register sets.
   // Interval c requests chunk c + 3 into set (c + 1) & 1 and activates chunk c + 2 from set c & 1 (requested an interval earlier),
   // one round behind each MFMA job: nothing in a wave ever waits for a pixel load, and the loads' issue and the GroupNorm +
   // SiLU arithmetic hide behind the MFMAs.  Otherwise one set: loads in front of the MFMA segment, activation behind it.
-  constexpr bool DEEP = UIT != 1;
+  constexpr bool DEEP = UIT != 1 || W44R_DEEP8;
 #ifndef W44R_SETS
 #define W44R_SETS 2
 #endif
@@ -346,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   constexpr int kAhead = DEEP3 || RELOAD ? 4 : DEEP ? 3 : 2;  // interval c requests chunk c + kAhead
   using praw_t = std::conditional_t<QUAD, v4f, float>;
   praw_t praw[NSET][NR];
-  float gs[NSET][NGS], gh[NSET][NGS];
+  float gs[NSET][NGL], gh[NSET][NGL];
   struct LoadCtx {  // wave-uniform addressing of one stream chunk's loads (SGPRs)
     __amdgpu_buffer_rsrc_t rs;
     int n_it, cx, cgl, cga, soff3;
@@ -412,10 +433,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     constexpr int S = decltype(setc)::value;
 #ifndef W44R_NO_PIXEL
     if (AFFINE) {
-      const int ni = min(L.n_it + i, g.NIMG - 1);
-      const int goff = (ni * g.Cin + L.cga) * 4;
-      gs[S][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, vzero, goff, 0));
-      gh[S][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, vzero, goff, 0));
+      const int nb = min(L.n_it + i, g.NIMG - 1);
+      const int goff = (nb * g.Cin + L.cga) * 4;
+      // PACKED: lane l = image min(n_it + (l & 7), NIMG - 1)
+      const int voff = PACKED ? max(0, min(lane & 7, g.NIMG - 1 - L.n_it)) * (g.Cin * 4) : vzero;
+      gs[S][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, voff, goff, 0));
+      gh[S][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, voff, goff, 0));
     }
 #endif
   };
@@ -424,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #pragma unroll
     for (int k = 0; k < NR; ++k) load_round(L, setc, k);
 #pragma unroll
-    for (int i = 0; i < NGS; ++i) load_affine(L, setc, i);
+    for (int i = 0; i < NGL; ++i) load_affine(L, setc, i);
   };
   // pixel value x 2^3 (2^0 without prologue): the transform's output is the pre-scaled V
   auto activate_round = [&](auto setc, int cc, int k) __attribute__((always_inline)) {
@@ -433,8 +456,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     float *const Pr = P + (2 * (cc & 1) + phalf) * g.HS + pw_of(k);
     float sa = 0.f, sb = 0.f, ta = 0.f, tb = 0.f;
     if (AFFINE) {
-      sa = gs[S][k / GDR];
-      sb = gh[S][k / GDR];
+      if (PACKED) {
+        sa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gs[S][0]), k / GDR));
+        sb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gh[S][0]), k / GDR));
+      } else {
+        sa = gs[S][k / GDR];
+        sb = gh[S][k / GDR];
+      }
       ta = -1.44269504088896341f * sa;
       tb = -1.44269504088896341f * sb;
     }
@@ -570,12 +598,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     const bool has_next = g.xitem && n_idx + 1 < nitems;
     // ---- fill.  A workgroup's first item stages chunks 0 and 1 from scratch; later items find them in the pixel ring (staged
     // during the previous item's last two chunk intervals: the ring survives the output transform) and only owe V of chunk 0.
+#ifdef W44R_PROBE
+    n_idx_probe = n_idx;
+#endif
+    W44R_FSTAMP(1)
     if (first_item) {
       grot = 0;
+      constexpr bool FILL2 = DEEP && !DEEP3 && !RELOAD;  // chunks 0 and 1 requested together, into their own sets: one memory round trip
       load_stage(I0{}, 0, n_cur, has_next);
+      if (FILL2) load_stage(I1{}, 1, n_cur, has_next);
+      W44R_FSTAMP(2)
       activate_stage(I0{}, 0);
-      load_stage(I0{}, 1, n_cur, has_next);
-      activate_stage(I0{}, 1);
+      W44R_FSTAMP(3)
+      if (FILL2) {
+        load_stage(I0{}, 2, n_cur, has_next);
+        activate_stage(I1{}, 1);
+      } else {
+        load_stage(I0{}, 1, n_cur, has_next);
+        activate_stage(I0{}, 1);
+      }
+      W44R_FSTAMP(4)
       // (a later item finds these in flight: requested in its predecessor's last interval(s))
       if (DEEP3) {  // first item: running index = chunk index
         load_stage(I2{}, 2, n_cur, has_next);
@@ -583,18 +625,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       } else if (RELOAD) {
         load_stage(I0{}, 2, n_cur, has_next);
         load_stage(I1{}, 3, n_cur, has_next);
-      } else if (DEEP) {
-        load_stage(I0{}, 2, n_cur, has_next);
       }
       barrier();
     } else if (RELOAD) {
       load_stage(I1{}, 3, n_cur, has_next);  // (chunk 2 has been in flight since the previous item's last-but-one interval)
     }
+    W44R_FSTAMP(5)
 #pragma unroll
     for (int jj = 0; jj < kAR; ++jj) Ar[jj] = load_a(0, jj);
     produce_task(0);
     zero_accumulators();
+    W44R_FSTAMP(6)
     barrier();
+    W44R_FSTAMP(7)
     // ---- chunk intervals.  Interval c of a wave: loads of chunk c + 2, the 18 MFMAs of chunk c, activation of chunk c + 2, and
     // its V task of chunk c + 1 -- waves 0-3 run that task LAST (before the interval's barrier), waves 4-7 FIRST (behind the
     // previous interval's barrier: their "interval" is shifted by one segment, so that the two waves of a SIMD are never in their
@@ -622,7 +665,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #pragma unroll
         for (int k = 0; k < NR; ++k) load_round(L, SL{}, k);
 #pragma unroll
-        for (int i = 0; i < NGS; ++i) load_affine(L, SL{}, i);
+        for (int i = 0; i < NGL; ++i) load_affine(L, SL{}, i);
       }
       W44R_STAMP(1)
       if (DEEP) asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL));
@@ -640,7 +683,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
             if ((jj & 1) == 1 && jj / 2 < NR) load_round(L, SL{}, jj / 2);
             if (jj == 7) {
 #pragma unroll
-              for (int i = 0; i < NGS; ++i) load_affine(L, SL{}, i);
+              for (int i = 0; i < NGL; ++i) load_affine(L, SL{}, i);
             }
           }
         } else if (RELOAD) {
@@ -662,7 +705,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #pragma unroll
             for (int kk = 8; kk < NRT; ++kk) load_round(L, SL{}, kk);
 #pragma unroll
-            for (int i = 0; i < NGS; ++i) load_affine(L, SL{}, i);
+            for (int i = 0; i < NGL; ++i) load_affine(L, SL{}, i);
           }
         } else if ((jj & 1) == 0) {
           const int k = 2 * (jj / 2) + part;
@@ -677,7 +720,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
             if (k / 3 == jj / 2 && (k % 3 == 0) == (part == 0)) load_round(L, SL{}, k);
           if (part == 1) {
 #pragma unroll
-            for (int i = 0; i < NGS; ++i)
+            for (int i = 0; i < NGL; ++i)
               if (i == jj / 2) load_affine(L, SL{}, i);
           }
         }
@@ -695,7 +738,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #pragma unroll
         for (int k = 0; k < NR; ++k) load_round(L, SL{}, k);
 #pragma unroll
-        for (int i = 0; i < NGS; ++i) load_affine(L, SL{}, i);
+        for (int i = 0; i < NGL; ++i) load_affine(L, SL{}, i);
       }
       if (cc + pahead < NCHs) produce_task(cc + pahead);
       W44R_STAMP(5)
@@ -722,6 +765,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     // ---- end of an item: Y = A^T M A through four exchange slabs [xi][cout block][lane] (the V ring: every stage of the item has
     // finished).  Pass q moves accumulator registers 4 q .. 4 q + 3 of all 36 positions; wave (cb, pg) then finishes register
     // 4 q + pg of cout block cb: cout = 32 cb + 8 q + 4 lhi + pg, tile = l31 (conv_wino44h.hip's output transform, verbatim).
+    W44R_FSTAMP(8)
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' passes
     int elane = lane;
     asm volatile("" : "+v"(elane));
@@ -772,7 +816,33 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       constexpr int q = decltype(qc)::value;
       const size_t obase = obase0 + (size_t)(8 * q) * cstr;
       float st_p = 0.f, st_s1 = 0.f, st_s2 = 0.f;  // this lane's 4x4 tile about a pivot (its first value)
-      {
+#ifndef W44R_XADDTID
+#define W44R_XADDTID 1  // 0: the exchange stores as ds_write_b32 (half the rate)
+#endif
+      if (W44R_XADDTID) {
+        // the slabs are [xi][cout block][lane]: lane-linear, so the 36 stores are ds_write_addtid_b32 (address = M0 + offset +
+        // 4 lane; twice the rate of ds_write_b32).  M0 = cout block + the wave's position row (x / 3) + slab pair; offsets: slab of
+        // the pair, column x % 3.
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+          for (int x3 = 0; x3 < 3; ++x3) {
+            const int m0v = __builtin_amdgcn_readfirstlane(((x3 == 0 ? xb0 : x3 == 1 ? xb1 : xb2) * 128 + cb * 64 + hh * 2 * kXS) * 4);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 1" ::"s"(m0v));
+#pragma unroll
+            for (int xc = 0; xc < 3; ++xc) {
+              const int x = 3 * x3 + xc;
+#pragma unroll
+              for (int r2 = 0; r2 < 2; ++r2) {
+                const int rr = 2 * hh + r2;
+                const float v = x == 8 ? acc8[4 * q + rr] : read_pinned(16 * (x & 7) + 4 * q + rr);
+                if (r2 == 0) asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(v), "n"(xc * 512) : "memory");
+                else asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(v), "n"(kXS * 4 + xc * 512) : "memory");
+              }
+            }
+          }
+        }
+      } else {
         float *xw = XS + cb * 64 + elane;
 #pragma unroll
         for (int x = 0; x < 9; ++x) {
@@ -847,10 +917,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 #ifndef W44R_NO_EPI  // (timing experiment: no output transform / stores -- wrong results)
+    W44R_FSTAMP(9)
     pass(I0{});
+    W44R_FSTAMP(10)
     pass(I1{});
+    W44R_FSTAMP(11)
     pass(I2{});
+    W44R_FSTAMP(12)
     pass(std::integral_constant<int, 3>{});
+    W44R_FSTAMP(13)
 #endif
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -865,13 +940,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 // every group sees {0,3,5,6} + {0,8,4,12} = all 16 residues.  Rows are 16-byte aligned (PW % 4 == 0; pixel (r, c) at r PW + c + 1,
 // so a tile's patch starts at column 4 tc).
 void w44r_relayout(const ddpm_conv_desc &d, W44HGeom &g) {
-  if (g.TI == 8) return;  // 8x8 images: conv_wino44h.hip's layout and its 4-byte patch reads
+  if (g.TI == 8 && !W44R_NEWLAY8) return;
   const int w = d.Wo + 2;
   int pw = (w + 3) & ~3;
   if (g.TWc == 8) while (pw % 16 != 8) pw += 4;
   if (g.TWc == 4) while (pw % 16 != 4) pw += 4;
   g.PW = pw;
   g.IS = g.prow * g.PW;
+  // eight 8x8 images per item (tile of 16 = 4 image + 2 tile row + tile column): the tile rows of an image fall into different
+  // groups, so U only has to tell apart (image parity, tile column): image stride IS = 8 (mod 16) floats (10 rows of 12: as it is)
+  if (g.TI == 8) while (g.IS % 16 != 8) g.IS += 4;
   g.PCH = g.TI * g.IS;
   while (g.PCH % 32 != 16) g.PCH += 1;
   g.HS = 4 * g.PCH + 272;  // = 16 (mod 64); the 256 dump floats of out-of-image lanes (four per lane) sit at 4 PCH + 1 ..
