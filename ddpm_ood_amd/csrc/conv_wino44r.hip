@@ -149,9 +149,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #ifdef W44R_PROBE
   if (blockIdx.x == 0 && lane == 0 && a.scratch) reinterpret_cast<unsigned long long *>(a.scratch)[512 + wave * 32 + 31] = __builtin_readcyclecounter();
 #endif
-  // ---- zero borders once (pixel writes only ever touch in-image pixels)
-  for (int i = tid; i < 4 * g.HS; i += 512) P[i] = 0.f;
-  __syncthreads();
+  // ---- borders are zeroed once (pixel writes only ever touch in-image pixels): behind the first item's first requests, whose
+  // memory round trip the zeroing then hides
+  auto zero_borders = [&]() __attribute__((always_inline)) {
+    const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < g.HS; i += 512) *reinterpret_cast<v4f *>(P + 4 * i) = z4;  // (4 HS floats; P is 16-byte aligned)
+    __syncthreads();
+  };
 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -607,6 +611,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       constexpr bool FILL2 = DEEP && !DEEP3 && !RELOAD;  // chunks 0 and 1 requested together, into their own sets: one memory round trip
       load_stage(I0{}, 0, n_cur, has_next);
       if (FILL2) load_stage(I1{}, 1, n_cur, has_next);
+      if (n_idx == 0) zero_borders();
       W44R_FSTAMP(2)
       activate_stage(I0{}, 0);
       W44R_FSTAMP(3)
