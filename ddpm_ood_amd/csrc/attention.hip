@@ -434,7 +434,7 @@ template <bool VEC>
 __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict__ qkv,
                                                          const float *__restrict__ residual,
                                                          float *__restrict__ out, int C, int N, int heads,
-                                                         float scale) {
+                                                         float scale, float *__restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *Ql = smem;                    // two f16 planes [32][64][8]: q hi, q lo 2^5
   float *KVl = Ql + kDH * kQB;         // [256][65]   K block (row stride 64) then V block (row stride 65)
@@ -732,14 +732,40 @@ __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int d = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        out[((size_t)n * C + hh * kDH + d) * N + i] = o[b][r] * inv + rv[r];
+        o[b][r] = o[b][r] * inv + rv[r];
+        out[((size_t)n * C + hh * kDH + d) * N + i] = o[b][r];
+      }
+    }
+  }
+  // ---- the next GroupNorm's per-channel statistics {mean, M2 about it} (launch_attention passes `stats` only for N == 64: this
+  // workgroup then holds every token of its 256 channels; a channel = two values in each lane of a half-wave)
+  if (stats) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // pairwise (Chan) merge on the DPP path: the lane's two values, then the 32 lanes of the half-wave (valid in its last lane)
+      float mean = 0.5f * (o[0][r] + o[1][r]);
+      const float dd = o[0][r] - o[1][r];
+      float m2 = 0.5f * dd * dd;
+      group_moments_last_lane(mean, m2, 2.f, 32);
+      if (l31 == 31) {
+        const int d = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        *reinterpret_cast<float2 *>(stats + ((size_t)n * C + hh * kDH + d) * 2) = make_float2(mean, m2);
       }
     }
   }
 }
 
+// true when launch_attention(...) with these arguments writes the per-channel {mean, M2} pairs of its output to `stats_out`
+// ([B, C, 1 slice, 2]): the eight-wave split-f16 kernel with all 64 tokens of an image in one workgroup
+bool attention_emits_stats(int B, int C, int N, int heads, const float *scratch, size_t scratch_floats) {
+  static const bool waves8 = !(getenv("DDPM_ATTN_WAVES") && atoi(getenv("DDPM_ATTN_WAVES")) == 4);
+  const bool f16x3 = split_f16_on(sw().attn_f16x3);
+  if (!f16x3 || !waves8 || N != kQB || C != heads * kDH) return false;
+  return !(sw().attn_fa && attention_fa_supported(B, C, N, heads, scratch, scratch_floats));
+}
+
 int launch_attention(const float *qkv, const float *residual, float *out, int B, int C, int N, int heads, float scale,
-                     hipStream_t s, float *scratch, size_t scratch_floats) {
+                     hipStream_t s, float *scratch, size_t scratch_floats, float *stats_out) {
   DDPM_CHECK_ARG(qkv && out && B > 0 && N > 0 && heads > 0, "attention: null pointer or empty shape");
   DDPM_CHECK_ARG(C == heads * kDH, "attention: only head dim 256 is built (C = %d, heads = %d)", C, heads);
   DDPM_CHECK_ARG(B <= 65535 && heads <= 65535, "attention: grid too large");
@@ -768,7 +794,8 @@ int launch_attention(const float *qkv, const float *residual, float *out, int B,
   const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv) & 15) == 0);
   if (f16x3 && waves8) {
     auto kern8 = vec ? attention8_kernel<true> : attention8_kernel<false>;
-    hipLaunchKernelGGL(kern8, grid, dim3(512), lds, s, qkv, residual, out, C, N, heads, scale);
+    float *const st = stats_out && attention_emits_stats(B, C, N, heads, scratch, scratch_floats) ? stats_out : nullptr;
+    hipLaunchKernelGGL(kern8, grid, dim3(512), lds, s, qkv, residual, out, C, N, heads, scale, st);
     DDPM_CHECK_LAUNCH();
     return 0;
   }

@@ -242,7 +242,8 @@ int launch_gn_finalize(const float *st1, int parts1, int C1, const float *st2, i
                        const float *beta, float *scale, float *shift, int B, int HW, int groups, float eps, hipStream_t s);
 int launch_channel_stats(const float *in, float *stats, int B, int C, int HW, hipStream_t s);
 int launch_attention(const float *qkv, const float *residual, float *out, int B, int C, int N, int heads, float scale,
-                     hipStream_t s, float *scratch = nullptr, size_t scratch_floats = 0);
+                     hipStream_t s, float *scratch = nullptr, size_t scratch_floats = 0, float *stats_out = nullptr);
+bool attention_emits_stats(int B, int C, int N, int heads, const float *scratch, size_t scratch_floats);
 size_t attention_fa_scratch_floats(int B, int C, int N, int heads);
 bool attention_fa_supported(int B, int C, int N, int heads, const float *scratch, size_t scratch_floats);
 int launch_attention_fa(const float *qkv, const float *residual, float *out, int B, int C, int N, int heads, float scale,

@@ -698,7 +698,12 @@ struct Runner {
     const size_t nplanes = attention_fa_scratch_floats(B, a.C, N, a.heads);  // f16 planes of q / k / v (attention_fa.hip)
     float *planes = nplanes ? ws.get(nplanes) : nullptr;
     if (!u->cfg.use_proj_attn) {
-      if (!ws.dry && !rc) rc = launch_attention(qkv, x.p, out.p, B, a.C, N, a.heads, scale, s, planes, nplanes);
+      // 64 tokens: the kernel's epilogue leaves the next GroupNorm's statistics behind (one slice per channel)
+      const bool st = fuse_stats && out.stats && out.sparts && attention_emits_stats(B, a.C, N, a.heads, planes, nplanes);
+      if (!ws.dry && !rc) {
+        rc = launch_attention(qkv, x.p, out.p, B, a.C, N, a.heads, scale, s, planes, nplanes, st ? out.stats : nullptr);
+        if (st && !rc) *out.sparts = 1;
+      }
     } else {
       Act o{ws.get((size_t)B * a.C * N), a.C, x.H, x.W, x.D};
       if (!ws.dry && !rc) rc = launch_attention(qkv, nullptr, o.p, B, a.C, N, a.heads, scale, s, planes, nplanes);

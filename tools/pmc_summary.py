@@ -70,7 +70,7 @@ def main(root, out_csv, out_json):
                          ("conv1x1_dma", r"conv1x1_dma_kernel"),
                          ("attention", r"attention_kernel"),
                          ("lpips_conv_mfma", r"lpips_conv_mfma_kernel")):
-        sel = m[m.kernel.str.contains(pattern)]
+        sel = m[m.kernel.notna() & m.kernel.str.contains(pattern, na=False)]  # (rows without a kernel name: copies, fills)
         if len(sel):
             wgt = sel.launches / sel.launches.sum()
             out[key + "_bytes_per_launch"] = float((sel.hbm_MB_per_launch * wgt).sum() * 1e6)
