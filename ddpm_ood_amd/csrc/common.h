@@ -114,6 +114,16 @@ __device__ __forceinline__ void chan_merge_dpp(float &mean, float &m2, float &ha
   mean = 0.5f * (mean + mo);
   halfn += halfn;
 }
+// plain sum of a wave's 64 values on the same DPP path (valid in lane 63 only)
+__device__ __forceinline__ float wave_sum_dpp_last_lane(float v) {
+  v += dpp_mov0<0x111>(v);
+  v += dpp_mov0<0x112>(v);
+  v += dpp_mov0<0x114>(v);
+  v += dpp_mov0<0x118>(v);
+  v += dpp_mov0<0x142>(v);
+  v += dpp_mov0<0x143>(v);
+  return v;
+}
 __device__ __forceinline__ void group_moments_last_lane(float &mean, float &m2, float cnt, int lanes) {  // lanes: 4, 16, 32, 64
   float halfn = 0.5f * cnt;
   chan_merge_dpp<0x111>(mean, m2, halfn);

@@ -330,6 +330,12 @@ __global__ __launch_bounds__(256) void conv_smallci_kernel(const ddpm_conv_desc 
   // (gridDim.z slices of the output channels: a launch of a few images has too few pixel blocks to fill the chip and every
   // thread's channel loop is a serial chain of scalar loads and stores -- 38 us for 16 images, 128 channels)
   const int cpz = (a.Cout + gridDim.z - 1) / gridDim.z, co_end = min(a.Cout, ((int)blockIdx.z + 1) * cpz);
+  // desc.stats_out (launch_conv_direct sets it only when HW is a multiple of 256: every lane of the workgroup holds a pixel): the
+  // next GroupNorm's {mean, M2} of this workgroup's 256 pixels = one slice of the image -- the wave's 64 values by a DPP sum,
+  // their squared deviations about the wave mean by another, the four waves merged (Chan, fixed order) through LDS at the end
+  extern __shared__ float2 wred[];  // [cout of this z slice][wave]
+  const bool emit = a.stats_out != nullptr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll 4
   for (int co = blockIdx.z * cpz; co < co_end; ++co) {  // (unrolled: the scalar weight loads of four channels go out together)
     const float *w = a.w_raw + (size_t)co * CIN * 9;  // wave-uniform
@@ -338,6 +344,25 @@ __global__ __launch_bounds__(256) void conv_smallci_kernel(const ddpm_conv_desc 
     for (int k = 0; k < CIN * 9; ++k) acc = fmaf(x[k], w[k], acc);  // (ci, kh, kw) order, as conv_direct_kernel
     if (a.bias) acc += a.bias[co];
     dst[(size_t)co * HW] = acc;
+    if (emit) {
+      const float mean = wave_sum_dpp_last_lane(acc);  // (valid in lane 63)
+      const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mean), 63)) * (1.f / 64.f);
+      const float dv = acc - mu;
+      const float q = wave_sum_dpp_last_lane(dv * dv);
+      if (lane == 63) wred[(co - blockIdx.z * cpz) * 4 + wave] = make_float2(mu, q);
+    }
+  }
+  if (emit) {
+    __syncthreads();
+    const int parts = HW / 256;
+    for (int c = threadIdx.x; c < co_end - (int)blockIdx.z * cpz; c += 256) {
+      const float2 w0 = wred[c * 4], w1 = wred[c * 4 + 1], w2 = wred[c * 4 + 2], w3 = wred[c * 4 + 3];
+      const float m01 = 0.5f * (w0.x + w1.x), d01 = w1.x - w0.x, q01 = (w0.y + w1.y) + d01 * d01 * 32.f;
+      const float m23 = 0.5f * (w2.x + w3.x), d23 = w3.x - w2.x, q23 = (w2.y + w3.y) + d23 * d23 * 32.f;
+      const float mm = 0.5f * (m01 + m23), dd = m23 - m01, qq = (q01 + q23) + dd * dd * 64.f;
+      const int co = blockIdx.z * cpz + c;
+      *reinterpret_cast<float2 *>(a.stats_out + (((size_t)n * a.Cout + co) * parts + blockIdx.x) * 2) = make_float2(mm, qq);
+    }
   }
 }
 
@@ -346,6 +371,13 @@ static bool smallci_supported(const ddpm_conv_desc &d) {
   return on && d.C2 == 0 && d.C1 >= 1 && d.C1 <= 4 && d.ksize == 3 && d.mode == DDPM_CONV_NORMAL && !d.gscale &&
          d.act == DDPM_ACT_NONE && !d.chan_add && !d.residual && d.out_act == DDPM_ACT_NONE && d.Cout >= 16 &&
          d.Di <= 1 && d.Do <= 1 && d.dims != 3;
+}
+
+// slices per (image, cout) of the statistics conv_smallci_kernel writes to desc.stats_out (0: it does not)
+static int smallci_stats_parts(const ddpm_conv_desc &d) {
+  const int HW = d.Ho * d.Wo;
+  if (!smallci_supported(d) || HW % 256 || HW / 256 > 8) return 0;
+  return HW / 256;
 }
 
 static bool smallco_supported(const ddpm_conv_desc &d, int &TH, int &RS, int &PS) {
@@ -373,7 +405,10 @@ int launch_conv_direct(const ddpm_conv_desc &d, hipStream_t s) {
     dim3 grid(d.Ho / TH, d.B);
     static const bool wave_ok = !(getenv("DDPM_CONVOUT_WAVE") && atoi(getenv("DDPM_CONVOUT_WAVE")) == 0);
     if (wave_ok && PS <= 64 * kSW_NJ && Cin_i >= 16) {
-      if ((long)grid.x * grid.y * 2 <= device_cus() && Cin_i >= 64) {  // a few images: sixteen waves per workgroup
+      static const long w16_max = getenv("DDPM_CONVOUT_W16_MAXWG") ? atol(getenv("DDPM_CONVOUT_W16_MAXWG")) : -1;
+      // up to two workgroups per CU (B <= 128 at 32x32: 54 -> 44 us at B = 128; at four per CU, B = 256, the four-wave form wins 70 vs 84)
+      const long w16_wgs = w16_max >= 0 ? w16_max : 2L * device_cus();
+      if ((long)grid.x * grid.y <= w16_wgs && Cin_i >= 64) {  // sixteen waves per workgroup
         const size_t lds_w = ((size_t)16 * 2 * PS + 16 * 256 * 4) * sizeof(float);
         static bool attr_done = false;
         if (!attr_done) {
@@ -402,13 +437,17 @@ int launch_conv_direct(const ddpm_conv_desc &d, hipStream_t s) {
                    4.0 * ((double)d.B * cin * HWo + (double)d.B * HWo * d.Cout + d.Cout * cin * 9));
     const long blocks = (long)((HWo + 255) / 256) * d.B;
     int zs = 1;
-    while (zs < 8 && blocks * zs * 2 <= device_cus() * 2 && d.Cout / (zs * 2) >= 16) zs *= 2;  // up to two blocks per CU
+    static const long zblk = getenv("DDPM_CONVIN_BLOCKS_PER_CU") ? atol(getenv("DDPM_CONVIN_BLOCKS_PER_CU")) : 8;  // (2 -> 8: 61 -> 35 us at B = 128, 75 -> 59 at B = 256)
+    while (zs < 8 && blocks * zs * 2 <= device_cus() * zblk && d.Cout / (zs * 2) >= 16) zs *= 2;  // up to `zblk` blocks per CU
     dim3 grid((HWo + 255) / 256, d.B, zs);
+    ddpm_conv_desc dk = d;
+    if (smallci_stats_parts(d) == 0) dk.stats_out = nullptr;
+    const size_t lds = dk.stats_out ? (size_t)((d.Cout + zs - 1) / zs) * 4 * sizeof(float2) : 0;
     switch (d.C1) {
-      case 1: hipLaunchKernelGGL(conv_smallci_kernel<1>, grid, dim3(256), 0, s, d); break;
-      case 2: hipLaunchKernelGGL(conv_smallci_kernel<2>, grid, dim3(256), 0, s, d); break;
-      case 3: hipLaunchKernelGGL(conv_smallci_kernel<3>, grid, dim3(256), 0, s, d); break;
-      default: hipLaunchKernelGGL(conv_smallci_kernel<4>, grid, dim3(256), 0, s, d); break;
+      case 1: hipLaunchKernelGGL(conv_smallci_kernel<1>, grid, dim3(256), lds, s, dk); break;
+      case 2: hipLaunchKernelGGL(conv_smallci_kernel<2>, grid, dim3(256), lds, s, dk); break;
+      case 3: hipLaunchKernelGGL(conv_smallci_kernel<3>, grid, dim3(256), lds, s, dk); break;
+      default: hipLaunchKernelGGL(conv_smallci_kernel<4>, grid, dim3(256), lds, s, dk); break;
     }
     DDPM_CHECK_LAUNCH();
     return 0;
@@ -448,6 +487,9 @@ int conv_stats_parts(const ddpm_conv_desc &d) {
   if (conv_wino44h_supported(d)) return conv_wino44h_stats_parts(d);
   if (conv_wino44_supported(d)) return 0;
   if (conv_wino_supported(d)) return conv_wino_stats_parts(d);  // (the Upsample form only)
+  int TH, RS, PS;
+  if (d.mode == DDPM_CONV_NORMAL && !conv_mfma_supported(d) && !smallco_supported(d, TH, RS, PS))
+    return smallci_stats_parts(d);  // conv_in (launch_conv_direct)
   return 0;
 }
 

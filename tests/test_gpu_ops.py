@@ -1192,6 +1192,37 @@ def test_conv_upsample_winograd_emits_groupnorm_statistics(device, case):
     assert ((st[..., 1] - m2).abs() / (m2 + 1e-3 * m2.mean())).max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("case", [(5, 1, 128, 32, 4), (3, 3, 128, 32, 4), (70, 1, 64, 16, 1), (2, 1, 128, 64, None), (4, 1, 128, 28, None)])
+def test_conv_in_emits_groupnorm_statistics(device, case):
+    """desc.stats_out of the small-cin kernel (conv_in): per-(image, cout, 256-pixel slice) {mean, M2} of the tensor it wrote;
+    sizes with more than eight slices per image or a ragged last workgroup report 0 parts."""
+    from ddpm_ood_amd import ops
+
+    B, Cin, Cout, H, parts = case
+    g = torch.Generator().manual_seed(B * 7 + H)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 3  # (means far from zero: the M2 must not be a difference of large numbers)
+    d = lambda t: t.to(device)
+    y_plain = ops.conv(d(x), d(w), d(b))
+    y, st = ops.conv(d(x), d(w), d(b), want_stats=True)
+    assert torch.equal(y, y_plain)
+    ref = torch.nn.functional.conv2d(x, w, b, padding=1)
+    assert (y.cpu() - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item())
+    if parts is None:
+        assert st is None
+        return
+    assert st is not None and tuple(st.shape) == (B, Cout, parts, 2)
+    yd = y.double().cpu().view(B, Cout, parts, -1)
+    mean = yd.mean(-1)
+    m2 = (yd - mean[..., None]).pow(2).sum(-1)
+    st2 = ops.conv(d(x), d(w), d(b), want_stats=True)[1]
+    assert torch.equal(st, st2)  # fixed order: bit-reproducible
+    st = st.cpu().double()
+    assert (st[..., 0] - mean).abs().max().item() <= 2e-6 * (1 + mean.abs().max().item() + (m2 / yd.shape[-1]).sqrt().max().item())
+    assert ((st[..., 1] - m2).abs() / (m2 + 1e-3 * m2.mean())).max().item() <= 2e-5
+
+
 @pytest.mark.parametrize("case", [(3, 128, (8, 8, 8), 2048), (2, 32, (4, 5, 6), 100), (5, 8, (7, 9), 17)])
 def test_vq_nearest(device, case):
     """VQ-VAE quantiser on the HIP kernel vs the oracle's formula (argmin of the expanded squared distance)."""
