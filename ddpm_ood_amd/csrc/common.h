@@ -220,6 +220,7 @@ bool conv_d3s_supported(const ddpm_conv_desc &d);
 int launch_conv_d3s(const ddpm_conv_desc &d, hipStream_t s);
 size_t conv_d3s_scratch_floats(const ddpm_conv_desc &d);
 int conv_d3s_stats_parts(const ddpm_conv_desc &d);
+int conv_s2h_stats_parts(const ddpm_conv_desc &d);
 int device_cus();
 size_t conv_d3h_weight_halves(int Cout, int Cin);
 int launch_pack_conv_d3h_weight(const float *w_raw, uint16_t *dst, int Cout, int Cin, hipStream_t s);

@@ -487,6 +487,7 @@ int conv_stats_parts(const ddpm_conv_desc &d) {
   if (conv_wino44h_supported(d)) return conv_wino44h_stats_parts(d);
   if (conv_wino44_supported(d)) return 0;
   if (conv_wino_supported(d)) return conv_wino_stats_parts(d);  // (the Upsample form only)
+  if (d.mode == DDPM_CONV_STRIDE2 && conv_s2h_supported(d)) return conv_s2h_stats_parts(d);  // Downsample
   int TH, RS, PS;
   if (d.mode == DDPM_CONV_NORMAL && !conv_mfma_supported(d) && !smallco_supported(d, TH, RS, PS))
     return smallci_stats_parts(d);  // conv_in (launch_conv_direct)

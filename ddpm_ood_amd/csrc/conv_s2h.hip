@@ -95,6 +95,49 @@ bool conv_s2h_supported(const ddpm_conv_desc &d) {
   return s2h_geom(d, g);
 }
 
+// slices per (image, cout) of the GroupNorm statistics the epilogues write to desc.stats_out (0: none).  A wave holds 32 output
+// pixels of each of its couts: an image's share of a tile has to be whole waves (32, 64 or 128 pixels); slices = tiles per image.
+int conv_s2h_stats_parts(const ddpm_conv_desc &d) {
+  S2Geom g;
+  if (!s2h_geom(d, g) || g.per % 32) return 0;
+  const int parts = g.TI == 1 ? g.TPI : 1;
+  return parts <= 8 ? parts : 0;
+}
+
+namespace {
+// sums over the two 32-lane halves of a wave on the DPP path (row_shr:1, 2, 4, 8, row_bcast:15): valid in lanes 31 and 63
+__device__ __forceinline__ float half_sum_dpp(float v) {
+  v += dpp_mov0<0x111>(v);
+  v += dpp_mov0<0x112>(v);
+  v += dpp_mov0<0x114>(v);
+  v += dpp_mov0<0x118>(v);
+  v += dpp_mov0<0x142>(v);
+  return v;
+}
+// {mean, M2 about it} of the 32 values a half-wave holds of one cout (valid in lanes 31 / 63)
+__device__ __forceinline__ float2 half_moments(float v, int lhi) {
+  const float sm = half_sum_dpp(v);
+  const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sm), 31));
+  const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sm), 63));
+  const float mu = (lhi ? s1 : s0) * (1.f / 32.f);
+  const float dv = v - mu;
+  return make_float2(mu, half_sum_dpp(dv * dv));
+}
+// W = 1, 2 or 4 such pairs (entries `stride` apart, 32 values each) merged pairwise in a fixed order (Chan)
+__device__ __forceinline__ float2 merge_half_moments(const float2 *e, int stride, int W) {
+  if (W == 1) return e[0];
+  const float2 a = e[0], b = e[stride];
+  const float d01 = b.x - a.x;
+  const float2 m01 = make_float2(0.5f * (a.x + b.x), (a.y + b.y) + d01 * d01 * 16.f);
+  if (W == 2) return m01;
+  const float2 c = e[2 * stride], f = e[3 * stride];
+  const float d23 = f.x - c.x;
+  const float2 m23 = make_float2(0.5f * (c.x + f.x), (c.y + f.y) + d23 * d23 * 16.f);
+  const float dd = m23.x - m01.x;
+  return make_float2(0.5f * (m01.x + m23.x), (m01.y + m23.y) + dd * dd * 32.f);
+}
+}  // namespace
+
 __global__ __launch_bounds__(256, 2) void conv_s2h_kernel(const ddpm_conv_desc a, const S2Geom g) {
   extern __shared__ __attribute__((aligned(16))) char smb[];
   const int tid = threadIdx.x;
@@ -284,16 +327,36 @@ __global__ __launch_bounds__(256, 2) void conv_s2h_kernel(const ddpm_conv_desc a
 
   // ---- epilogue: D[row = cout][col = pixel] -> NCHW; the power-of-two pre-scales come off in the fma that adds the bias
   const float oscale = reinterpret_cast<const float *>(a.w_wino44h + (size_t)a.Cout * Cin * 18)[1];
-  if (pn < a.B) {
-    const size_t obase = ((size_t)pn * a.Cout + ct * kS2K + 4 * lhi) * (a.Ho * a.Wo) + (size_t)py * a.Wo + px;
+  const bool emit = a.stats_out != nullptr;  // (launch_conv_s2h passes it only where conv_s2h_stats_parts(d) > 0)
+  float2 *const red = reinterpret_cast<float2 *>(smb);  // [wave][cout 64] (the operand buffers are free: the loop ends on a barrier)
+  {
+    const bool valid = pn < a.B;
+    const size_t obase = ((size_t)min(pn, a.B - 1) * a.Cout + ct * kS2K + 4 * lhi) * (a.Ho * a.Wo) + (size_t)py * a.Wo + px;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int dco = 32 * i + (r & 3) + 8 * (r >> 2);
         const float b = a.bias ? a.bias[ct * kS2K + 4 * lhi + dco] : 0.f;
-        a.out[obase + (size_t)dco * (a.Ho * a.Wo)] = __builtin_fmaf(acc[i][r], oscale, b);
+        const float v = __builtin_fmaf(acc[i][r], oscale, b);
+        if (valid) a.out[obase + (size_t)dco * (a.Ho * a.Wo)] = v;
+        if (emit) {  // the next GroupNorm's statistics: this wave's 32 pixels of the cout
+          const float2 mq = half_moments(v, lhi);
+          if (l31 == 31) red[wave * kS2K + 4 * lhi + dco] = mq;
+        }
       }
+  }
+  if (emit) {
+    __syncthreads();
+    const int W = g.per / 32, nimg = kS2P / g.per;  // waves per image share, image shares per tile
+    const int parts = g.TI == 1 ? g.TPI : 1, part = g.TI == 1 ? (int)(ptile % g.TPI) : 0;
+    for (int e = tid; e < nimg * kS2K; e += 256) {
+      const int ti = e / kS2K, c = e - ti * kS2K;
+      const int n = n0 + ti;
+      if (n < a.B)
+        *reinterpret_cast<float2 *>(a.stats_out + (((size_t)n * a.Cout + ct * kS2K + c) * parts + part) * 2) =
+            merge_half_moments(red + (ti * W) * kS2K + c, kS2K, W);
+    }
   }
 }
 
@@ -482,6 +545,8 @@ __global__ __launch_bounds__(512, 1) void conv_s2h4_kernel(const ddpm_conv_desc 
 
   const float oscale = reinterpret_cast<const float *>(a.w_wino44h + (size_t)a.Cout * Cin * 18)[1];
   const int co0 = (2 * ct2 + cb2) * kS2K + 4 * lhi;
+  const bool emit = a.stats_out != nullptr;
+  float2 *const red = reinterpret_cast<float2 *>(smb);  // (the operand buffers are free: the step loop ends on a barrier)
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
     const int st = 4 * pgrp + sub;
@@ -494,16 +559,42 @@ __global__ __launch_bounds__(512, 1) void conv_s2h4_kernel(const ddpm_conv_desc 
       y0 = 0;
     }
     const int n = n0 + pti;
-    if (st < g.PT && n < a.B) {
-      const size_t obase = ((size_t)n * a.Cout + co0) * HWo + (size_t)(y0 + pty) * a.Wo + pxx;
+    const bool valid = st < g.PT && n < a.B;
+    {
+      const size_t obase = ((size_t)min(n, a.B - 1) * a.Cout + co0) * HWo + (size_t)(y0 + pty) * a.Wo + pxx;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dco = 32 * i + (r & 3) + 8 * (r >> 2);
           const float b = a.bias ? a.bias[co0 + dco] : 0.f;
-          a.out[obase + (size_t)dco * HWo] = __builtin_fmaf(acc[sub][i][r], oscale, b);
+          const float v = __builtin_fmaf(acc[sub][i][r], oscale, b);
+          if (valid) a.out[obase + (size_t)dco * HWo] = v;
+          if (emit) {  // [tile of the four][pixel block][cout of the pair's 128]
+            const float2 mq = half_moments(v, lhi);
+            if (l31 == 31) red[(sub * 4 + pb) * (2 * kS2K) + cb2 * kS2K + 4 * lhi + dco] = mq;
+          }
         }
+    }
+  }
+  if (emit) {
+    __syncthreads();
+    const int W = g.per / 32, nimg = kS2P / g.per;
+    const int parts = g.TI == 1 ? g.TPI : 1;
+    for (int e = tid; e < 4 * nimg * 2 * kS2K; e += 512) {
+      const int sub = e / (nimg * 2 * kS2K), rem = e - sub * (nimg * 2 * kS2K);
+      const int ti = rem / (2 * kS2K), c = rem - ti * (2 * kS2K);
+      const int st = 4 * pgrp + sub;
+      int n, part = 0;
+      if (g.TI == 1) {
+        n = st / g.TPI;
+        part = st - n * g.TPI;
+      } else {
+        n = st * g.TI + ti;
+      }
+      if (st < g.PT && n < a.B)
+        *reinterpret_cast<float2 *>(a.stats_out + (((size_t)n * a.Cout + (size_t)ct2 * 2 * kS2K + c) * parts + part) * 2) =
+            merge_half_moments(red + (sub * 4 + ti * W) * (2 * kS2K) + c, 2 * kS2K, W);
     }
   }
 }
@@ -515,6 +606,8 @@ int launch_conv_s2h(const ddpm_conv_desc &d, hipStream_t s) {
     return DDPM_EINVAL;
   }
   const size_t lds = 2 * ((size_t)kS2A + 2 * (size_t)g.units * 16);
+  ddpm_conv_desc dk = d;
+  if (conv_s2h_stats_parts(d) == 0) dk.stats_out = nullptr;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_s2h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -543,12 +636,12 @@ int launch_conv_s2h(const ddpm_conv_desc &d, hipStream_t s) {
       attr4_done = true;
     }
     const unsigned grid4 = 8u * (unsigned)((PG + 7) / 8) * (unsigned)(g.CT / 2);
-    hipLaunchKernelGGL(conv_s2h4_kernel, dim3(grid4), dim3(512), lds4, s, d, g);
+    hipLaunchKernelGGL(conv_s2h4_kernel, dim3(grid4), dim3(512), lds4, s, dk, g);
     DDPM_CHECK_LAUNCH();
     return 0;
   }
   const unsigned grid = 8u * (unsigned)((g.PT + 7) / 8) * (unsigned)g.CT;
-  hipLaunchKernelGGL(conv_s2h_kernel, dim3(grid), dim3(256), lds, s, d, g);
+  hipLaunchKernelGGL(conv_s2h_kernel, dim3(grid), dim3(256), lds, s, dk, g);
   DDPM_CHECK_LAUNCH();
   return 0;
 }

@@ -126,7 +126,10 @@ typedef struct ddpm_conv_desc {
    * the next block's norm1) needs no pass of its own over the activation.  Layout [B, Cout, parts, 2] floats:
    * {mean, sum of squared deviations} of each channel over one of `parts` equal slices of the image's pixels
    * (parts = ddpm_conv_stats_parts(d); 0 = this dispatch does not emit them and stats_out is ignored).  Merged pairwise
-   * in a fixed order (no atomics): bit-reproducible.  ddpm_gn_finalize_f32 turns them into scale / shift.  */
+   * in a fixed order (no atomics): bit-reproducible.  ddpm_gn_finalize_f32 turns them into scale / shift.  Emitting
+   * dispatches: the split-f16 F(4x4) 3x3 kernels (ResnetBlock convolutions, Upsample), the reduce pass of the small-launch
+   * forms, and since round 5 conv_in's small-cin kernel (pixels per image a multiple of 256, at most 2 048) and the Downsample
+   * kernels (an image's share of a 128-pixel tile at least 32 pixels).  */
   float *stats_out;
   /* Optional, 2-D 3x3 (ABI 8): the weights as split-f16 planes of the DIRECT convolution (nine taps on
    * v_mfma_f32_32x32x16_f16, three exact f16 partial products per fp32 product, fp32 accumulate), packed by

@@ -1372,6 +1372,37 @@ def test_conv_stride2_split_f16_vs_conv2d(device, case):
     assert torch.equal(y, ops.conv(d(x), d(w), d(b), mode=ops.CONV_STRIDE2, wino44h=ws))
 
 
+@pytest.mark.parametrize("case", S2H_CASES)
+def test_conv_stride2_emits_groupnorm_statistics(device, case):
+    """desc.stats_out of the Downsample kernels (both forms): per-(image, cout, tile-of-the-image) {mean, M2} of the tensor they
+    wrote; images smaller than a wave's 32 pixels report 0 parts."""
+    from ddpm_ood_amd import ops
+
+    B, Cin, Cout, H = case
+    g = torch.Generator().manual_seed(B + Cin + H)
+    x = torch.randn(B, Cin, H, H, generator=g) * 1.3 + 0.2
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 2
+    d = lambda t: t.to(device)
+    ws = ops.pack_conv_s2h_weight(d(w))
+    y_plain = ops.conv(d(x), d(w), d(b), mode=ops.CONV_STRIDE2, wino44h=ws)
+    y, st = ops.conv(d(x), d(w), d(b), mode=ops.CONV_STRIDE2, wino44h=ws, want_stats=True)
+    assert torch.equal(y, y_plain)
+    Ho = H // 2
+    parts = {16: 2, 8: 1, 32: 8, 4: None}[Ho]  # 128-pixel tiles: 2 per 16x16 image, 8 per 32x32; whole 8x8 images; 4x4: half a wave
+    if parts is None:
+        assert st is None
+        return
+    assert st is not None and tuple(st.shape) == (B, Cout, parts, 2)
+    assert torch.equal(st, ops.conv(d(x), d(w), d(b), mode=ops.CONV_STRIDE2, wino44h=ws, want_stats=True)[1])
+    yd = y.double().cpu().view(B, Cout, parts, -1)
+    mean = yd.mean(-1)
+    m2 = (yd - mean[..., None]).pow(2).sum(-1)
+    st = st.cpu().double()
+    assert (st[..., 0] - mean).abs().max().item() <= 2e-6 * (1 + mean.abs().max().item() + (m2 / yd.shape[-1]).sqrt().max().item())
+    assert ((st[..., 1] - m2).abs() / (m2 + 1e-3 * m2.mean())).max().item() <= 2e-5
+
+
 @pytest.mark.parametrize("case", [(16, 128, 128, 32), (16, 256, 256, 16), (5, 256, 256, 16), (3, 64, 128, 32), (1, 64, 128, 16)])
 def test_conv_stride2_small_launch_vs_conv2d(device, case, monkeypatch):
     """conv_d3s.hip's stride-2 form: the Downsample convolutions of a forward over a few images (32 -> 16, 16 -> 8), channel
