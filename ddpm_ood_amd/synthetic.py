@@ -37,6 +37,27 @@ def random_state_dict(model_type: str = "small", channels: int = 1, spatial_dims
     return sd
 
 
+def condition_vqvae_state_dict(sd: dict, enc_gain: float = 256.0, dec_gain: float = 64.0) -> dict:
+    """A freshly initialised VQ-VAE (generative's VQVAE, /root/reference/src/trainers/base.py:44-61) is degenerate as a test
+    object: its encoder output is ~1e-2 against codebook rows of norm ~11 (every position of every volume lands on the same one
+    or two codes) and its decoder output is a bias-driven constant below zero (clamp -> 0: the reconstruction, hence both scores,
+    ignore the codes).  This turns such a state_dict into one that behaves like a trained model in the two respects the
+    reconstruction path is sensitive to, by a fixed rule (no data, no RNG): every convolution bias is zeroed, the encoder's last
+    convolution is scaled by `enc_gain` (latents of the codebook's scale: tens of distinct codes per volume), the decoder's
+    last transposed convolution is scaled by `dec_gain` around a bias of 0.5 (reconstructions that span [0, 1] and move with the
+    codes).  Key names: `encoder.blocks.<i>.conv.*` / `decoder.blocks.<i>.conv.*` (the oracle's and the product's VQVAE)."""
+    out = {k: v.clone() for k, v in sd.items()}
+    enc_last = max(int(k.split(".")[2]) for k in out if k.startswith("encoder.blocks."))
+    dec_last = max(int(k.split(".")[2]) for k in out if k.startswith("decoder.blocks."))
+    for k in out:
+        if (k.startswith("encoder.") or k.startswith("decoder.")) and k.endswith(".bias"):
+            out[k].zero_()
+    out[f"encoder.blocks.{enc_last}.conv.weight"] *= enc_gain
+    out[f"decoder.blocks.{dec_last}.conv.weight"] *= dec_gain
+    out[f"decoder.blocks.{dec_last}.conv.bias"].fill_(0.5)
+    return out
+
+
 def write_checkpoint(run_dir, model_type: str = "small", channels: int = 1, seed: int = 1, config: dict = None):
     run_dir = Path(run_dir)
     run_dir.mkdir(parents=True, exist_ok=True)

@@ -15,6 +15,12 @@ import torch
 
 SCHED = dict(beta_schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0195)
 
+# the VQ-VAE of BASELINE configs[4] (/root/reference/README.md:153-158): 4 x k4-s2 levels, 256 channels, 3 residual units per
+# level, 2 048 codes x 128
+VQ_README = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(256, 256, 256, 256), num_res_layers=3,
+                 num_res_channels=(256, 256, 256, 256), downsample_parameters=((2, 4, 1, 1),) * 4,
+                 upsample_parameters=((2, 4, 1, 1, 0),) * 4, num_embeddings=2048, embedding_dim=128)
+
 
 def make_args(tmp_path, **kw):
     d = dict(seed=2, output_dir=str(tmp_path), model_name="synth", validation_ids=None, in_ids=None, out_ids=None,
@@ -125,7 +131,8 @@ def golden_rows(case: str):
     from ddpm_ood_amd.synthetic import random_state_dict
 
     spec, rows = mg.load(case)
-    assert state_dict_digest(random_state_dict(spec["model_type"], spec["channels"], seed=1)) == spec["state_dict_sha256"]
+    assert state_dict_digest(random_state_dict(spec["model_type"], spec["channels"], spatial_dims=spec.get("spatial_dims", 2),
+                                               seed=1)) == spec["state_dict_sha256"]
     assert state_dict_digest(LPIPS().state_dict()) == spec["lpips_sha256"]
     return spec, rows
 
