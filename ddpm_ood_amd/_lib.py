@@ -14,7 +14,7 @@ import torch
 
 _LIB = None
 LIB_NAME = "libddpm_ood_hip.so"
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class HipLibraryMissing(RuntimeError):
@@ -48,6 +48,21 @@ class UNetConfig(C.Structure):
         ("num_channels", C.c_int * MAX_LEVELS), ("attention_levels", C.c_int * MAX_LEVELS),
         ("num_res_blocks", C.c_int * MAX_LEVELS), ("num_head_channels", C.c_int * MAX_LEVELS),
         ("norm_num_groups", C.c_int), ("norm_eps", C.c_float), ("use_proj_attn", C.c_int),
+    ]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("k_inner", C.c_int),
+        ("a_m", C.c_int64), ("a_k", C.c_int64), ("a_k_outer", C.c_int64),
+        ("b_n", C.c_int64), ("b_k", C.c_int64), ("b_k_outer", C.c_int64),
+        ("c_m", C.c_int64), ("c_n", C.c_int64),
+        ("batch", C.c_int), ("batch_inner", C.c_int),
+        ("a_batch", C.c_int64), ("a_batch_outer", C.c_int64), ("b_batch", C.c_int64), ("b_batch_outer", C.c_int64),
+        ("c_batch", C.c_int64), ("c_batch_outer", C.c_int64),
+        ("alpha", C.c_float), ("beta", C.c_float),
+        ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t),
     ]
 
 
@@ -119,6 +134,7 @@ SIGNATURES = {
     "ddpm_vq_near_ties_read": (C.c_int, [C.POINTER(C.c_uint), C.c_int, C.c_void_p]),
     "ddpm_set_split_f16": (C.c_int, [C.c_int]),
     "ddpm_get_split_f16": (C.c_int, []),
+    "ddpm_split_f16_active": (C.c_int, []),
     "ddpm_reload_env": (C.c_int, []),
     "ddpm_unet_create": (C.c_void_p, [C.POINTER(UNetConfig)]),
     "ddpm_unet_destroy": (None, [C.c_void_p]),
@@ -137,6 +153,28 @@ SIGNATURES = {
     "ddpm_unet_num_graphs": (C.c_int, [C.c_void_p]),
     "ddpm_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    # ---- training step (ABI 10)
+    "ddpm_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "ddpm_gemm_scratch_floats": (C.c_size_t, [C.POINTER(GemmDesc)]),
+    "ddpm_conv_wgrad_scratch_floats": (C.c_size_t, [C.c_int] * 9),
+    "ddpm_conv_wgrad_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 9 + [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "ddpm_conv_weight_rot180t_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_gn_stats_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "ddpm_gn_apply_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
+    "ddpm_gn_backward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
+    "ddpm_row_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "ddpm_col_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
+    "ddpm_silu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ddpm_silu_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ddpm_axpby_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_void_p]),
+    "ddpm_chan_copy_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
+    "ddpm_resample2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_softmax_rows_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "ddpm_softmax_backward_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "ddpm_mse_loss_grad_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_float, C.c_void_p]),
+    "ddpm_fill_f32": (C.c_int, [C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
+    "ddpm_randn_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "ddpm_adam_step_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_void_p]),
 }
 
 
@@ -222,7 +260,13 @@ def set_split_f16(on: bool) -> bool:
 
 
 def split_f16() -> bool:
+    """The master switch (what set_split_f16 sets)."""
     return bool(load().ddpm_get_split_f16())
+
+
+def split_f16_active() -> bool:
+    """Master switch on AND at least one split-f16 family enabled: would set_split_f16(False) change the dispatch?"""
+    return bool(load().ddpm_split_f16_active())
 
 
 def reload_env() -> None:

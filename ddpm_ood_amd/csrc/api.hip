@@ -36,7 +36,6 @@ static void load_switches() {
   n.wino44_split = env_int("DDPM_WINO44_SPLIT", 4);
   n.wino_split = env_int("DDPM_WINO_SPLIT", 8);
   n.w44h_xitem = env_int("DDPM_W44H_XITEM", 1);
-  n.w44h_reg = env_int("DDPM_W44H_REG", 1);
   n.w44r_serp = env_int("DDPM_W44R_SERP", 0);
   n.wino44_xmap = env_int("DDPM_WINO44_XMAP", -1);
   n.w44_abl = env_int("DDPM_W44_ABL", 0);
@@ -49,6 +48,11 @@ static void load_switches() {
   n.d1s_maxpx = env_int("DDPM_D1S_MAXPX", 16384);
   n.conv_splitk = env_int("DDPM_CONV_SPLITK", 1) != 0;
   n.gn_fused = env_int("DDPM_GN_FUSED", 1) != 0;
+  n.attn_waves8 = env_int("DDPM_ATTN_WAVES", 8) != 4;
+  n.convin_fast = env_int("DDPM_CONVIN_FAST", 1) != 0;
+  n.convout_wave = env_int("DDPM_CONVOUT_WAVE", 1) != 0;
+  n.convout_w16_maxwg = getenv("DDPM_CONVOUT_W16_MAXWG") ? atol(getenv("DDPM_CONVOUT_W16_MAXWG")) : -1;
+  n.convin_blocks_per_cu = getenv("DDPM_CONVIN_BLOCKS_PER_CU") ? atol(getenv("DDPM_CONVIN_BLOCKS_PER_CU")) : 8;
   n.prof_shapes = getenv("DDPM_PROF_SHAPES") != nullptr;
   n.split_f16 = g_sw_loaded ? keep : true;
   g_sw = n;
@@ -150,9 +154,12 @@ extern "C" int ddpm_set_split_f16(int on) {
   return was;
 }
 
+// the master switch, exactly what ddpm_set_split_f16 sets and returns (prev = get(); set(0); ...; set(prev) restores it)
+extern "C" int ddpm_get_split_f16(void) { return sw().split_f16 ? 1 : 0; }
+
 // 1 only when the master switch is on AND at least one split-f16 family is enabled: "would ddpm_set_split_f16(0) change
 // which kernels run?" (the trainer's re-run guard asks exactly that)
-extern "C" int ddpm_get_split_f16(void) {
+extern "C" int ddpm_split_f16_active(void) {
   const Switches &w = sw();
   const bool any = w.wino44_f16x3 || w.conv1x1_f16x3 || w.attn_f16x3 || w.down_s2h != 0 || w.conv_d3s != 0 || w.up_wino44h;
   return w.split_f16 && any ? 1 : 0;

@@ -758,7 +758,7 @@ __global__ __launch_bounds__(512) void attention8_kernel(const float *__restrict
 // true when launch_attention(...) with these arguments writes the per-channel {mean, M2} pairs of its output to `stats_out`
 // ([B, C, 1 slice, 2]): the eight-wave split-f16 kernel with all 64 tokens of an image in one workgroup
 bool attention_emits_stats(int B, int C, int N, int heads, const float *scratch, size_t scratch_floats) {
-  static const bool waves8 = !(getenv("DDPM_ATTN_WAVES") && atoi(getenv("DDPM_ATTN_WAVES")) == 4);
+  const bool waves8 = sw().attn_waves8;
   const bool f16x3 = split_f16_on(sw().attn_f16x3);
   if (!f16x3 || !waves8 || N != kQB || C != heads * kDH) return false;
   return !(sw().attn_fa && attention_fa_supported(B, C, N, heads, scratch, scratch_floats));
@@ -790,7 +790,7 @@ int launch_attention(const float *qkv, const float *residual, float *out, int B,
   }
   ProfScope prof(s, "attention", 4.0 * B * (double)N * N * C, 4.0 * B * C * (double)N * (residual ? 5 : 4));
   // eight-wave form by default (n = 4096: 892 vs 918 us, n = 256: 32.3 vs 34.8 us); DDPM_ATTN_WAVES=4 selects the other
-  static const bool waves8 = !(getenv("DDPM_ATTN_WAVES") && atoi(getenv("DDPM_ATTN_WAVES")) == 4);
+  const bool waves8 = sw().attn_waves8;
   const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv) & 15) == 0);
   if (f16x3 && waves8) {
     auto kern8 = vec ? attention8_kernel<true> : attention8_kernel<false>;

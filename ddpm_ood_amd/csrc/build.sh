@@ -9,7 +9,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 JOBS="${JOBS:-4}"
 mkdir -p "${obj}"
 srcs=(api conv_mfma conv_wino conv_wino44 conv_wino44h conv_wino44r conv_d3s conv_s2h conv1x1_dma conv_direct conv3d_edge linear_skinny groupnorm attention attention_fa elementwise lpips vq
-      unet_engine)
+      unet_engine train_gemm train_ops)
 common=(--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value)
 # per-file flags: declare an array flags_<source> to add options to one translation unit, e.g.
 #   flags_attention=(-mllvm -amdgpu-mfma-vgpr-form=1)   # measured: 80 vs 86 TFLOP/s at n = 4096, not used

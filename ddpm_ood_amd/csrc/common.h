@@ -43,8 +43,6 @@ struct Switches {
   int wino_split = 8;           // DDPM_WINO_SPLIT: most channel-stream splits of a conv_wino.hip launch smaller than half the chip (power of two)
   int wino44_xmap = -1;         // DDPM_WINO44_XMAP (-1: unset, each kernel has its own default)
   int w44_abl = 0;              // DDPM_W44_ABL
-  int w44h_reg = 1;             // DDPM_W44H_REG: 0 the LDS-fed form of the split-f16 F(4x4) kernel (conv_wino44h.hip; A/B), 1 the register-fed
-                                // form (conv_wino44r.hip, round 5)
   int w44r_serp = 0;            // DDPM_W44R_SERP: 1 consecutive launches of conv_wino44r.hip walk their items in alternating order (measured: +-0)
   int w44h_xitem = 1;           // DDPM_W44H_XITEM: 0 every item of conv_wino44h.hip refills its pixel ring from scratch (A/B)
   bool up_wino44h = true;       // DDPM_UP_WINO44H
@@ -57,6 +55,11 @@ struct Switches {
                                 // register-resident kernel for every multiple of 64 tokens, not only from 1 024)
   bool conv_splitk = true;      // DDPM_CONV_SPLITK
   bool gn_fused = true;         // DDPM_GN_FUSED
+  bool attn_waves8 = true;      // DDPM_ATTN_WAVES: 4 selects the four-wave split-f16 attention kernel
+  bool convin_fast = true;      // DDPM_CONVIN_FAST
+  bool convout_wave = true;     // DDPM_CONVOUT_WAVE
+  long convout_w16_maxwg = -1;  // DDPM_CONVOUT_W16_MAXWG (-1: two workgroups per CU)
+  long convin_blocks_per_cu = 8;  // DDPM_CONVIN_BLOCKS_PER_CU
   bool prof_shapes = false;     // DDPM_PROF_SHAPES
   bool split_f16 = true;        // ddpm_set_split_f16(): false = every split-f16 family runs its fp32-MFMA form
 };

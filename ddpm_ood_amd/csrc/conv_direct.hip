@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void conv_smallci_kernel(const ddpm_conv_desc 
 }
 
 static bool smallci_supported(const ddpm_conv_desc &d) {
-  static const bool on = !(getenv("DDPM_CONVIN_FAST") && atoi(getenv("DDPM_CONVIN_FAST")) == 0);
+  const bool on = sw().convin_fast;
   return on && d.C2 == 0 && d.C1 >= 1 && d.C1 <= 4 && d.ksize == 3 && d.mode == DDPM_CONV_NORMAL && !d.gscale &&
          d.act == DDPM_ACT_NONE && !d.chan_add && !d.residual && d.out_act == DDPM_ACT_NONE && d.Cout >= 16 &&
          d.Di <= 1 && d.Do <= 1 && d.dims != 3;
@@ -403,9 +403,9 @@ int launch_conv_direct(const ddpm_conv_desc &d, hipStream_t s) {
     ProfScope prof(s, "conv3x3_small_cout", 2.0 * d.B * HWo * d.Cout * cin * 9,
                    4.0 * ((double)d.B * cin * HWo + (double)d.B * HWo * d.Cout + d.Cout * cin * 9));
     dim3 grid(d.Ho / TH, d.B);
-    static const bool wave_ok = !(getenv("DDPM_CONVOUT_WAVE") && atoi(getenv("DDPM_CONVOUT_WAVE")) == 0);
+    const bool wave_ok = sw().convout_wave;
     if (wave_ok && PS <= 64 * kSW_NJ && Cin_i >= 16) {
-      static const long w16_max = getenv("DDPM_CONVOUT_W16_MAXWG") ? atol(getenv("DDPM_CONVOUT_W16_MAXWG")) : -1;
+      const long w16_max = sw().convout_w16_maxwg;
       // up to two workgroups per CU (B <= 128 at 32x32: 54 -> 44 us at B = 128; at four per CU, B = 256, the four-wave form wins 70 vs 84)
       const long w16_wgs = w16_max >= 0 ? w16_max : 2L * device_cus();
       if ((long)grid.x * grid.y <= w16_wgs && Cin_i >= 64) {  // sixteen waves per workgroup
@@ -437,7 +437,7 @@ int launch_conv_direct(const ddpm_conv_desc &d, hipStream_t s) {
                    4.0 * ((double)d.B * cin * HWo + (double)d.B * HWo * d.Cout + d.Cout * cin * 9));
     const long blocks = (long)((HWo + 255) / 256) * d.B;
     int zs = 1;
-    static const long zblk = getenv("DDPM_CONVIN_BLOCKS_PER_CU") ? atol(getenv("DDPM_CONVIN_BLOCKS_PER_CU")) : 8;  // (2 -> 8: 61 -> 35 us at B = 128, 75 -> 59 at B = 256)
+    const long zblk = sw().convin_blocks_per_cu;  // (2 -> 8: 61 -> 35 us at B = 128, 75 -> 59 at B = 256)
     while (zs < 8 && blocks * zs * 2 <= device_cus() * zblk && d.Cout / (zs * 2) >= 16) zs *= 2;  // up to `zblk` blocks per CU
     dim3 grid((HWo + 255) / 256, d.B, zs);
     ddpm_conv_desc dk = d;

@@ -1,0 +1,572 @@
+// train_gemm.hip -- the two fp32-MFMA contractions of the native training step (reference:
+// /root/reference/src/trainers/ddpm_trainer.py:78-109 -- loss.backward() through generative's DiffusionModelUNet -- and
+// /root/reference/src/trainers/base.py:156).  Round 6.
+//
+//   gemm_f32_kernel        C[z] = alpha op(A[z]) op(B[z]) + beta C[z], every operand addressed by element strides, the K index and
+//                          the batch index each split in two levels (k = k0 K1 + k1, z = z0 Z1 + z1).  One kernel therefore
+//                          covers everything in the backward pass that is not a 3x3 convolution: Linear weight / input gradients
+//                          (time_embed, time_emb_proj, to_q / to_k / to_v), 1x1-convolution weight gradients (K = (image, pixel)),
+//                          1x1 input gradients, and the five batched products of the attention block's forward and backward
+//                          (Q^T K, V P^T, dO^T V, dS K, dS^T Q) on channel-major [B, C, N] tensors without a transpose pass.
+//   conv3x3_wgrad_kernel   dW[co, ci, ky, kx] = sum over (image, output pixel) of dY[co, p] A[ci, s p + (ky, kx) - 1]: 64 couts x
+//                          64 cins x 9 taps per workgroup (a wave holds nine 32x32 accumulator tiles, one per tap), the pixel
+//                          stream split over workgroups, partial sums reduced in a fixed order by a second pass (no atomics:
+//                          bit-reproducible).  stride 1 (ResnetBlock / Upsample convolutions) and stride 2 (Downsample).
+//
+// Both multiply on v_mfma_f32_32x32x2_f32 (157 TFLOP/s dense): training needs gradients to ~1e-6 of their scale (the Adam step
+// of the test is compared with CPU autograd), so the products are plain fp32 -- the split-f16 forms of the inference path buy
+// nothing here until the loop is MFMA-bound, which a once-per-dataset training run is not.
+// Operand lanes: A: lane -> (m = lane % 32, k = lane / 32); B: lane -> (k = lane / 32, n = lane % 32);
+// accumulator register i of lane l: row m = 8 (i / 4) + 4 (l / 32) + i % 4, column n = l % 32.
+#include "common.h"
+
+namespace ddpm {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmP {
+  const float *A, *B;
+  float *C;
+  int M, N, K, K1;  // K = K0 * K1
+  long long sAm, sAk0, sAk1;
+  long long sBn, sBk0, sBk1;
+  long long sCm, sCn;
+  int Z, Z1;  // Z = Z0 * Z1
+  long long sAz0, sAz1, sBz0, sBz1, sCz0, sCz1;
+  float alpha, beta;
+  int S, kchunk;  // S > 1: the K range is cut into S slices of kchunk (a multiple of kGK); slice sp of batch item z writes its raw
+  float *part;    // sums to part[(z S + sp) M N + m N + n], gemm_splitk_reduce_kernel adds them in order and applies alpha / beta
+};
+
+constexpr int kGT = 64;   // C tile (rows and columns) per workgroup
+constexpr int kGK = 16;   // K per LDS stage
+constexpr int kGP = 65;   // padded LDS row (k-major: [k][m])
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
+  __shared__ float As[kGK * kGP], Bs[kGK * kGP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int z = blockIdx.z / p.S, sp = blockIdx.z - z * p.S;
+  const int z0 = z / p.Z1, z1 = z - z0 * p.Z1;
+  const int kbeg = sp * p.kchunk, kend = p.S > 1 ? min(p.K, kbeg + p.kchunk) : p.K;
+  const float *A = p.A + z0 * p.sAz0 + z1 * p.sAz1;
+  const float *B = p.B + z0 * p.sBz0 + z1 * p.sBz1;
+  float *C = p.C + z0 * p.sCz0 + z1 * p.sCz1;
+  const int m0 = blockIdx.y * kGT, n0 = blockIdx.x * kGT;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  // staging map: the index whose stride is 1 runs fastest over the threads
+  const bool a_kfast = p.sAk1 == 1 && p.sAm != 1, b_kfast = p.sBk1 == 1 && p.sBn != 1;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int kt = kbeg; kt < kend; kt += kGK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;  // 0 .. 1023
+      {
+        const int k = a_kfast ? (e & 15) : (e >> 6), m = a_kfast ? (e >> 4) : (e & 63);
+        const int kg = kt + k, mg = m0 + m;
+        float v = 0.f;
+        if (kg < kend && mg < p.M) {
+          const int k0 = kg / p.K1, k1 = kg - k0 * p.K1;
+          v = A[mg * p.sAm + k0 * p.sAk0 + k1 * p.sAk1];
+        }
+        As[k * kGP + m] = v;
+      }
+      {
+        const int k = b_kfast ? (e & 15) : (e >> 6), n = b_kfast ? (e >> 4) : (e & 63);
+        const int kg = kt + k, ng = n0 + n;
+        float v = 0.f;
+        if (kg < kend && ng < p.N) {
+          const int k0 = kg / p.K1, k1 = kg - k0 * p.K1;
+          v = B[ng * p.sBn + k0 * p.sBk0 + k1 * p.sBk1];
+        }
+        Bs[k * kGP + n] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kGK; k += 2) {
+      const float a = As[(k + (lane >> 5)) * kGP + wm + (lane & 31)];
+      const float b = Bs[(k + (lane >> 5)) * kGP + wn + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int n = n0 + wn + (lane & 31);
+  if (p.S > 1) {
+    float *out = p.part + (size_t)blockIdx.z * p.M * p.N;
+    if (n < p.N) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = m0 + wm + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+        if (m < p.M) out[(size_t)m * p.N + n] = acc[i];
+      }
+    }
+    return;
+  }
+  if (n < p.N) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = m0 + wm + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+      if (m < p.M) {
+        float *c = C + m * p.sCm + n * p.sCn;
+        const float v = p.alpha * acc[i];
+        *c = p.beta != 0.f ? v + p.beta * *c : v;
+      }
+    }
+  }
+}
+
+__global__ void gemm_splitk_reduce_kernel(const GemmP p) {
+  const size_t mn = (size_t)p.M * p.N;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= mn * p.Z) return;
+  const int z = (int)(i / mn);
+  const size_t r = i - (size_t)z * mn;
+  const int m = (int)(r / p.N), n = (int)(r - (size_t)m * p.N);
+  const float *src = p.part + (size_t)z * p.S * mn + r;
+  float sum = 0.f;
+  for (int k = 0; k < p.S; ++k) sum += src[(size_t)k * mn];
+  const int z0 = z / p.Z1, z1 = z - z0 * p.Z1;
+  float *c = p.C + z0 * p.sCz0 + z1 * p.sCz1 + m * p.sCm + n * p.sCn;
+  const float v = p.alpha * sum;
+  *c = p.beta != 0.f ? v + p.beta * *c : v;
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3 weight gradient
+constexpr int kWT = 64;  // couts and cins per workgroup
+
+struct WgradP {
+  const float *a;   // [B, Cin, Hi, Wi]
+  const float *dy;  // [B, Cout, Ho, Wo]
+  float *part;      // [S][9][Cout][Cin]
+  int B, Cin, Cout, Hi, Wi, Ho, Wo, stride;
+  int R;            // output rows per pixel tile
+  int tiles_per_img, T, S;  // T = B * tiles_per_img pixel tiles, walked by S workgroups per (cout, cin) block
+  int AR, AW, ACS;  // input tile: rows, row length (with halo), channel stride (odd)
+  int DCS;          // dY tile channel stride (odd)
+  // staged form (Wi % 4 == 0, Wo % 4 == 0, 16-byte aligned tensors): 16-byte global loads into registers one pixel tile ahead
+  int fast;
+  int LPR, RPI, NA;  // lanes per input row (Wi / 4), (channel, row) pairs per wave instruction, staging iterations of the input tile
+  int LPD, CPI, ND;  // lanes per dY channel (PT / 4), channels per wave instruction, staging iterations of the dY tile
+};
+
+constexpr int kNA = 12, kND = 4;  // most staging iterations per thread (register arrays)
+
+template <int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradP p) {
+  extern __shared__ float smem[];
+  float *Ds = smem;                   // [64 co][DCS]
+  float *As = smem + kWT * p.DCS;     // [64 ci][ACS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int cob = blockIdx.x * kWT, cib = blockIdx.y * kWT, sp = blockIdx.z;
+  const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+  const int PT = p.R * p.Wo;  // pixels per tile (even)
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const size_t hw_i = (size_t)p.Hi * p.Wi, hw_o = (size_t)p.Ho * p.Wo;
+  for (int tile = sp; tile < p.T; tile += p.S) {
+    const int b = tile / p.tiles_per_img, rb = tile - b * p.tiles_per_img;
+    const int yo0 = rb * p.R;
+    const int rows = min(p.R, p.Ho - yo0);  // (a ragged last tile: the missing rows are zero)
+    // ---- dY tile: 64 couts x PT pixels (contiguous in memory)
+    const float *dyb = p.dy + ((size_t)b * p.Cout + cob) * hw_o + (size_t)yo0 * p.Wo;
+    for (int e = tid; e < kWT * PT; e += 256) {
+      const int c = e / PT, px = e - c * PT;
+      Ds[c * p.DCS + px] = px < rows * p.Wo ? dyb[(size_t)c * hw_o + px] : 0.f;
+    }
+    // ---- input tile: 64 cins x AR rows x AW columns, zero halo; tile row r holds input row STRIDE yo0 - 1 + r
+    const float *ab = p.a + ((size_t)b * p.Cin + cib) * hw_i;
+    const int yi0 = STRIDE * yo0 - 1;
+    for (int e = tid; e < kWT * p.AR * p.AW; e += 256) {
+      const int c = e / (p.AR * p.AW), rem = e - c * (p.AR * p.AW);
+      const int r = rem / p.AW, col = rem - r * p.AW;
+      const int yi = yi0 + r, xi = col - 1;
+      float v = 0.f;
+      if (yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi) v = ab[(size_t)c * hw_i + (size_t)yi * p.Wi + xi];
+      As[c * p.ACS + r * p.AW + col] = v;
+    }
+    __syncthreads();
+    const float *dsw = Ds + (wco + l31) * p.DCS + lhi;
+    const float *asw = As + (wci + l31) * p.ACS;
+    for (int px = 0; px < PT; px += 2) {
+      const int pp = px + lhi;
+      const int yo = pp / p.Wo, xo = pp - yo * p.Wo;
+      const float a = dsw[px];
+      const float *ap = asw + (STRIDE * yo) * p.AW + STRIDE * xo;  // tap (ky, kx): + ky AW + kx
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float bv = ap[(t / 3) * p.AW + (t % 3)];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // partial sums: part[sp][tap][co][ci] (ci fastest: coalesced)
+  float *out = p.part + (size_t)sp * 9 * p.Cout * p.Cin;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = cob + wco + 8 * (i >> 2) + 4 * lhi + (i & 3);
+      out[((size_t)t * p.Cout + co) * p.Cin + cib + wci + l31] = acc[t][i];
+    }
+}
+
+// The same contraction with the staging rebuilt (the form above spent more time computing addresses for its 4-byte staging loads
+// than multiplying: 33 TFLOP/s): every (channel, input row) of the tile is fetched by 16-byte loads -- Wi / 4 lanes per row --
+// into registers ONE PIXEL TILE AHEAD, so the global-memory latency of tile i + 1 hides behind the 288 MFMAs per wave of tile i;
+// LDS offsets and global offsets of a thread's loads are computed once per kernel, the K loop walks rows and pixel pairs
+// without a division.  The halo columns of the input tile are zeroed once (no load ever writes them), rows outside the image
+// are written as zeros per tile.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_staged_kernel(const WgradP p) {
+  extern __shared__ float smem[];
+  float *Ds = smem;                   // [64 co][DCS]
+  float *As = smem + kWT * p.DCS;     // [64 ci][ACS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int cob = blockIdx.x * kWT, cib = blockIdx.y * kWT, sp = blockIdx.z;
+  const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+  const int hw_i = p.Hi * p.Wi, hw_o = p.Ho * p.Wo;
+  // ---- this thread's staging slots
+  int a_lds[kNA], a_g[kNA], a_r[kNA];
+#pragma unroll
+  for (int it = 0; it < kNA; ++it) {
+    const int q = (it * 4 + wave) * p.RPI + lane / p.LPR, lc = lane % p.LPR;
+    const bool ok = it < p.NA && q < kWT * p.AR && lane < p.RPI * p.LPR;
+    const int c = q / p.AR, r = q - c * p.AR;
+    a_lds[it] = c * p.ACS + r * p.AW + 1 + 4 * lc;
+    a_g[it] = c * hw_i + r * p.Wi + 4 * lc;
+    a_r[it] = ok ? r : -(1 << 20);
+  }
+  int d_lds[kND], d_g[kND], d_px[kND];
+#pragma unroll
+  for (int it = 0; it < kND; ++it) {
+    const int c = (it * 4 + wave) * p.CPI + lane / p.LPD, px0 = 4 * (lane % p.LPD);
+    const bool ok = it < p.ND && c < kWT && lane < p.CPI * p.LPD;
+    d_lds[it] = c * p.DCS + px0;
+    d_g[it] = c * hw_o + px0;
+    d_px[it] = ok ? px0 : (1 << 20);
+  }
+  for (int e = tid; e < kWT * p.ACS; e += 256) As[e] = 0.f;  // the halo columns stay zero for the whole kernel
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  v4 ra[kNA], rd[kND];
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    const int b = tile / p.tiles_per_img, rb = tile - b * p.tiles_per_img;
+    const int yo0 = rb * p.R, yi0 = STRIDE * yo0 - 1;
+    const int rows_px = min(p.R, p.Ho - yo0) * p.Wo;
+    const float *ab = p.a + ((size_t)b * p.Cin + cib) * hw_i + (ptrdiff_t)yi0 * p.Wi;
+    const float *dyb = p.dy + ((size_t)b * p.Cout + cob) * hw_o + (size_t)yo0 * p.Wo;
+#pragma unroll
+    for (int it = 0; it < kNA; ++it) {
+      const int yi = yi0 + a_r[it];
+      ra[it] = yi >= 0 && yi < p.Hi ? *reinterpret_cast<const v4 *>(ab + a_g[it]) : v4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < kND; ++it)
+      rd[it] = d_px[it] < rows_px ? *reinterpret_cast<const v4 *>(dyb + d_g[it]) : v4{0.f, 0.f, 0.f, 0.f};
+  };
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const float *dsw = Ds + (wco + l31) * p.DCS + lhi;
+  const float *asw = As + (wci + l31) * p.ACS + STRIDE * lhi;
+  const int aw = p.AW, aw2 = 2 * p.AW;
+  if (sp < p.T) fetch(sp);
+  for (int tile = sp; tile < p.T; tile += p.S) {
+    __syncthreads();  // the previous tile's MFMAs have read their operands (first pass: the zeroing above is done)
+#pragma unroll
+    for (int it = 0; it < kNA; ++it)
+      if (a_r[it] >= 0) {
+        float *o = As + a_lds[it];
+        o[0] = ra[it][0]; o[1] = ra[it][1]; o[2] = ra[it][2]; o[3] = ra[it][3];
+      }
+#pragma unroll
+    for (int it = 0; it < kND; ++it)
+      if (d_px[it] < (1 << 20)) {
+        float *o = Ds + d_lds[it];
+        o[0] = rd[it][0]; o[1] = rd[it][1]; o[2] = rd[it][2]; o[3] = rd[it][3];
+      }
+    __syncthreads();
+    if (tile + p.S < p.T) fetch(tile + p.S);  // in flight while this tile multiplies
+    for (int yo = 0; yo < p.R; ++yo) {
+      const float *drow = dsw + yo * p.Wo;
+      const float *arow = asw + (STRIDE * yo) * aw;
+#pragma unroll 2
+      for (int xo = 0; xo < p.Wo; xo += 2) {
+        const float a = drow[xo];
+        const float *ap = arow + STRIDE * xo;
+        const float b0 = ap[0], b1 = ap[1], b2 = ap[2], b3 = ap[aw], b4 = ap[aw + 1], b5 = ap[aw + 2], b6 = ap[aw2], b7 = ap[aw2 + 1],
+                    b8 = ap[aw2 + 2];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b4, acc[4], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b5, acc[5], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b6, acc[6], 0, 0, 0);
+        acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b7, acc[7], 0, 0, 0);
+        acc[8] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b8, acc[8], 0, 0, 0);
+      }
+    }
+  }
+  float *out = p.part + (size_t)sp * 9 * p.Cout * p.Cin;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = cob + wco + 8 * (i >> 2) + 4 * lhi + (i & 3);
+      out[((size_t)t * p.Cout + co) * p.Cin + cib + wci + l31] = acc[t][i];
+    }
+}
+
+// dW[co][ci][tap] = sum over the S partial slabs, slab order fixed
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int S, int Cout, int Cin, int taps) {
+  const size_t n = (size_t)Cout * Cin * taps;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int tap = (int)(i % taps);
+  const size_t cc = i / taps;  // co * Cin + ci
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += part[((size_t)k * taps + tap) * Cout * Cin + cc];
+  dw[i] = s;
+}
+
+// Any (Cout, Cin), ksize 1 or 3, stride 1 or 2, padding ksize / 2: one workgroup per (cout, cin) pair and image slice, its
+// ksize^2 taps summed over the slice's images and output pixels in a fixed order (the first / last convolution of the UNet -- 1 or
+// 3 channels on one side -- and the reference of the MFMA kernel's tests).  gridDim.y > 1: image slices, partial sums to
+// part[slice][tap][cout][cin] for wgrad_reduce_kernel (128 workgroups walking 65 536 pixels each were 0.4 ms per launch).
+__global__ __launch_bounds__(256) void conv_wgrad_generic_kernel(const float *__restrict__ a, const float *__restrict__ dy,
+                                                                 float *__restrict__ dw, float *__restrict__ part, int B, int Cin,
+                                                                 int Cout, int Hi, int Wi, int Ho, int Wo, int k, int stride) {
+  __shared__ float red[4];
+  const int co = blockIdx.x / Cin, ci = blockIdx.x - co * Cin;
+  const int pad = k / 2, taps = k * k;
+  const int bper = (B + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * bper, b1 = min(B, b0 + bper);
+  float s[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[t] = 0.f;
+  const int npx = Ho * Wo;
+  for (int e = threadIdx.x; e < (b1 - b0) * npx; e += 256) {
+    const int b = b0 + e / npx, px = e % npx;
+    const int yo = px / Wo, xo = px - yo * Wo;
+    const float g = dy[((size_t)b * Cout + co) * npx + px];
+    const float *ap = a + ((size_t)b * Cin + ci) * Hi * Wi;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t < taps) {
+        const int yi = yo * stride + t / k - pad, xi = xo * stride + t % k - pad;
+        if (yi >= 0 && yi < Hi && xi >= 0 && xi < Wi) s[t] = __builtin_fmaf(g, ap[yi * Wi + xi], s[t]);
+      }
+    }
+  }
+  for (int t = 0; t < taps; ++t) {
+    const float v = block_sum_256(s[t], red);
+    if (threadIdx.x == 0) {
+      if (gridDim.y > 1) part[(((size_t)blockIdx.y * taps + t) * Cout + co) * Cin + ci] = v;
+      else dw[((size_t)co * Cin + ci) * taps + t] = v;
+    }
+  }
+}
+
+}  // namespace
+
+}  // namespace ddpm
+
+using namespace ddpm;
+
+namespace {
+// K slices of a product whose (M, N, batch) grid leaves most of the chip idle (a 1x1 convolution's weight gradient: 256 x 512
+// outputs, K = images x pixels = 65 536): enough slices for two workgroups per CU, at least 64 K per slice
+int gemm_ksplit(const ddpm_gemm_desc *g, int &kchunk) {
+  const long wgs = (long)((g->N + kGT - 1) / kGT) * ((g->M + kGT - 1) / kGT) * g->batch;
+  const long want = 2L * device_cus();
+  kchunk = g->K;
+  if (wgs >= want || g->K < 256) return 1;
+  long S = (want + wgs - 1) / wgs;
+  const long smax = g->K / 64;
+  if (S > smax) S = smax;
+  if (S * g->batch > 65535) S = 65535 / g->batch;
+  if (S < 2) return 1;
+  long kc = (g->K + S - 1) / S;
+  kc = (kc + kGK - 1) / kGK * kGK;
+  S = (g->K + kc - 1) / kc;
+  kchunk = (int)kc;
+  return S < 2 ? 1 : (int)S;
+}
+}  // namespace
+
+extern "C" size_t ddpm_gemm_scratch_floats(const ddpm_gemm_desc *g) {
+  if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0 || g->batch <= 0) return 0;
+  int kchunk;
+  const int S = gemm_ksplit(g, kchunk);
+  return S > 1 ? (size_t)S * g->batch * g->M * g->N : 0;
+}
+
+extern "C" int ddpm_gemm_f32(const ddpm_gemm_desc *g, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(g && g->A && g->B && g->C, "gemm: null operand");
+  DDPM_CHECK_ARG(g->M > 0 && g->N > 0 && g->K > 0 && g->batch > 0, "gemm: empty extent");
+  GemmP p;
+  p.A = g->A; p.B = g->B; p.C = g->C;
+  p.M = g->M; p.N = g->N; p.K = g->K;
+  p.K1 = g->k_inner > 0 ? g->k_inner : g->K;
+  DDPM_CHECK_ARG(p.K % p.K1 == 0, "gemm: K %d is not a multiple of k_inner %d", p.K, p.K1);
+  p.sAm = g->a_m; p.sAk0 = g->a_k_outer; p.sAk1 = g->a_k;
+  p.sBn = g->b_n; p.sBk0 = g->b_k_outer; p.sBk1 = g->b_k;
+  p.sCm = g->c_m; p.sCn = g->c_n;
+  p.Z = g->batch;
+  p.Z1 = g->batch_inner > 0 ? g->batch_inner : g->batch;  // one level: z1 = z, the *_batch strides
+  DDPM_CHECK_ARG(p.Z % p.Z1 == 0, "gemm: batch %d is not a multiple of batch_inner %d", p.Z, p.Z1);
+  DDPM_CHECK_ARG(p.Z <= 65535, "gemm: batch %d beyond the grid's z extent", p.Z);
+  p.sAz0 = g->a_batch_outer; p.sAz1 = g->a_batch;
+  p.sBz0 = g->b_batch_outer; p.sBz1 = g->b_batch;
+  p.sCz0 = g->c_batch_outer; p.sCz1 = g->c_batch;
+  p.alpha = g->alpha; p.beta = g->beta;
+  p.S = 1; p.kchunk = g->K; p.part = nullptr;
+  int kchunk;
+  const int S = gemm_ksplit(g, kchunk);
+  if (S > 1 && g->scratch && g->scratch_floats >= (size_t)S * g->batch * g->M * g->N) {
+    p.S = S; p.kchunk = kchunk; p.part = g->scratch;
+  }
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(s, "train_gemm_f32", 2.0 * g->M * g->N * (double)g->K * g->batch,
+                 4.0 * ((double)g->M * g->K + (double)g->K * g->N + (double)g->M * g->N) * g->batch);
+  dim3 grid((g->N + kGT - 1) / kGT, (g->M + kGT - 1) / kGT, g->batch * p.S);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, p);
+  if (p.S > 1) {
+    const size_t n = (size_t)g->M * g->N * g->batch;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+  }
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+namespace {
+// DDPM_WGRAD_STAGED=0: the first form of the kernel (4-byte staging loads, no prefetch) -- the A/B partner of the staged form
+bool wgrad_plain_form() {
+  const char *v = getenv("DDPM_WGRAD_STAGED");
+  return v && atoi(v) == 0;
+}
+bool wgrad_plan(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ksize, int stride, WgradP &p) {
+  if (ksize != 3 || (stride != 1 && stride != 2) || Cin % kWT || Cout % kWT) return false;
+  if (stride == 1 ? (Ho != Hi || Wo != Wi) : (Ho != (Hi + 1) / 2 || Wo != (Wi + 1) / 2)) return false;
+  if (Wo > 64 || (Wo & 1)) return false;  // pixel pairs stay inside a row
+  p.B = B; p.Cin = Cin; p.Cout = Cout; p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.stride = stride;
+  // output rows per pixel tile: 64 pixels where the tiles fit 64 KB of LDS (two workgroups per CU), else fewer rows
+  p.R = 64 / Wo < Ho ? 64 / Wo : Ho;
+  if (p.R < 1) p.R = 1;
+  for (;; p.R = (p.R + 1) / 2) {
+    p.AR = stride * (p.R - 1) + 3;
+    p.AW = Wi + 2;
+    p.ACS = p.AR * p.AW;
+    if (!(p.ACS & 1)) p.ACS += 1;
+    p.DCS = p.R * Wo + 1;
+    const size_t lds = (size_t)kWT * (p.ACS + p.DCS) * sizeof(float);
+    if (lds <= 64 * 1024) break;
+    if (p.R == 1) {  // a single row of a wide image: one workgroup per CU
+      if (lds > 150 * 1024) return false;
+      break;
+    }
+  }
+  p.tiles_per_img = (Ho + p.R - 1) / p.R;
+  p.T = B * p.tiles_per_img;
+  p.fast = 0;
+  if (Wi % 4 == 0 && Wo % 4 == 0 && Wi <= 256 && (Hi * Wi) % 4 == 0) {
+    p.LPR = Wi / 4;
+    p.RPI = 64 / p.LPR;
+    p.NA = (kWT * p.AR + 4 * p.RPI - 1) / (4 * p.RPI);
+    p.LPD = p.R * Wo / 4;
+    p.CPI = 64 / p.LPD;
+    p.ND = p.CPI > 0 ? (kWT + 4 * p.CPI - 1) / (4 * p.CPI) : kND + 1;
+    p.fast = p.RPI > 0 && p.NA <= kNA && p.ND <= kND;
+  }
+  const int blocks = (Cout / kWT) * (Cin / kWT);
+  const int cus = device_cus();
+  int S = (cus + blocks - 1) / blocks;  // one workgroup per CU is what the kernel's 300 registers allow: more slices only feed the reduce
+  if (S > p.T) S = p.T;
+  if (S < 1) S = 1;
+  p.S = S;
+  return true;
+}
+}  // namespace
+
+namespace {
+// image slices of the generic form: enough workgroups for the chip when there are few (cout, cin) pairs and many pixels
+int wgrad_generic_slices(int B, int Cin, int Cout, int Ho, int Wo) {
+  const long pairs = (long)Cout * Cin;
+  if (pairs >= 2L * device_cus() || (long)B * Ho * Wo < 16384) return 1;
+  long S = (2L * device_cus() + pairs - 1) / pairs;
+  if (S > B) S = B;
+  return S < 2 ? 1 : (int)S;
+}
+}  // namespace
+
+extern "C" size_t ddpm_conv_wgrad_scratch_floats(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ksize, int stride) {
+  WgradP p;
+  if (wgrad_plan(B, Cin, Cout, Hi, Wi, Ho, Wo, ksize, stride, p)) return (size_t)p.S * 9 * Cout * Cin;
+  const int S = wgrad_generic_slices(B, Cin, Cout, Ho, Wo);
+  return S > 1 ? (size_t)S * ksize * ksize * Cout * Cin : 0;
+}
+
+extern "C" int ddpm_conv_wgrad_f32(const float *a, const float *dy, float *dw, int B, int Cin, int Cout, int Hi, int Wi, int Ho,
+                                   int Wo, int ksize, int stride, float *scratch, size_t scratch_floats, int force_generic,
+                                   ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(a && dy && dw, "conv_wgrad: null operand");
+  DDPM_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "conv_wgrad: ksize %d / stride %d", ksize, stride);
+  DDPM_CHECK_ARG(B > 0 && Cin > 0 && Cout > 0 && Ho == (Hi + 2 * (ksize / 2) - ksize) / stride + 1 &&
+                     Wo == (Wi + 2 * (ksize / 2) - ksize) / stride + 1,
+                 "conv_wgrad: extents %dx%d -> %dx%d do not match ksize %d stride %d", Hi, Wi, Ho, Wo, ksize, stride);
+  hipStream_t s = as_stream(stream);
+  const double flops = 2.0 * B * Ho * Wo * (double)Cout * Cin * ksize * ksize;
+  const double bytes = 4.0 * ((double)B * Cin * Hi * Wi + (double)B * Cout * Ho * Wo + (double)Cout * Cin * ksize * ksize);
+  WgradP p;
+  if (!force_generic && wgrad_plan(B, Cin, Cout, Hi, Wi, Ho, Wo, ksize, stride, p) && scratch &&
+      scratch_floats >= (size_t)p.S * 9 * Cout * Cin) {
+    p.a = a; p.dy = dy; p.part = scratch;
+    const size_t lds = (size_t)kWT * (p.ACS + p.DCS) * sizeof(float);
+    {
+      ProfScope prof(s, "train_conv3x3_wgrad", flops, bytes);
+      dim3 grid(Cout / kWT, Cin / kWT, p.S);
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+      }
+      const bool staged = p.fast && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0 && !wgrad_plain_form();
+      if (staged && stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<1>, grid, dim3(256), lds, s, p);
+      else if (staged) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<2>, grid, dim3(256), lds, s, p);
+      else if (stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), lds, s, p);
+      else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(256), lds, s, p);
+      DDPM_CHECK_LAUNCH();
+    }
+    ProfScope prof(s, "train_wgrad_reduce", 0.0, 4.0 * (p.S + 1.0) * 9 * Cout * Cin);
+    const size_t n = (size_t)Cout * Cin * 9;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, dw, p.S, Cout, Cin, 9);
+    DDPM_CHECK_LAUNCH();
+    return 0;
+  }
+  DDPM_CHECK_ARG((long long)Cout * Cin <= 0x7fffffffLL, "conv_wgrad: too many (cout, cin) pairs for the generic kernel");
+  int S = force_generic ? 1 : wgrad_generic_slices(B, Cin, Cout, Ho, Wo);
+  if (S > 1 && (!scratch || scratch_floats < (size_t)S * ksize * ksize * Cout * Cin)) S = 1;
+  ProfScope prof(s, "train_conv_wgrad_generic", flops, bytes);
+  hipLaunchKernelGGL(conv_wgrad_generic_kernel, dim3(Cout * Cin, S), dim3(256), 0, s, a, dy, dw, scratch, B, Cin, Cout, Hi, Wi, Ho, Wo,
+                     ksize, stride);
+  if (S > 1) {
+    const size_t n = (size_t)Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, dw, S, Cout, Cin, ksize * ksize);
+  }
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,474 @@
+// train_ops.hip -- the element-wise, normalisation and reduction kernels of the native training step (SURVEY.md 8(f) row f-3;
+// reference: /root/reference/src/trainers/ddpm_trainer.py:78-109 -- F.mse_loss(model(noisy, t), noise), loss.backward(),
+// optimizer.step() -- with Adam(lr = 2.5e-5) of /root/reference/src/trainers/base.py:156).  Round 6.
+//
+// The forward of a training step runs on the inference path's convolution kernels (ddpm_conv_f32) over MATERIALISED
+// GroupNorm + SiLU outputs (the backward needs them as the weight-gradient operand anyway); the backward is
+//   3x3 / 1x1 input gradients    = ddpm_conv_f32 with the weights rotated by 180 degrees and transposed (conv_weight_rot180t),
+//                                  a Downsample's through a zero-stuffed dY, an Upsample's followed by a 2x2 sum,
+//   weight gradients             = train_gemm.hip,
+//   everything else              = the kernels below.  All HBM-bound, all deterministic (fixed-order reductions, no atomics).
+#include "common.h"
+
+namespace ddpm {
+
+namespace {
+
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// ---- GroupNorm, training form: statistics kept for the backward --------------------------------------------------------------
+// one workgroup per (image, group): mean and 1 / sqrt(var + eps) of the group's Cg * HW values (two passes: exact mean first)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, float *__restrict__ mr, int C, int HW, int G,
+                                                       float eps) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int Cg = C / G;
+  const size_t n = (size_t)Cg * HW;
+  const float *p = x + ((size_t)b * C + (size_t)g * Cg) * HW;
+  float s = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 256) s += p[i];
+  const float mean = block_sum_256(s, red) / (float)n;
+  float q = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 256) {
+    const float d = p[i] - mean;
+    q = __builtin_fmaf(d, d, q);
+  }
+  const float var = block_sum_256(q, red) / (float)n;
+  if (threadIdx.x == 0) {
+    mr[2 * blockIdx.x] = mean;
+    mr[2 * blockIdx.x + 1] = 1.0f / sqrtf(var + eps);
+  }
+}
+
+// y = act((x - mean) rstd gamma + beta); one workgroup per (image, channel) plane
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ mr,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       float *__restrict__ y, int C, int HW, int G, int act) {
+  const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+  const int g = c / (C / G);
+  const float mean = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
+  const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
+  const float *p = x + (size_t)blockIdx.x * HW;
+  float *o = y + (size_t)blockIdx.x * HW;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float v = __builtin_fmaf(p[i], sc, sh);
+    o[i] = act == DDPM_ACT_SILU ? v * sigmoid_f(v) : v;
+  }
+}
+
+// backward, pass 1: per (image, channel) plane  s1 = sum dz, s2 = sum dz xhat  with dz = dy act'(z), z = xhat gamma + beta
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                            const float *__restrict__ mr, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float *__restrict__ ws, int C, int HW,
+                                                            int G, int act) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+  const int g = c / (C / G);
+  const float mean = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
+  const float ga = gamma[c], be = beta[c];
+  const float *p = x + (size_t)blockIdx.x * HW, *d = dy + (size_t)blockIdx.x * HW;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float xh = (p[i] - mean) * rstd;
+    float dz = d[i];
+    if (act == DDPM_ACT_SILU) {
+      const float z = __builtin_fmaf(xh, ga, be), sg = sigmoid_f(z);
+      dz *= sg * (1.0f + z * (1.0f - sg));
+    }
+    s1 += dz;
+    s2 = __builtin_fmaf(dz, xh, s2);
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) {
+    ws[2 * blockIdx.x] = s1;
+    ws[2 * blockIdx.x + 1] = s2;
+  }
+}
+
+// backward, pass 2: dx = rstd (dz gamma - (A + xhat Bq) / (Cg HW)),  A = sum_{c in group} gamma_c s1_c, Bq = sum gamma_c s2_c
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                           const float *__restrict__ mr, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, const float *__restrict__ ws,
+                                                           float *__restrict__ dx, int C, int HW, int G, int act, int accumulate) {
+  const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+  const int Cg = C / G, g = c / Cg;
+  const float mean = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
+  const float ga = gamma[c], be = beta[c];
+  float A = 0.f, Bq = 0.f;
+  for (int k = 0; k < Cg; ++k) {  // (every thread the same few values: the scalar cache serves them)
+    const int cc = g * Cg + k;
+    A = __builtin_fmaf(gamma[cc], ws[2 * ((size_t)b * C + cc)], A);
+    Bq = __builtin_fmaf(gamma[cc], ws[2 * ((size_t)b * C + cc) + 1], Bq);
+  }
+  const float inv = 1.0f / ((float)Cg * (float)HW);
+  const float *p = x + (size_t)blockIdx.x * HW, *d = dy + (size_t)blockIdx.x * HW;
+  float *o = dx + (size_t)blockIdx.x * HW;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float xh = (p[i] - mean) * rstd;
+    float dz = d[i];
+    if (act == DDPM_ACT_SILU) {
+      const float z = __builtin_fmaf(xh, ga, be), sg = sigmoid_f(z);
+      dz *= sg * (1.0f + z * (1.0f - sg));
+    }
+    const float v = rstd * (dz * ga - (A + xh * Bq) * inv);
+    o[i] = accumulate ? o[i] + v : v;
+  }
+}
+
+__global__ void gn_param_grads_kernel(const float *__restrict__ ws, float *__restrict__ dgamma, float *__restrict__ dbeta, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    s1 += ws[2 * ((size_t)b * C + c)];
+    s2 += ws[2 * ((size_t)b * C + c) + 1];
+  }
+  dbeta[c] = s1;
+  dgamma[c] = s2;
+}
+
+// ---- reductions ---------------------------------------------------------------------------------------------------------------
+// out[r] = sum of the r-th row of `cols` contiguous floats (bias / temb gradients: rows = (image, channel) planes)
+__global__ __launch_bounds__(256) void row_sum_kernel(const float *__restrict__ in, float *__restrict__ out, int cols) {
+  __shared__ float red[4];
+  const float *p = in + (size_t)blockIdx.x * cols;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < cols; i += 256) s += p[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+// out[c] (+)= alpha * sum_r in[r * stride + c], r = 0 .. rows - 1 in order (rows = batch: a few dozen)
+__global__ void col_sum_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int cols, long long stride, float alpha,
+                               int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += in[(size_t)r * stride + c];
+  s *= alpha;
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// ---- element-wise -------------------------------------------------------------------------------------------------------------
+__global__ void silu_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = x[i] * sigmoid_f(x[i]);
+}
+__global__ void silu_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i], sg = sigmoid_f(v);
+  dx[i] = dy[i] * sg * (1.0f + v * (1.0f - sg));
+}
+__global__ void axpby_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, float alpha, float beta,
+                             int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+// dst[b, cd0 + c, :] (+)= src[b, cs0 + c, :]  (torch.cat in the forward, its split in the backward)
+__global__ void chan_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int Cs, int cs0, int Cd, int cd0, int HW,
+                                 int64_t n, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int px = (int)(i % HW);
+  const int64_t r = i / HW;
+  const int c = (int)(r % C), b = (int)(r / C);
+  const float v = src[((size_t)b * Cs + cs0 + c) * HW + px];
+  float *o = dst + ((size_t)b * Cd + cd0 + c) * HW + px;
+  *o = accumulate ? *o + v : v;
+}
+// mode 0: nearest x2 (F.interpolate);  1: its adjoint (sum of each 2x2 block);  2: zero-stuffing x2 (value at even, even)
+__global__ void resample2_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t planes, int H, int W, int mode) {
+  // H, W: extent of the SMALL image
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (mode == 1) {
+    if (i >= planes * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const int64_t pl = i / ((int64_t)H * W);
+    const float *p = in + pl * 4 * H * W + (size_t)(2 * y) * (2 * W) + 2 * x;
+    out[i] = (p[0] + p[1]) + (p[2 * W] + p[2 * W + 1]);
+  } else {
+    if (i >= planes * 4 * H * W) return;
+    const int x = (int)(i % (2 * W)), y = (int)((i / (2 * W)) % (2 * H));
+    const int64_t pl = i / ((int64_t)4 * H * W);
+    const float v = in[pl * H * W + (size_t)(y >> 1) * W + (x >> 1)];
+    out[i] = mode == 0 ? v : (((x | y) & 1) ? 0.f : v);
+  }
+}
+// wt[ci][co][ky][kx] = w[co][ci][k - 1 - ky][k - 1 - kx]: the weights of the input-gradient convolution
+__global__ void conv_weight_rot180t_kernel(const float *__restrict__ w, float *__restrict__ wt, int Cout, int Cin, int kk) {
+  const int64_t n = (int64_t)Cout * Cin * kk;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = (int)(i % kk);
+  const int64_t r = i / kk;
+  const int co = (int)(r % Cout), ci = (int)(r / Cout);
+  wt[i] = w[((size_t)co * Cin + ci) * kk + (kk - 1 - t)];
+}
+// softmax over rows of `cols` floats, in place (one wave per row, the attention block of the training forward)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ s, int64_t rows, int cols) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float *p = s + r * cols;
+  float m = -3.402823466e+38f;
+  for (int i = lane; i < cols; i += 64) m = fmaxf(m, p[i]);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int i = lane; i < cols; i += 64) {
+    const float e = expf(p[i] - m);
+    p[i] = e;
+    sum += e;
+  }
+  const float inv = 1.0f / wave_sum(sum);
+  for (int i = lane; i < cols; i += 64) p[i] *= inv;
+}
+// ds = p (dp - sum_j dp p) per row, in place over dp
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float *__restrict__ pr, float *__restrict__ dp, int64_t rows, int cols) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float *p = pr + r * cols;
+  float *d = dp + r * cols;
+  float dot = 0.f;
+  for (int i = lane; i < cols; i += 64) dot = __builtin_fmaf(d[i], p[i], dot);
+  dot = wave_sum(dot);
+  for (int i = lane; i < cols; i += 64) d[i] = p[i] * (d[i] - dot);
+}
+// F.mse_loss(pred, target): dpred = 2 (pred - target) / n, partial[block] = sum (pred - target)^2 of the block's elements
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float *__restrict__ pred, const float *__restrict__ target,
+                                                       float *__restrict__ dpred, float *__restrict__ partial, int64_t n, float scale) {
+  __shared__ float red[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float q = 0.f;
+  if (i < n) {
+    const float d = pred[i] - target[i];
+    dpred[i] = scale * d;
+    q = d * d;
+  }
+  q = block_sum_256(q, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = q;
+}
+// torch.optim.Adam (no weight decay, no amsgrad), one flat parameter buffer: bias corrections c1 = 1 - b1^t, c2 = 1 - b2^t from the host
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, int64_t n,
+                            float lr, float b1, float b2, float eps, float c1, float sqrt_c2, float gscale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * gscale;
+  const float mi = m[i] + (gi - m[i]) * (1.0f - b1);  // torch: exp_avg.lerp_(grad, 1 - beta1)
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / sqrt_c2 + eps;
+  p[i] -= (lr / c1) * (mi / denom);
+}
+
+__global__ void fill_kernel(float *__restrict__ out, float value, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = value;
+}
+// Standard normals from Philox-4x32-10 (counter = (element / 4, stream), key = seed) + Box-Muller: four values per counter, a
+// pure function of (seed, stream, element index) -- the training noise does not have to reproduce torch's generator, it has to
+// be reproducible and independent across ranks / steps (stream = step counter, seed mixes in the rank).
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  k[0] += 0x9E3779B9u;
+  k[1] += 0xBB67AE85u;
+}
+__global__ void randn_kernel(float *__restrict__ out, int64_t n, uint64_t seed, uint64_t stream) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // four outputs per thread
+  if (4 * q >= n) return;
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) philox_round(c, k);
+  float z[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)c[2 * h] + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
+    const float u2 = (float)c[2 * h + 1] * 2.3283064365386963e-10f;
+    const float rad = sqrtf(-2.0f * logf(u1 < 1e-30f ? 1e-30f : u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    z[2 * h] = rad * cs;
+    z[2 * h + 1] = rad * sn;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (4 * q + j < n) out[4 * q + j] = z[j];
+}
+
+inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+}  // namespace ddpm
+
+using namespace ddpm;
+
+extern "C" int ddpm_gn_stats_f32(const float *x, float *mean_rstd, int B, int C, int HW, int groups, float eps, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(x && mean_rstd && B > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_stats: bad arguments");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(s, "train_gn_stats", 0.0, 8.0 * B * C * (double)HW);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, s, x, mean_rstd, C, HW, groups, eps);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_gn_apply_f32(const float *x, const float *mean_rstd, const float *gamma, const float *beta, float *y, int B, int C,
+                                 int HW, int groups, int act, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(x && mean_rstd && gamma && beta && y && C % groups == 0 && (act == DDPM_ACT_NONE || act == DDPM_ACT_SILU),
+                 "gn_apply: bad arguments");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(s, "train_gn_apply", 0.0, 8.0 * B * C * (double)HW);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(B * C), dim3(256), 0, s, x, mean_rstd, gamma, beta, y, C, HW, groups, act);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_gn_backward_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta,
+                                    float *dx, int accumulate_dx, float *dgamma, float *dbeta, float *ws, int B, int C, int HW,
+                                    int groups, int act, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(x && dy && mean_rstd && gamma && beta && dx && dgamma && dbeta && ws && C % groups == 0, "gn_backward: bad arguments");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(s, "train_gn_backward", 0.0, 4.0 * 5 * B * C * (double)HW);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B * C), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, C, HW, groups, act);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, dx, C, HW, groups, act,
+                     accumulate_dx);
+  // dbeta[c] = sum_b s1[b, c], dgamma[c] = sum_b s2[b, c]  (ws is [B][C][{s1, s2}]; images in order)
+  hipLaunchKernelGGL(gn_param_grads_kernel, dim3(blocks_for(C)), dim3(256), 0, s, ws, dgamma, dbeta, B, C);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_row_sum_f32(const float *in, float *out, int64_t rows, int cols, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(in && out && rows > 0 && rows <= 0x7fffffff && cols > 0, "row_sum: bad arguments");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(s, "train_row_sum", 0.0, 4.0 * rows * (double)cols);
+  hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)rows), dim3(256), 0, s, in, out, cols);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_col_sum_f32(const float *in, float *out, int rows, int cols, int64_t row_stride, float alpha, int accumulate,
+                                ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(in && out && rows > 0 && cols > 0, "col_sum: bad arguments");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(s, "train_col_sum", 0.0, 4.0 * rows * (double)cols);
+  hipLaunchKernelGGL(col_sum_kernel, dim3(blocks_for(cols)), dim3(256), 0, s, in, out, rows, cols, (long long)row_stride, alpha, accumulate);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_silu_f32(const float *x, float *y, int64_t n, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(x && y && n > 0, "silu: bad arguments");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(silu_kernel, dim3(blocks_for(n)), dim3(256), 0, s, x, y, n);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_silu_backward_f32(const float *x, const float *dy, float *dx, int64_t n, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(x && dy && dx && n > 0, "silu_backward: bad arguments");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, s, x, dy, dx, n);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_axpby_f32(const float *a, const float *b, float *out, float alpha, float beta, int64_t n, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(a && out && n > 0, "axpby: bad arguments");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(s, "train_axpby", 0.0, 12.0 * n);
+  hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(n)), dim3(256), 0, s, a, b, out, alpha, beta, n);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_chan_copy_f32(const float *src, float *dst, int B, int C, int Csrc, int csrc0, int Cdst, int cdst0, int HW,
+                                  int accumulate, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(src && dst && B > 0 && C > 0 && HW > 0 && csrc0 >= 0 && cdst0 >= 0 && csrc0 + C <= Csrc && cdst0 + C <= Cdst,
+                 "chan_copy: bad arguments");
+  hipStream_t s = as_stream(stream);
+  const int64_t n = (int64_t)B * C * HW;
+  ProfScope prof(s, "train_chan_copy", 0.0, 8.0 * n);
+  hipLaunchKernelGGL(chan_copy_kernel, dim3(blocks_for(n)), dim3(256), 0, s, src, dst, C, Csrc, csrc0, Cdst, cdst0, HW, n, accumulate);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_resample2_f32(const float *in, float *out, int64_t planes, int H, int W, int mode, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(in && out && planes > 0 && H > 0 && W > 0 && mode >= 0 && mode <= 2, "resample2: bad arguments");
+  hipStream_t s = as_stream(stream);
+  const int64_t n = mode == 1 ? planes * H * W : planes * 4 * H * W;
+  ProfScope prof(s, "train_resample2", 0.0, 5.0 * 4 * planes * H * W);
+  hipLaunchKernelGGL(resample2_kernel, dim3(blocks_for(n)), dim3(256), 0, s, in, out, planes, H, W, mode);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_conv_weight_rot180t_f32(const float *w, float *wt, int Cout, int Cin, int ksize, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(w && wt && Cout > 0 && Cin > 0 && ksize > 0, "conv_weight_rot180t: bad arguments");
+  hipStream_t s = as_stream(stream);
+  const int64_t n = (int64_t)Cout * Cin * ksize * ksize;
+  hipLaunchKernelGGL(conv_weight_rot180t_kernel, dim3(blocks_for(n)), dim3(256), 0, s, w, wt, Cout, Cin, ksize * ksize);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_softmax_rows_f32(float *s_inout, int64_t rows, int cols, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(s_inout && rows > 0 && cols > 0, "softmax_rows: bad arguments");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(s, "train_softmax", 0.0, 8.0 * rows * (double)cols);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(blocks_for(rows, 4)), dim3(256), 0, s, s_inout, rows, cols);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_softmax_backward_rows_f32(const float *p, float *dp_inout, int64_t rows, int cols, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(p && dp_inout && rows > 0 && cols > 0, "softmax_backward_rows: bad arguments");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(s, "train_softmax_bwd", 0.0, 12.0 * rows * (double)cols);
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(blocks_for(rows, 4)), dim3(256), 0, s, p, dp_inout, rows, cols);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_mse_loss_grad_f32(const float *pred, const float *target, float *dpred, float *partial, int64_t n, float grad_scale,
+                                      ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(pred && target && dpred && partial && n > 0, "mse_loss_grad: bad arguments");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(mse_grad_kernel, dim3(blocks_for(n)), dim3(256), 0, s, pred, target, dpred, partial, n, grad_scale);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                  int step, float grad_scale, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+  hipStream_t s = as_stream(stream);
+  const double c1 = 1.0 - pow((double)beta1, step), c2 = 1.0 - pow((double)beta2, step);
+  ProfScope prof(s, "train_adam", 0.0, 28.0 * n);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, (float)c1,
+                     (float)sqrt(c2), grad_scale);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_fill_f32(float *out, float value, int64_t n, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(out && n > 0, "fill: bad arguments");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks_for(n)), dim3(256), 0, s, out, value, n);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_randn_f32(float *out, int64_t n, uint64_t seed, uint64_t stream_id, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(out && n > 0, "randn: bad arguments");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(randn_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, s, out, n, seed, stream_id);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,7 +1,6 @@
-// wino44h_common.h -- what the two split-f16 Winograd F(4x4, 3x3) kernels share (conv_wino44h.hip: LDS-fed U, one barrier per
-// 12-position phase; conv_wino44r.hip: register-fed U, one barrier per 8-channel chunk): item constants, the pinned-accumulator
-// MFMA helpers, the 1-D transforms, the pair split, the item geometry and the packed-weight layout.  See conv_wino44h.hip's header
-// comment for the arithmetic.
+// wino44h_common.h -- shared by the split-f16 Winograd F(4x4, 3x3) kernel (conv_wino44r.hip) and its host side (conv_wino44h.hip:
+// geometry, dispatch, weight packing): item constants, the pinned-accumulator MFMA helpers, the 1-D transforms, the pair split,
+// the item geometry and the packed-weight layout.  See conv_wino44h.hip's header comment for the arithmetic.
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
@@ -210,6 +209,6 @@ bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing = false);  // c
 inline size_t w44h_lds_bytes(const W44HGeom &g) { return ((size_t)kRINGF + 4 * (size_t)g.HS) * sizeof(float); }
 // conv_wino44r.hip: the same fused convolution, item and packed weights on the register-fed form of the kernel
 int launch_conv_wino44r(const ddpm_conv_desc &dk, const W44HGeom &g, size_t lds, hipStream_t s);
-void w44r_relayout(const ddpm_conv_desc &d, W44HGeom &g);  // its pixel-tile layout (never larger than conv_wino44h.hip's)
+void w44r_relayout(const ddpm_conv_desc &d, W44HGeom &g);  // its pixel-tile layout (called by w44h_geom, which checks the LDS size)
 
 }  // namespace ddpm

@@ -7,10 +7,12 @@ output and the noise) with Adam(lr = 2.5e-5) as at /root/reference/src/trainers/
 dict of base.py:166-187.  Differences, on purpose:
   * fp32 by default; ``--amp 1`` mirrors the reference's fp16 autocast + GradScaler
     (/root/reference/src/trainers/ddpm_trainer.py:96-109, base.py:122) over the same ATen ops;
-  * the backward pass is PyTorch-ROCm autograd: ``unet_forward_torch`` evaluates the SAME parameter holders the HIP
-    engine reads (``DiffusionModelUNet``) with differentiable ATen ops, so a checkpoint written here loads into the
-    HIP inference path unchanged.  Training is off the hot path (it runs once; reconstruction runs per image x
-    t_start x step) -- its kernels are rocBLAS / MIOpen via ATen, not hand-written;
+  * since round 6 the training step of a 2-D UNet is NATIVE (``train_native.NativeUNetStep``: forward on the inference path's
+    convolution kernels, backward and Adam on hand-written HIP kernels -- ddpm_conv_wgrad_f32, ddpm_gemm_f32, train_ops.hip; no
+    ATen / MIOpen / rocBLAS kernel between the noisy batch and the updated parameters).  ``DDPM_TRAIN_NATIVE=0``, ``--amp 1`` and
+    the 3-D latent UNet take the older route: PyTorch-ROCm autograd over ``unet_forward_torch``, which evaluates the SAME
+    parameter holders the HIP engine reads (``DiffusionModelUNet``) with differentiable ATen ops.  Either way a checkpoint
+    written here loads into the HIP inference path unchanged;
   * multi-GPU: one process per GPU; rank 0's initial parameters and buffers are broadcast once (what
     DistributedDataParallel's constructor does for the reference, base.py:160-163), gradients are averaged with ONE flat
     RCCL all_reduce per step (17.7 M parameters = 71 MB for `small`) instead of DDP's bucket hooks, and every rank
@@ -27,13 +29,16 @@ dict of base.py:166-187.  Differences, on purpose:
 from __future__ import annotations
 
 import math
+import os
 import time
 
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import train_ops as T
 from .data import get_data_loader
+from .train_native import NativeUNetStep, native_supported
 from .trainer import BaseTrainer
 
 
@@ -114,23 +119,37 @@ class DDPMTrainer(BaseTrainer):
         self.seed = int(args.seed)
         self.amp = bool(getattr(args, "amp", 0))
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp)
-        for p in self.model.parameters():
-            p.requires_grad_(True)
-        self._broadcast_initial_state()
-        self.optimizer = torch.optim.Adam(params=self.model.parameters(), lr=2.5e-5)  # base.py:156
+        # native step (hand-written HIP forward / backward / Adam) unless switched off, under AMP, or for the 3-D latent UNet
+        self.native = (os.environ.get("DDPM_TRAIN_NATIVE", "1") not in ("0", "off") and not self.amp
+                       and native_supported(self.model) and not self.do_latent_pad)
+        if self.native:
+            with torch.no_grad():
+                self.stepper = NativeUNetStep(self.model, lr=2.5e-5)  # base.py:156
+            self._broadcast_initial_state()
+            self.optimizer = self.stepper  # state_dict() / load_state_dict() in torch.optim.Adam's format
+        else:
+            for p in self.model.parameters():
+                p.requires_grad_(True)
+            self._broadcast_initial_state()
+            self.optimizer = torch.optim.Adam(params=self.model.parameters(), lr=2.5e-5)  # base.py:156
         if self.found_checkpoint and self.optimizer_state:
             self.optimizer.load_state_dict(self.optimizer_state)
+        self.noise_calls = 0  # stream id of the native noise generator: one per drawn tensor
         kw = dict(batch_size=args.batch_size, is_grayscale=bool(args.is_grayscale), image_size=self.image_size,
                   spatial_dimension=args.spatial_dimension, image_roi=args.image_roi)
         self.train_loader = get_data_loader(args.training_ids, rank=self.rank, world=self.world, **kw)
         self.val_loader = get_data_loader(args.validation_ids, rank=self.rank, world=self.world, **kw)
         self.gen = torch.Generator(device=self.device).manual_seed(self.seed * 7919 + self.rank)
+        self.host_gen = torch.Generator().manual_seed(self.seed * 7919 + self.rank)  # native step: timesteps are drawn on the host
         self.history = []  # (epoch, mean train loss)
 
     def _broadcast_initial_state(self):
         """Every rank starts from rank 0's parameters and buffers (torch's default init is unseeded per process; a
         resumed run loads the same file everywhere and the broadcast is a no-op in value)."""
         if not self.ddp:
+            return
+        if getattr(self, "native", False) and not list(self.model.buffers()):
+            self._dist_all(dist.broadcast, self.stepper.flat, src=0)  # the holders' .data are views of this buffer
             return
         tensors = [p.data for p in self.model.parameters()] + [b.data for b in self.model.buffers()]
         flat = torch.cat([t.reshape(-1).float() for t in tensors])
@@ -157,8 +176,35 @@ class DDPMTrainer(BaseTrainer):
             # the reference regresses onto the noise whatever --prediction_type says (ddpm_trainer.py:99-100)
             return F.mse_loss(pred.float(), noise.float())
 
+    @torch.no_grad()
+    def _loss_native(self, images: torch.Tensor, backward: bool) -> torch.Tensor:
+        """The same step on the native kernels: timesteps drawn on the host, noise by ddpm_randn_f32 (a pure function of seed, rank
+        and draw counter), add_noise / UNet forward / MSE (/ backward) in HIP.  Returns the loss as a 1-element device tensor."""
+        images = self.vqvae_model.encode_stage_2_inputs(images).float().contiguous()
+        b = images.shape[0]
+        timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (b,), generator=self.host_gen).long()
+        self.noise_calls += 1
+        noise = T.randn(tuple(images.shape), self.device, self.seed * 7919 + self.rank, self.noise_calls)
+        noisy = self.scheduler.add_noise(original_samples=images, noise=noise, timesteps=timesteps, b_scale=self.b_scale)
+        t_dev = timesteps.to(self.device)
+        if backward:
+            return self.stepper.loss_and_grads(noisy, t_dev, noise)
+        loss, _ = T.mse_loss_grad(self.stepper.forward(noisy, t_dev), noise)
+        return loss
+
+    def _dist_all(self, fn, flat, **kw):
+        if dist.get_backend() == "gloo" and flat.is_cuda:  # test hook: two ranks on one GPU (see trainer.BaseTrainer)
+            host = flat.cpu()
+            fn(host, **kw)
+            flat.copy_(host)
+        else:
+            fn(flat, **kw)  # RCCL over xGMI: one collective
+
     def _sync_grads(self):
         if not self.ddp:
+            return
+        if self.native:  # every gradient already lives in one flat buffer; the 1 / world factor rides in the Adam kernel
+            self._dist_all(dist.all_reduce, self.stepper.gflat)
             return
         grads = [p.grad for p in self.model.parameters() if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])
@@ -195,12 +241,17 @@ class DDPMTrainer(BaseTrainer):
             # a loader over images of different shapes holds a list: stack the selected items
             images = (src[idx] if torch.is_tensor(src) else torch.stack([src[int(i)] for i in idx])).to(
                 self.device, non_blocking=True)
-            self.optimizer.zero_grad(set_to_none=True)
-            loss = self._loss(images)
-            self.scaler.scale(loss).backward()  # (identity without --amp)
-            self._sync_grads()
-            self.scaler.step(self.optimizer)
-            self.scaler.update()
+            if self.native:
+                loss = self._loss_native(images, backward=True)  # every gradient has one writer: nothing to zero
+                self._sync_grads()
+                self.stepper.adam_step(grad_scale=1.0 / self.world if self.ddp else 1.0)
+            else:
+                self.optimizer.zero_grad(set_to_none=True)
+                loss = self._loss(images)
+                self.scaler.scale(loss).backward()  # (identity without --amp)
+                self._sync_grads()
+                self.scaler.step(self.optimizer)
+                self.scaler.update()
             epoch_loss += loss.item()
             self.global_step += images.shape[0]
             epoch_step += images.shape[0]
@@ -214,7 +265,8 @@ class DDPMTrainer(BaseTrainer):
         self.model.eval()
         tot, n = 0.0, 0
         for batch in self.val_loader:
-            tot += self._loss(batch["image"].to(self.device)).item()
+            img = batch["image"].to(self.device)
+            tot += (self._loss_native(img, backward=False) if self.native else self._loss(img)).item()
             n += batch["image"].shape[0]
             if self.quick_test:
                 break

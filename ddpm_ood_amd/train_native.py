@@ -1,0 +1,406 @@
+"""Native training step of the 2-D DiffusionModelUNet: forward, backward and Adam on hand-written HIP kernels only
+(the step of /root/reference/src/trainers/ddpm_trainer.py:78-109 with the optimiser of
+/root/reference/src/trainers/base.py:156).
+
+``NativeUNetStep`` evaluates the SAME parameter holders the inference engine reads (``unet.DiffusionModelUNet``, MONAI-Generative
+key names) -- a checkpoint written after native steps loads into the reconstruction path unchanged -- and keeps every
+parameter / gradient / Adam moment in ONE flat device buffer each (the holders' ``.data`` and ``.grad`` become views of them): one
+Adam launch, one all-reduce payload.  No ATen / MIOpen / rocBLAS kernel runs between handing over (noisy, timesteps, noise) and
+the updated parameters; ``torch.empty`` only asks the caching allocator for memory.
+
+Forward (activations kept for the backward):
+  GroupNorm statistics + a MATERIALISED GroupNorm/SiLU output (ddpm_gn_stats_f32 / ddpm_gn_apply_f32) -> the inference path's
+  convolution kernels (ddpm_conv_f32: split-f16 F(4x4) Winograd where a launch fills the chip, its bias / temb / residual
+  epilogue), attention as two batched GEMMs around a row softmax (the probabilities are kept).
+Backward:
+  3x3 / 1x1 input gradients = ddpm_conv_f32 with the weights rotated by 180 degrees and transposed; Downsample through a
+  zero-stuffed dY; Upsample followed by a 2x2 sum; 3x3 weight gradients on ddpm_conv_wgrad_f32 (fp32 MFMA, 64 x 64 x 9 taps per
+  workgroup); every other contraction (Linear / 1x1 weight and input gradients, the five attention products) on ddpm_gemm_f32;
+  GroupNorm + SiLU backward, bias sums, SiLU backward, softmax backward, MSE, Adam in train_ops.hip.
+"""
+
+from __future__ import annotations
+
+import math
+import os
+
+import torch
+
+from . import ops
+from . import train_ops as T
+
+SILU, NONE = T.ACT_SILU, T.ACT_NONE
+
+
+def native_supported(model) -> bool:
+    """2-D UNets only (the 3-D latent UNet of the LDM configuration trains through the ATen path: no conv3d weight gradient)."""
+    return getattr(model, "spatial_dims", 2) == 2
+
+
+class NativeUNetStep:
+    def __init__(self, model, lr: float = 2.5e-5, betas=(0.9, 0.999), eps: float = 1e-8):
+        if not native_supported(model):
+            raise NotImplementedError("native training covers the 2-D DiffusionModelUNet")
+        self.model = model
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        self.G, self.gn_eps = model.norm_num_groups, model.norm_eps
+        # Which 3x3 kernel multiplies (see _conv).  The forward keeps the inference path's F(4x4); the INPUT gradients default to
+        # F(2x2): a gradient passes through ~45 convolutions on its way back and F(4x4)'s transform rounding accumulated to 1.4e-4
+        # of a parameter gradient's scale at the first layers (F(2x2): measured in tests/test_gpu_train.py, bar 1e-4).
+        self.fwd_form = os.environ.get("DDPM_TRAIN_FWD", "wino44h")
+        self.dgrad_form = os.environ.get("DDPM_TRAIN_DGRAD", "wino")
+        self._flatten()
+
+    # ---- flat parameter / gradient / moment buffers ----------------------------------------------------------------------
+    def _flatten(self):
+        params = list(self.model.parameters())
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("native training needs the model on a ROCm device (no CPU fallback)")
+        total = sum(p.numel() for p in params)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.gflat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.m = torch.empty(total, dtype=torch.float32, device=dev)
+        self.v = torch.empty(total, dtype=torch.float32, device=dev)
+        for t in (self.gflat, self.m, self.v):
+            T.fill_(t, 0.0)
+        self.offsets = {}
+        off = 0
+        for p in params:
+            n = p.numel()
+            view = self.flat[off: off + n].view(p.shape)
+            src = p.data.float().contiguous()
+            T.axpby(src.view(-1), None, 1.0, 0.0, out=self.flat[off: off + n])  # copy (a HIP kernel of this library)
+            p.data = view
+            p.grad = self.gflat[off: off + n].view(p.shape)
+            self.offsets[id(p)] = (off, n)
+            off += n
+        self.params = params
+        self.model._plist = None  # the engine's change detector looks at data pointers / versions
+        self.model._synced_key = None
+
+    def g(self, p):
+        return p.grad
+
+    # ---- primitives --------------------------------------------------------------------------------------------------------
+    def _conv(self, x, w, b=None, *, chan_add=None, residual=None, stride2=False, form=None):
+        """ddpm_conv_f32.  form of a stride-1 3x3: "wino44h" = split-f16 F(4x4) Winograd where the launch fills the chip (the
+        inference path's kernel: ~3e-6 rms relative rounding per convolution, from the 6x6 transforms), "wino" = F(2x2) on the
+        fp32 MFMA (~1e-6), "direct" = the fp32 MFMA direct form (bit-exact fp32 products)."""
+        if stride2:
+            return ops.conv(x, w, b, mode=ops.CONV_STRIDE2, wino44h=ops.pack_conv_s2h_weight(w))
+        if w.ndim == 4 and w.shape[2] == 3:
+            form = form or self.fwd_form
+            return ops.conv(x, w, b, chan_add=chan_add, residual=residual,
+                            wino44h=ops.pack_wino44h_weight(w) if form == "wino44h" else None,
+                            wino=ops.pack_wino_weight(w) if form in ("wino44h", "wino") else None)
+        return ops.conv(x, w, b, chan_add=chan_add, residual=residual)
+
+    def _bias_grad(self, dy, bias_param, keep_rows=False):
+        B, Cc = dy.shape[:2]
+        rows = T.row_sum(dy, B * Cc, dy[0, 0].numel())  # [B, C]: also the temb gradient of a ResnetBlock
+        if bias_param is not None:
+            T.col_sum(rows, B, Cc, out=self.g(bias_param))
+        return rows if keep_rows else None
+
+    def _linear_fwd(self, x, lin):
+        return ops.conv(x, lin.weight, lin.bias)  # [B, Cin] -> [B, Cout]
+
+    def _linear_bwd(self, x, lin, dy, dx=None, accumulate=False, need_dx=True):
+        B, cin = x.shape
+        cout = dy.shape[1]
+        # dW[o, i] = sum_b dy[b, o] x[b, i]
+        T.gemm(dy, x, self.g(lin.weight), cout, cin, B, a_m=1, a_k=cout, b_k=cin, b_n=1, c_m=cin, c_n=1)
+        T.col_sum(dy, B, cout, out=self.g(lin.bias))
+        if not need_dx:
+            return None
+        if dx is None:
+            dx, accumulate = torch.empty_like(x), False
+        # dx[b, i] = sum_o dy[b, o] W[o, i]
+        T.gemm(dy, lin.weight, dx, B, cin, cout, a_m=cout, a_k=1, b_k=cin, b_n=1, c_m=cin, c_n=1, beta=1.0 if accumulate else 0.0)
+        return dx
+
+    def _gn_fwd(self, x, norm, act):
+        mr = T.gn_stats(x, self.G, self.gn_eps)
+        return T.gn_apply(x, mr, norm.weight, norm.bias, self.G, act), (x, mr, norm, act)
+
+    def _gn_bwd(self, ctx, da, dx=None, accumulate=False):
+        x, mr, norm, act = ctx
+        return T.gn_backward(x, da, mr, norm.weight, norm.bias, self.G, act, self.g(norm.weight), self.g(norm.bias), dx=dx,
+                             accumulate=accumulate)
+
+    def _conv3_bwd(self, a, w, dy, need_dx=True):
+        """dW into the weight's gradient view; returns da = conv(dy, rot180(w)^T)."""
+        T.conv_wgrad(a, dy, 3, 1, out=self.g(w))
+        if not need_dx:
+            return None
+        return self._conv(dy, T.conv_weight_rot180t(w), form=self.dgrad_form)
+
+    def _conv1_wgrad(self, x, w, dy):
+        """1x1 convolution / per-pixel Linear: dW[o, i] = sum over (image, pixel) dy[b, o, p] x[b, i, p]."""
+        B, cin = x.shape[:2]
+        cout, hw = dy.shape[1], dy[0, 0].numel()
+        T.gemm(dy, x, self.g(w), cout, cin, B * hw, k_inner=hw, a_m=hw, a_k=1, a_k_outer=cout * hw, b_n=hw, b_k=1,
+               b_k_outer=cin * hw, c_m=cin, c_n=1)
+
+    def _conv1_dgrad(self, w, dy, dx, accumulate):
+        """dx[b, i, p] (+)= sum_o W[o, i] dy[b, o, p]."""
+        B, cout = dy.shape[:2]
+        cin, hw = dx.shape[1], dy[0, 0].numel()
+        T.gemm(w, dy, dx, cin, hw, cout, a_m=1, a_k=cin, b_k=hw, b_n=1, c_m=hw, c_n=1, batch=B, a_batch=0, b_batch=cout * hw,
+               c_batch=cin * hw, beta=1.0 if accumulate else 0.0)
+
+    # ---- ResnetBlock --------------------------------------------------------------------------------------------------------
+    def _resnet_fwd(self, blk, x, es):
+        a1, c1 = self._gn_fwd(x, blk.norm1, SILU)
+        te = self._linear_fwd(es, blk.time_emb_proj)
+        h1 = self._conv(a1, blk.conv1.conv.weight, blk.conv1.conv.bias, chan_add=te)
+        a2, c2 = self._gn_fwd(h1, blk.norm2, SILU)
+        ident = isinstance(blk.skip_connection, torch.nn.Identity)
+        skip = x if ident else self._conv(x, blk.skip_connection.conv.weight, blk.skip_connection.conv.bias)
+        out = self._conv(a2, blk.conv2.conv.weight, blk.conv2.conv.bias, residual=skip)
+        return out, (blk, x, a1, c1, a2, c2, ident)
+
+    def _resnet_bwd(self, ctx, dout):
+        blk, x, a1, c1, a2, c2, ident = ctx
+        es = self._es
+        rows = self._bias_grad(dout, blk.conv2.conv.bias, keep_rows=not ident)
+        da2 = self._conv3_bwd(a2, blk.conv2.conv.weight, dout)
+        dh1 = self._gn_bwd(c2, da2)
+        dte = self._bias_grad(dh1, blk.conv1.conv.bias, keep_rows=True).view(dh1.shape[0], dh1.shape[1])
+        self._linear_bwd(es, blk.time_emb_proj, dte, dx=self._des, accumulate=True)
+        da1 = self._conv3_bwd(a1, blk.conv1.conv.weight, dh1)
+        dx = self._gn_bwd(c1, da1)
+        if ident:
+            T.axpby(dx, dout, 1.0, 1.0, out=dx)
+        else:
+            sk = blk.skip_connection.conv
+            self._conv1_wgrad(x, sk.weight, dout)
+            T.col_sum(rows, dout.shape[0], dout.shape[1], out=self.g(sk.bias))
+            self._conv1_dgrad(sk.weight, dout, dx, accumulate=True)
+        return dx
+
+    # ---- AttentionBlock -------------------------------------------------------------------------------------------------------
+    def _attn_fwd(self, blk, x, head_channels):
+        B, Cc = x.shape[:2]
+        n = x[0, 0].numel()
+        heads = Cc // head_channels if head_channels else 1
+        d = Cc // heads
+        scale = 1.0 / math.sqrt(d)
+        xn, c = self._gn_fwd(x, blk.norm, NONE)
+        q = self._conv(xn, blk.to_q.weight, blk.to_q.bias)
+        k = self._conv(xn, blk.to_k.weight, blk.to_k.bias)
+        v = self._conv(xn, blk.to_v.weight, blk.to_v.bias)
+        P = torch.empty((B * heads, n, n), dtype=torch.float32, device=x.device)
+        zb = dict(batch=B * heads, batch_inner=heads, a_batch=d * n, a_batch_outer=Cc * n, b_batch=d * n, b_batch_outer=Cc * n)
+        # S[z, i, j] = scale sum_c q[z, c, i] k[z, c, j]
+        T.gemm(q, k, P, n, n, d, a_m=1, a_k=n, b_k=n, b_n=1, c_m=n, c_n=1, c_batch=n * n, c_batch_outer=heads * n * n, alpha=scale,
+               **zb)
+        T.softmax_rows_(P, B * heads * n, n)
+        o = torch.empty_like(x)
+        # o[z, c, i] = sum_j v[z, c, j] P[z, i, j]
+        T.gemm(v, P, o, d, n, n, a_m=n, a_k=1, b_k=1, b_n=n, c_m=n, c_n=1, batch=B * heads, batch_inner=heads, a_batch=d * n,
+               a_batch_outer=Cc * n, b_batch=n * n, b_batch_outer=heads * n * n, c_batch=d * n, c_batch_outer=Cc * n)
+        if self.model.use_proj_attn:
+            o_in = o
+            o = self._conv(o_in, blk.proj_attn.weight, blk.proj_attn.bias)
+        else:
+            o_in = None
+        out = T.axpby(o, x, 1.0, 1.0)
+        return out, (blk, c, xn, q, k, v, P, o_in, heads, d, scale)
+
+    def _attn_bwd(self, ctx, dout):
+        blk, c, xn, q, k, v, P, o_in, heads, d, scale = ctx
+        B, Cc = dout.shape[:2]
+        n = dout[0, 0].numel()
+        do = dout
+        if o_in is not None:
+            self._conv1_wgrad(o_in, blk.proj_attn.weight, dout)
+            self._bias_grad(dout, blk.proj_attn.bias)
+            do = torch.empty_like(dout)
+            self._conv1_dgrad(blk.proj_attn.weight, dout, do, accumulate=False)
+        zq = dict(batch=B * heads, batch_inner=heads)
+        cn = dict(c_m=n, c_n=1)
+        dv, dq, dk = torch.empty_like(v), torch.empty_like(q), torch.empty_like(k)
+        dP = torch.empty_like(P)
+        # dv[z, c, j] = sum_i do[z, c, i] P[z, i, j]
+        T.gemm(do, P, dv, d, n, n, a_m=n, a_k=1, b_k=n, b_n=1, a_batch=d * n, a_batch_outer=Cc * n, b_batch=n * n,
+               b_batch_outer=heads * n * n, c_batch=d * n, c_batch_outer=Cc * n, **cn, **zq)
+        # dP[z, i, j] = sum_c do[z, c, i] v[z, c, j]
+        T.gemm(do, v, dP, n, n, d, a_m=1, a_k=n, b_k=n, b_n=1, a_batch=d * n, a_batch_outer=Cc * n, b_batch=d * n,
+               b_batch_outer=Cc * n, c_batch=n * n, c_batch_outer=heads * n * n, **cn, **zq)
+        T.softmax_backward_rows_(P, dP, B * heads * n, n)  # dP now holds dS
+        # dq[z, c, i] = scale sum_j dS[z, i, j] k[z, c, j]
+        T.gemm(k, dP, dq, d, n, n, a_m=n, a_k=1, b_k=1, b_n=n, a_batch=d * n, a_batch_outer=Cc * n, b_batch=n * n,
+               b_batch_outer=heads * n * n, c_batch=d * n, c_batch_outer=Cc * n, alpha=scale, **cn, **zq)
+        # dk[z, c, j] = scale sum_i dS[z, i, j] q[z, c, i]
+        T.gemm(q, dP, dk, d, n, n, a_m=n, a_k=1, b_k=n, b_n=1, a_batch=d * n, a_batch_outer=Cc * n, b_batch=n * n,
+               b_batch_outer=heads * n * n, c_batch=d * n, c_batch_outer=Cc * n, alpha=scale, **cn, **zq)
+        dxn = torch.empty_like(xn)
+        for i, (lin, dt) in enumerate(((blk.to_q, dq), (blk.to_k, dk), (blk.to_v, dv))):
+            self._conv1_wgrad(xn, lin.weight, dt)
+            self._bias_grad(dt, lin.bias)
+            self._conv1_dgrad(lin.weight, dt, dxn, accumulate=i > 0)
+        dx = self._gn_bwd(c, dxn)
+        T.axpby(dx, dout, 1.0, 1.0, out=dx)
+        return dx
+
+    # ---- the network ----------------------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        m = self.model
+        tape = []
+        ch0 = m.block_out_channels[0]
+        if ch0 % 2:
+            raise NotImplementedError("odd num_channels[0]")
+        if getattr(self, "_freqs", None) is None or self._freqs.device != x.device:
+            self._freqs = m._freqs().to(x.device)
+        e0 = ops.timestep_embedding(timesteps, self._freqs, ch0)
+        te0, te2 = m.time_embed[0], m.time_embed[2]
+        e1 = self._linear_fwd(e0, te0)
+        e2 = T.silu(e1)
+        emb = self._linear_fwd(e2, te2)
+        self._es = T.silu(emb)
+        self._emb_ctx = (e0, e1, e2, emb)
+        h = self._conv(x, m.conv_in.conv.weight, m.conv_in.conv.bias)
+        tape.append(("conv_in", x))
+        skips = [h]
+        for blk, hc in zip(m.down_blocks, m.num_head_channels):
+            for j, r in enumerate(blk.resnets):
+                h, ctx = self._resnet_fwd(r, h, self._es)
+                tape.append(("resnet", ctx))
+                if hasattr(blk, "attentions"):
+                    h, ctx = self._attn_fwd(blk.attentions[j], h, hc)
+                    tape.append(("attn", ctx))
+                skips.append(h)
+                tape.append(("skip_push", None))
+            if blk.downsampler is not None:
+                op = blk.downsampler.op.conv
+                tape.append(("down", (op, h)))
+                h = self._conv(h, op.weight, op.bias, stride2=True)
+                skips.append(h)
+                tape.append(("skip_push", None))
+        mid = m.middle_block
+        h, ctx = self._resnet_fwd(mid.resnet_1, h, self._es)
+        tape.append(("resnet", ctx))
+        h, ctx = self._attn_fwd(mid.attention, h, m.num_head_channels[-1])
+        tape.append(("attn", ctx))
+        h, ctx = self._resnet_fwd(mid.resnet_2, h, self._es)
+        tape.append(("resnet", ctx))
+        for blk, hc in zip(m.up_blocks, reversed(m.num_head_channels)):
+            for j, r in enumerate(blk.resnets):
+                s = skips.pop()
+                c1, c2 = h.shape[1], s.shape[1]
+                cat = torch.empty((h.shape[0], c1 + c2) + tuple(h.shape[2:]), dtype=torch.float32, device=h.device)
+                T.chan_copy(h, cat, c1, 0, 0)
+                T.chan_copy(s, cat, c2, 0, c1)
+                tape.append(("cat", (c1, c2)))
+                h, ctx = self._resnet_fwd(r, cat, self._es)
+                tape.append(("resnet", ctx))
+                if hasattr(blk, "attentions"):
+                    h, ctx = self._attn_fwd(blk.attentions[j], h, hc)
+                    tape.append(("attn", ctx))
+            if blk.upsampler is not None:
+                op = blk.upsampler.conv.conv
+                u = T.upsample2(h)
+                tape.append(("up", (op, u)))
+                h = self._conv(u, op.weight, op.bias)
+        a, c = self._gn_fwd(h, m.out[0], SILU)
+        oc = m.out[2].conv
+        tape.append(("out", (oc, a, c)))
+        pred = self._conv(a, oc.weight, oc.bias)
+        self._tape = tape
+        return pred
+
+    def backward(self, dpred: torch.Tensor) -> None:
+        """Fills every parameter's gradient view (overwrites: call after zeroing is NOT needed, each gradient has one writer)."""
+        m = self.model
+        self._des = T.fill_(torch.empty_like(self._es), 0.0)
+        dskips = []  # gradients of the skip tensors, in the order the skips were created
+        dh = None
+        for kind, ctx in reversed(self._tape):
+            if kind == "out":
+                oc, a, c = ctx
+                self._bias_grad(dpred, oc.bias)
+                T.conv_wgrad(a, dpred, 3, 1, out=self.g(oc.weight))
+                da = self._conv(dpred, T.conv_weight_rot180t(oc.weight), form=self.dgrad_form)
+                dh = self._gn_bwd(c, da)
+            elif kind == "up":
+                op, u = ctx
+                self._bias_grad(dh, op.bias)
+                du = self._conv3_bwd(u, op.weight, dh)
+                dh = T.sumpool2(du)
+            elif kind == "resnet":
+                dh = self._resnet_bwd(ctx, dh)
+            elif kind == "attn":
+                dh = self._attn_bwd(ctx, dh)
+            elif kind == "cat":
+                c1, c2 = ctx
+                dcat = dh
+                shp = tuple(dcat.shape)
+                dh = torch.empty((shp[0], c1) + shp[2:], dtype=torch.float32, device=dcat.device)
+                ds = torch.empty((shp[0], c2) + shp[2:], dtype=torch.float32, device=dcat.device)
+                T.chan_copy(dcat, dh, c1, 0, 0)
+                T.chan_copy(dcat, ds, c2, c1, 0)
+                dskips.append(ds)
+            elif kind == "skip_push":
+                T.axpby(dh, dskips.pop(), 1.0, 1.0, out=dh)
+            elif kind == "down":
+                op, hin = ctx
+                self._bias_grad(dh, op.bias)
+                T.conv_wgrad(hin, dh, 3, 2, out=self.g(op.weight))
+                dh = self._conv(T.zero_stuff2(dh), T.conv_weight_rot180t(op.weight), form=self.dgrad_form)
+            elif kind == "conv_in":
+                T.axpby(dh, dskips.pop(), 1.0, 1.0, out=dh)  # skips[0] = conv_in's output
+                ci = m.conv_in.conv
+                self._bias_grad(dh, ci.bias)
+                T.conv_wgrad(ctx, dh, 3, 1, out=self.g(ci.weight))
+        assert not dskips
+        # time embedding: es = silu(emb), emb = Linear2(silu(Linear0(e0)))
+        e0, e1, e2, emb = self._emb_ctx
+        demb = T.silu_backward(emb, self._des)
+        de2 = self._linear_bwd(e2, m.time_embed[2], demb)
+        de1 = T.silu_backward(e1, de2)
+        self._linear_bwd(e0, m.time_embed[0], de1, need_dx=False)
+        self._tape = None
+
+    def loss_and_grads(self, noisy, timesteps, target):
+        """F.mse_loss(model(noisy, timesteps), target) and every parameter gradient; returns the loss as a 1-element device tensor."""
+        pred = self.forward(noisy, timesteps)
+        loss, dpred = T.mse_loss_grad(pred, target)
+        self.backward(dpred)
+        return loss
+
+    def adam_step(self, grad_scale: float = 1.0):
+        self.step_count += 1
+        T.adam_step_(self.flat, self.gflat, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count,
+                     grad_scale)
+        self.model._synced_key = None  # updated in place by a kernel torch knows nothing about: the inference engine re-packs
+
+    # ---- torch.optim.Adam-compatible state (the checkpoint dict of base.py:166-187 carries optimizer.state_dict()) -----------
+    def state_dict(self):
+        state = {}
+        for i, p in enumerate(self.params):
+            off, n = self.offsets[id(p)]
+            if self.step_count:
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.m[off: off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.v[off: off + n].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        if not sd or not sd.get("state"):
+            return
+        steps = set()
+        for i, p in enumerate(self.params):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            off, n = self.offsets[id(p)]
+            self.m[off: off + n].copy_(st["exp_avg"].reshape(-1).to(self.m.device))
+            self.v[off: off + n].copy_(st["exp_avg_sq"].reshape(-1).to(self.v.device))
+            steps.add(int(float(st["step"])))
+        if steps:
+            self.step_count = max(steps)

@@ -105,6 +105,16 @@ def gather_scores(ids: torch.Tensor, scores: torch.Tensor, n_max: int = None):
     return out[:, 0].to(torch.int32), out[:, 1:].reshape(-1, n_t, 2), [int(c) for c in counts]
 
 
+def sub_batch(batch: dict, keep):
+    """The loader batch restricted to the items `keep` (the numeric guard re-runs only the images that overflowed)."""
+    img = batch["image"]
+    sel = torch.as_tensor(keep, dtype=torch.long)
+    image = img[sel.to(img.device)] if torch.is_tensor(img) else torch.stack([img[int(i)] for i in keep])
+    names = batch["image_meta_dict"]["filename_or_obj"]
+    return {"image": image, "index": [batch["index"][i] for i in keep],
+            "image_meta_dict": {"filename_or_obj": [names[i] for i in keep]}}
+
+
 def rows_from_scores(ids, scores, counts, t_values, name_of, batch_size: int, dataset_name: str):
     """Dense gathered scores -> the reference's row dicts, in the reference's order: rank-major
     (all_gather_object, reconstruct.py:238-242), and inside a rank per batch, per t_start, per image
@@ -339,21 +349,35 @@ class Reconstruct(BaseTrainer):
             scores, t_values, n_r, n_f, B, dt = self._score_batch(batch, pl, inference_skip_factor)
             # numeric guard (include/ddpm_ood_hip.h): a non-finite eps / reconstruction / latent set the device status word.
             # With the split-f16 kernels on, that may be an operand beyond the f16 range rather than a genuine fp32
-            # overflow: run THIS batch again on the fp32-MFMA kernels; what is still non-finite then is written as NaN,
-            # like the reference would (reconstruct.py:188-204 has no check).
+            # overflow: run the affected IMAGES again on the fp32-MFMA kernels; what is still non-finite then is written as
+            # NaN, like the reference would (reconstruct.py:188-204 has no check).
             word = _lib.status_read(clear=True)
-            if word and _lib.split_f16():
-                print(f"WARNING: {_lib.status_text(word)} in a batch of {B} on the split-f16 kernels: running the batch "
+            if word and _lib.split_f16_active():
+                # only the images that came out non-finite ride again (clamp + MSE keeps a NaN: a non-finite eps, latent or
+                # reconstruction ends as a non-finite score of ITS image; a per-image result does not depend on the batch it
+                # rides in -- noise is a function of the image index, the PLMS history is per element)
+                bad = (~torch.isfinite(scores).all(dim=2).all(dim=1)).nonzero().flatten().cpu().tolist()
+                if not bad:
+                    bad = list(range(B))
+                print(f"WARNING: {_lib.status_text(word)} in a batch of {B} on the split-f16 kernels: running {len(bad)} image(s) "
                       f"again with fp32 MFMA products (ddpm_set_split_f16(0); permanently: DDPM_WINO44_F16X3=0 "
                       f"DDPM_CONV1X1_F16X3=0 DDPM_ATTN_F16X3=0 DDPM_DOWN_S2H=0)", file=sys.__stderr__, flush=True)
+                if quantises:  # the counter must match the scores that are KEPT: a wholly discarded pass contributes nothing
+                    first_pass = _lib.vq_near_ties_read(clear=True)
+                    if len(bad) < B:  # (includes the re-run images' share of the first pass: an upper bound)
+                        guard["vq_near_ties"] += first_pass
                 prev = _lib.set_split_f16(False)
                 try:
-                    scores, t_values, n_r, n_f, B, dt2 = self._score_batch(batch, pl, inference_skip_factor)
+                    sub = sub_batch(batch, bad)
+                    scores_b, t_values, _, n_f2, _, dt2 = self._score_batch(sub, pl, inference_skip_factor)
+                    scores[torch.as_tensor(bad, device=scores.device)] = scores_b
+                    n_f += n_f2
                     dt += dt2
                     word = _lib.status_read(clear=True)
                 finally:
                     _lib.set_split_f16(prev)
                 guard["batches_rerun_fp32"] += 1
+                guard["images_rerun_fp32"] = guard.get("images_rerun_fp32", 0) + len(bad)
             if quantises:
                 guard["vq_near_ties"] += _lib.vq_near_ties_read(clear=True)
             if word:

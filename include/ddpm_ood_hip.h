@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDPM_ABI_VERSION 9
+#define DDPM_ABI_VERSION 10
 
 #define DDPM_EINVAL (-1)      /* bad argument / unsupported shape      */
 #define DDPM_ENOPARAM (-2)    /* unknown or missing parameter name     */
@@ -442,9 +442,106 @@ int ddpm_vq_near_ties_read(unsigned *count, int clear, ddpm_stream_t stream);
  * environment switches say; on = 1: back to what the environment selects (default: split-f16).  Returns the previous
  * setting.  Process-wide; not thread-safe against concurrent launches. */
 int ddpm_set_split_f16(int on);
+/* The master switch as ddpm_set_split_f16 set it (prev = get(); set(0); ...; set(prev) restores it).  */
 int ddpm_get_split_f16(void);
+/* ABI 10: 1 only when the master switch is on AND at least one split-f16 family is enabled by the environment -- "would
+ * ddpm_set_split_f16(0) change which kernels run?", the question the caller's re-run guard asks (trainer.py::get_scores).
+ * (ABI 9 answered it through ddpm_get_split_f16, which broke the get / set / restore idiom when every family was off.)  */
+int ddpm_split_f16_active(void);
 /* Parses the DDPM_* environment switches again (they are read once per process otherwise). */
 int ddpm_reload_env(void);
+
+/* ------------------------------------------------------------------------------------
+ * Training step (ABI 10).  Replaces, for the epsilon-MSE step of
+ * /root/reference/src/trainers/ddpm_trainer.py:78-109 over generative's DiffusionModelUNet with
+ * torch.optim.Adam(lr = 2.5e-5) (/root/reference/src/trainers/base.py:156), what loss.backward() and
+ * optimizer.step() dispatch to (cuDNN / cuBLAS weight and data gradients, ATen GroupNorm / SiLU / softmax backward,
+ * the foreach Adam kernels).  The forward of a step runs on ddpm_conv_f32 over materialised GroupNorm + SiLU outputs;
+ * input gradients of convolutions are ddpm_conv_f32 with ddpm_conv_weight_rot180t_f32's weights.  Everything below is
+ * deterministic (fixed-order reductions, no atomics).  ddpm_ood_amd/train_native.py drives them.
+ * ---------------------------------------------------------------------------------- */
+
+/* C[z] = alpha * A[z] B[z] + beta * C[z] on the fp32 MFMA, every operand addressed by ELEMENT strides (a transpose is a
+ * stride swap): A(z, m, k) = A[a_batch_outer z0 + a_batch z1 + a_m m + a_k_outer k0 + a_k k1] with k = k0 k_inner + k1
+ * (k_inner = 0: one level, k1 = k) and z = z0 batch_inner + z1 (batch_inner = 0: one level, z1 = z); B(z, k, n), C(z, m, n)
+ * alike.  One call covers a Linear's weight / input gradient, a 1x1 convolution's weight gradient over NCHW tensors
+ * (K = (image, pixel): k_inner = HW), and the batched Q^T K, V P^T, dO^T V, dS K, dS^T Q products of AttentionBlock on
+ * channel-major [B, C, N] tensors.  batch <= 65 535.  */
+typedef struct ddpm_gemm_desc {
+  const float *A, *B;
+  float *C;
+  int M, N, K, k_inner;
+  int64_t a_m, a_k, a_k_outer;
+  int64_t b_n, b_k, b_k_outer;
+  int64_t c_m, c_n;
+  int batch, batch_inner;
+  int64_t a_batch, a_batch_outer, b_batch, b_batch_outer, c_batch, c_batch_outer;
+  float alpha, beta;
+  /* Optional: ddpm_gemm_scratch_floats(g) floats.  A product whose (M, N, batch) grid leaves most of the chip idle while K is
+   * long (a 1x1 convolution's weight gradient) is cut into K slices, one workgroup each, whose partial sums go here and are
+   * added in slice order by a second pass (deterministic).  NULL / too small: one workgroup walks the whole K range.  */
+  float *scratch;
+  size_t scratch_floats;
+} ddpm_gemm_desc;
+size_t ddpm_gemm_scratch_floats(const ddpm_gemm_desc *g);
+int ddpm_gemm_f32(const ddpm_gemm_desc *g, ddpm_stream_t stream);
+
+/* Weight gradient of F.conv2d(a, w, stride, padding = ksize / 2): dw[Cout, Cin, k, k] (torch layout, overwritten) =
+ * sum over images and output pixels of dy[b, co, p] a[b, ci, stride p + tap - pad].  a: [B, Cin, Hi, Wi] (the convolution's
+ * input as it was multiplied: after GroupNorm / SiLU / concat / upsampling), dy: [B, Cout, Ho, Wo].  ksize 3 with
+ * Cin % 64 == 0, Cout % 64 == 0 and an even Wo <= 64 runs on the fp32 MFMA (64 couts x 64 cins x 9 taps per workgroup, the
+ * pixel stream split over workgroups into `scratch` -- ddpm_conv_wgrad_scratch_floats floats, 0 = no such tiling -- and
+ * reduced in a fixed order); anything else (ksize 1; the 1- / 3-channel first and last convolutions) one workgroup per
+ * (cout, cin) pair.  force_generic != 0: always the latter (tests).  */
+size_t ddpm_conv_wgrad_scratch_floats(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ksize, int stride);
+int ddpm_conv_wgrad_f32(const float *a, const float *dy, float *dw, int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo,
+                        int ksize, int stride, float *scratch, size_t scratch_floats, int force_generic, ddpm_stream_t stream);
+/* wt[Cin, Cout, k, k] = w[Cout, Cin, k, k] rotated by 180 degrees and transposed: conv(dy, wt, padding = k / 2) is the input
+ * gradient of a stride-1 convolution (of a stride-2 one after ddpm_resample2_f32(mode 2) of dy).  */
+int ddpm_conv_weight_rot180t_f32(const float *w, float *wt, int Cout, int Cin, int ksize, ddpm_stream_t stream);
+
+/* F.group_norm in its training form.  mean_rstd: [B, groups, 2] = {mean, 1 / sqrt(var + eps)} (biased variance), kept for the
+ * backward; ddpm_gn_apply_f32: y = act((x - mean) rstd gamma + beta), act = DDPM_ACT_NONE or DDPM_ACT_SILU;
+ * ddpm_gn_backward_f32: dx (+= if accumulate_dx) the gradient of that through act and the normalisation, dgamma / dbeta [C]
+ * overwritten; ws: B * C * 2 floats of scratch.  x, y, dy, dx: [B, C, HW].  */
+int ddpm_gn_stats_f32(const float *x, float *mean_rstd, int B, int C, int HW, int groups, float eps, ddpm_stream_t stream);
+int ddpm_gn_apply_f32(const float *x, const float *mean_rstd, const float *gamma, const float *beta, float *y, int B, int C, int HW,
+                      int groups, int act, ddpm_stream_t stream);
+int ddpm_gn_backward_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta, float *dx,
+                         int accumulate_dx, float *dgamma, float *dbeta, float *ws, int B, int C, int HW, int groups, int act,
+                         ddpm_stream_t stream);
+
+/* out[r] = sum of row r of a [rows, cols] matrix (bias gradients: rows = (image, channel) planes);
+ * out[c] (+= if accumulate) alpha * sum over rows of in[r * row_stride + c], rows in order.  */
+int ddpm_row_sum_f32(const float *in, float *out, int64_t rows, int cols, ddpm_stream_t stream);
+int ddpm_col_sum_f32(const float *in, float *out, int rows, int cols, int64_t row_stride, float alpha, int accumulate,
+                     ddpm_stream_t stream);
+int ddpm_silu_f32(const float *x, float *y, int64_t n, ddpm_stream_t stream);
+int ddpm_silu_backward_f32(const float *x, const float *dy, float *dx, int64_t n, ddpm_stream_t stream);
+/* out = alpha a + beta b (b may be NULL; out may alias a or b)  */
+int ddpm_axpby_f32(const float *a, const float *b, float *out, float alpha, float beta, int64_t n, ddpm_stream_t stream);
+/* dst[b, cdst0 + c, :] (+= if accumulate) src[b, csrc0 + c, :], c < C: torch.cat in the forward, its split in the backward  */
+int ddpm_chan_copy_f32(const float *src, float *dst, int B, int C, int Csrc, int csrc0, int Cdst, int cdst0, int HW, int accumulate,
+                       ddpm_stream_t stream);
+/* planes of H x W (the SMALL extent) <-> 2H x 2W.  mode 0: nearest x2 (F.interpolate of generative's Upsample); 1: its adjoint,
+ * out[y, x] = sum of in's 2x2 block; 2: zero-stuffing, out[2y, 2x] = in[y, x], 0 elsewhere (a stride-2 convolution's dy).  */
+int ddpm_resample2_f32(const float *in, float *out, int64_t planes, int H, int W, int mode, ddpm_stream_t stream);
+/* softmax over each row in place; its backward ds = p (dp - sum(dp p)) in place over dp  */
+int ddpm_softmax_rows_f32(float *s_inout, int64_t rows, int cols, ddpm_stream_t stream);
+int ddpm_softmax_backward_rows_f32(const float *p, float *dp_inout, int64_t rows, int cols, ddpm_stream_t stream);
+/* F.mse_loss(pred, target): dpred = grad_scale (pred - target) (grad_scale = 2 / n), partial[i] = sum of (pred - target)^2
+ * over elements [256 i, 256 i + 256): the caller sums ceil(n / 256) partials (ddpm_col_sum_f32) and divides by n.  */
+int ddpm_mse_loss_grad_f32(const float *pred, const float *target, float *dpred, float *partial, int64_t n, float grad_scale,
+                           ddpm_stream_t stream);
+int ddpm_fill_f32(float *out, float value, int64_t n, ddpm_stream_t stream);
+/* torch.randn for the training noise (ddpm_trainer.py:81): standard normals from Philox-4x32-10 + Box-Muller, a pure function
+ * of (seed, stream_id, element index).  Not torch's generator stream -- the noise of a training step only has to be
+ * reproducible.  */
+int ddpm_randn_f32(float *out, int64_t n, uint64_t seed, uint64_t stream_id, ddpm_stream_t stream);
+/* torch.optim.Adam.step (no weight decay, no amsgrad) over one flat buffer; step = 1, 2, ...; g is multiplied by grad_scale first
+ * (1 / world size after a sum all-reduce).  */
+int ddpm_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
+                       int step, float grad_scale, ddpm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -43,10 +43,14 @@ def test_struct_layouts_match_header(lib):
     # field order of the C structs (pointers 8 B, ints 4 B): sizes computed by hand from the header
     assert C.sizeof(ConvDesc) == 8 + 8 + 4 + 4 + 8 * 5 + 8 + 8 + 8 + 8 + 4 * 10 + 4 * 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # incl. padding after stride; + scratch, scratch_floats, w_wino44, w_wino44h, stats_out, w_d3h
     assert C.sizeof(UNetConfig) == 4 * 4 + 4 * 8 * 4 + 4 + 4 + 4
+    from ddpm_ood_amd._lib import GemmDesc
+
+    assert C.sizeof(GemmDesc) == 3 * 8 + 4 * 4 + 8 * 8 + 2 * 4 + 6 * 8 + 2 * 4 + 8 + 8  # ddpm_gemm_desc (ABI 10)
+    assert GemmDesc.a_m.offset == 40 and GemmDesc.batch.offset == 104 and GemmDesc.alpha.offset == 160
 
 
 def test_host_only_entry_points(lib):
-    assert lib.ddpm_abi_version() == 9
+    assert lib.ddpm_abi_version() == 10
     assert lib.ddpm_set_split_f16(0) == 1 and lib.ddpm_get_split_f16() == 0 and lib.ddpm_set_split_f16(1) == 0
     assert lib.ddpm_reload_env() == 0 and lib.ddpm_get_split_f16() == 1  # a reload keeps the run-time switch
     assert lib.ddpm_packed_conv_weight_floats(128, 128, 3) == 128 * 128 * 9

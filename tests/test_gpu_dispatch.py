@@ -183,7 +183,7 @@ def _cfg4_rec(tmp_path, spec):
 
     sets = spec["sets"]
     args = make_args(tmp_path, model_type="big", is_grayscale=0, inference_skip_factor=spec["skip"], batch_size=spec["batch"],
-                     validation_ids=sets.get("val"), in_ids=sets["in"])
+                     validation_ids=sets.get("val", sets["in"]), in_ids=sets["in"])
     write_checkpoint(tmp_path, args, synthetic.random_state_dict("big", 3, seed=1))
     rec = Reconstruct(args)
     rec.quiet = True

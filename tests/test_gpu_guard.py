@@ -169,7 +169,7 @@ def test_trainer_reruns_an_overflowing_batch_on_fp32_products(device, tmp_path, 
     h = hip_scores(args, rec, ids, "in")
     err = capfd.readouterr().err
     assert rec.last_stats["batches_rerun_fp32"] == 1 and rec.last_stats["batches_nonfinite"] == 0, rec.last_stats
-    assert "running the batch again with fp32 MFMA products" in err
+    assert "running 3 image(s) again with fp32 MFMA products" in err and rec.last_stats["images_rerun_fp32"] == 3
     assert _lib.split_f16() is True and _lib.status_read() == 0
     assert_rows_close(h, o, 1e-3, "guarded")  # (fp32 on a 3e4-scale stream: absolute rounding is 3e4 x the usual)
     # the small-launch kernels take the same stream without a second pass (raw inputs are split at 2^0: range 65 504)

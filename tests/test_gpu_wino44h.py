@@ -284,14 +284,32 @@ def test_conv3d_wino44h_stream_across_items_is_bit_identical(device, monkeypatch
     assert (y1 - ref).abs().max().item() < 2e-4 * (1 + ref.abs().max().item())
 
 
-# ---- the register-fed form (conv_wino44r.hip, round 5) against the LDS-fed form (conv_wino44h.hip) -------------------------
+# ---- every item shape of the kernel, pinned bit for bit ------------------------------------------------------------------------
+# Until round 6 conv_wino44r.hip was held, output bit for output bit, to its LDS-fed predecessor (conv_wino44h_kernel, retired in
+# round 6) over these 72 + 6 cases.  The predecessor's place is taken by digests of those very outputs, written from the
+# unchanged kernel source that round 5's suite (and profiles/r06_w44r_ir_route_sets3_bit_identity.log, this round) had held
+# to it (tests/golden/wino44h_digests.json, tools/r06/make_w44_digests.py): a refactor of the kernel
+# that changes one rounding anywhere shows up here, on every item shape (one image per item, two, eight; concat; residual; no
+# prologue; several items per workgroup; channel-split launches; the 3-D and the Upsample form).
 
-@pytest.mark.parametrize("case", CASES + XITEM_CASES + SPLIT_CASES)
-def test_register_fed_form_is_bit_identical_to_the_lds_fed_form(device, case, monkeypatch):
-    """conv_wino44r.hip (DDPM_W44H_REG=1, the default since round 5: U operands from global memory into a register ring, one
-    barrier per 8-channel chunk, V tasks as whole segments) runs the same arithmetic in the same order as conv_wino44h.hip
-    (DDPM_W44H_REG=0): same output and same GroupNorm statistics, bit for bit, on every item shape (one image per item, two, eight;
-    concat; residual; no prologue; several items per workgroup; channel-split launches)."""
+def _digest(*tensors):
+    import hashlib
+
+    h = hashlib.sha256()
+    for t in tensors:
+        if t is not None:
+            h.update(t.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()[:24]
+
+
+def _digests():
+    import json
+    from pathlib import Path
+
+    return json.load(open(Path(__file__).resolve().parent / "golden" / "wino44h_digests.json"))
+
+
+def _run_pinned_2d(device, case, monkeypatch):
     from ddpm_ood_amd import ops
 
     t = _inputs(case)
@@ -303,55 +321,52 @@ def test_register_fed_form_is_bit_identical_to_the_lds_fed_form(device, case, mo
     else:
         monkeypatch.setenv("DDPM_CONV_WINO44", "2")
     kw = dict(wino=ops.pack_wino_weight(w)) if split else {}
-    monkeypatch.setenv("DDPM_W44H_REG", "1")
     y1, st1 = _run(device, case, t, wino44h=wh, want_stats=True, **kw)
     y1b = _run(device, case, t, wino44h=wh, **kw)
-    monkeypatch.setenv("DDPM_W44H_REG", "0")
-    y0, st0 = _run(device, case, t, wino44h=wh, want_stats=True, **kw)
     torch.cuda.synchronize()
-    bad = (y1 != y0)
-    assert not bool(bad.any()), (int(bad.sum()), (y1 - y0).abs().max().item(), bad.nonzero()[:8].tolist())
-    assert torch.equal(y1, y1b)
-    assert (st1 is None) == (st0 is None) and (st1 is None or torch.equal(st1, st0))
+    return t, y1, st1, y1b
+
+
+@pytest.mark.parametrize("case", CASES + XITEM_CASES + SPLIT_CASES)
+def test_every_item_shape_is_pinned_bit_for_bit(device, case, monkeypatch):
+    t, y1, st1, y1b = _run_pinned_2d(device, case, monkeypatch)
+    assert torch.equal(y1, y1b)  # with and without statistics: the same output
     B, C1, C2, Cout, H, gn, chan, res = case
     x, x2, wt, b, gamma, beta, chan_add, residual = t
     ref = _ref_conv(x, x2, wt, b, (gamma, beta) if gn else None, chan_add[:, 32:32 + Cout] if chan else None, residual)
     assert (y1.cpu() - ref).abs().max().item() < 2e-4 * (1 + ref.abs().max().item())
+    assert _digest(y1, st1) == _digests()["2d"][repr(tuple(case))], "the kernel's rounding changed (see the comment above)"
 
 
-@pytest.mark.parametrize("case", CASES_3D)
-def test_register_fed_form_3d_and_upsample_bit_identical(device, case, monkeypatch):
-    """The 3-D form (depth taps in the chunk stream) and the Upsample form (nearest x2 read on the fly) of the same pair."""
+def _run_pinned_3d(device, case, monkeypatch):
     monkeypatch.setenv("DDPM_CONV_WINO44", "2")
     from ddpm_ood_amd import ops
 
     B, C, Cout, D, H, res = case
-    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    g = torch.Generator().manual_seed(sum(case) * 7 + 1)
     x = torch.randn(B, C, D, H, H, generator=g).to(device)
     w = (torch.randn(Cout, C, 3, 3, 3, generator=g) / math.sqrt(27 * C)).to(device)
     b = torch.randn(Cout, generator=g).to(device)
     r = torch.randn(B, Cout, D, H, H, generator=g).to(device) if res else None
     kw = dict(residual=r, out_act=ops.ACT_RELU if res else ops.ACT_NONE)
-    wh = ops.pack_wino44h_3d_weight(w)
-    monkeypatch.setenv("DDPM_W44H_REG", "1")
-    y1 = ops.conv3d(x, w, b, wino44h=wh, **kw)
-    monkeypatch.setenv("DDPM_W44H_REG", "0")
-    y0 = ops.conv3d(x, w, b, wino44h=wh, **kw)
-    torch.cuda.synchronize()
-    assert torch.equal(y1, y0), (y1 - y0).abs().max().item()
-    # Upsample form: 2-D, the same channel counts, low-res H / 2 -> H
-    x2d = torch.randn(max(B, 2) * 9, C, H // 2, H // 2, generator=g).to(device)
-    w2 = (torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C)).to(device)
-    if H <= 32:
-        wh2 = ops.pack_wino44h_weight(w2)
-        monkeypatch.setenv("DDPM_W44H_REG", "1")
-        u1 = ops.conv(x2d, w2, b, mode=ops.CONV_UPSAMPLE2, wino44h=wh2)
-        monkeypatch.setenv("DDPM_W44H_REG", "0")
-        u0 = ops.conv(x2d, w2, b, mode=ops.CONV_UPSAMPLE2, wino44h=wh2)
-        torch.cuda.synchronize()
-        assert torch.equal(u1, u0), (u1 - u0).abs().max().item()
+    y1 = ops.conv3d(x, w, b, wino44h=ops.pack_wino44h_3d_weight(w), **kw)
+    u1 = ref = None
+    if H <= 32:  # Upsample form: 2-D, the same channel counts, low-res H / 2 -> H
+        x2d = torch.randn(max(B, 2) * 9, C, H // 2, H // 2, generator=g).to(device)
+        w2 = (torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C)).to(device)
+        u1 = ops.conv(x2d, w2, b, mode=ops.CONV_UPSAMPLE2, wino44h=ops.pack_wino44h_weight(w2))
         ref = F.conv2d(F.interpolate(x2d, scale_factor=2.0, mode="nearest"), w2, b, padding=1)
+    torch.cuda.synchronize()
+    return y1, u1, ref
+
+
+@pytest.mark.parametrize("case", CASES_3D)
+def test_3d_and_upsample_forms_are_pinned_bit_for_bit(device, case, monkeypatch):
+    """The 3-D form (depth taps in the chunk stream) and the Upsample form (nearest x2 read on the fly)."""
+    y1, u1, ref = _run_pinned_3d(device, case, monkeypatch)
+    if u1 is not None:
         assert (u1 - ref).abs().max().item() < 2e-4 * (1 + ref.abs().max().item())
+    assert _digest(y1, u1) == _digests()["3d"][repr(tuple(case))]
 
 
 # ---- GroupNorm statistics from the epilogue (ddpm_conv_desc.stats_out, ABI 7) ------------------------------------------

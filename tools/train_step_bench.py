@@ -1,0 +1,73 @@
+"""Training-step throughput of the `small` UNet on one MI355X: the native step (train_native.NativeUNetStep -- hand-written HIP forward /
+backward / Adam) beside the ATen route (PyTorch-ROCm autograd over MIOpen / rocBLAS, DDPM_TRAIN_NATIVE=0), same weights, same batch.
+    python tools/train_step_bench.py [batch] [steps] [native|aten|both]
+Row f-3 (/root/reference/src/trainers/ddpm_trainer.py:78-109, base.py:156).  `rocprofv3 --kernel-trace --stats -- python
+tools/train_step_bench.py 64 5 native` is the profile committed as profiles/r06_train_native_kernel_trace_stats.csv."""
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch  # noqa: E402
+
+from ddpm_ood_amd import DiffusionModelUNet  # noqa: E402
+from ddpm_ood_amd import train_ops as T  # noqa: E402
+from ddpm_ood_amd.synthetic import random_state_dict  # noqa: E402
+from ddpm_ood_amd.train import unet_forward_torch  # noqa: E402
+from ddpm_ood_amd.train_native import NativeUNetStep  # noqa: E402
+from ddpm_ood_amd.trainer import MODEL_CONFIGS  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+which = sys.argv[3] if len(sys.argv) > 3 else "both"
+dev = torch.device("cuda:0")
+sd = random_state_dict("small", 1, seed=1)
+x = torch.rand(B, 1, 32, 32, device=dev)
+t = torch.randint(0, 1000, (B,)).to(dev)
+
+
+def model():
+    m = DiffusionModelUNet(2, 1, 1, **MODEL_CONFIGS["small"])
+    m.load_state_dict(sd)
+    return m.to(dev).train()
+
+
+def timed(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+if which in ("native", "both"):
+    with torch.no_grad():
+        st = NativeUNetStep(model())
+        k = [0]
+
+        def native_step():
+            k[0] += 1
+            noise = T.randn((B, 1, 32, 32), dev, 1, k[0])
+            st.loss_and_grads(x, t, noise)
+            st.adam_step()
+
+        dt = timed(native_step)
+    print(f"native: batch {B}: {dt * 1e3:.2f} ms per step = {B / dt:.0f} images/s")
+if which in ("aten", "both"):
+    m = model()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    opt = torch.optim.Adam(m.parameters(), lr=2.5e-5)
+
+    def aten_step():
+        noise = torch.randn(B, 1, 32, 32, device=dev)
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(unet_forward_torch(m, x, t), noise)
+        loss.backward()
+        opt.step()
+
+    dt = timed(aten_step)
+    print(f"aten:   batch {B}: {dt * 1e3:.2f} ms per step = {B / dt:.0f} images/s")
