@@ -53,12 +53,8 @@ __device__ __forceinline__ void v_store_row_addtid(int m0base, const uint32_t (&
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 1" ::"s"(m0base));  // (SALU write of M0 -> add-TID LDS instruction: one wait state)
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
-#ifdef W44R_NO_VSTORE  // (timing experiment)
-    asm volatile("" ::"v"(hi6[q]), "v"(lo6[q]));
-#else
     asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(hi6[q]), "n"((2 * (O + q)) * (kT * 16)) : "memory");
     asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(lo6[q]), "n"((2 * (O + q) + 1) * (kT * 16)) : "memory");
-#endif
   }
 }
 
@@ -75,12 +71,8 @@ template <int O>
 __device__ __forceinline__ void v_store_row(int vwa, const uint32_t (&hi6)[6], const uint32_t (&lo6)[6]) {
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
-#ifdef W44R_NO_VSTORE  // (timing experiment)
-    asm volatile("" ::"v"(vwa), "v"(hi6[q]), "v"(lo6[q]));
-#else
     asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(hi6[q]), "n"((2 * (O + q)) * (kT * 16)) : "memory");
     asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vwa), "v"(lo6[q]), "n"((2 * (O + q) + 1) * (kT * 16)) : "memory");
-#endif
   }
 }
 
@@ -228,12 +220,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       // rows 4, 2, 1 and: pair (0, 5) rows 0, 5, 3; pairs (1, 2), (3, 4) row 3 -- those pairs use rows 2 and 1 twice (same
       // operation order as conv_wino44h.hip's cstep, which re-reads them: bit-identical)
       auto row = [&](int r, float (&dst)[6]) __attribute__((always_inline)) {
-#ifdef W44R_NO_PREAD  // (timing experiment: the patch rows come from nowhere)
-        float fk;
-        asm volatile("v_mov_b32 %0, 1.0" : "=v"(fk));
-#pragma unroll
-        for (int q = 0; q < 6; ++q) dst[q] = fk;
-#else
         if (NEWLAY) {  // 16-byte aligned (w44r_relayout): columns 0-3 conflict-free by ds_read_b128, columns 4-5 by ds_read_b64
           // (as a second b128 with two dead floats hipcc overlapped the destination registers of consecutive rows and put a
           // full lgkmcnt(0) between them: eight exposed LDS latencies per task)
@@ -244,7 +230,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
 #pragma unroll
           for (int q = 0; q < 6; ++q) dst[q] = p[r * g.PW + q];
         }
-#endif
       };
 #ifdef W44R_VREADS_UPFRONT
       if (!t0 && NEWLAY) {
@@ -292,13 +277,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     else v_store_row<6>(vwa, hi6, lo6);
   };
   auto produce_task = [&](int cc) __attribute__((always_inline)) {
-#ifndef W44R_NO_PROD
     if (ptask < 0) return;
     const int t = ptask >> 1;
     if (t == 0) produce(I0{}, cc);
     else if (t == 1) produce(I1{}, cc);
     else produce(I2{}, cc);
-#endif
   };
 
   // ================================================================================================ pixel staging
@@ -404,38 +387,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   };
   auto load_round = [&](const LoadCtx &L, auto setc, int k) __attribute__((always_inline)) {
     constexpr int S = decltype(setc)::value;
-#ifndef W44R_NO_PIXEL
     const int ni = min(L.n_it + (ONEIMG ? 0 : k / GDR), g.NIMG - 1);
     const int soff = D3 ? L.soff3 : (ni * L.cx + L.cgl) * (UP ? g.HWin : g.HW) * 4;
-#ifdef W44R_PIX_HITLOAD  // (timing experiment: the same load instructions, always the same 256 bytes -- an L1 / L2 hit)
-    const int voff = (lane & 63) * 4;
-    (void)soff;
-#define soff 0
-#else
     const int voff = D3 && !L.dok ? (int)0x80000000 : pix_of(k);
-#endif
-#ifdef W44R_PIX_NOLOAD  // (timing experiment)
-    (void)voff; (void)soff;
-    {
-      float one;
-      asm volatile("v_mov_b32 %0, 1.0" : "=v"(one));
-      if constexpr (QUAD) praw[S][k] = v4f{one, one, one, one};
-      else praw[S][k] = one;
-    }
-#else
     if constexpr (QUAD)
       praw[S][k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(L.rs, voff, soff, 0));
     else
       praw[S][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(L.rs, voff, soff, 0));
-#endif
-#ifdef W44R_PIX_HITLOAD
-#undef soff
-#endif
-#endif
   };
   auto load_affine = [&](const LoadCtx &L, auto setc, int i) __attribute__((always_inline)) {
     constexpr int S = decltype(setc)::value;
-#ifndef W44R_NO_PIXEL
     if (AFFINE) {
       const int nb = min(L.n_it + i, g.NIMG - 1);
       const int goff = (nb * g.Cin + L.cga) * 4;
@@ -444,7 +405,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       gs[S][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, voff, goff, 0));
       gh[S][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, voff, goff, 0));
     }
-#endif
   };
   auto load_stage = [&](auto setc, int cc, int n_cur, bool has_next) __attribute__((always_inline)) {
     const LoadCtx L = load_prep(cc, n_cur, has_next);
@@ -456,7 +416,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
   // pixel value x 2^3 (2^0 without prologue): the transform's output is the pre-scaled V
   auto activate_round = [&](auto setc, int cc, int k) __attribute__((always_inline)) {
     constexpr int S = decltype(setc)::value;
-#ifndef W44R_NO_PIXEL
     float *const Pr = P + (2 * (cc & 1) + phalf) * g.HS + pw_of(k);
     float sa = 0.f, sb = 0.f, ta = 0.f, tb = 0.f;
     if (AFFINE) {
@@ -471,9 +430,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       tb = -1.44269504088896341f * sb;
     }
     auto act = [&](float x) __attribute__((always_inline)) {
-#ifdef W44R_PIX_NOMATH  // (timing experiment)
-      return x;
-#endif
       if (AFFINE) {
         const float v = __builtin_fmaf(x, sa, sb);
         const float t = __builtin_fmaf(x, ta, tb);
@@ -481,17 +437,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       }
       return kVScaleRaw * (silu ? silu_fast(x) : x);
     };
-#ifdef W44R_PIX_NOSTORE  // (timing experiment)
-    if constexpr (QUAD) {
-      const v4f x = praw[S][k];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { float y = act(x[i]); asm volatile("" ::"v"(y)); }
-    } else {
-      float y = act(praw[S][k]);
-      asm volatile("" ::"v"(y));
-    }
-    (void)Pr;
-#else
     if constexpr (QUAD) {
       const v4f x = praw[S][k];
 #pragma unroll
@@ -499,8 +444,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     } else {
       Pr[0] = act(praw[S][k]);
     }
-#endif
-#endif
   };
   auto activate_stage = [&](auto setc, int cc) __attribute__((always_inline)) {
     asm volatile("" : "+v"(pix0), "+v"(pw0), "+v"(pixL), "+v"(pwL));
@@ -527,11 +470,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     constexpr int PAR = decltype(parc)::value;
     asm volatile("" : "+v"(ua), "+v"(va));
     const int vb = va + (cl & 1) * kVCB;
-#ifdef W44R_NO_ALOAD
-#define W44R_LOAD_A(ri, cl_, jj_) asm volatile("" : "+v"(Ar[ri]))
-#else
-#define W44R_LOAD_A(ri, cl_, jj_) Ar[ri] = load_a(cl_, jj_)
-#endif
     h8 Bh[2], Bl[2];
 #ifndef W44R_BVIS
 #define W44R_BVIS 0  // (1: measured equal, 4 808 vs 4 810 us over the six layers; the hand-counted form is the one the full suite validated)
@@ -555,7 +493,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
         __builtin_amdgcn_sched_barrier(0);
       }
       const int ri = (PAR * 9 + jj) % kAR;  // ring index of this job's A
-#ifndef W44R_NO_MFMA
 #if W44R_BVIS
       if (jj == 8) {  // the ninth tile (arch VGPRs): both MFMAs and their completion in one statement
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\tv_mfma_f32_32x32x16_f16 %0, %1, %3, %0\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7"
@@ -580,16 +517,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
         mfma_pin(jj, Ar[ri], Bl[jj & 1]);
       }
 #endif
-#endif
       __builtin_amdgcn_sched_barrier(0);
       // the A operand six jobs ahead (this ring register is free: the MFMAs above have read it)
-      W44R_LOAD_A(ri, jj + kAR < 9 ? cl : cl + 1, (jj + kAR) % 9);
+      Ar[ri] = load_a(jj + kAR < 9 ? cl : cl + 1, (jj + kAR) % 9);
       if (jj == 8) slice(jj, 0);
       slice(jj, 1);
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef W44R_BREAD
-#undef W44R_LOAD_A
   };
 
   // static priority for the second-dispatched half of the workgroup: at equal priority the older wave of a SIMD wins every VALU
@@ -921,7 +856,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
-#ifndef W44R_NO_EPI  // (timing experiment: no output transform / stores -- wrong results)
     W44R_FSTAMP(9)
     pass(I0{});
     W44R_FSTAMP(10)
@@ -931,7 +865,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino44r_kernel(const ddpm_conv_de
     W44R_FSTAMP(12)
     pass(std::integral_constant<int, 3>{});
     W44R_FSTAMP(13)
-#endif
     __builtin_amdgcn_sched_barrier(0);
   }
 }

@@ -112,6 +112,9 @@ struct ddpm_unet {
   hipStream_t gstream = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   void drop_graphs() {
+    // a replay may still be in flight on the private stream (the API does not ask the caller to synchronise before flipping a
+    // switch or rebinding parameters): an executing graph must not be destroyed under it
+    if (gstream && !graphs.empty()) (void)hipStreamSynchronize(gstream);
     for (auto &kv : graphs) {
       if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
       if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);

@@ -45,35 +45,39 @@ def count_model_evaluations(t_values, num_inference_steps: int = 100) -> int:
     return int(sum((ts <= t).sum() for t in t_values))
 
 
-def score(results_df_val: pd.DataFrame, results_df_in: pd.DataFrame, results_df_out: pd.DataFrame,
-          max_t: int = 1000, min_t: int = 0, plot_target: str = "mse"):
-    results_df_val = results_df_val.drop_duplicates(subset=["filename", "t"], keep="first")
-    t_values = results_df_val["t"].unique()
-    t_values = t_values[(t_values < max_t)]
-    t_values = t_values[(min_t < t_values)]
-    results_df_val = results_df_val[results_df_val["t"].isin(t_values)]
-    t_values = results_df_val["t"].unique()
-    results_df_in = results_df_in.drop_duplicates(subset=["filename", "t"], keep="first")
-    results_df_out = results_df_out.drop_duplicates(subset=["filename", "t"], keep="first")
-    results_df_in = results_df_in[results_df_in["t"].isin(t_values)]
-    results_df_out = results_df_out[results_df_out["t"].isin(t_values)]
-    results_df = pd.concat((results_df_in, results_df_out))
-    for target in ["perceptual_difference", "mse"]:
-        agg = (results_df_val.groupby(["t"]).agg({target: ["mean", "std"]})[target].reset_index()
-               .rename({"mean": f"val_mean_{target}", "std": f"val_std_{target}"}, axis=1))
-        results_df = results_df.merge(agg, on=["t"], how="left")
-        results_df[f"z_score_{target}"] = (results_df[target] - results_df[f"val_mean_{target}"]) / \
-            results_df[f"val_std_{target}"]
+TARGETS = ("perceptual_difference", "mse")
+
+
+def _rows(df: pd.DataFrame, keep_t=None) -> pd.DataFrame:
+    """One row per (image, t-start) -- a padded DDP shard repeats images, the first copy counts -- inside the t window."""
+    rows = df[~df.duplicated(subset=["filename", "t"])]
+    return rows if keep_t is None else rows[rows["t"].isin(keep_t)]
+
+
+def score(val: pd.DataFrame, ind: pd.DataFrame, ood: pd.DataFrame, max_t: int = 1000, min_t: int = 0, plot_target: str = "mse"):
+    """Z-scores and AUROC of one in- / out-of-distribution pair of result tables against the validation table
+    (what /root/reference/ood_detection.py:141-206 computes per out-dataset).
+
+    For every t-start inside the open window (min_t, max_t): the validation set's mean and sample standard deviation of each
+    similarity column; every in / out row gets z = (x - mean_t) / std_t; an image's score is the mean of its z over the
+    t-starts; AUROC with in = 0, out = 1.  Returns (rows with `val_mean_*`, `val_std_*`, `z_score_*` columns,
+    per-image means, AUROC).  NaN rows (a genuine overflow, written as the reference would) are skipped by the per-t
+    statistics and by an image's mean; an image with no finite row makes roc_auc_score raise, as it does for the reference."""
+    val_rows = _rows(val)
+    window = val_rows["t"][(val_rows["t"] > min_t) & (val_rows["t"] < max_t)].unique()
+    stats = val_rows[val_rows["t"].isin(window)].groupby("t")[list(TARGETS)].agg(["mean", "std"])  # NaN-skipping, ddof = 1
+    table = pd.concat((_rows(ind, window), _rows(ood, window)), ignore_index=True)
+    for col in TARGETS:
+        mu, sigma = table["t"].map(stats[(col, "mean")]), table["t"].map(stats[(col, "std")])
+        table[f"val_mean_{col}"], table[f"val_std_{col}"] = mu.to_numpy(), sigma.to_numpy()
+        table[f"z_score_{col}"] = ((table[col] - mu) / sigma).to_numpy()
     if plot_target == "mse+perceptual":
-        results_df["z_score_mse+perceptual"] = results_df["z_score_mse"] + results_df["z_score_perceptual_difference"]
-    target = f"z_score_{plot_target}"
-    results_df_mean = results_df.groupby(["filename", "type"]).mean().reset_index()
-    all_scores = results_df_mean.loc[results_df_mean["type"] == "in"][[target]].values.tolist()
-    all_class = [0] * len(all_scores)
-    out_scores = results_df_mean.loc[results_df_mean["type"] == "out"][[target]].values.tolist()
-    all_scores.extend(out_scores)
-    all_class.extend([1] * len(out_scores))
-    return results_df, results_df_mean, roc_auc_score(all_class, all_scores)
+        table["z_score_mse+perceptual"] = table["z_score_mse"] + table["z_score_perceptual_difference"]
+    per_image = table.groupby(["filename", "type"]).mean(numeric_only=True).reset_index()
+    z = per_image[f"z_score_{plot_target}"].to_numpy()
+    is_ood = (per_image["type"] == "out").to_numpy()
+    known = is_ood | (per_image["type"] == "in").to_numpy()
+    return table, per_image, roc_auc_score(is_ood[known].astype(int), z[known])
 
 
 def main(args, out_data=None):
