@@ -186,7 +186,7 @@ def cpu_baseline():
 MFMA_KERNELS = [
     # split-f16 F(4x4): 36 of 144 multiplies, each as FOUR exact f16 partial products (two K = 16 MFMAs per 8 channels) ->
     # executed f16 MFMA FLOPs = 4 x 36 / 144 = 1.0 x the direct convolution's, priced against the dense f16 peak
-    ("conv3x3_wino44h", "conv_wino44r_kernel (register-fed form of conv_wino44h_kernel; DDPM_W44H_REG=0 selects the LDS-fed one): 3x3 conv "
+    ("conv3x3_wino44h", "conv_wino44r_kernel (conv_wino44r.hip; host side conv_wino44h.hip): 3x3 conv "
                         "as Winograd F(4x4,3x3), position GEMMs on v_mfma_f32_32x32x16_f16 with split-f16 operands (hi + lo, four exact "
                         "partial products per fp32 product, fp32 accumulate), fp32 transforms, GN+SiLU prologue, persistent",
      ("f16", 4.0 * 36.0 / 144.0)),
