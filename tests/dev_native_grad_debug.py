@@ -1,8 +1,9 @@
-"""Development: per-parameter gradient error of the native training step against CPU float64 autograd over the oracle UNet."""
+"""Development (not collected by pytest; lives under tests/ because it runs the CPU oracle, which only tests may import):
+per-parameter gradient error of the native training step against CPU float64 autograd over the oracle UNet."""
 import sys
 from pathlib import Path
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch  # noqa: E402
 
 import oracle  # noqa: E402

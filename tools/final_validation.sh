@@ -23,7 +23,7 @@ python tools/wino_ab.py 1024 2>&1 | grep -v amdgpu.ids >> gpurun_out/wino_ab_fin
 DDPM_WINO44_F16X3=0 python tools/wino_ab.py 1024 2>&1 | grep -v amdgpu.ids >> gpurun_out/wino_ab_final.log
 python tools/vqvae_bench.py 2 2>&1 | grep -v amdgpu.ids > gpurun_out/vqvae_bench_final.log
 python tools/attn_ab.py 2>&1 | grep -v amdgpu.ids > gpurun_out/attn_ab_final.log
-python tools/parity_report.py --n 64 --skip 500 2>&1 | grep -v amdgpu.ids | tail -12 > gpurun_out/parity_report_final.log
+python tests/parity_report.py --n 64 --skip 500 2>&1 | grep -v amdgpu.ids | tail -12 > gpurun_out/parity_report_final.log
 for c in 1 2 3 4 5; do python -c "
 import json; d=json.load(open('gpurun_out/bench_cfg$c.json')); print('cfg$c', d['value'], d.get('value_batch256'), d['roofline']['profile_key'], d['roofline']['frac'])"; done
 tail -3 gpurun_out/gpu_tests_final.log; tail -4 gpurun_out/parity_report_final.log

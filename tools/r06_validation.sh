@@ -33,7 +33,7 @@ python tools/microbench.py --batch 256 2>&1 | grep -v amdgpu.ids > $o/microbench
 python tools/microbench.py --batch 128 2>&1 | grep -v amdgpu.ids > $o/microbench_small_b128.log
 python tools/vqvae_bench.py 2 2>&1 | grep -v amdgpu.ids > $o/vqvae_bench_final.log
 python tools/conv1x1_ab.py --batch 1024 2>&1 | grep -v amdgpu.ids > $o/conv1x1_ab_final.log
-python tools/parity_report.py --n 64 --skip 500 2>&1 | grep -v amdgpu.ids | tail -12 > $o/parity_report_final.log
+python tests/parity_report.py --n 64 --skip 500 2>&1 | grep -v amdgpu.ids | tail -12 > $o/parity_report_final.log
 for c in 1 2 3 4 5; do python -c "
 import json; d=json.load(open('$o/bench_cfg$c.json')); print('cfg$c', d['value'], d.get('value_batch256'), d.get('value_fp32_products'), d['roofline']['profile_key'], d['roofline']['frac'])"; done
 tail -3 $o/gpu_tests_final.log; tail -4 $o/parity_report_final.log; cat $o/train_step_native_vs_aten.log
