@@ -137,9 +137,10 @@ def shard_sizes(scaling: str, world: int, batch: int, images: int):
 
 def cpu_baseline_worker():
     """Runs in a fresh subprocess (own OpenMP pool): the oracle on the host cores.
-    Sample: 8 images x t in {10, 490, 970} (inference_skip_factor=48) = 24 reconstructions,
+    Sample: 16 images x t in {10, 490, 970} (inference_skip_factor=48) = 48 reconstructions,
     150 UNet forwards per image -- the same mean of 50 forwards per reconstruction as the timed
-    workload.  kind "port": the reference's own dependencies cannot be installed."""
+    workload; 15-25 s of CPU work on the GPU boxes' hosts (round 5 timed half of it: the figure moved
+    1.9-3.3 box to box on 8-13 s samples).  kind "port": the reference's own dependencies cannot be installed."""
     import oracle
     from ddpm_ood_amd.data import get_data_loader
     from ddpm_ood_amd.synthetic import random_state_dict
@@ -148,7 +149,7 @@ def cpu_baseline_worker():
     model = oracle.DiffusionModelUNet(2, 1, 1, **MODEL_CONFIGS["small"]).eval()
     model.load_state_dict(random_state_dict("small", 1, seed=1))
     pl = oracle.PerceptualLoss(dimensions=2, include_pixel_loss=False, is_fake_3d=False, lpips_normalize=True)
-    loader = get_data_loader("synthetic:blobs:n=8:seed=0", batch_size=8, is_grayscale=True)
+    loader = get_data_loader("synthetic:blobs:n=16:seed=0", batch_size=16, is_grayscale=True)
     kw = dict(model=model, vqvae=oracle.PassthroughVQVAE(), perceptual=pl,
               noise_fn=lambda batch, t, shape: batch_noise(2, batch["index"], t, shape),
               beta_schedule=SCHED["beta_schedule"], beta_start=SCHED["beta_start"], beta_end=SCHED["beta_end"])
@@ -159,7 +160,7 @@ def cpu_baseline_worker():
     assert sorted({r["t"] for r in rows}) == [10, 490, 970]
     print(json.dumps({"value": round(len(rows) / dt, 4), "unit": "reconstructions/s",
                       "cores": torch.get_num_threads(), "kind": "port", "seconds": round(dt, 2),
-                      "sample": "8 images x t_start in {10, 490, 970}: 24 reconstructions, 1200 UNet "
+                      "sample": "16 images x t_start in {10, 490, 970}: 48 reconstructions, 2400 UNet "
                                 "image-forwards (mean 50 per reconstruction as in the timed workload), CPU fp32 "
                                 "oracle incl. LPIPS + MSE"}))
 

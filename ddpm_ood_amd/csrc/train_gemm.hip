@@ -225,6 +225,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradP p) {
 // LDS offsets and global offsets of a thread's loads are computed once per kernel, the K loop walks rows and pixel pairs
 // without a division.  The halo columns of the input tile are zeroed once (no load ever writes them), rows outside the image
 // are written as zeros per tile.
+// (Measured and not kept: the same kernel WITHOUT the register set for the next tile, 256 registers per lane and two workgroups per
+// CU, the second hiding the first's load latency -- 2 970-2 993 against 3 085-3 095 images/s at batch 64, 3 811 against 3 969 at 256:
+// profiles/r06_wgrad_two_workgroups_per_cu_ab.log.)
 template <int STRIDE>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_staged_kernel(const WgradP p) {
   extern __shared__ float smem[];
