@@ -1,6 +1,7 @@
 """Training-step throughput of the `small` UNet on one MI355X: the native step (train_native.NativeUNetStep -- hand-written HIP forward /
 backward / Adam) beside the ATen route (PyTorch-ROCm autograd over MIOpen / rocBLAS, DDPM_TRAIN_NATIVE=0), same weights, same batch.
-    python tools/train_step_bench.py [batch] [steps] [native|aten|both]
+    python tools/train_step_bench.py [batch] [steps] [native|aten|amp|both|all]
+(amp: the ATen route under fp16 autocast + GradScaler -- the reference's own training arithmetic, ddpm_trainer.py:96-109.)
 Row f-3 (/root/reference/src/trainers/ddpm_trainer.py:78-109, base.py:156).  `rocprofv3 --kernel-trace --stats -- python
 tools/train_step_bench.py 64 5 native` is the profile committed as profiles/r06_train_native_kernel_trace_stats.csv."""
 import sys
@@ -43,7 +44,7 @@ def timed(fn):
     return (time.perf_counter() - t0) / steps
 
 
-if which in ("native", "both"):
+if which in ("native", "both", "all"):
     with torch.no_grad():
         st = NativeUNetStep(model())
         k = [0]
@@ -56,7 +57,7 @@ if which in ("native", "both"):
 
         dt = timed(native_step)
     print(f"native: batch {B}: {dt * 1e3:.2f} ms per step = {B / dt:.0f} images/s")
-if which in ("aten", "both"):
+if which in ("aten", "both", "all"):
     m = model()
     for p in m.parameters():
         p.requires_grad_(True)
@@ -71,3 +72,21 @@ if which in ("aten", "both"):
 
     dt = timed(aten_step)
     print(f"aten:   batch {B}: {dt * 1e3:.2f} ms per step = {B / dt:.0f} images/s")
+if which in ("amp", "all"):
+    m = model()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    opt = torch.optim.Adam(m.parameters(), lr=2.5e-5)
+    scaler = torch.amp.GradScaler("cuda")
+
+    def amp_step():
+        noise = torch.randn(B, 1, 32, 32, device=dev)
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = torch.nn.functional.mse_loss(unet_forward_torch(m, x, t).float(), noise)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+
+    dt = timed(amp_step)
+    print(f"aten fp16 autocast: batch {B}: {dt * 1e3:.2f} ms per step = {B / dt:.0f} images/s")
