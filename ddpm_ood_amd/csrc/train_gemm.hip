@@ -143,6 +143,10 @@ struct WgradP {
   const float *dy;  // [B, Cout, Ho, Wo]
   float *part;      // [S][9][Cout][Cin]
   int B, Cin, Cout, Hi, Wi, Ho, Wo, stride;
+  // 3-D (conv3d weight gradient, one launch per depth tap kd): an "image" is one (batch item, output slice zo); its input slice is
+  // zi = stride zo + kd - 1 (outside the volume: the tile contributes nothing).  2-D: Do = Di = 1, kd = 1.
+  int Di, Do, kd;
+  long long a_cs, dy_cs;  // channel strides of a / dy in floats (Di Hi Wi / Do Ho Wo)
   int R;            // output rows per pixel tile
   int tiles_per_img, T, S;  // T = B * tiles_per_img pixel tiles, walked by S workgroups per (cout, cin) block
   int AR, AW, ACS;  // input tile: rows, row length (with halo), channel stride (odd)
@@ -172,24 +176,26 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradP p) {
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   const size_t hw_i = (size_t)p.Hi * p.Wi, hw_o = (size_t)p.Ho * p.Wo;
   for (int tile = sp; tile < p.T; tile += p.S) {
-    const int b = tile / p.tiles_per_img, rb = tile - b * p.tiles_per_img;
+    const int sl = tile / p.tiles_per_img, rb = tile - sl * p.tiles_per_img;
+    const int b = sl / p.Do, zo = sl - b * p.Do, zi = STRIDE * zo + p.kd - 1;
+    if (zi < 0 || zi >= p.Di) continue;  // (uniform over the workgroup)
     const int yo0 = rb * p.R;
     const int rows = min(p.R, p.Ho - yo0);  // (a ragged last tile: the missing rows are zero)
     // ---- dY tile: 64 couts x PT pixels (contiguous in memory)
-    const float *dyb = p.dy + ((size_t)b * p.Cout + cob) * hw_o + (size_t)yo0 * p.Wo;
+    const float *dyb = p.dy + ((size_t)b * p.Cout + cob) * p.dy_cs + (size_t)zo * hw_o + (size_t)yo0 * p.Wo;
     for (int e = tid; e < kWT * PT; e += 256) {
       const int c = e / PT, px = e - c * PT;
-      Ds[c * p.DCS + px] = px < rows * p.Wo ? dyb[(size_t)c * hw_o + px] : 0.f;
+      Ds[c * p.DCS + px] = px < rows * p.Wo ? dyb[(size_t)c * p.dy_cs + px] : 0.f;
     }
     // ---- input tile: 64 cins x AR rows x AW columns, zero halo; tile row r holds input row STRIDE yo0 - 1 + r
-    const float *ab = p.a + ((size_t)b * p.Cin + cib) * hw_i;
+    const float *ab = p.a + ((size_t)b * p.Cin + cib) * p.a_cs + (size_t)zi * hw_i;
     const int yi0 = STRIDE * yo0 - 1;
     for (int e = tid; e < kWT * p.AR * p.AW; e += 256) {
       const int c = e / (p.AR * p.AW), rem = e - c * (p.AR * p.AW);
       const int r = rem / p.AW, col = rem - r * p.AW;
       const int yi = yi0 + r, xi = col - 1;
       float v = 0.f;
-      if (yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi) v = ab[(size_t)c * hw_i + (size_t)yi * p.Wi + xi];
+      if (yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi) v = ab[(size_t)c * p.a_cs + (size_t)yi * p.Wi + xi];
       As[c * p.ACS + r * p.AW + col] = v;
     }
     __syncthreads();
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_staged_kernel(const WgradP 
     const bool ok = it < p.NA && q < kWT * p.AR && lane < p.RPI * p.LPR;
     const int c = q / p.AR, r = q - c * p.AR;
     a_lds[it] = c * p.ACS + r * p.AW + 1 + 4 * lc;
-    a_g[it] = c * hw_i + r * p.Wi + 4 * lc;
+    a_g[it] = c * (int)p.a_cs + r * p.Wi + 4 * lc;
     a_r[it] = ok ? r : -(1 << 20);
   }
   int d_lds[kND], d_g[kND], d_px[kND];
@@ -255,22 +261,24 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_staged_kernel(const WgradP 
     const int c = (it * 4 + wave) * p.CPI + lane / p.LPD, px0 = 4 * (lane % p.LPD);
     const bool ok = it < p.ND && c < kWT && lane < p.CPI * p.LPD;
     d_lds[it] = c * p.DCS + px0;
-    d_g[it] = c * hw_o + px0;
+    d_g[it] = c * (int)p.dy_cs + px0;
     d_px[it] = ok ? px0 : (1 << 20);
   }
   for (int e = tid; e < kWT * p.ACS; e += 256) As[e] = 0.f;  // the halo columns stay zero for the whole kernel
   typedef float v4 __attribute__((ext_vector_type(4)));
   v4 ra[kNA], rd[kND];
   auto fetch = [&](int tile) __attribute__((always_inline)) {
-    const int b = tile / p.tiles_per_img, rb = tile - b * p.tiles_per_img;
+    const int sl = tile / p.tiles_per_img, rb = tile - sl * p.tiles_per_img;
+    const int b = sl / p.Do, zo = sl - b * p.Do, zi = STRIDE * zo + p.kd - 1;
+    const bool zok = zi >= 0 && zi < p.Di;  // an input slice outside the volume: the whole tile is zero
     const int yo0 = rb * p.R, yi0 = STRIDE * yo0 - 1;
-    const int rows_px = min(p.R, p.Ho - yo0) * p.Wo;
-    const float *ab = p.a + ((size_t)b * p.Cin + cib) * hw_i + (ptrdiff_t)yi0 * p.Wi;
-    const float *dyb = p.dy + ((size_t)b * p.Cout + cob) * hw_o + (size_t)yo0 * p.Wo;
+    const int rows_px = zok ? min(p.R, p.Ho - yo0) * p.Wo : 0;
+    const float *ab = p.a + ((size_t)b * p.Cin + cib) * p.a_cs + (ptrdiff_t)(zok ? zi : 0) * hw_i + (ptrdiff_t)yi0 * p.Wi;
+    const float *dyb = p.dy + ((size_t)b * p.Cout + cob) * p.dy_cs + (size_t)zo * hw_o + (size_t)yo0 * p.Wo;
 #pragma unroll
     for (int it = 0; it < kNA; ++it) {
       const int yi = yi0 + a_r[it];
-      ra[it] = yi >= 0 && yi < p.Hi ? *reinterpret_cast<const v4 *>(ab + a_g[it]) : v4{0.f, 0.f, 0.f, 0.f};
+      ra[it] = zok && yi >= 0 && yi < p.Hi ? *reinterpret_cast<const v4 *>(ab + a_g[it]) : v4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int it = 0; it < kND; ++it)
@@ -333,7 +341,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_staged_kernel(const WgradP 
 }
 
 // dW[co][ci][tap] = sum over the S partial slabs, slab order fixed
-__global__ void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int S, int Cout, int Cin, int taps) {
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int S, int Cout, int Cin, int taps,
+                                    int out_taps, int out_off) {
   const size_t n = (size_t)Cout * Cin * taps;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -341,7 +350,7 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, float *__res
   const size_t cc = i / taps;  // co * Cin + ci
   float s = 0.f;
   for (int k = 0; k < S; ++k) s += part[((size_t)k * taps + tap) * Cout * Cin + cc];
-  dw[i] = s;
+  dw[cc * out_taps + out_off + tap] = s;  // (out_taps = 27, out_off = 9 kd: one depth tap of a [Cout, Cin, 3, 3, 3] weight)
 }
 
 // Any (Cout, Cin), ksize 1 or 3, stride 1 or 2, padding ksize / 2: one workgroup per (cout, cin) pair and image slice, its
@@ -459,11 +468,14 @@ bool wgrad_plain_form() {
   const char *v = getenv("DDPM_WGRAD_STAGED");
   return v && atoi(v) == 0;
 }
-bool wgrad_plan(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ksize, int stride, WgradP &p) {
+bool wgrad_plan(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ksize, int stride, WgradP &p, int Di = 1, int Do = 1) {
   if (ksize != 3 || (stride != 1 && stride != 2) || Cin % kWT || Cout % kWT) return false;
   if (stride == 1 ? (Ho != Hi || Wo != Wi) : (Ho != (Hi + 1) / 2 || Wo != (Wi + 1) / 2)) return false;
   if (Wo > 64 || (Wo & 1)) return false;  // pixel pairs stay inside a row
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Hi = Hi; p.Wi = Wi; p.Ho = Ho; p.Wo = Wo; p.stride = stride;
+  p.Di = Di; p.Do = Do; p.kd = 1;
+  p.a_cs = (long long)Di * Hi * Wi; p.dy_cs = (long long)Do * Ho * Wo;
+  if ((double)Cin * p.a_cs >= 2147483648.0 || (double)Cout * p.dy_cs >= 2147483648.0) return false;  // 32-bit offsets inside a tile
   // output rows per pixel tile: 64 pixels where the tiles fit 64 KB of LDS (two workgroups per CU), else fewer rows
   p.R = 64 / Wo < Ho ? 64 / Wo : Ho;
   if (p.R < 1) p.R = 1;
@@ -481,7 +493,7 @@ bool wgrad_plan(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ks
     }
   }
   p.tiles_per_img = (Ho + p.R - 1) / p.R;
-  p.T = B * p.tiles_per_img;
+  p.T = B * Do * p.tiles_per_img;
   p.fast = 0;
   if (Wi % 4 == 0 && Wo % 4 == 0 && Wi <= 256 && (Hi * Wi) % 4 == 0) {
     p.LPR = Wi / 4;
@@ -556,7 +568,7 @@ extern "C" int ddpm_conv_wgrad_f32(const float *a, const float *dy, float *dw, i
     }
     ProfScope prof(s, "train_wgrad_reduce", 0.0, 4.0 * (p.S + 1.0) * 9 * Cout * Cin);
     const size_t n = (size_t)Cout * Cin * 9;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, dw, p.S, Cout, Cin, 9);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, dw, p.S, Cout, Cin, 9, 9, 0);
     DDPM_CHECK_LAUNCH();
     return 0;
   }
@@ -568,7 +580,53 @@ extern "C" int ddpm_conv_wgrad_f32(const float *a, const float *dy, float *dw, i
                      ksize, stride);
   if (S > 1) {
     const size_t n = (size_t)Cout * Cin * ksize * ksize;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, dw, S, Cout, Cin, ksize * ksize);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, dw, S, Cout, Cin, ksize * ksize, ksize * ksize,
+                       0);
+  }
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t ddpm_conv3d_wgrad_scratch_floats(int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int stride) {
+  WgradP p;
+  if (!wgrad_plan(B, Cin, Cout, Hi, Wi, Ho, Wo, 3, stride, p, Di, Do)) return 0;
+  return (size_t)p.S * 9 * Cout * Cin;
+}
+
+extern "C" int ddpm_conv3d_wgrad_f32(const float *a, const float *dy, float *dw, int B, int Cin, int Cout, int Di, int Hi, int Wi,
+                                     int Do, int Ho, int Wo, int stride, float *scratch, size_t scratch_floats, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(a && dy && dw && scratch, "conv3d_wgrad: null operand (the scratch of ddpm_conv3d_wgrad_scratch_floats is required)");
+  DDPM_CHECK_ARG(stride == 1 || stride == 2, "conv3d_wgrad: stride %d", stride);
+  DDPM_CHECK_ARG(Do == (Di - 1) / stride + 1 && Ho == (Hi - 1) / stride + 1 && Wo == (Wi - 1) / stride + 1,
+                 "conv3d_wgrad: extents do not match kernel 3, padding 1, stride %d", stride);
+  WgradP p;
+  DDPM_CHECK_ARG(wgrad_plan(B, Cin, Cout, Hi, Wi, Ho, Wo, 3, stride, p, Di, Do),
+                 "conv3d_wgrad: needs Cin %% 64 == 0, Cout %% 64 == 0 and an even W <= 64 (the 3-D latent UNet's shapes)");
+  DDPM_CHECK_ARG(scratch_floats >= (size_t)p.S * 9 * Cout * Cin, "conv3d_wgrad: scratch too small");
+  hipStream_t s = as_stream(stream);
+  p.a = a; p.dy = dy; p.part = scratch;
+  const size_t lds = (size_t)kWT * (p.ACS + p.DCS) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    for (const void *f : {reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<1>), reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<2>),
+                          reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<1>),
+                          reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<2>)})
+      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const bool staged = p.fast && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0 && !wgrad_plain_form();
+  const double M = (double)B * Do * Ho * Wo;
+  ProfScope prof(s, "train_conv3d_wgrad", 2.0 * M * Cout * Cin * 27,
+                 4.0 * ((double)B * Cin * Di * Hi * Wi + M * Cout + 27.0 * Cout * Cin));
+  dim3 grid(Cout / kWT, Cin / kWT, p.S);
+  const size_t n = (size_t)Cout * Cin * 9;
+  for (int kd = 0; kd < 3; ++kd) {  // one depth tap per launch: 9 accumulator tiles per wave is what the register file holds
+    p.kd = kd;
+    if (staged && stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<1>, grid, dim3(256), lds, s, p);
+    else if (staged) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<2>, grid, dim3(256), lds, s, p);
+    else if (stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, dw, p.S, Cout, Cin, 9, 27, 9 * kd);
   }
   DDPM_CHECK_LAUNCH();
   return 0;

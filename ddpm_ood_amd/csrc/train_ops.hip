@@ -195,6 +195,25 @@ __global__ void resample2_kernel(const float *__restrict__ in, float *__restrict
     out[i] = mode == 0 ? v : (((x | y) & 1) ? 0.f : v);
   }
 }
+// the same three maps on volumes (D, H, W: the SMALL extent): nearest x2, its adjoint (sum of each 2x2x2 block), zero-stuffing x2
+__global__ void resample3_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t planes, int D, int H, int W, int mode) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t small = (int64_t)D * H * W;
+  if (mode == 1) {
+    if (i >= planes * small) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)((i / ((int64_t)W * H)) % D);
+    const int64_t pl = i / small;
+    const float *p = in + pl * 8 * small + ((size_t)(2 * z) * (2 * H) + 2 * y) * (2 * W) + 2 * x;
+    const size_t zs = (size_t)4 * H * W;
+    out[i] = ((p[0] + p[1]) + (p[2 * W] + p[2 * W + 1])) + ((p[zs] + p[zs + 1]) + (p[zs + 2 * W] + p[zs + 2 * W + 1]));
+  } else {
+    if (i >= planes * 8 * small) return;
+    const int x = (int)(i % (2 * W)), y = (int)((i / (2 * W)) % (2 * H)), z = (int)((i / ((int64_t)4 * W * H)) % (2 * D));
+    const int64_t pl = i / (8 * small);
+    const float v = in[pl * small + ((size_t)(z >> 1) * H + (y >> 1)) * W + (x >> 1)];
+    out[i] = mode == 0 ? v : (((x | y | z) & 1) ? 0.f : v);
+  }
+}
 // wt[ci][co][ky][kx] = w[co][ci][k - 1 - ky][k - 1 - kx]: the weights of the input-gradient convolution
 __global__ void conv_weight_rot180t_kernel(const float *__restrict__ w, float *__restrict__ wt, int Cout, int Cin, int kk) {
   const int64_t n = (int64_t)Cout * Cin * kk;
@@ -409,11 +428,21 @@ extern "C" int ddpm_resample2_f32(const float *in, float *out, int64_t planes, i
   return 0;
 }
 
-extern "C" int ddpm_conv_weight_rot180t_f32(const float *w, float *wt, int Cout, int Cin, int ksize, ddpm_stream_t stream) {
-  DDPM_CHECK_ARG(w && wt && Cout > 0 && Cin > 0 && ksize > 0, "conv_weight_rot180t: bad arguments");
+extern "C" int ddpm_resample3_f32(const float *in, float *out, int64_t planes, int D, int H, int W, int mode, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(in && out && planes > 0 && D > 0 && H > 0 && W > 0 && mode >= 0 && mode <= 2, "resample3: bad arguments");
   hipStream_t s = as_stream(stream);
-  const int64_t n = (int64_t)Cout * Cin * ksize * ksize;
-  hipLaunchKernelGGL(conv_weight_rot180t_kernel, dim3(blocks_for(n)), dim3(256), 0, s, w, wt, Cout, Cin, ksize * ksize);
+  const int64_t n = (mode == 1 ? 1 : 8) * planes * D * H * W;
+  ProfScope prof(s, "train_resample3", 0.0, 9.0 * 4 * planes * D * H * W);
+  hipLaunchKernelGGL(resample3_kernel, dim3(blocks_for(n)), dim3(256), 0, s, in, out, planes, D, H, W, mode);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_conv_weight_rot180t_f32(const float *w, float *wt, int Cout, int Cin, int taps, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(w && wt && Cout > 0 && Cin > 0 && taps > 0, "conv_weight_rot180t: bad arguments");
+  hipStream_t s = as_stream(stream);
+  const int64_t n = (int64_t)Cout * Cin * taps;
+  hipLaunchKernelGGL(conv_weight_rot180t_kernel, dim3(blocks_for(n)), dim3(256), 0, s, w, wt, Cout, Cin, taps);
   DDPM_CHECK_LAUNCH();
   return 0;
 }

@@ -237,7 +237,7 @@ def conv3d_supported(weight: torch.Tensor, stride: int = 1, transposed: bool = F
     k = tuple(weight.shape[2:])
     if transposed:
         return k == (4, 4, 4) and stride == 2 and weight.shape[0] % 8 == 0 and weight.shape[1] % 128 == 0
-    if not ((k == (3, 3, 3) and stride == 1) or (k == (4, 4, 4) and stride == 2)):
+    if not ((k == (3, 3, 3) and stride in (1, 2)) or (k == (4, 4, 4) and stride == 2)):
         return False
     return weight.shape[0] % 128 == 0 and weight.shape[1] % 4 == 0
 
@@ -304,9 +304,9 @@ def pack_wino44h_3d_weight(weight: torch.Tensor) -> torch.Tensor | None:
 
 
 def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=None, packed=None, stride: int = 1,
-           wino=None, out=None, wino44=None, wino44h=None):
-    """F.conv3d(act(x), weight, bias, stride, padding=1) (+ residual, + output activation) on NCDHW tensors:
-    kernel 3 stride 1, or kernel 4 stride 2.  ONE launch of the MFMA kernel: the depth taps are part of its chunk
+           wino=None, out=None, wino44=None, wino44h=None, chan_add=None):
+    """F.conv3d(act(x), weight, bias, stride, padding=1) (+ chan_add[n, co] + residual, + output activation) on NCDHW tensors:
+    kernel 3 stride 1 or 2 (the 3-D UNet's ResnetBlock / Downsample convolutions), or kernel 4 stride 2 (the VQ-VAE's).  ONE launch of the MFMA kernel: the depth taps are part of its chunk
     stream (chunk = (depth tap, channel group)), so the output is written once.  ``wino`` (pack_wino3d_weight): a
     stride-1 conv without input activation whose slices hold >= 64 2x2 tiles takes the Winograd kernel instead (2-D
     F(2x2, 3x3) per depth tap, the taps accumulated in the transform domain: 2.25x fewer multiplies); ``wino44``
@@ -322,7 +322,12 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
         raise ValueError(f"conv3d: input has {Cc} channels, weight expects {w.shape[1]}")
     if stride == 2 and (D < 2 or H < 2 or W < 2):
         raise ValueError("conv3d k4 s2: every extent must be >= 2")
-    Do, Ho, Wo = (D, H, W) if stride == 1 else (D // 2, H // 2, W // 2)
+    if stride == 1:
+        Do, Ho, Wo = D, H, W
+    elif k == 3:
+        Do, Ho, Wo = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+    else:
+        Do, Ho, Wo = D // 2, H // 2, W // 2
     if packed is None:
         packed = pack_conv3d_weight(w)
     if out is None:
@@ -340,7 +345,7 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
             for s0 in range(0, B, nb):
                 conv3d(x[s0:s0 + nb], w, bias, act=act, out_act=out_act, packed=packed, stride=stride, wino=wino,
                        wino44=wino44, wino44h=wino44h, residual=None if residual is None else residual[s0:s0 + nb],
-                       out=out[s0:s0 + nb])
+                       out=out[s0:s0 + nb], chan_add=None if chan_add is None else chan_add[s0:s0 + nb])
             return out
     d = ConvDesc()
     d.in1, d.C1 = ptr(x), Cc
@@ -349,6 +354,9 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
     d.B, d.Cout, d.Hi, d.Wi, d.Ho, d.Wo = B, cout, H, W, Ho, Wo
     d.ksize, d.mode, d.act, d.out_act = k, (CONV_NORMAL if stride == 1 else CONV_STRIDE2), act, out_act
     d.Di, d.Do, d.dims = D, Do, 3
+    if chan_add is not None:
+        chan_add = require_device_f32(chan_add, "chan_add")
+        d.chan_add, d.chan_add_stride = ptr(chan_add), chan_add.shape[1]
     if wino is not None and stride == 1:
         d.w_wino = ptr(wino)
     if wino44 is not None and stride == 1:

@@ -9,8 +9,9 @@ dict of base.py:166-187.  Differences, on purpose:
     (/root/reference/src/trainers/ddpm_trainer.py:96-109, base.py:122) over the same ATen ops;
   * since round 6 the training step of a 2-D UNet is NATIVE (``train_native.NativeUNetStep``: forward on the inference path's
     convolution kernels, backward and Adam on hand-written HIP kernels -- ddpm_conv_wgrad_f32, ddpm_gemm_f32, train_ops.hip; no
-    ATen / MIOpen / rocBLAS kernel between the noisy batch and the updated parameters).  ``DDPM_TRAIN_NATIVE=0``, ``--amp 1`` and
-    the 3-D latent UNet take the older route: PyTorch-ROCm autograd over ``unet_forward_torch``, which evaluates the SAME
+    ATen / MIOpen / rocBLAS kernel between the noisy batch and the updated parameters), and so is the 3-D latent UNet's of the LDM
+    configuration (conv3d weight gradient per depth tap).  ``DDPM_TRAIN_NATIVE=0``, ``--amp 1`` and 3-D UNets without an MFMA
+    tiling take the older route: PyTorch-ROCm autograd over ``unet_forward_torch``, which evaluates the SAME
     parameter holders the HIP engine reads (``DiffusionModelUNet``) with differentiable ATen ops.  Either way a checkpoint
     written here loads into the HIP inference path unchanged;
   * multi-GPU: one process per GPU; rank 0's initial parameters and buffers are broadcast once (what
@@ -119,7 +120,7 @@ class DDPMTrainer(BaseTrainer):
         self.seed = int(args.seed)
         self.amp = bool(getattr(args, "amp", 0))
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp)
-        # native step (hand-written HIP forward / backward / Adam) unless switched off, under AMP, or for the 3-D latent UNet
+        # native step (hand-written HIP forward / backward / Adam) unless switched off, under AMP, or for a 3-D UNet without an MFMA tiling
         self.native = (os.environ.get("DDPM_TRAIN_NATIVE", "1") not in ("0", "off") and not self.amp
                        and native_supported(self.model) and not self.do_latent_pad)
         if self.native:

@@ -33,14 +33,20 @@ SILU, NONE = T.ACT_SILU, T.ACT_NONE
 
 
 def native_supported(model) -> bool:
-    """2-D UNets only (the 3-D latent UNet of the LDM configuration trains through the ATen path: no conv3d weight gradient)."""
-    return getattr(model, "spatial_dims", 2) == 2
+    """Every 2-D UNet; 3-D UNets whose convolutions all have an MFMA tiling (the latent UNet of the LDM configuration, BASELINE
+    configs[4]: 128 latent channels in and out, num_channels multiples of 128) -- the conv3d forward and weight-gradient kernels
+    have no generic form; a 3-D UNet over 1-channel volumes keeps the ATen route."""
+    sd = getattr(model, "spatial_dims", 2)
+    if sd == 2:
+        return True
+    return (sd == 3 and model.in_channels % 64 == 0 and model.out_channels % 128 == 0
+            and all(c % 128 == 0 for c in model.block_out_channels))
 
 
 class NativeUNetStep:
     def __init__(self, model, lr: float = 2.5e-5, betas=(0.9, 0.999), eps: float = 1e-8):
         if not native_supported(model):
-            raise NotImplementedError("native training covers the 2-D DiffusionModelUNet")
+            raise NotImplementedError("native training covers 2-D UNets and 3-D UNets whose channel counts have an MFMA tiling")
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
@@ -87,15 +93,33 @@ class NativeUNetStep:
     def _conv(self, x, w, b=None, *, chan_add=None, residual=None, stride2=False, form=None):
         """ddpm_conv_f32.  form of a stride-1 3x3: "wino44h" = split-f16 F(4x4) Winograd where the launch fills the chip (the
         inference path's kernel: ~3e-6 rms relative rounding per convolution, from the 6x6 transforms), "wino" = F(2x2) on the
-        fp32 MFMA (~1e-6), "direct" = the fp32 MFMA direct form (bit-exact fp32 products)."""
+        fp32 MFMA (~1e-6), "direct" = the fp32 MFMA direct form (bit-exact fp32 products).  5-D inputs: F.conv3d on NCDHW (a
+        1x1x1 convolution / per-voxel Linear is the 2-D op over a (D H) x W image)."""
+        form = form or self.fwd_form
+        if x.ndim == 5:
+            if w.ndim == 5 and w.shape[2] == 3:
+                s1 = not stride2
+                return ops.conv3d(x, w, b, chan_add=chan_add, residual=residual, stride=1 if s1 else 2,
+                                  wino44h=ops.pack_wino44h_3d_weight(w) if s1 and form == "wino44h" else None,
+                                  wino=ops.pack_wino3d_weight(w) if s1 and form in ("wino44h", "wino") else None)
+            B, Cc, D, H, W = x.shape
+            w2 = w.reshape(w.shape[0], w.shape[1], 1, 1)
+            r2 = None if residual is None else residual.reshape(B, -1, D * H, W)
+            return ops.conv(x.reshape(B, Cc, D * H, W), w2, b, chan_add=chan_add, residual=r2).reshape(B, w.shape[0], D, H, W)
         if stride2:
             return ops.conv(x, w, b, mode=ops.CONV_STRIDE2, wino44h=ops.pack_conv_s2h_weight(w))
         if w.ndim == 4 and w.shape[2] == 3:
-            form = form or self.fwd_form
             return ops.conv(x, w, b, chan_add=chan_add, residual=residual,
                             wino44h=ops.pack_wino44h_weight(w) if form == "wino44h" else None,
                             wino=ops.pack_wino_weight(w) if form in ("wino44h", "wino") else None)
         return ops.conv(x, w, b, chan_add=chan_add, residual=residual)
+
+    def _wgrad3(self, a, dy, w, stride=1):
+        """The 3x3(x3) weight gradient into the weight's gradient view."""
+        if a.ndim == 5:
+            T.conv3d_wgrad(a, dy, stride, out=self.g(w))
+        else:
+            T.conv_wgrad(a, dy, 3, stride, out=self.g(w))
 
     def _bias_grad(self, dy, bias_param, keep_rows=False):
         B, Cc = dy.shape[:2]
@@ -132,7 +156,7 @@ class NativeUNetStep:
 
     def _conv3_bwd(self, a, w, dy, need_dx=True):
         """dW into the weight's gradient view; returns da = conv(dy, rot180(w)^T)."""
-        T.conv_wgrad(a, dy, 3, 1, out=self.g(w))
+        self._wgrad3(a, dy, w)
         if not need_dx:
             return None
         return self._conv(dy, T.conv_weight_rot180t(w), form=self.dgrad_form)
@@ -322,7 +346,7 @@ class NativeUNetStep:
             if kind == "out":
                 oc, a, c = ctx
                 self._bias_grad(dpred, oc.bias)
-                T.conv_wgrad(a, dpred, 3, 1, out=self.g(oc.weight))
+                self._wgrad3(a, dpred, oc.weight)
                 da = self._conv(dpred, T.conv_weight_rot180t(oc.weight), form=self.dgrad_form)
                 dh = self._gn_bwd(c, da)
             elif kind == "up":
@@ -348,13 +372,13 @@ class NativeUNetStep:
             elif kind == "down":
                 op, hin = ctx
                 self._bias_grad(dh, op.bias)
-                T.conv_wgrad(hin, dh, 3, 2, out=self.g(op.weight))
+                self._wgrad3(hin, dh, op.weight, stride=2)
                 dh = self._conv(T.zero_stuff2(dh), T.conv_weight_rot180t(op.weight), form=self.dgrad_form)
             elif kind == "conv_in":
                 T.axpby(dh, dskips.pop(), 1.0, 1.0, out=dh)  # skips[0] = conv_in's output
                 ci = m.conv_in.conv
                 self._bias_grad(dh, ci.bias)
-                T.conv_wgrad(ctx, dh, 3, 1, out=self.g(ci.weight))
+                self._wgrad3(ctx, dh, ci.weight)
         assert not dskips
         # time embedding: es = silu(emb), emb = Linear2(silu(Linear0(e0)))
         e0, e1, e2, emb = self._emb_ctx

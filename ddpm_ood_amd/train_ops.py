@@ -60,13 +60,33 @@ def conv_wgrad(a, dy, ksize: int, stride: int = 1, out=None, force_generic: bool
 
 
 def conv_weight_rot180t(w, out=None):
-    """[Cout, Cin, k, k] (or [Cout, Cin]) -> [Cin, Cout, k, k]: the weights of the input-gradient convolution."""
+    """[Cout, Cin, k, k(, k)] (or [Cout, Cin]) -> [Cin, Cout, k, k(, k)]: the weights of the input-gradient convolution."""
     w = require_device_f32(w, "w")
     cout, cin = w.shape[:2]
-    k = w.shape[2] if w.ndim == 4 else 1
+    spatial = tuple(w.shape[2:])
+    taps = 1
+    for k in spatial:
+        taps *= k
     if out is None:
-        out = _empty((cin, cout, k, k), w)
-    check(_lib.load().ddpm_conv_weight_rot180t_f32(ptr(w), ptr(out), cout, cin, k, stream_ptr()), "conv_weight_rot180t")
+        out = _empty((cin, cout) + (spatial if spatial else (1, 1)), w)
+    check(_lib.load().ddpm_conv_weight_rot180t_f32(ptr(w), ptr(out), cout, cin, taps, stream_ptr()), "conv_weight_rot180t")
+    return out
+
+
+def conv3d_wgrad(a, dy, stride: int = 1, out=None):
+    """dw[Cout, Cin, 3, 3, 3] of F.conv3d(a, w, stride=stride, padding=1) given dy (NCDHW)."""
+    lib = _lib.load()
+    a, dy = require_device_f32(a, "a"), require_device_f32(dy, "dy")
+    B, Cin, Di, Hi, Wi = a.shape
+    Cout, Do, Ho, Wo = dy.shape[1:]
+    if out is None:
+        out = _empty((Cout, Cin, 3, 3, 3), a)
+    need = lib.ddpm_conv3d_wgrad_scratch_floats(B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, stride)
+    if need == 0:
+        raise ValueError("conv3d_wgrad: needs Cin % 64 == 0, Cout % 64 == 0 and an even W <= 64")
+    scratch = _empty((need,), a)
+    check(lib.ddpm_conv3d_wgrad_f32(ptr(a), ptr(dy), ptr(out), B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, stride, ptr(scratch), need,
+                                    stream_ptr()), "conv3d_wgrad")
     return out
 
 
@@ -138,25 +158,30 @@ def chan_copy(src, dst, C_, csrc0: int = 0, cdst0: int = 0, accumulate: bool = F
     return dst
 
 
-def upsample2(x):
-    B, Cc, H, W = x.shape
-    out = _empty((B, Cc, 2 * H, 2 * W), x)
-    check(_lib.load().ddpm_resample2_f32(ptr(x), ptr(out), B * Cc, H, W, 0, stream_ptr()), "upsample2")
+def _resample(x, mode: int):
+    """mode 0: nearest x2; 1: its adjoint (2x2(x2) block sums); 2: zero-stuffing x2 -- on [B, C, H, W] or [B, C, D, H, W]."""
+    lib = _lib.load()
+    B, Cc = x.shape[:2]
+    sp = tuple(x.shape[2:])
+    small = tuple(v // 2 for v in sp) if mode == 1 else sp
+    out = _empty((B, Cc) + (small if mode == 1 else tuple(2 * v for v in sp)), x)
+    if len(sp) == 2:
+        check(lib.ddpm_resample2_f32(ptr(x), ptr(out), B * Cc, small[0], small[1], mode, stream_ptr()), "resample2")
+    else:
+        check(lib.ddpm_resample3_f32(ptr(x), ptr(out), B * Cc, small[0], small[1], small[2], mode, stream_ptr()), "resample3")
     return out
+
+
+def upsample2(x):
+    return _resample(x, 0)
 
 
 def sumpool2(x):
-    B, Cc, H2, W2 = x.shape
-    out = _empty((B, Cc, H2 // 2, W2 // 2), x)
-    check(_lib.load().ddpm_resample2_f32(ptr(x), ptr(out), B * Cc, H2 // 2, W2 // 2, 1, stream_ptr()), "sumpool2")
-    return out
+    return _resample(x, 1)
 
 
 def zero_stuff2(x):
-    B, Cc, H, W = x.shape
-    out = _empty((B, Cc, 2 * H, 2 * W), x)
-    check(_lib.load().ddpm_resample2_f32(ptr(x), ptr(out), B * Cc, H, W, 2, stream_ptr()), "zero_stuff2")
-    return out
+    return _resample(x, 2)
 
 
 def softmax_rows_(s, rows: int, cols: int):

@@ -496,9 +496,16 @@ int ddpm_gemm_f32(const ddpm_gemm_desc *g, ddpm_stream_t stream);
 size_t ddpm_conv_wgrad_scratch_floats(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ksize, int stride);
 int ddpm_conv_wgrad_f32(const float *a, const float *dy, float *dw, int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo,
                         int ksize, int stride, float *scratch, size_t scratch_floats, int force_generic, ddpm_stream_t stream);
-/* wt[Cin, Cout, k, k] = w[Cout, Cin, k, k] rotated by 180 degrees and transposed: conv(dy, wt, padding = k / 2) is the input
- * gradient of a stride-1 convolution (of a stride-2 one after ddpm_resample2_f32(mode 2) of dy).  */
-int ddpm_conv_weight_rot180t_f32(const float *w, float *wt, int Cout, int Cin, int ksize, ddpm_stream_t stream);
+/* The same for F.conv3d(a, w[Cout, Cin, 3, 3, 3], stride, padding = 1) on NCDHW tensors (the 3-D latent UNet of the LDM
+ * configuration): one launch of the 3x3 kernel per depth tap, an "image" = (batch item, output slice).  Needs Cin % 64 == 0,
+ * Cout % 64 == 0, an even Wo <= 64 and the scratch of ddpm_conv3d_wgrad_scratch_floats.  */
+size_t ddpm_conv3d_wgrad_scratch_floats(int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int stride);
+int ddpm_conv3d_wgrad_f32(const float *a, const float *dy, float *dw, int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho,
+                          int Wo, int stride, float *scratch, size_t scratch_floats, ddpm_stream_t stream);
+/* wt[Cin, Cout, taps] = w[Cout, Cin, taps] with the taps in reverse order (taps = k^2 or k^3: the kernel rotated by 180 degrees
+ * about every axis) and the channel axes transposed: conv(dy, wt, padding = k / 2) is the input gradient of a stride-1
+ * convolution (of a stride-2 one after ddpm_resample2_f32 / ddpm_resample3_f32(mode 2) of dy).  */
+int ddpm_conv_weight_rot180t_f32(const float *w, float *wt, int Cout, int Cin, int taps, ddpm_stream_t stream);
 
 /* F.group_norm in its training form.  mean_rstd: [B, groups, 2] = {mean, 1 / sqrt(var + eps)} (biased variance), kept for the
  * backward; ddpm_gn_apply_f32: y = act((x - mean) rstd gamma + beta), act = DDPM_ACT_NONE or DDPM_ACT_SILU;
@@ -526,6 +533,8 @@ int ddpm_chan_copy_f32(const float *src, float *dst, int B, int C, int Csrc, int
 /* planes of H x W (the SMALL extent) <-> 2H x 2W.  mode 0: nearest x2 (F.interpolate of generative's Upsample); 1: its adjoint,
  * out[y, x] = sum of in's 2x2 block; 2: zero-stuffing, out[2y, 2x] = in[y, x], 0 elsewhere (a stride-2 convolution's dy).  */
 int ddpm_resample2_f32(const float *in, float *out, int64_t planes, int H, int W, int mode, ddpm_stream_t stream);
+/* the same three maps on volumes of D x H x W (the SMALL extent) <-> 2D x 2H x 2W  */
+int ddpm_resample3_f32(const float *in, float *out, int64_t planes, int D, int H, int W, int mode, ddpm_stream_t stream);
 /* softmax over each row in place; its backward ds = p (dp - sum(dp p)) in place over dp  */
 int ddpm_softmax_rows_f32(float *s_inout, int64_t rows, int cols, ddpm_stream_t stream);
 int ddpm_softmax_backward_rows_f32(const float *p, float *dp_inout, int64_t rows, int cols, ddpm_stream_t stream);

@@ -133,12 +133,14 @@ def test_one_adam_step_on_rocm_matches_cpu_torch(device, tmp_path, native):
     print(f"one Adam step: loss {loss_r.item():.6f}, worst gradient max-norm relative error {worst:.2e}")
 
 
-@pytest.mark.parametrize("model_type,channels,size,B", [("big", 3, 64, 2), ("small", 3, 32, 8)])
-def test_native_step_matches_aten_autograd_on_other_unets(device, model_type, channels, size, B):
+@pytest.mark.parametrize("model_type,channels,size,B,dims", [("big", 3, 64, 2, 2), ("small", 3, 32, 8, 2), ("small", 128, 8, 4, 3)])
+def test_native_step_matches_aten_autograd_on_other_unets(device, model_type, channels, size, B, dims):
     """The native backward against an INDEPENDENT implementation on the same device (PyTorch-ROCm autograd over MIOpen / rocBLAS,
     the DDPM_TRAIN_NATIVE=0 route) where the CPU oracle would take minutes: the `big` UNet of BASELINE configs[3]
     (/root/reference/src/trainers/base.py:77-86: two ResnetBlocks per level, attention on every level -- 4 096 tokens at 64x64,
-    one / two / three heads of 256 channels) on 3-channel 64x64 images, and the 3-channel `small` UNet of configs[2].  Loss and
+    one / two / three heads of 256 channels) on 3-channel 64x64 images, the 3-channel `small` UNet of configs[2], and the 3-D
+    latent UNet of configs[4] (128 latent channels, 8^3 latents: conv3d forward / input gradients, the per-depth-tap weight
+    gradient, 3-D nearest x2 / zero stuffing).  Loss and
     every parameter gradient (max-norm relative error <= 1e-4 of the larger of its own scale and 1e-5 of the model's largest)."""
     from ddpm_ood_amd import DiffusionModelUNet
     from ddpm_ood_amd.synthetic import random_state_dict
@@ -146,14 +148,15 @@ def test_native_step_matches_aten_autograd_on_other_unets(device, model_type, ch
     from ddpm_ood_amd.train_native import NativeUNetStep
     from ddpm_ood_amd.trainer import MODEL_CONFIGS
 
-    sd = random_state_dict(model_type, channels, seed=1)
+    sd = random_state_dict(model_type, channels, spatial_dims=dims, seed=1)
     g = torch.Generator().manual_seed(5)
-    x = torch.rand(B, channels, size, size, generator=g).to(device)
+    shape = (B, channels) + (size,) * dims
+    x = torch.rand(shape, generator=g).to(device)
     t = torch.randint(0, 1000, (B,), generator=g).to(device)
-    noise = torch.randn(B, channels, size, size, generator=g).to(device)
+    noise = torch.randn(shape, generator=g).to(device)
 
     def build():
-        m = DiffusionModelUNet(2, channels, channels, **MODEL_CONFIGS[model_type])
+        m = DiffusionModelUNet(dims, channels, channels, **MODEL_CONFIGS[model_type])
         m.load_state_dict(sd)
         return m.to(device).train()
 
@@ -177,7 +180,38 @@ def test_native_step_matches_aten_autograd_on_other_unets(device, model_type, ch
         rel = float((ph[k].grad - pr[k].grad).abs().max() / max(float(pr[k].grad.abs().max()), 1e-5 * gmax))
         worst = max(worst, (k, rel), key=lambda kv: kv[1])
         assert rel <= 1e-4, (k, rel)
-    print(f"{model_type}, {channels} x {size}^2, B = {B}: loss {loss_r.item():.6f}, worst gradient error {worst[1]:.2e} ({worst[0]})")
+    print(f"{model_type}, {channels} x {size}^{dims}, B = {B}: loss {loss_r.item():.6f}, worst gradient error {worst[1]:.2e} ({worst[0]})")
+
+
+def test_ldm_training_runs_natively_on_vqvae_latents(device, tmp_path):
+    """BASELINE configs[4]'s training side (the reference trains the latent DDPM with --vqvae_checkpoint and
+    --spatial_dimension=3, /root/reference/src/trainers/ddpm_trainer.py:78-101 over base.py:44-61): 32^3 volumes -> a small
+    VQ-VAE (HIP) -> [128, 8, 8, 8] latents -> the 3-D `small` UNet, two epochs on the NATIVE step (conv3d forward, per-depth-tap
+    weight gradient, 3-D zero-stuffed / summed resampling); the loss goes down and the checkpoint loads back."""
+    import json
+
+    from ddpm_ood_amd.train import DDPMTrainer
+    from ddpm_ood_amd.vqvae import VQVAE
+
+    cfg = dict(spatial_dims=3, in_channels=1, out_channels=1, num_channels=(16, 32), num_res_layers=1,
+               num_res_channels=(16, 32), downsample_parameters=((2, 4, 1, 1), (2, 4, 1, 1)),
+               upsample_parameters=((2, 4, 1, 1, 0), (2, 4, 1, 1, 0)), num_embeddings=64, embedding_dim=128)
+    torch.manual_seed(3)
+    vq = VQVAE(**cfg).eval()
+    vq_dir = tmp_path / "vqvae"
+    vq_dir.mkdir()
+    torch.save({"model_state_dict": vq.state_dict()}, vq_dir / "checkpoint.pth")
+    json.dump(cfg, open(vq_dir / "vqvae_config.json", "w"))
+    args = _train_args(tmp_path, model_name="decathlon_trained", spatial_dimension=3, vqvae_checkpoint=str(vq_dir / "checkpoint.pth"),
+                       training_ids="synthetic:blobs3d:n=8:size=32:seed=1", validation_ids="synthetic:blobs3d:n=2:size=32:seed=10",
+                       batch_size=4, n_epochs=3, eval_freq=3, checkpoint_every=0)
+    tr = DDPMTrainer(args)
+    assert tr.native and tr.model.spatial_dims == 3 and tr.model.in_channels == 128
+    tr.train(args)
+    losses = [l for _, l in tr.history]
+    assert len(losses) == 3 and all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
+    ck = torch.load(tmp_path / args.model_name / "checkpoint.pth", map_location="cpu", weights_only=False)
+    assert ck["model_state_dict"]["conv_in.conv.weight"].shape == (128, 128, 3, 3, 3) and ck["optimizer_state_dict"]["state"]
 
 
 def test_native_training_step_launches_no_aten_or_library_kernels(device):

@@ -95,6 +95,44 @@ def test_conv_wgrad_vs_autograd(device, case):
         assert torch.equal(dw, T.conv_wgrad(a.to(device), dy.to(device), k, s))
 
 
+@pytest.mark.parametrize("case", [(2, 128, 128, 8, 1), (3, 64, 128, 4, 1), (2, 128, 64, 8, 2), (2, 64, 64, 4, 2), (1, 64, 64, 2, 1)])
+def test_conv3d_wgrad_and_input_gradient_vs_autograd(device, case):
+    """F.conv3d(k3, padding 1, stride 1 / 2) on NCDHW latents: the per-depth-tap weight gradient and the input gradient through
+    ops.conv3d with rotated / transposed weights (stride 2: through a zero-stuffed dy)."""
+    from ddpm_ood_amd import ops
+    from ddpm_ood_amd import train_ops as T
+
+    B, cin, cout, S, stride = case
+    g = torch.Generator().manual_seed(sum(case))
+    a = torch.randn(B, cin, S, S, S, generator=g)
+    w0 = torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)
+    ad, wd = a.double().requires_grad_(True), w0.double().requires_grad_(True)
+    y = F.conv3d(ad, wd, stride=stride, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    ra, rw = torch.autograd.grad(y, (ad, wd), dy.double())
+    dw = T.conv3d_wgrad(a.to(device), dy.to(device), stride)
+    assert dw.shape == rw.shape and _rel(dw, rw) < 3e-6, _rel(dw, rw)
+    assert torch.equal(dw, T.conv3d_wgrad(a.to(device), dy.to(device), stride))
+    if cin % 128 == 0 and cout % 4 == 0:  # the input-gradient convolution is cout -> cin: needs an MFMA tiling of its own
+        wt = T.conv_weight_rot180t(w0.to(device))
+        assert torch.equal(wt.cpu(), w0.flip(2, 3, 4).transpose(0, 1).contiguous())
+        d = dy.to(device) if stride == 1 else T.zero_stuff2(dy.to(device))
+        dx = ops.conv3d(d, wt, wino=ops.pack_wino3d_weight(wt))
+        assert dx.shape == ra.shape and _rel(dx, ra) < 2e-5, _rel(dx, ra)
+
+
+def test_volume_resampling_kernels(device):
+    from ddpm_ood_amd import train_ops as T
+
+    g = torch.Generator().manual_seed(3)
+    s = torch.randn(2, 3, 4, 5, 6, generator=g)
+    assert torch.equal(T.upsample2(s.to(device)).cpu(), F.interpolate(s, scale_factor=2.0, mode="nearest"))
+    big = torch.randn(2, 3, 8, 10, 12, generator=g)
+    assert _rel(T.sumpool2(big.to(device)), 8 * F.avg_pool3d(big.double(), 2)) < 1e-6
+    z = T.zero_stuff2(s.to(device)).cpu()
+    assert torch.equal(z[:, :, ::2, ::2, ::2], s) and float(z.abs().sum()) == float(s.abs().sum())
+
+
 # ---- input gradients through ddpm_conv_f32 with rotated / transposed weights ------------------------------------------------
 @pytest.mark.parametrize("case", [(4, 128, 128, 32, "s1"), (4, 128, 256, 16, "s1"), (4, 128, 128, 32, "s2"), (3, 256, 256, 8, "up"),
                                   (4, 128, 1, 32, "s1")])
