@@ -44,6 +44,11 @@ def native_supported(model) -> bool:
 
 
 class NativeUNetStep:
+    """Build it AFTER the model is on its device: construction re-homes every parameter into one flat buffer (``.data`` becomes a
+    view of ``self.flat``, ``.grad`` a view of ``self.gflat``); a later ``model.to(...)`` / ``load_state_dict(assign=True)`` would
+    replace those views and silently detach the model from the stepper (``load_state_dict`` with the default ``assign=False``
+    copies INTO the views and is fine -- that is how a checkpoint is resumed)."""
+
     def __init__(self, model, lr: float = 2.5e-5, betas=(0.9, 0.999), eps: float = 1e-8):
         if not native_supported(model):
             raise NotImplementedError("native training covers 2-D UNets and 3-D UNets whose channel counts have an MFMA tiling")

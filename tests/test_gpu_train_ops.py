@@ -244,7 +244,7 @@ def test_elementwise_and_reduction_kernels(device):
     lr = F.mse_loss(pdd, tgt.double())
     (rg,) = torch.autograd.grad(lr, pdd)
     loss, dpred = T.mse_loss_grad(pred.to(device), tgt.to(device))
-    assert abs(float(loss.cpu()) - float(lr)) < 2e-6 * float(lr) and _rel(dpred, rg) < 2e-6
+    assert abs(float(loss.cpu()) - lr.item()) < 2e-6 * lr.item() and _rel(dpred, rg) < 2e-6
     t = T.fill_(torch.empty(1000, device=device), 2.5)
     assert bool((t == 2.5).all())
 

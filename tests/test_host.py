@@ -568,3 +568,24 @@ def test_product_lpips_refuses_cpu_tensors():
     pl = PerceptualLoss(dimensions=2, include_pixel_loss=False, is_fake_3d=False, lpips_normalize=True)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pl(torch.rand(2, 1, 32, 32), torch.rand(2, 1, 32, 32))
+
+
+def test_native_training_host_logic():
+    """Row f-3, CPU-checkable parts: which UNets the native step covers, that it refuses a model on the CPU (no fallback), and
+    that the GEMM descriptor the Python wrapper fills has the header's field order."""
+    import ctypes as C
+
+    from ddpm_ood_amd import DiffusionModelUNet
+    from ddpm_ood_amd._lib import GemmDesc
+    from ddpm_ood_amd.train_native import NativeUNetStep, native_supported
+    from ddpm_ood_amd.trainer import MODEL_CONFIGS
+
+    small2d = DiffusionModelUNet(2, 1, 1, **MODEL_CONFIGS["small"])
+    assert native_supported(small2d)
+    assert native_supported(DiffusionModelUNet(3, 128, 128, **MODEL_CONFIGS["small"]))       # the LDM's latent UNet
+    assert not native_supported(DiffusionModelUNet(3, 1, 1, **MODEL_CONFIGS["small"]))        # 1-channel volumes: no conv3d tiling
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        NativeUNetStep(small2d)
+    names = [f[0] for f in GemmDesc._fields_]
+    assert names[:7] == ["A", "B", "C", "M", "N", "K", "k_inner"] and names[-2:] == ["scratch", "scratch_floats"]
+    assert C.sizeof(GemmDesc) % 8 == 0
