@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("B", C.c_int), ("Cout", C.c_int),
         ("Hi", C.c_int), ("Wi", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
         ("ksize", C.c_int), ("mode", C.c_int), ("act", C.c_int), ("force_direct", C.c_int),
-        ("Di", C.c_int), ("Do", C.c_int), ("dims", C.c_int), ("reserved0", C.c_int),
+        ("Di", C.c_int), ("Do", C.c_int), ("dims", C.c_int), ("depth_taps", C.c_int),
         ("w_folded", C.c_void_p), ("out_act", C.c_int), ("reserved", C.c_int), ("w_wino", C.c_void_p),
         ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t), ("w_wino44", C.c_void_p),
         ("w_wino44h", C.c_void_p), ("stats_out", C.c_void_p), ("w_d3h", C.c_void_p),
@@ -90,6 +90,8 @@ SIGNATURES = {
     "ddpm_packed_convtr_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ddpm_pack_convtr_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_conv3d_k4s2_cin1_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
+    "ddpm_convtr3d_parity_weights_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ddpm_parity_interleave3_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_convtr3d_k4s2_cout1_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "ddpm_wino_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_wino_weight_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -205,4 +205,55 @@ int launch_convnd_generic(const float *in, const float *w, const float *bias, co
   return 0;
 }
 
+
+// ---- ConvTranspose3d k4 s2 p1 as eight parity convolutions (ddpm_convtr3d_parity_weights_f32 in the header) -----------------
+// tap t (0..2, input offset t - 1) of parity q reads kernel element: q = 0: (3, 1, none), q = 1: (none, 2, 0)
+__device__ __forceinline__ int convtr_parity_tap(int q, int t) { return q == 0 ? (t == 0 ? 3 : t == 1 ? 1 : -1) : (t == 1 ? 2 : t == 2 ? 0 : -1); }
+
+__global__ void convtr3d_parity_weights_kernel(const float *__restrict__ w, float *__restrict__ g, int Cin, int Cout) {
+  const int64_t per = (int64_t)Cout * Cin * 27, total = 8 * per;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int q = (int)(i / per);
+  const int64_t r = i - q * per;
+  const int tap = (int)(r % 27);
+  const int ci = (int)((r / 27) % Cin), co = (int)(r / ((int64_t)27 * Cin));
+  const int kz = convtr_parity_tap(q >> 2, tap / 9), ky = convtr_parity_tap((q >> 1) & 1, (tap / 3) % 3), kx = convtr_parity_tap(q & 1, tap % 3);
+  g[i] = (kz < 0 || ky < 0 || kx < 0) ? 0.f : w[(((size_t)ci * Cout + co) * 4 + kz) * 16 + ky * 4 + kx];
+}
+
+// one thread per (plane, output z, output y, input x): the two x parities of an output row pair as one 8-byte store
+__global__ void parity_interleave3_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t planes, int D, int H, int W) {
+  const int64_t n = planes * 2 * D * 2 * H * W;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W);
+  const int y2 = (int)((i / W) % (2 * H)), z2 = (int)((i / ((int64_t)W * 2 * H)) % (2 * D));
+  const int64_t pl = i / ((int64_t)W * 2 * H * 2 * D);
+  const int q = ((z2 & 1) << 2) | ((y2 & 1) << 1);
+  const size_t vol = (size_t)D * H * W, qs = (size_t)planes * vol;
+  const size_t so = pl * vol + ((size_t)(z2 >> 1) * H + (y2 >> 1)) * W + x;
+  const float2 v = make_float2(src[q * qs + so], src[(q | 1) * qs + so]);
+  *reinterpret_cast<float2 *>(dst + ((pl * 2 * D + z2) * 2 * H + y2) * (size_t)(2 * W) + 2 * x) = v;
+}
+
 }  // namespace ddpm
+
+extern "C" int ddpm_convtr3d_parity_weights_f32(const float *w, float *g, int Cin, int Cout, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(w && g && Cin > 0 && Cout > 0, "convtr3d_parity_weights: bad arguments");
+  const int64_t total = (int64_t)8 * Cout * Cin * 27;
+  hipLaunchKernelGGL(ddpm::convtr3d_parity_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ddpm::as_stream(stream), w, g,
+                     Cin, Cout);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_parity_interleave3_f32(const float *src, float *dst, int64_t planes, int D, int H, int W, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(src && dst && planes > 0 && D > 0 && H > 0 && W > 0, "parity_interleave3: bad arguments");
+  hipStream_t s = ddpm::as_stream(stream);
+  const int64_t n = planes * 4 * D * H * W;
+  ddpm::ProfScope prof(s, "convT3d_parity_interleave", 0.0, 64.0 * planes * D * H * W);
+  hipLaunchKernelGGL(ddpm::parity_interleave3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, planes, D, H, W);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}

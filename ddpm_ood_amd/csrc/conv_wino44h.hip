@@ -83,6 +83,12 @@ bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing) {
   g.NCHc = Cin / kC;
   g.kd0 = is3d && Dd == 1 ? 1 : 0;
   g.nkd = is3d && Dd > 1 ? 3 : 1;
+  // ddpm_conv_desc.depth_taps (ABI 10): a 3x3x3 weight whose first or last depth tap is all zeros (the parity convolutions a
+  // ConvTranspose k4 s2 decomposes into, vqvae.py) walks two taps instead of three
+  if (is3d && Dd > 1 && (d.depth_taps == 3 || d.depth_taps == 6)) {
+    g.kd0 = d.depth_taps == 6 ? 1 : 0;
+    g.nkd = 2;
+  }
   g.nkd_w = is3d ? 3 : 1;
   g.NCH = g.nkd * g.NCHc;
   g.HW = d.Ho * d.Wo;

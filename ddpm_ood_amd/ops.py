@@ -304,7 +304,7 @@ def pack_wino44h_3d_weight(weight: torch.Tensor) -> torch.Tensor | None:
 
 
 def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=None, packed=None, stride: int = 1,
-           wino=None, out=None, wino44=None, wino44h=None, chan_add=None):
+           wino=None, out=None, wino44=None, wino44h=None, chan_add=None, depth_taps: int = 0):
     """F.conv3d(act(x), weight, bias, stride, padding=1) (+ chan_add[n, co] + residual, + output activation) on NCDHW tensors:
     kernel 3 stride 1 or 2 (the 3-D UNet's ResnetBlock / Downsample convolutions), or kernel 4 stride 2 (the VQ-VAE's).  ONE launch of the MFMA kernel: the depth taps are part of its chunk
     stream (chunk = (depth tap, channel group)), so the output is written once.  ``wino`` (pack_wino3d_weight): a
@@ -345,7 +345,7 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
             for s0 in range(0, B, nb):
                 conv3d(x[s0:s0 + nb], w, bias, act=act, out_act=out_act, packed=packed, stride=stride, wino=wino,
                        wino44=wino44, wino44h=wino44h, residual=None if residual is None else residual[s0:s0 + nb],
-                       out=out[s0:s0 + nb], chan_add=None if chan_add is None else chan_add[s0:s0 + nb])
+                       out=out[s0:s0 + nb], chan_add=None if chan_add is None else chan_add[s0:s0 + nb], depth_taps=depth_taps)
             return out
     d = ConvDesc()
     d.in1, d.C1 = ptr(x), Cc
@@ -354,6 +354,7 @@ def conv3d(x, weight, bias=None, *, act=ACT_NONE, out_act=ACT_NONE, residual=Non
     d.B, d.Cout, d.Hi, d.Wi, d.Ho, d.Wo = B, cout, H, W, Ho, Wo
     d.ksize, d.mode, d.act, d.out_act = k, (CONV_NORMAL if stride == 1 else CONV_STRIDE2), act, out_act
     d.Di, d.Do, d.dims = D, Do, 3
+    d.depth_taps = depth_taps  # 3 / 6: the first / last depth tap of the weight is all zeros (conv_transpose_parity)
     if chan_add is not None:
         chan_add = require_device_f32(chan_add, "chan_add")
         d.chan_add, d.chan_add_stride = ptr(chan_add), chan_add.shape[1]
@@ -397,6 +398,51 @@ def conv_transpose(x, weight, bias=None, *, out_act=ACT_NONE, packed=None):
     if dims == 3:
         d.Di, d.Do, d.dims = D, 2 * D, 3
     check(lib.ddpm_conv_f32(C_byref(d), stream_ptr()), "conv_transpose")
+    return out
+
+
+def conv_transpose_parity_supported(x, weight) -> bool:
+    """ConvTranspose3d k4 s2 p1 whose eight parity convolutions (3x3x3 over the INPUT grid) have the split-f16 F(4x4) tiling:
+    slices of at least 32 4x4 tiles in whole tile rows, channel counts with an MFMA tiling."""
+    if x.ndim != 5 or weight.ndim != 5 or tuple(weight.shape[2:]) != (4, 4, 4):
+        return False
+    cin, cout = weight.shape[0], weight.shape[1]
+    D, H, W = x.shape[2:]
+    if D < 2 or H % 4 or W % 4 or cin % 16 or cout % 128:
+        return False
+    twc, thr = W // 4, H // 4
+    tr = 32 // twc if twc and 32 % twc == 0 else 0  # tile rows per item
+    # (the kernel's item: 32 tiles in whole tile rows, its 4 tr + 2 staged rows inside the slice)
+    return tr > 0 and thr % tr == 0 and H >= 4 * tr + 2 and W <= 64
+
+
+def pack_convT_parity_weights(weight):
+    """[Cin, Cout, 4, 4, 4] -> per output parity q = 4 qz + 2 qy + qx: (the 3x3x3 weight [Cout, Cin, 3, 3, 3], its MFMA-packed form,
+    its split-f16 F(4x4) planes)."""
+    lib = _lib.load()
+    w = require_device_f32(weight, "weight")
+    cin, cout = w.shape[0], w.shape[1]
+    g = torch.empty((8, cout, cin, 3, 3, 3), dtype=torch.float32, device=w.device)
+    check(lib.ddpm_convtr3d_parity_weights_f32(ptr(w), ptr(g), cin, cout, stream_ptr()), "convtr3d_parity_weights")
+    return [(g[q], pack_conv3d_weight(g[q]), pack_wino44h_3d_weight(g[q])) for q in range(8)]
+
+
+def conv_transpose_parity(x, parity_weights, bias=None, *, out_act=ACT_NONE, sub_batch: int = 8):
+    """F.conv_transpose3d(x, w, bias, stride 2, padding 1) (+ ReLU) as eight stride-1 3x3x3 convolutions -- each on the split-f16
+    F(4x4) kernel, walking only its two non-zero depth taps -- and one interleave pass; `sub_batch` volumes at a time so that
+    the eight parity tensors stay a bounded scratch (8 x the input extent x Cout)."""
+    lib = _lib.load()
+    x = require_device_f32(x, "x")
+    B, _, D, H, W = x.shape
+    cout = parity_weights[0][0].shape[0]
+    out = torch.empty((B, cout, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    for s0 in range(0, B, sub_batch):
+        xb = x[s0:s0 + sub_batch]
+        nb = xb.shape[0]
+        tmp = torch.empty((8, nb, cout, D, H, W), dtype=torch.float32, device=x.device)
+        for q, (g, packed, w44h) in enumerate(parity_weights):
+            conv3d(xb, g, bias, out_act=out_act, packed=packed, wino44h=w44h, out=tmp[q], depth_taps=6 if q & 4 else 3)
+        check(lib.ddpm_parity_interleave3_f32(ptr(tmp), ptr(out[s0:s0 + nb]), nb * cout, D, H, W, stream_ptr()), "parity_interleave3")
     return out
 
 

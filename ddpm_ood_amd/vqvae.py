@@ -9,16 +9,20 @@ configuration: ctor from ``vqvae_config.json`` + ``load_state_dict`` (base.py:44
 ``encode_stage_2_inputs`` / ``decode_stage_2_outputs`` (reconstruct.py:124,166).  SURVEY.md 8(f) row f-1: on a
 ROCm device every layer of the reference configuration (README.md:153-158: 4 stride-2 levels, 256 channels,
 embedding 128 x 2 048) runs on the library's HIP kernels -- the 3x3x3 convolutions, the k4 s2 down-convolutions and
-the k4 s2 transposed convolutions on the fp32-MFMA kernel (one launch each, depth taps / output parities inside),
-the single-channel first / last layers on ``conv3d_edge.hip``, the nearest-code search on ``vq.hip``.  Shapes
-without an MFMA tiling (channel counts not multiples of 128 / 8) fall back to PyTorch-ROCm ops and say so once.
+the k4 s2 transposed convolutions on the fp32-MFMA kernel (one launch each, depth taps / output parities inside) -- the
+largest one (32^3 -> 64^3) since round 6 as eight parity convolutions on the split-f16 F(4x4) kernel + one interleave
+pass (``ops.conv_transpose_parity``) --, the single-channel first / last layers on ``conv3d_edge.hip``, the nearest-code
+search on ``vq.hip``.  Shapes without an MFMA tiling (channel counts not multiples of 128 / 8) take the library's generic
+HIP convolution and say so once (no PyTorch-ROCm route).
 """
+
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 
 
 class PassthroughVQVAE(torch.nn.Module):
@@ -94,6 +98,11 @@ class _Convolution(nn.Module):
             if (k, s) != (4, 2):
                 return None
             if ops.conv3d_supported(w, 2, transposed=True):
+                # the split-f16 form (eight parity convolutions on the F(4x4) kernel, round 6) where its tiling exists and the
+                # split-f16 families are on; the fp32-MFMA transposed kernel otherwise (smaller levels, ddpm_set_split_f16(0))
+                if ops.conv_transpose_parity_supported(x, w) and _lib.split_f16_active() and \
+                        os.environ.get("DDPM_CONVT_PARITY", "1") != "0":
+                    return "convT_parity"
                 return "convT"
             return "convT_cout1" if w.shape[1] == 1 else None
         if (k, s) == (3, 1):
@@ -117,6 +126,11 @@ class _Convolution(nn.Module):
                 self._packed = (key, ops.pack_conv_weight(w.detach()), wino)
             return ops.conv(x.float().contiguous(), w.detach(), b.detach() if b is not None else None, packed=self._packed[1],
                             wino=self._packed[2], out_act=out_act)
+        if kind == "convT_parity":
+            key = (w.data_ptr(), w._version, "parity")
+            if self._packed is None or self._packed[0] != key:
+                self._packed = (key, ops.pack_convT_parity_weights(w.detach()))
+            return ops.conv_transpose_parity(x.float().contiguous(), self._packed[1], b.detach(), out_act=out_act)
         if kind in ("conv", "convT"):
             key = (w.data_ptr(), w._version)
             if self._packed is None or self._packed[0] != key:

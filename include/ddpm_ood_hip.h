@@ -88,7 +88,11 @@ typedef struct ddpm_conv_desc {
    * conv is the 2-D op over an (D*H) x W image.  dims = 0 or 2: plain 2-D (Di = Do = 0).                     */
   int Di, Do;
   int dims;
-  int reserved0;
+  /* dims = 3, kernel 3 (ABI 10; was reserved): bit kd set = depth tap kd of the 3x3x3 weight may be non-zero; 0 = all three.
+   * 3 (taps 0, 1) and 6 (taps 1, 2) let the split-f16 F(4x4) form skip the all-zero tap; every other kernel ignores the field
+   * (the zero tap then costs time, never correctness).  Set by the parity decomposition of ConvTranspose3d k4 s2
+   * (ddpm_convtr3d_parity_weights_f32).  */
+  int depth_taps;
   /* Optional, 2-D DDPM_CONV_UPSAMPLE2 only: weights folded by ddpm_fold_upsample_weight_f32.  A 3x3
    * conv over a nearest-x2 upsampled image is, for each of the 4 output parities (dy, dx), a 2x2 conv
    * over the low-res image whose taps are sums of the 3x3 taps that read the same source pixel:
@@ -201,6 +205,14 @@ int ddpm_convnd_generic_f32(const float *in, const float *w, const float *bias, 
                             ddpm_stream_t stream);
 int ddpm_convtr3d_k4s2_cout1_f32(const float *in, const float *w, const float *bias, float *out, int B, int Cin, int D,
                                 int H, int W, ddpm_stream_t stream);
+/* ConvTranspose3d(k = 4, stride 2, padding 1) as EIGHT stride-1 3x3x3 convolutions over the input grid, one per output parity
+ * (qz, qy, qx): out[2j] = w[1] x[j] + w[3] x[j - 1], out[2j + 1] = w[2] x[j] + w[0] x[j + 1] per axis, i.e. 3-tap kernels
+ * (w[3], w[1], 0) and (0, w[2], w[0]) -- so that the VQ-VAE decoder's largest up-convolution (256 -> 256, 32^3 -> 64^3; reference
+ * call site src/trainers/reconstruct.py:166) runs on the split-f16 F(4x4) kernel (ddpm_conv_desc.depth_taps = 3 for qz = 0, 6 for
+ * qz = 1) instead of the fp32-MFMA transposed kernel.  g: [8][Cout, Cin, 3, 3, 3] from the torch weight w [Cin, Cout, 4, 4, 4];
+ * parity q = 4 qz + 2 qy + qx.  ddpm_parity_interleave3_f32: dst[pl, 2z + qz, 2y + qy, 2x + qx] = src[q][pl, z, y, x].  */
+int ddpm_convtr3d_parity_weights_f32(const float *w, float *g, int Cin, int Cout, ddpm_stream_t stream);
+int ddpm_parity_interleave3_f32(const float *src, float *dst, int64_t planes, int D, int H, int W, ddpm_stream_t stream);
 
 /* Pack `ksize*ksize` taps starting at `tap_off` out of the `src_taps` taps of a wider torch kernel, e.g. depth
  * tap kd of a conv3d weight [Cout, Cin, 3, 3, 3]: src_taps = 27, tap_off = 9 * kd.                       */

@@ -479,6 +479,59 @@ def test_conv_transpose3d_k4s2_matches_torch(device, B, Cin, Cout, D, H, W):
     _close(ops.conv_transpose(d(x), d(w), None), F.conv_transpose3d(x, w, None, stride=2, padding=1))
 
 
+@pytest.mark.parametrize("B,Cin,Cout,D,H,W,force", [(1, 64, 128, 4, 32, 32, True), (1, 64, 128, 4, 32, 32, False),
+                                                      (1, 256, 256, 32, 32, 32, False), (3, 32, 128, 2, 32, 64, True)])
+def test_conv_transpose3d_as_eight_parity_convolutions(device, monkeypatch, B, Cin, Cout, D, H, W, force):
+    """The round-6 form of the VQ-VAE's largest up-convolution (reference: src/trainers/reconstruct.py:166 via the decoder): eight
+    stride-1 3x3x3 convolutions over the input grid, one per output parity, on the split-f16 F(4x4) kernel walking its two
+    non-zero depth taps (ddpm_conv_desc.depth_taps), then one interleave pass -- against F.conv_transpose3d.  force: the F(4x4)
+    kernel whatever the launch size (a 4-slice volume does not fill the chip: it would take the fallbacks, which ignore the mask
+    and multiply the zero tap -- the other branch of this test); the 256 -> 256, 32^3 case is the decoder's own launch."""
+    from ddpm_ood_amd import ops
+
+    if force:
+        monkeypatch.setenv("DDPM_CONV_WINO44", "2")
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, D, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 4, 4, 4, generator=g) / math.sqrt(Cin * 8)
+    b = torch.randn(Cout, generator=g)
+    d = lambda t: t.to(device)
+    assert ops.conv_transpose_parity_supported(d(x), d(w))
+    if W == 32:  # (four tile rows per item: its 18 staged rows do not fit a 16-row slice)
+        assert not ops.conv_transpose_parity_supported(d(x)[:, :, :, :16], d(w))
+    pw = ops.pack_convT_parity_weights(d(w))
+    # the parity weights are what the closed form says: 3-tap kernels (w[3], w[1], 0) / (0, w[2], w[0]) per axis
+    g0 = pw[0][0].cpu()
+    assert torch.equal(g0[:, :, 0, 1, 1], w[:, :, 3, 1, 1].t()) and float(g0[:, :, 2].abs().max()) == 0.0
+    g7 = pw[7][0].cpu()
+    assert torch.equal(g7[:, :, 2, 2, 1], w[:, :, 0, 0, 2].t()) and float(g7[:, :, 0].abs().max()) == 0.0
+    prof_on = _prof(True)
+    y = ops.conv_transpose_parity(d(x), pw, d(b), out_act=ops.ACT_RELU, sub_batch=2)
+    prof = _prof(False, prof_on)
+    _close(y, F.relu(F.conv_transpose3d(x, w, b, stride=2, padding=1)))
+    _close(ops.conv_transpose_parity(d(x), pw, None), F.conv_transpose3d(x, w, None, stride=2, padding=1))
+    if force or (Cin, D) == (256, 32):
+        assert "conv3d_wino44h" in prof and prof["conv3d_wino44h"]["launches"] == 8 * ((B + 1) // 2), sorted(prof)
+    assert "convT3d_parity_interleave" in prof
+
+
+def _prof(on, token=None):
+    import ctypes
+    import json
+
+    from ddpm_ood_amd import _lib
+
+    lib = _lib.load()
+    if on:
+        lib.ddpm_prof_enable(1)
+        return True
+    torch.cuda.synchronize()
+    lib.ddpm_prof_enable(0)
+    buf = ctypes.create_string_buffer(1 << 18)
+    n = lib.ddpm_prof_report(buf, len(buf))
+    return json.loads(buf.value.decode()) if n > 0 else {}
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 128, 128, 8, 8), (1, 64, 256, 16, 32), (3, 8, 128, 1, 3)])
 def test_conv_transpose2d_k4s2_matches_torch(device, B, Cin, Cout, H, W):
     from ddpm_ood_amd import ops
