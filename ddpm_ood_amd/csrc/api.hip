@@ -43,6 +43,7 @@ static void load_switches() {
   n.down_s2h = env_int("DDPM_DOWN_S2H", 1);
   n.conv1x1_f16x3 = env_int("DDPM_CONV1X1_F16X3", 1) != 0;
   n.attn_f16x3 = env_int("DDPM_ATTN_F16X3", 1) != 0;
+  n.wgrad_f16x3 = env_int("DDPM_WGRAD_F16X3", 1) != 0;
   n.attn_fa = env_int("DDPM_ATTN_FA", 1);
   n.conv_d3s = env_int("DDPM_CONV_D3S", 1);
   n.d1s_maxpx = env_int("DDPM_D1S_MAXPX", 16384);

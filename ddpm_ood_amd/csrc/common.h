@@ -60,6 +60,7 @@ struct Switches {
   bool convout_wave = true;     // DDPM_CONVOUT_WAVE
   long convout_w16_maxwg = -1;  // DDPM_CONVOUT_W16_MAXWG (-1: two workgroups per CU)
   long convin_blocks_per_cu = 8;  // DDPM_CONVIN_BLOCKS_PER_CU
+  bool wgrad_f16x3 = true;      // DDPM_WGRAD_F16X3: 0 the 3x3 weight gradient of the training step stays on the fp32 MFMA
   bool prof_shapes = false;     // DDPM_PROF_SHAPES
   bool split_f16 = true;        // ddpm_set_split_f16(): false = every split-f16 family runs its fp32-MFMA form
 };

@@ -20,6 +20,8 @@
 // accumulator register i of lane l: row m = 8 (i / 4) + 4 (l / 32) + i % 4, column n = l % 32.
 #include "common.h"
 
+#include <algorithm>
+
 namespace ddpm {
 
 namespace {
@@ -155,6 +157,11 @@ struct WgradP {
   int fast;
   int LPR, RPI, NA;  // lanes per input row (Wi / 4), (channel, row) pairs per wave instruction, staging iterations of the input tile
   int LPD, CPI, ND;  // lanes per dY channel (PT / 4), channels per wave instruction, staging iterations of the dY tile
+  // split-f16 form (stride 1, W a power of two in 8 .. 64, 64-pixel tiles): f16 LDS tiles, v_mfma_f32_32x32x16_f16
+  int h16;                // the form applies
+  int ACSh;               // input tile channel stride in halves ((R + 2) W + 8: a multiple of 8 with an odd 16-byte count)
+  const unsigned *amax;   // float bits of the partial maxima of |dY| (amax_nd of them) then |a| (amax_na) (wgrad_absmax_kernel)
+  int amax_nd, amax_na;
 };
 
 constexpr int kNA = 12, kND = 4;  // most staging iterations per thread (register arrays)
@@ -340,6 +347,221 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_staged_kernel(const WgradP 
     }
 }
 
+// ---- the split-f16 form -------------------------------------------------------------------------------------------
+// The same contraction on v_mfma_f32_32x32x16_f16 at split precision (common.h: a b ~= ah bh + (ah 2^-5)(bl 2^5) + (al 2^5)(bh 2^-5),
+// fp32 accumulate), 16 pixels per instruction instead of 2: per 64-pixel tile a wave issues 4 x 27 MFMAs of 8 passes where the fp32
+// form issues 32 x 9 of 16 -- 3 456 against 18 432 matrix-pipe cycles.
+// K runs over INPUT pixels q = (y, x + kx - 1), so that the eight consecutive k of a lane are eight consecutive, 16-byte-aligned
+// halves of one input row for every tap: dW[co][ci][ky][kx] = sum_{y, q} dY[co][y][q - kx + 1] a[ci][y + ky - 1][q].  The kx shift
+// sits on the dY side, staged as three shifted copies (dY is the smaller tile: 64 couts x 64 pixels), the ky shift is a row offset
+// into the single copy of the input tile (rows y - 1 .. y + R, no column halo: q is a real pixel).  Positions a shifted copy never
+// receives (dY[.][-1], dY[.][W]) are zeroed once.
+// Both operands are scaled by a power of two chosen from their largest magnitude (wgrad_absmax_kernel, read from device memory: no
+// host round trip) so that the high halves sit at 2^13 .. 2^14 and the scaled low halves stay normal for every element within 2^-21
+// of the maximum; the accumulators are scaled back as they are written.
+constexpr int kDH = 72;  // dY tile channel stride in halves (64 pixels + 8: 9 16-byte slots, odd)
+
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+
+constexpr int kAmaxBlocks = 512;  // most partial maxima per operand (two per thread of the consumer)
+
+// partial maxima of |x| as float bit patterns, one per workgroup (no atomics: 8 192 waves on one address cost more than the read)
+__global__ __launch_bounds__(256) void wgrad_absmax_kernel(const float *__restrict__ x, size_t n4, unsigned *__restrict__ out) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  __shared__ unsigned red[4];
+  // (NaN: fmaxf would drop it -- keep the bit pattern, which orders above every finite value)
+  unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const u4 *x4 = reinterpret_cast<const u4 *>(x);
+  for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent 16-byte loads in flight
+    const u4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+    m0 = max(m0, max(max(a[0] & 0x7fffffffu, a[1] & 0x7fffffffu), max(a[2] & 0x7fffffffu, a[3] & 0x7fffffffu)));
+    m1 = max(m1, max(max(b[0] & 0x7fffffffu, b[1] & 0x7fffffffu), max(b[2] & 0x7fffffffu, b[3] & 0x7fffffffu)));
+    m2 = max(m2, max(max(c[0] & 0x7fffffffu, c[1] & 0x7fffffffu), max(c[2] & 0x7fffffffu, c[3] & 0x7fffffffu)));
+    m3 = max(m3, max(max(d[0] & 0x7fffffffu, d[1] & 0x7fffffffu), max(d[2] & 0x7fffffffu, d[3] & 0x7fffffffu)));
+  }
+  for (; i < n4; i += stride) {
+    const u4 a = x4[i];
+    m0 = max(m0, max(max(a[0] & 0x7fffffffu, a[1] & 0x7fffffffu), max(a[2] & 0x7fffffffu, a[3] & 0x7fffffffu)));
+  }
+  unsigned b = max(max(m0, m1), max(m2, m3));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+// 2^(13 - floor(log2 max)): max scale in [2^13, 2^14); 1 for an all-zero tensor
+__device__ __forceinline__ float wgrad_scale_of(unsigned maxbits) {
+  const int e = (int)((maxbits >> 23) & 255);
+  if (maxbits == 0) return 1.f;
+  const int se = min(254, max(1, 267 - e));
+  return __uint_as_float((unsigned)se << 23);
+}
+
+__device__ __forceinline__ void wgrad_split4(const float (&v)[4], h4v &hi, h4v &lo) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const _Float16 h = (_Float16)v[t];
+    hi[t] = h;
+    lo[t] = (_Float16)((v[t] - (float)h) * kF16LoScale);
+  }
+}
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_kernel(const WgradP p) {
+  extern __shared__ float smem[];
+  _Float16 *Dh = reinterpret_cast<_Float16 *>(smem);  // [3 kx][hi, lo][64 co][kDH]
+  _Float16 *Ah = Dh + 3 * 2 * kWT * kDH;              // [hi, lo][64 ci][ACSh]: rows y0 - 1 .. y0 + R of W pixels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int cob = blockIdx.x * kWT, cib = blockIdx.y * kWT, sp = blockIdx.z;
+  const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+  const int hw_i = p.Hi * p.Wi, hw_o = p.Ho * p.Wo;
+  const int W = p.Wo, ACS = p.ACSh;
+  const int aplane = kWT * ACS, dplane = kWT * kDH;
+  // ---- this thread's staging slots (as in the staged fp32 form; LDS offsets in halves, no column halo)
+  int a_lds[kNA], a_g[kNA], a_r[kNA];
+#pragma unroll
+  for (int it = 0; it < kNA; ++it) {
+    const int q = (it * 4 + wave) * p.RPI + lane / p.LPR, lc = lane % p.LPR;
+    const bool ok = it < p.NA && q < kWT * p.AR && lane < p.RPI * p.LPR;
+    const int c = q / p.AR, r = q - c * p.AR;
+    a_lds[it] = c * ACS + r * W + 4 * lc;
+    a_g[it] = c * (int)p.a_cs + r * p.Wi + 4 * lc;
+    a_r[it] = ok ? r : -(1 << 20);
+  }
+  int d_lds[kND], d_g[kND], d_px[kND];
+#pragma unroll
+  for (int it = 0; it < kND; ++it) {
+    const int c = (it * 4 + wave) * p.CPI + lane / p.LPD, px0 = 4 * (lane % p.LPD);
+    const bool ok = it < p.ND && c < kWT && lane < p.CPI * p.LPD;
+    d_lds[it] = c * kDH + px0;
+    d_g[it] = c * (int)p.dy_cs + px0;
+    d_px[it] = ok ? px0 : (1 << 20);
+  }
+  const int dx = (4 * (lane % p.LPD)) & (W - 1);  // column of this thread's dY quads (the same for every slot)
+  const bool d_left = dx > 0, d_right = dx + 4 < W;
+  {
+    const int n16 = (3 * 2 * dplane + 2 * aplane) / 8;  // (both extents are multiples of 8 halves)
+    uint4 *z = reinterpret_cast<uint4 *>(smem);
+    for (int e = tid; e < n16; e += 256) z[e] = uint4{0u, 0u, 0u, 0u};
+  }
+  float sD, sA;
+  {  // the operand maxima from their per-workgroup parts
+    unsigned md = 0, ma = 0;
+    for (int e = tid; e < p.amax_nd; e += 256) md = max(md, p.amax[e]);
+    for (int e = tid; e < p.amax_na; e += 256) ma = max(ma, p.amax[p.amax_nd + e]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      md = max(md, (unsigned)__shfl_xor((int)md, o, 64));
+      ma = max(ma, (unsigned)__shfl_xor((int)ma, o, 64));
+    }
+    unsigned *red = reinterpret_cast<unsigned *>(smem);
+    __syncthreads();  // (the zeroing above is complete before its first words are borrowed ...)
+    if (lane == 0) { red[wave] = md; red[4 + wave] = ma; }
+    __syncthreads();
+    md = max(max(red[0], red[1]), max(red[2], red[3]));
+    ma = max(max(red[4], red[5]), max(red[6], red[7]));
+    __syncthreads();
+    if (tid < 8) red[tid] = 0u;  // (... and they are zero again before the first tile is staged: the loop opens with a barrier)
+    sD = wgrad_scale_of(md);
+    sA = wgrad_scale_of(ma);
+  }
+  const float inv = 1.f / (sD * sA);
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  v4 ra[kNA], rd[kND];
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    const int sl = tile / p.tiles_per_img, rb = tile - sl * p.tiles_per_img;
+    const int b = sl / p.Do, zo = sl - b * p.Do, zi = zo + p.kd - 1;
+    const bool zok = zi >= 0 && zi < p.Di;
+    const int yo0 = rb * p.R, yi0 = yo0 - 1;
+    const int rows_px = zok ? min(p.R, p.Ho - yo0) * p.Wo : 0;
+    const float *ab = p.a + ((size_t)b * p.Cin + cib) * p.a_cs + (ptrdiff_t)(zok ? zi : 0) * hw_i + (ptrdiff_t)yi0 * p.Wi;
+    const float *dyb = p.dy + ((size_t)b * p.Cout + cob) * p.dy_cs + (size_t)zo * hw_o + (size_t)yo0 * p.Wo;
+#pragma unroll
+    for (int it = 0; it < kNA; ++it) {
+      const int yi = yi0 + a_r[it];
+      ra[it] = zok && yi >= 0 && yi < p.Hi ? *reinterpret_cast<const v4 *>(ab + a_g[it]) : v4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < kND; ++it)
+      rd[it] = d_px[it] < rows_px ? *reinterpret_cast<const v4 *>(dyb + d_g[it]) : v4{0.f, 0.f, 0.f, 0.f};
+  };
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const _Float16 *dsw = Dh + (wco + l31) * kDH + 8 * lhi;
+  const _Float16 *asw = Ah + (wci + l31) * ACS + 8 * lhi;
+  const f16x8 down = {(_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale),
+                      (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale)};
+  if (sp < p.T) fetch(sp);
+  for (int tile = sp; tile < p.T; tile += p.S) {
+    __syncthreads();  // the previous tile's MFMAs have read their operands (first pass: the zeroing above is done)
+#pragma unroll
+    for (int it = 0; it < kNA; ++it)
+      if (a_r[it] >= 0) {
+        const float v[4] = {ra[it][0] * sA, ra[it][1] * sA, ra[it][2] * sA, ra[it][3] * sA};
+        h4v hi, lo;
+        wgrad_split4(v, hi, lo);
+        *reinterpret_cast<h4v *>(Ah + a_lds[it]) = hi;
+        *reinterpret_cast<h4v *>(Ah + aplane + a_lds[it]) = lo;
+      }
+#pragma unroll
+    for (int it = 0; it < kND; ++it)
+      if (d_px[it] < (1 << 20)) {
+        const float v[4] = {rd[it][0] * sD, rd[it][1] * sD, rd[it][2] * sD, rd[it][3] * sD};
+        h4v q[2];
+        wgrad_split4(v, q[0], q[1]);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          _Float16 *o0 = Dh + (0 * 2 + pl) * dplane + d_lds[it];  // kx = 0: dY[x'] -> q = x' - 1
+          _Float16 *o1 = Dh + (1 * 2 + pl) * dplane + d_lds[it];  // kx = 1: q = x'
+          _Float16 *o2 = Dh + (2 * 2 + pl) * dplane + d_lds[it];  // kx = 2: q = x' + 1
+          const h4v h = q[pl];
+          *reinterpret_cast<h4v *>(o1) = h;
+          if (d_left) o0[-1] = h[0];
+          *reinterpret_cast<h2v *>(o0) = h2v{h[1], h[2]};
+          o0[2] = h[3];
+          o2[1] = h[0];
+          *reinterpret_cast<h2v *>(o2 + 2) = h2v{h[1], h[2]};
+          if (d_right) o2[4] = h[3];
+        }
+      }
+    __syncthreads();
+    if (tile + p.S < p.T) fetch(tile + p.S);  // in flight while this tile multiplies
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {  // 16 pixels per step: this lane's k are pixels 16 s + 8 lhi .. + 7 of the tile
+      f16x8 ah[3], al[3], as[3], bh[3], bl[3], bs[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        ah[k] = *reinterpret_cast<const f16x8 *>(dsw + (k * 2 + 0) * dplane + 16 * s);
+        al[k] = *reinterpret_cast<const f16x8 *>(dsw + (k * 2 + 1) * dplane + 16 * s);
+        bh[k] = *reinterpret_cast<const f16x8 *>(asw + k * W + 16 * s);           // input row y + ky - 1 = tile row y + ky
+        bl[k] = *reinterpret_cast<const f16x8 *>(asw + aplane + k * W + 16 * s);
+        as[k] = ah[k] * down;
+        bs[k] = bh[k] * down;
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) DDPM_MFMA_F16X3(acc[3 * ky + kx], ah[kx], al[kx], as[kx], bh[ky], bl[ky], bs[ky]);
+    }
+  }
+  float *out = p.part + (size_t)sp * 9 * p.Cout * p.Cin;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = cob + wco + 8 * (i >> 2) + 4 * lhi + (i & 3);
+      out[((size_t)t * p.Cout + co) * p.Cin + cib + wci + l31] = acc[t][i] * inv;
+    }
+}
+
 // dW[co][ci][tap] = sum over the S partial slabs, slab order fixed
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int S, int Cout, int Cin, int taps,
                                     int out_taps, int out_off) {
@@ -504,6 +726,11 @@ bool wgrad_plan(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ks
     p.ND = p.CPI > 0 ? (kWT + 4 * p.CPI - 1) / (4 * p.CPI) : kND + 1;
     p.fast = p.RPI > 0 && p.NA <= kNA && p.ND <= kND;
   }
+  p.h16 = 0; p.ACSh = 0; p.amax = nullptr; p.amax_nd = p.amax_na = 0;
+  if (p.fast && stride == 1 && (Wo == 8 || Wo == 16 || Wo == 32 || Wo == 64) && p.R * Wo == 64) {
+    p.h16 = 1;
+    p.ACSh = (p.R + 2) * Wo + 8;
+  }
   const int blocks = (Cout / kWT) * (Cin / kWT);
   const int cus = device_cus();
   int S = (cus + blocks - 1) / blocks;  // one workgroup per CU is what the kernel's 300 registers allow: more slices only feed the reduce
@@ -515,6 +742,46 @@ bool wgrad_plan(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ks
 }  // namespace
 
 namespace {
+constexpr size_t kWgradHead = 2 * kAmaxBlocks;  // words in front of the partial slabs: the operand maxima of the split-f16 form
+size_t wgrad_scratch(const WgradP &p) { return kWgradHead + (size_t)p.S * 9 * p.Cout * p.Cin; }
+
+void wgrad_attrs() {
+  static bool done = false;
+  if (done) return;
+  for (const void *f : {reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<1>), reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<2>),
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<1>),
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<2>),
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel)})
+    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done = true;
+}
+
+// the operand maxima of the split-f16 form into scratch[0 .. 1] (p.part already points behind the head)
+bool wgrad_use_h16(const WgradP &p, bool aligned) { return p.h16 && aligned && split_f16_on(sw().wgrad_f16x3) && !wgrad_plain_form(); }
+void wgrad_h16_maxima(WgradP &p, float *scratch, hipStream_t s) {
+  unsigned *mx = reinterpret_cast<unsigned *>(scratch);
+  const size_t nd = (size_t)p.B * p.Cout * p.dy_cs / 4, na = (size_t)p.B * p.Cin * p.a_cs / 4;
+  // 16 KB per workgroup and pass, up to two workgroups per CU
+  p.amax_nd = (int)std::min<size_t>((nd + 4095) / 4096, kAmaxBlocks);
+  p.amax_na = (int)std::min<size_t>((na + 4095) / 4096, kAmaxBlocks);
+  hipLaunchKernelGGL(wgrad_absmax_kernel, dim3(p.amax_nd), dim3(256), 0, s, p.dy, nd, mx);
+  hipLaunchKernelGGL(wgrad_absmax_kernel, dim3(p.amax_na), dim3(256), 0, s, p.a, na, mx + p.amax_nd);
+  p.amax = mx;
+}
+// one launch of the MFMA form the plan and the switches select
+void wgrad_launch(const WgradP &p, bool aligned, hipStream_t s) {
+  dim3 grid(p.Cout / kWT, p.Cin / kWT, p.S);
+  const size_t lds = (size_t)kWT * (p.ACS + p.DCS) * sizeof(float);
+  const bool staged = p.fast && aligned && !wgrad_plain_form();
+  if (p.amax) {
+    const size_t ldsh = ((size_t)3 * 2 * kWT * kDH + (size_t)2 * kWT * p.ACSh) * sizeof(_Float16);
+    hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel, grid, dim3(256), ldsh, s, p);
+  } else if (staged && p.stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<1>, grid, dim3(256), lds, s, p);
+  else if (staged) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<2>, grid, dim3(256), lds, s, p);
+  else if (p.stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), lds, s, p);
+  else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(256), lds, s, p);
+}
+
 // image slices of the generic form: enough workgroups for the chip when there are few (cout, cin) pairs and many pixels
 int wgrad_generic_slices(int B, int Cin, int Cout, int Ho, int Wo) {
   const long pairs = (long)Cout * Cin;
@@ -527,7 +794,7 @@ int wgrad_generic_slices(int B, int Cin, int Cout, int Ho, int Wo) {
 
 extern "C" size_t ddpm_conv_wgrad_scratch_floats(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ksize, int stride) {
   WgradP p;
-  if (wgrad_plan(B, Cin, Cout, Hi, Wi, Ho, Wo, ksize, stride, p)) return (size_t)p.S * 9 * Cout * Cin;
+  if (wgrad_plan(B, Cin, Cout, Hi, Wi, Ho, Wo, ksize, stride, p)) return wgrad_scratch(p);
   const int S = wgrad_generic_slices(B, Cin, Cout, Ho, Wo);
   return S > 1 ? (size_t)S * ksize * ksize * Cout * Cin : 0;
 }
@@ -544,31 +811,19 @@ extern "C" int ddpm_conv_wgrad_f32(const float *a, const float *dy, float *dw, i
   const double flops = 2.0 * B * Ho * Wo * (double)Cout * Cin * ksize * ksize;
   const double bytes = 4.0 * ((double)B * Cin * Hi * Wi + (double)B * Cout * Ho * Wo + (double)Cout * Cin * ksize * ksize);
   WgradP p;
-  if (!force_generic && wgrad_plan(B, Cin, Cout, Hi, Wi, Ho, Wo, ksize, stride, p) && scratch &&
-      scratch_floats >= (size_t)p.S * 9 * Cout * Cin) {
-    p.a = a; p.dy = dy; p.part = scratch;
-    const size_t lds = (size_t)kWT * (p.ACS + p.DCS) * sizeof(float);
+  if (!force_generic && wgrad_plan(B, Cin, Cout, Hi, Wi, Ho, Wo, ksize, stride, p) && scratch && scratch_floats >= wgrad_scratch(p)) {
+    p.a = a; p.dy = dy; p.part = scratch + kWgradHead;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+    wgrad_attrs();
     {
       ProfScope prof(s, "train_conv3x3_wgrad", flops, bytes);
-      dim3 grid(Cout / kWT, Cin / kWT, p.S);
-      static bool attr_done = false;
-      if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-      }
-      const bool staged = p.fast && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0 && !wgrad_plain_form();
-      if (staged && stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<1>, grid, dim3(256), lds, s, p);
-      else if (staged) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<2>, grid, dim3(256), lds, s, p);
-      else if (stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), lds, s, p);
-      else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(256), lds, s, p);
+      if (wgrad_use_h16(p, aligned)) wgrad_h16_maxima(p, scratch, s);
+      wgrad_launch(p, aligned, s);
       DDPM_CHECK_LAUNCH();
     }
     ProfScope prof(s, "train_wgrad_reduce", 0.0, 4.0 * (p.S + 1.0) * 9 * Cout * Cin);
     const size_t n = (size_t)Cout * Cin * 9;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, dw, p.S, Cout, Cin, 9, 9, 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.part, dw, p.S, Cout, Cin, 9, 9, 0);
     DDPM_CHECK_LAUNCH();
     return 0;
   }
@@ -590,7 +845,7 @@ extern "C" int ddpm_conv_wgrad_f32(const float *a, const float *dy, float *dw, i
 extern "C" size_t ddpm_conv3d_wgrad_scratch_floats(int B, int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int stride) {
   WgradP p;
   if (!wgrad_plan(B, Cin, Cout, Hi, Wi, Ho, Wo, 3, stride, p, Di, Do)) return 0;
-  return (size_t)p.S * 9 * Cout * Cin;
+  return wgrad_scratch(p);
 }
 
 extern "C" int ddpm_conv3d_wgrad_f32(const float *a, const float *dy, float *dw, int B, int Cin, int Cout, int Di, int Hi, int Wi,
@@ -602,31 +857,20 @@ extern "C" int ddpm_conv3d_wgrad_f32(const float *a, const float *dy, float *dw,
   WgradP p;
   DDPM_CHECK_ARG(wgrad_plan(B, Cin, Cout, Hi, Wi, Ho, Wo, 3, stride, p, Di, Do),
                  "conv3d_wgrad: needs Cin %% 64 == 0, Cout %% 64 == 0 and an even W <= 64 (the 3-D latent UNet's shapes)");
-  DDPM_CHECK_ARG(scratch_floats >= (size_t)p.S * 9 * Cout * Cin, "conv3d_wgrad: scratch too small");
+  DDPM_CHECK_ARG(scratch_floats >= wgrad_scratch(p), "conv3d_wgrad: scratch too small");
   hipStream_t s = as_stream(stream);
-  p.a = a; p.dy = dy; p.part = scratch;
-  const size_t lds = (size_t)kWT * (p.ACS + p.DCS) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    for (const void *f : {reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<1>), reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<2>),
-                          reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<1>),
-                          reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<2>)})
-      (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
-  const bool staged = p.fast && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0 && !wgrad_plain_form();
+  p.a = a; p.dy = dy; p.part = scratch + kWgradHead;
+  wgrad_attrs();
+  const bool aligned = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
   const double M = (double)B * Do * Ho * Wo;
   ProfScope prof(s, "train_conv3d_wgrad", 2.0 * M * Cout * Cin * 27,
                  4.0 * ((double)B * Cin * Di * Hi * Wi + M * Cout + 27.0 * Cout * Cin));
-  dim3 grid(Cout / kWT, Cin / kWT, p.S);
+  if (wgrad_use_h16(p, aligned)) wgrad_h16_maxima(p, scratch, s);
   const size_t n = (size_t)Cout * Cin * 9;
   for (int kd = 0; kd < 3; ++kd) {  // one depth tap per launch: 9 accumulator tiles per wave is what the register file holds
     p.kd = kd;
-    if (staged && stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<1>, grid, dim3(256), lds, s, p);
-    else if (staged) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<2>, grid, dim3(256), lds, s, p);
-    else if (stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(256), lds, s, p);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, dw, p.S, Cout, Cin, 9, 27, 9 * kd);
+    wgrad_launch(p, aligned, s);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.part, dw, p.S, Cout, Cin, 9, 27, 9 * kd);
   }
   DDPM_CHECK_LAUNCH();
   return 0;

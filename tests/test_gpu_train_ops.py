@@ -95,6 +95,44 @@ def test_conv_wgrad_vs_autograd(device, case):
         assert torch.equal(dw, T.conv_wgrad(a.to(device), dy.to(device), k, s))
 
 
+@pytest.mark.parametrize("case", [(4, 128, 128, 32, 32), (3, 192, 64, 16, 16), (5, 64, 128, 8, 8), (2, 64, 64, 64, 64)])
+@pytest.mark.parametrize("dy_scale,a_scale", [(1.0, 1.0), (3e-7, 40.0), (5e3, 1e-3)])
+def test_conv_wgrad_split_f16_form(device, monkeypatch, case, dy_scale, a_scale):
+    """The split-f16 form of the 3x3 weight gradient (stride 1, W in 8 .. 64): operands of any magnitude (both are rescaled by a
+    power of two from their measured maxima) and a wide spread inside one tensor; it is at least as close to float64 as the fp32-MFMA
+    form's bound, and DDPM_WGRAD_F16X3=0 / ddpm_set_split_f16(0) select the fp32 form."""
+    from ddpm_ood_amd import _lib
+    from ddpm_ood_amd import train_ops as T
+
+    B, cin, cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    # a: SiLU-like (many small values, a few large ones); dy: gradients spread over four decades
+    a = a_scale * torch.randn(B, cin, H, W, generator=g) * torch.exp(1.5 * torch.randn(B, cin, 1, 1, generator=g))
+    dy = dy_scale * torch.randn(B, cout, H, W, generator=g) * torch.exp(2.0 * torch.randn(B, cout, 1, 1, generator=g))
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(a.double(), w, padding=1), w, dy.double())
+    ad, dyd = a.to(device), dy.to(device)
+    dw = T.conv_wgrad(ad, dyd, 3, 1)
+    assert _rel(dw, ref) < 3e-6, _rel(dw, ref)
+    assert torch.equal(dw, T.conv_wgrad(ad, dyd, 3, 1))
+    monkeypatch.setenv("DDPM_WGRAD_F16X3", "0")
+    f32 = T.conv_wgrad(ad, dyd, 3, 1)
+    assert _rel(f32, ref) < 3e-6
+    assert not torch.equal(f32, dw)  # (a different kernel ran)
+    monkeypatch.delenv("DDPM_WGRAD_F16X3")
+    _lib.load().ddpm_set_split_f16(0)
+    try:
+        assert torch.equal(T.conv_wgrad(ad, dyd, 3, 1), f32)
+    finally:
+        _lib.load().ddpm_set_split_f16(1)
+    # a non-finite gradient stays non-finite (the scale is taken from the maximum's bit pattern, NaN included)
+    bad = dyd.clone()
+    bad[0, 0, 0, 0] = float("nan")
+    assert not bool(torch.isfinite(T.conv_wgrad(ad, bad, 3, 1)).all())
+    # an all-zero gradient gives an all-zero weight gradient
+    assert float(T.conv_wgrad(ad, torch.zeros_like(dyd), 3, 1).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("case", [(2, 128, 128, 8, 1), (3, 64, 128, 4, 1), (2, 128, 64, 8, 2), (2, 64, 64, 4, 2), (1, 64, 64, 2, 1)])
 def test_conv3d_wgrad_and_input_gradient_vs_autograd(device, case):
     """F.conv3d(k3, padding 1, stride 1 / 2) on NCDHW latents: the per-depth-tap weight gradient and the input gradient through
