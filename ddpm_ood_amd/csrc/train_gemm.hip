@@ -121,6 +121,99 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
   }
 }
 
+// The same product with 16-byte staging loads, 32 K per stage and the next stage's loads in flight while this one multiplies -- for
+// operands whose unit-stride index is K (AK / BK) or the row / column index, 16-byte aligned with every other stride a multiple of
+// four floats (gemm_fast_ok): the 1x1 convolutions' weight gradients (both operands K-major, K = images x pixels) ran at 19 TFLOP/s
+// through the 4-byte, 16-K form above, whose loads touch 64 bytes per row.
+constexpr int kGKF = 32;
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256) void gemm_f32_v4_kernel(const GemmP p) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  __shared__ float As[kGKF * kGP], Bs[kGKF * kGP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int z = blockIdx.z / p.S, sp = blockIdx.z - z * p.S;
+  const int z0 = z / p.Z1, z1 = z - z0 * p.Z1;
+  const int kbeg = sp * p.kchunk, kend = p.S > 1 ? min(p.K, kbeg + p.kchunk) : p.K;
+  const float *A = p.A + z0 * p.sAz0 + z1 * p.sAz1;
+  const float *B = p.B + z0 * p.sBz0 + z1 * p.sBz1;
+  float *C = p.C + z0 * p.sCz0 + z1 * p.sCz1;
+  const int m0 = blockIdx.y * kGT, n0 = blockIdx.x * kGT;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  // staging slots: two quads per operand and thread.  K-major: quad = (row e / 8, k = 4 (e % 8) .. + 3); row-major: (k = e / 16,
+  // rows 4 (e % 16) .. + 3)
+  int a_k[2], a_m[2], b_k[2], b_n[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + 256 * i;
+    a_k[i] = AK ? 4 * (e & 7) : (e >> 4);
+    a_m[i] = AK ? (e >> 3) : 4 * (e & 15);
+    b_k[i] = BK ? 4 * (e & 7) : (e >> 4);
+    b_n[i] = BK ? (e >> 3) : 4 * (e & 15);
+  }
+  v4 ra[2], rb[2];
+  auto fetch = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      {
+        const int kg = kt + a_k[i], mg = m0 + a_m[i];
+        const int k0 = kg / p.K1, k1 = kg - k0 * p.K1;
+        ra[i] = kg < kend && mg < p.M ? *reinterpret_cast<const v4 *>(A + mg * p.sAm + k0 * p.sAk0 + k1 * p.sAk1) : v4{0.f, 0.f, 0.f, 0.f};
+      }
+      {
+        const int kg = kt + b_k[i], ng = n0 + b_n[i];
+        const int k0 = kg / p.K1, k1 = kg - k0 * p.K1;
+        rb[i] = kg < kend && ng < p.N ? *reinterpret_cast<const v4 *>(B + ng * p.sBn + k0 * p.sBk0 + k1 * p.sBk1) : v4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (kbeg < kend) fetch(kbeg);
+  for (int kt = kbeg; kt < kend; kt += kGKF) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        As[AK ? (a_k[i] + j) * kGP + a_m[i] : a_k[i] * kGP + a_m[i] + j] = ra[i][j];
+        Bs[BK ? (b_k[i] + j) * kGP + b_n[i] : b_k[i] * kGP + b_n[i] + j] = rb[i][j];
+      }
+    }
+    __syncthreads();
+    if (kt + kGKF < kend) fetch(kt + kGKF);
+#pragma unroll
+    for (int k = 0; k < kGKF; k += 2) {
+      const float a = As[(k + (lane >> 5)) * kGP + wm + (lane & 31)];
+      const float b = Bs[(k + (lane >> 5)) * kGP + wn + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  const int n = n0 + wn + (lane & 31);
+  if (p.S > 1) {
+    float *out = p.part + (size_t)blockIdx.z * p.M * p.N;
+    if (n < p.N) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = m0 + wm + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+        if (m < p.M) out[(size_t)m * p.N + n] = acc[i];
+      }
+    }
+    return;
+  }
+  if (n < p.N) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = m0 + wm + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+      if (m < p.M) {
+        float *c = C + m * p.sCm + n * p.sCn;
+        const float v = p.alpha * acc[i];
+        *c = p.beta != 0.f ? v + p.beta * *c : v;
+      }
+    }
+  }
+}
+
 __global__ void gemm_splitk_reduce_kernel(const GemmP p) {
   const size_t mn = (size_t)p.M * p.N;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -632,7 +725,7 @@ int gemm_ksplit(const ddpm_gemm_desc *g, int &kchunk) {
   if (S * g->batch > 65535) S = 65535 / g->batch;
   if (S < 2) return 1;
   long kc = (g->K + S - 1) / S;
-  kc = (kc + kGK - 1) / kGK * kGK;
+  kc = (kc + kGKF - 1) / kGKF * kGKF;
   S = (g->K + kc - 1) / kc;
   kchunk = (int)kc;
   return S < 2 ? 1 : (int)S;
@@ -672,10 +765,36 @@ extern "C" int ddpm_gemm_f32(const ddpm_gemm_desc *g, ddpm_stream_t stream) {
     p.S = S; p.kchunk = kchunk; p.part = g->scratch;
   }
   hipStream_t s = as_stream(stream);
-  ProfScope prof(s, "train_gemm_f32", 2.0 * g->M * g->N * (double)g->K * g->batch,
+  const char *kname = "train_gemm_f32";
+  char kshape[96];
+  if (g_prof_on && sw().prof_shapes) {  // development: one profile row per product shape
+    snprintf(kshape, sizeof(kshape), "train_gemm_f32|%dx%dx%d b%d S%d", g->M, g->N, g->K, g->batch, p.S);
+    kname = kshape;
+  }
+  ProfScope prof(s, kname, 2.0 * g->M * g->N * (double)g->K * g->batch,
                  4.0 * ((double)g->M * g->K + (double)g->K * g->N + (double)g->M * g->N) * g->batch);
   dim3 grid((g->N + kGT - 1) / kGT, (g->M + kGT - 1) / kGT, g->batch * p.S);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, p);
+  // 16-byte staging: each operand either K-major (unit k stride; rows, K levels and batches at multiples of four floats, four
+  // consecutive k inside one k_inner run) or row-major (unit row stride, the row count a multiple of four)
+  const auto quad = [](long long v) { return (v & 3) == 0; };
+  const bool kq = quad(p.K1) && quad(p.K) && quad(p.kchunk);
+  const int fa = (reinterpret_cast<uintptr_t>(p.A) & 15) || !quad(p.sAz0) || !quad(p.sAz1) || !quad(p.sAk0) ? 0
+                 : p.sAk1 == 1 && quad(p.sAm) && kq                                                         ? 1
+                 : p.sAm == 1 && quad(p.sAk1) && quad(p.M)                                                  ? 2
+                                                                                                            : 0;
+  const int fb = (reinterpret_cast<uintptr_t>(p.B) & 15) || !quad(p.sBz0) || !quad(p.sBz1) || !quad(p.sBk0) ? 0
+                 : p.sBk1 == 1 && quad(p.sBn) && kq                                                         ? 1
+                 : p.sBn == 1 && quad(p.sBk1) && quad(p.N)                                                  ? 2
+                                                                                                            : 0;
+  static const bool plain = getenv("DDPM_GEMM_V4") && atoi(getenv("DDPM_GEMM_V4")) == 0;  // (A/B switch)
+  if (fa && fb && !plain) {
+    if (fa == 1 && fb == 1) hipLaunchKernelGGL((gemm_f32_v4_kernel<true, true>), grid, dim3(256), 0, s, p);
+    else if (fa == 1) hipLaunchKernelGGL((gemm_f32_v4_kernel<true, false>), grid, dim3(256), 0, s, p);
+    else if (fb == 1) hipLaunchKernelGGL((gemm_f32_v4_kernel<false, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_v4_kernel<false, false>), grid, dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, p);
+  }
   if (p.S > 1) {
     const size_t n = (size_t)g->M * g->N * g->batch;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
@@ -733,7 +852,9 @@ bool wgrad_plan(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ks
   }
   const int blocks = (Cout / kWT) * (Cin / kWT);
   const int cus = device_cus();
-  int S = (cus + blocks - 1) / blocks;  // one workgroup per CU is what the kernel's 300 registers allow: more slices only feed the reduce
+  // one workgroup per CU is what the kernel's registers allow: the most slices that still run as ONE round (12 blocks x 22 slices
+  // = 264 workgroups took two rounds on 256 CUs, the second for 8 of them: 137 against 220-250 TFLOP/s for the other shapes)
+  int S = cus / blocks;
   if (S > p.T) S = p.T;
   if (S < 1) S = 1;
   p.S = S;
@@ -816,7 +937,13 @@ extern "C" int ddpm_conv_wgrad_f32(const float *a, const float *dy, float *dw, i
     const bool aligned = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
     wgrad_attrs();
     {
-      ProfScope prof(s, "train_conv3x3_wgrad", flops, bytes);
+      const char *kname = "train_conv3x3_wgrad";
+      char kshape[96];
+      if (g_prof_on && sw().prof_shapes) {
+        snprintf(kshape, sizeof(kshape), "train_conv3x3_wgrad|%d->%d@%dx%d s%d B%d S%d", Cin, Cout, Ho, Wo, stride, B, p.S);
+        kname = kshape;
+      }
+      ProfScope prof(s, kname, flops, bytes);
       if (wgrad_use_h16(p, aligned)) wgrad_h16_maxima(p, scratch, s);
       wgrad_launch(p, aligned, s);
       DDPM_CHECK_LAUNCH();

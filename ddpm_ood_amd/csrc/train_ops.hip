@@ -10,6 +10,8 @@
 //   everything else              = the kernels below.  All HBM-bound, all deterministic (fixed-order reductions, no atomics).
 #include "common.h"
 
+#include <initializer_list>
+
 namespace ddpm {
 
 namespace {
@@ -17,7 +19,13 @@ namespace {
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // ---- GroupNorm, training form: statistics kept for the backward --------------------------------------------------------------
-// one workgroup per (image, group): mean and 1 / sqrt(var + eps) of the group's Cg * HW values (two passes: exact mean first)
+// All four kernels: one workgroup per (image, group), one WAVE per channel plane of the group (channels w, w + 4, ... of the group
+// for wave w), 16-byte loads when the plane length is a multiple of 4 (VEC).  Sums inside a plane: per-lane partial sums in element
+// order, then the fixed butterfly of wave_sum -- deterministic.
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// mean and 1 / sqrt(var + eps) of the group's Cg * HW values (two passes: exact mean first; the second pass reads the L2's copy)
+template <bool VEC>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, float *__restrict__ mr, int C, int HW, int G,
                                                        float eps) {
   __shared__ float red[4];
@@ -26,12 +34,32 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
   const size_t n = (size_t)Cg * HW;
   const float *p = x + ((size_t)b * C + (size_t)g * Cg) * HW;
   float s = 0.f;
-  for (size_t i = threadIdx.x; i < n; i += 256) s += p[i];
+  if (VEC) {
+    const f4 *p4 = reinterpret_cast<const f4 *>(p);
+    for (size_t i = threadIdx.x; i < n / 4; i += 256) {
+      const f4 v = p4[i];
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  } else {
+    for (size_t i = threadIdx.x; i < n; i += 256) s += p[i];
+  }
   const float mean = block_sum_256(s, red) / (float)n;
   float q = 0.f;
-  for (size_t i = threadIdx.x; i < n; i += 256) {
-    const float d = p[i] - mean;
-    q = __builtin_fmaf(d, d, q);
+  if (VEC) {
+    const f4 *p4 = reinterpret_cast<const f4 *>(p);
+    for (size_t i = threadIdx.x; i < n / 4; i += 256) {
+      const f4 v = p4[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[j] - mean;
+        q = __builtin_fmaf(d, d, q);
+      }
+    }
+  } else {
+    for (size_t i = threadIdx.x; i < n; i += 256) {
+      const float d = p[i] - mean;
+      q = __builtin_fmaf(d, d, q);
+    }
   }
   const float var = block_sum_256(q, red) / (float)n;
   if (threadIdx.x == 0) {
@@ -40,113 +68,175 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
   }
 }
 
-// y = act((x - mean) rstd gamma + beta); one workgroup per (image, channel) plane
+// y = act((x - mean) rstd gamma + beta)
+template <bool VEC>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ mr,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        float *__restrict__ y, int C, int HW, int G, int act) {
-  const int b = blockIdx.x / C, c = blockIdx.x - b * C;
-  const int g = c / (C / G);
-  const float mean = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
-  const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
-  const float *p = x + (size_t)blockIdx.x * HW;
-  float *o = y + (size_t)blockIdx.x * HW;
-  for (int i = threadIdx.x; i < HW; i += 256) {
-    const float v = __builtin_fmaf(p[i], sc, sh);
-    o[i] = act == DDPM_ACT_SILU ? v * sigmoid_f(v) : v;
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int Cg = C / G, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float mean = mr[2 * blockIdx.x], rstd = mr[2 * blockIdx.x + 1];
+  for (int k = wave; k < Cg; k += 4) {
+    const int c = g * Cg + k;
+    const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
+    const float *p = x + ((size_t)b * C + c) * HW;
+    float *o = y + ((size_t)b * C + c) * HW;
+    if (VEC) {
+      for (int i = lane; i < HW / 4; i += 64) {
+        f4 v = reinterpret_cast<const f4 *>(p)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float z = __builtin_fmaf(v[j], sc, sh);
+          v[j] = act == DDPM_ACT_SILU ? z * sigmoid_f(z) : z;
+        }
+        reinterpret_cast<f4 *>(o)[i] = v;
+      }
+    } else {
+      for (int i = lane; i < HW; i += 64) {
+        const float z = __builtin_fmaf(p[i], sc, sh);
+        o[i] = act == DDPM_ACT_SILU ? z * sigmoid_f(z) : z;
+      }
+    }
   }
 }
 
-// backward, pass 1: per (image, channel) plane  s1 = sum dz, s2 = sum dz xhat  with dz = dy act'(z), z = xhat gamma + beta
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
-                                                            const float *__restrict__ mr, const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta, float *__restrict__ ws, int C, int HW,
-                                                            int G, int act) {
-  __shared__ float red[4];
-  const int b = blockIdx.x / C, c = blockIdx.x - b * C;
-  const int g = c / (C / G);
-  const float mean = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
-  const float ga = gamma[c], be = beta[c];
-  const float *p = x + (size_t)blockIdx.x * HW, *d = dy + (size_t)blockIdx.x * HW;
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < HW; i += 256) {
-    const float xh = (p[i] - mean) * rstd;
-    float dz = d[i];
+// backward: per channel plane  s1 = sum dz, s2 = sum dz xhat  with dz = dy act'(z), z = xhat gamma + beta  (ws[b][c] = {s1, s2} for
+// the parameter gradients), then  dx = rstd (dz gamma - (A + xhat Bq) / (Cg HW)),  A = sum_{c in group} gamma_c s1_c,
+// Bq = sum gamma_c s2_c.  The second pass reads x and dy again -- out of the L2, the group's planes were just streamed through it.
+constexpr int kGnMaxCg = 64;  // channels per group the fused backward keeps sums for in LDS
+template <bool VEC>
+__global__ __launch_bounds__(256) void gn_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                     const float *__restrict__ mr, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, float *__restrict__ ws, float *__restrict__ dx,
+                                                     int C, int HW, int G, int act, int accumulate) {
+  __shared__ float sums[2 * kGnMaxCg];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int Cg = C / G, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float mean = mr[2 * blockIdx.x], rstd = mr[2 * blockIdx.x + 1];
+  auto dz_of = [&](float d, float xh, float ga, float be) __attribute__((always_inline)) {
     if (act == DDPM_ACT_SILU) {
       const float z = __builtin_fmaf(xh, ga, be), sg = sigmoid_f(z);
-      dz *= sg * (1.0f + z * (1.0f - sg));
+      d *= sg * (1.0f + z * (1.0f - sg));
     }
-    s1 += dz;
-    s2 = __builtin_fmaf(dz, xh, s2);
+    return d;
+  };
+  for (int k = wave; k < Cg; k += 4) {
+    const int c = g * Cg + k;
+    const float ga = gamma[c], be = beta[c];
+    const float *p = x + ((size_t)b * C + c) * HW, *d = dy + ((size_t)b * C + c) * HW;
+    float s1 = 0.f, s2 = 0.f;
+    if (VEC) {
+      for (int i = lane; i < HW / 4; i += 64) {
+        const f4 xv = reinterpret_cast<const f4 *>(p)[i], dv = reinterpret_cast<const f4 *>(d)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xv[j] - mean) * rstd, dz = dz_of(dv[j], xh, ga, be);
+          s1 += dz;
+          s2 = __builtin_fmaf(dz, xh, s2);
+        }
+      }
+    } else {
+      for (int i = lane; i < HW; i += 64) {
+        const float xh = (p[i] - mean) * rstd, dz = dz_of(d[i], xh, ga, be);
+        s1 += dz;
+        s2 = __builtin_fmaf(dz, xh, s2);
+      }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+      sums[2 * k] = s1;
+      sums[2 * k + 1] = s2;
+      ws[2 * ((size_t)b * C + c)] = s1;
+      ws[2 * ((size_t)b * C + c) + 1] = s2;
+    }
   }
-  s1 = block_sum_256(s1, red);
-  s2 = block_sum_256(s2, red);
-  if (threadIdx.x == 0) {
-    ws[2 * blockIdx.x] = s1;
-    ws[2 * blockIdx.x + 1] = s2;
-  }
-}
-
-// backward, pass 2: dx = rstd (dz gamma - (A + xhat Bq) / (Cg HW)),  A = sum_{c in group} gamma_c s1_c, Bq = sum gamma_c s2_c
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
-                                                           const float *__restrict__ mr, const float *__restrict__ gamma,
-                                                           const float *__restrict__ beta, const float *__restrict__ ws,
-                                                           float *__restrict__ dx, int C, int HW, int G, int act, int accumulate) {
-  const int b = blockIdx.x / C, c = blockIdx.x - b * C;
-  const int Cg = C / G, g = c / Cg;
-  const float mean = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
-  const float ga = gamma[c], be = beta[c];
+  __syncthreads();
   float A = 0.f, Bq = 0.f;
-  for (int k = 0; k < Cg; ++k) {  // (every thread the same few values: the scalar cache serves them)
-    const int cc = g * Cg + k;
-    A = __builtin_fmaf(gamma[cc], ws[2 * ((size_t)b * C + cc)], A);
-    Bq = __builtin_fmaf(gamma[cc], ws[2 * ((size_t)b * C + cc) + 1], Bq);
+  for (int k = 0; k < Cg; ++k) {
+    const float gk = gamma[g * Cg + k];
+    A = __builtin_fmaf(gk, sums[2 * k], A);
+    Bq = __builtin_fmaf(gk, sums[2 * k + 1], Bq);
   }
   const float inv = 1.0f / ((float)Cg * (float)HW);
-  const float *p = x + (size_t)blockIdx.x * HW, *d = dy + (size_t)blockIdx.x * HW;
-  float *o = dx + (size_t)blockIdx.x * HW;
-  for (int i = threadIdx.x; i < HW; i += 256) {
-    const float xh = (p[i] - mean) * rstd;
-    float dz = d[i];
-    if (act == DDPM_ACT_SILU) {
-      const float z = __builtin_fmaf(xh, ga, be), sg = sigmoid_f(z);
-      dz *= sg * (1.0f + z * (1.0f - sg));
+  for (int k = wave; k < Cg; k += 4) {
+    const int c = g * Cg + k;
+    const float ga = gamma[c], be = beta[c];
+    const float *p = x + ((size_t)b * C + c) * HW, *d = dy + ((size_t)b * C + c) * HW;
+    float *o = dx + ((size_t)b * C + c) * HW;
+    if (VEC) {
+      for (int i = lane; i < HW / 4; i += 64) {
+        const f4 xv = reinterpret_cast<const f4 *>(p)[i], dv = reinterpret_cast<const f4 *>(d)[i];
+        f4 r = accumulate ? reinterpret_cast<const f4 *>(o)[i] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xv[j] - mean) * rstd, dz = dz_of(dv[j], xh, ga, be);
+          const float v = rstd * (dz * ga - (A + xh * Bq) * inv);
+          r[j] = accumulate ? r[j] + v : v;
+        }
+        reinterpret_cast<f4 *>(o)[i] = r;
+      }
+    } else {
+      for (int i = lane; i < HW; i += 64) {
+        const float xh = (p[i] - mean) * rstd, dz = dz_of(d[i], xh, ga, be);
+        const float v = rstd * (dz * ga - (A + xh * Bq) * inv);
+        o[i] = accumulate ? o[i] + v : v;
+      }
     }
-    const float v = rstd * (dz * ga - (A + xh * Bq) * inv);
-    o[i] = accumulate ? o[i] + v : v;
   }
-}
-
-__global__ void gn_param_grads_kernel(const float *__restrict__ ws, float *__restrict__ dgamma, float *__restrict__ dbeta, int B, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int b = 0; b < B; ++b) {
-    s1 += ws[2 * ((size_t)b * C + c)];
-    s2 += ws[2 * ((size_t)b * C + c) + 1];
-  }
-  dbeta[c] = s1;
-  dgamma[c] = s2;
 }
 
 // ---- reductions ---------------------------------------------------------------------------------------------------------------
-// out[r] = sum of the r-th row of `cols` contiguous floats (bias / temb gradients: rows = (image, channel) planes)
-__global__ __launch_bounds__(256) void row_sum_kernel(const float *__restrict__ in, float *__restrict__ out, int cols) {
-  __shared__ float red[4];
-  const float *p = in + (size_t)blockIdx.x * cols;
+// out[r] = sum of the r-th row of `cols` contiguous floats (bias / temb gradients: rows = (image, channel) planes): one wave per row
+template <bool VEC>
+__global__ __launch_bounds__(256) void row_sum_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *p = in + (size_t)row * cols;
   float s = 0.f;
-  for (int i = threadIdx.x; i < cols; i += 256) s += p[i];
-  s = block_sum_256(s, red);
-  if (threadIdx.x == 0) out[blockIdx.x] = s;
+  if (VEC) {
+    for (int i = lane; i < cols / 4; i += 64) {
+      const f4 v = reinterpret_cast<const f4 *>(p)[i];
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  } else {
+    for (int i = lane; i < cols; i += 64) s += p[i];
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
 }
-// out[c] (+)= alpha * sum_r in[r * stride + c], r = 0 .. rows - 1 in order (rows = batch: a few dozen)
-__global__ void col_sum_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int cols, long long stride, float alpha,
-                               int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// out[c] (+)= alpha * sum_r in[r * stride + c].  A workgroup owns CW = 2^cwl columns (64, or every column of a narrow matrix) and
+// splits the rows over its 256 / CW thread groups (group q: rows q, q + RG, ... in four interleaved chains, so that the loads of a
+// long column -- the batch, or the loss's per-workgroup partial sums -- are in flight together instead of one latency after the
+// other); the groups' sums are added in group order.  out1 != NULL: columns alternate between two outputs (out0[c / 2] for even c,
+// out1[c / 2] for odd c -- the {s1, s2} pairs of the GroupNorm backward).
+__global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ in, float *__restrict__ out0, float *__restrict__ out1,
+                                                      int rows, int cols, long long stride, float alpha, int accumulate, int cwl) {
+  __shared__ float part[256];
+  const int CW = 1 << cwl, RG = 256 >> cwl;
+  const int cl = threadIdx.x & (CW - 1), rg = threadIdx.x >> cwl;
+  const int c = blockIdx.x * CW + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    const float *p = in + c;
+    int r = rg;
+    for (; r + 3 * RG < rows; r += 4 * RG) {
+      s0 += p[(size_t)r * stride];
+      s1 += p[(size_t)(r + RG) * stride];
+      s2 += p[(size_t)(r + 2 * RG) * stride];
+      s3 += p[(size_t)(r + 3 * RG) * stride];
+    }
+    for (; r < rows; r += RG) s0 += p[(size_t)r * stride];
+  }
+  part[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg != 0 || c >= cols) return;
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += in[(size_t)r * stride + c];
+  for (int k = 0; k < RG; ++k) s += part[k * CW + cl];
   s *= alpha;
-  out[c] = accumulate ? out[c] + s : s;
+  float *o = out1 ? ((c & 1) ? out1 : out0) + (c >> 1) : out0 + c;
+  *o = accumulate ? *o + s : s;
 }
 
 // ---- element-wise -------------------------------------------------------------------------------------------------------------
@@ -327,22 +417,39 @@ inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)((n + pe
 
 using namespace ddpm;
 
+namespace {
+inline bool vec4_ok(int HW, std::initializer_list<const void *> ptrs) {
+  if (HW & 3) return false;
+  for (const void *q : ptrs)
+    if (reinterpret_cast<uintptr_t>(q) & 15) return false;
+  return true;
+}
+inline int col_sum_cwl(int cols) {
+  int l = 0;
+  while (l < 6 && (1 << l) < cols) ++l;
+  return l;
+}
+}  // namespace
+
 extern "C" int ddpm_gn_stats_f32(const float *x, float *mean_rstd, int B, int C, int HW, int groups, float eps, ddpm_stream_t stream) {
   DDPM_CHECK_ARG(x && mean_rstd && B > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, "gn_stats: bad arguments");
   hipStream_t s = as_stream(stream);
-  ProfScope prof(s, "train_gn_stats", 0.0, 8.0 * B * C * (double)HW);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, s, x, mean_rstd, C, HW, groups, eps);
+  ProfScope prof(s, "train_gn_stats", 0.0, 4.0 * B * C * (double)HW);
+  if (vec4_ok(HW, {x})) hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(B * groups), dim3(256), 0, s, x, mean_rstd, C, HW, groups, eps);
+  else hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(B * groups), dim3(256), 0, s, x, mean_rstd, C, HW, groups, eps);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int ddpm_gn_apply_f32(const float *x, const float *mean_rstd, const float *gamma, const float *beta, float *y, int B, int C,
                                  int HW, int groups, int act, ddpm_stream_t stream) {
-  DDPM_CHECK_ARG(x && mean_rstd && gamma && beta && y && C % groups == 0 && (act == DDPM_ACT_NONE || act == DDPM_ACT_SILU),
+  DDPM_CHECK_ARG(x && mean_rstd && gamma && beta && y && groups > 0 && C % groups == 0 && (act == DDPM_ACT_NONE || act == DDPM_ACT_SILU),
                  "gn_apply: bad arguments");
   hipStream_t s = as_stream(stream);
   ProfScope prof(s, "train_gn_apply", 0.0, 8.0 * B * C * (double)HW);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(B * C), dim3(256), 0, s, x, mean_rstd, gamma, beta, y, C, HW, groups, act);
+  if (vec4_ok(HW, {x, y}))
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(B * groups), dim3(256), 0, s, x, mean_rstd, gamma, beta, y, C, HW, groups, act);
+  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(B * groups), dim3(256), 0, s, x, mean_rstd, gamma, beta, y, C, HW, groups, act);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
@@ -350,14 +457,22 @@ extern "C" int ddpm_gn_apply_f32(const float *x, const float *mean_rstd, const f
 extern "C" int ddpm_gn_backward_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta,
                                     float *dx, int accumulate_dx, float *dgamma, float *dbeta, float *ws, int B, int C, int HW,
                                     int groups, int act, ddpm_stream_t stream) {
-  DDPM_CHECK_ARG(x && dy && mean_rstd && gamma && beta && dx && dgamma && dbeta && ws && C % groups == 0, "gn_backward: bad arguments");
+  DDPM_CHECK_ARG(x && dy && mean_rstd && gamma && beta && dx && dgamma && dbeta && ws && groups > 0 && C % groups == 0,
+                 "gn_backward: bad arguments");
+  DDPM_CHECK_ARG(C / groups <= kGnMaxCg, "gn_backward: %d channels per group (at most %d)", C / groups, kGnMaxCg);
   hipStream_t s = as_stream(stream);
-  ProfScope prof(s, "train_gn_backward", 0.0, 4.0 * 5 * B * C * (double)HW);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B * C), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, C, HW, groups, act);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, dx, C, HW, groups, act,
-                     accumulate_dx);
-  // dbeta[c] = sum_b s1[b, c], dgamma[c] = sum_b s2[b, c]  (ws is [B][C][{s1, s2}]; images in order)
-  hipLaunchKernelGGL(gn_param_grads_kernel, dim3(blocks_for(C)), dim3(256), 0, s, ws, dgamma, dbeta, B, C);
+  // algorithmic traffic: x and dy read, dx written (and read when it accumulates)
+  ProfScope prof(s, "train_gn_backward", 0.0, 4.0 * (3 + (accumulate_dx ? 1 : 0)) * B * C * (double)HW);
+  if (vec4_ok(HW, {x, dy, dx}))
+    hipLaunchKernelGGL(gn_bwd_kernel<true>, dim3(B * groups), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, dx, C, HW, groups, act,
+                       accumulate_dx);
+  else
+    hipLaunchKernelGGL(gn_bwd_kernel<false>, dim3(B * groups), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, dx, C, HW, groups, act,
+                       accumulate_dx);
+  // dbeta[c] = sum_b s1[b, c], dgamma[c] = sum_b s2[b, c]  (ws is [B][C][{s1, s2}]: 2 C columns, alternating outputs)
+  const int cwl = col_sum_cwl(2 * C);
+  hipLaunchKernelGGL(col_sum_kernel, dim3((2 * C + (1 << cwl) - 1) >> cwl), dim3(256), 0, s, ws, dbeta, dgamma, B, 2 * C, (long long)2 * C,
+                     1.0f, 0, cwl);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
@@ -366,7 +481,9 @@ extern "C" int ddpm_row_sum_f32(const float *in, float *out, int64_t rows, int c
   DDPM_CHECK_ARG(in && out && rows > 0 && rows <= 0x7fffffff && cols > 0, "row_sum: bad arguments");
   hipStream_t s = as_stream(stream);
   ProfScope prof(s, "train_row_sum", 0.0, 4.0 * rows * (double)cols);
-  hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)rows), dim3(256), 0, s, in, out, cols);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (vec4_ok(cols, {in})) hipLaunchKernelGGL(row_sum_kernel<true>, grid, dim3(256), 0, s, in, out, rows, cols);
+  else hipLaunchKernelGGL(row_sum_kernel<false>, grid, dim3(256), 0, s, in, out, rows, cols);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
@@ -376,7 +493,9 @@ extern "C" int ddpm_col_sum_f32(const float *in, float *out, int rows, int cols,
   DDPM_CHECK_ARG(in && out && rows > 0 && cols > 0, "col_sum: bad arguments");
   hipStream_t s = as_stream(stream);
   ProfScope prof(s, "train_col_sum", 0.0, 4.0 * rows * (double)cols);
-  hipLaunchKernelGGL(col_sum_kernel, dim3(blocks_for(cols)), dim3(256), 0, s, in, out, rows, cols, (long long)row_stride, alpha, accumulate);
+  const int cwl = col_sum_cwl(cols);
+  hipLaunchKernelGGL(col_sum_kernel, dim3((cols + (1 << cwl) - 1) >> cwl), dim3(256), 0, s, in, out, static_cast<float *>(nullptr), rows, cols,
+                     (long long)row_stride, alpha, accumulate, cwl);
   DDPM_CHECK_LAUNCH();
   return 0;
 }

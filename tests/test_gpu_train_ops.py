@@ -15,7 +15,7 @@ def _rel(a, b):
 
 
 # ---- ddpm_gemm_f32 -----------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (100, 70, 45), (256, 512, 32), (5, 300, 257)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (100, 70, 45), (256, 512, 32), (5, 300, 257), (128, 192, 4096), (68, 132, 72)])
 def test_gemm_plain_and_transposed_operands(device, M, N, K):
     from ddpm_ood_amd import train_ops as T
 
@@ -202,7 +202,8 @@ def test_conv_input_gradient_forms_vs_autograd(device, case):
 
 
 # ---- GroupNorm (+ SiLU) training form -----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,C,H,act", [(4, 128, 32, 1), (3, 256, 8, 1), (2, 384, 16, 0), (2, 64, 4, 1)])
+@pytest.mark.parametrize("B,C,H,act", [(4, 128, 32, 1), (3, 256, 8, 1), (2, 384, 16, 0), (2, 64, 4, 1), (2, 64, 5, 1), (5, 512, 8, 1),
+                                       (2, 96, 7, 0)])
 def test_group_norm_forward_and_backward_vs_autograd(device, B, C, H, act):
     from ddpm_ood_amd import train_ops as T
 
@@ -236,8 +237,15 @@ def test_elementwise_and_reduction_kernels(device):
     x = torch.randn(6, 40, 7, 9, generator=g)
     xd = x.to(device)
     assert _rel(T.row_sum(xd, 6 * 40, 63).view(6, 40), x.double().sum(dim=(2, 3))) < 2e-6
+    x4 = torch.randn(37, 256, generator=g)  # (the 16-byte-load form: row length a multiple of 4; rows not a multiple of the 4 waves)
+    assert _rel(T.row_sum(x4.to(device), 37, 256), x4.double().sum(1)) < 2e-6
     m = torch.randn(13, 50, generator=g)
     assert _rel(T.col_sum(m.to(device), 13, 50), m.double().sum(0)) < 2e-6
+    for rows, cols in ((1000, 1), (300, 700), (256, 3), (5, 64)):  # one column (the loss's partial sums), many rows, several workgroups
+        mm = torch.randn(rows, cols, generator=g)
+        got = T.col_sum(mm.to(device), rows, cols, alpha=0.25)
+        assert _rel(got, 0.25 * mm.double().sum(0)) < 2e-6, (rows, cols)
+        assert torch.equal(got, T.col_sum(mm.to(device), rows, cols, alpha=0.25))
     acc = torch.randn(50, generator=g)
     out = T.col_sum(m.to(device), 13, 50, out=acc.clone().to(device), alpha=0.5, accumulate=True)
     assert _rel(out, acc.double() + 0.5 * m.double().sum(0)) < 2e-6

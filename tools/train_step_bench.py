@@ -4,6 +4,7 @@ backward / Adam) beside the ATen route (PyTorch-ROCm autograd over MIOpen / rocB
 (amp: the ATen route under fp16 autocast + GradScaler -- the reference's own training arithmetic, ddpm_trainer.py:96-109.)
 Row f-3 (/root/reference/src/trainers/ddpm_trainer.py:78-109, base.py:156).  `rocprofv3 --kernel-trace --stats -- python
 tools/train_step_bench.py 64 5 native` is the profile committed as profiles/r06_train_native_kernel_trace_stats.csv."""
+import os
 import sys
 import time
 from pathlib import Path
@@ -56,6 +57,27 @@ if which in ("native", "both", "all"):
             st.adam_step()
 
         dt = timed(native_step)
+        if os.environ.get("DDPM_PROF_SHAPES"):  # one step under the library's own per-launch timers, one row per layer shape
+            import ctypes
+
+            from ddpm_ood_amd import _lib
+
+            lib = _lib.load()
+            lib.ddpm_prof_enable(1)
+            native_step()
+            torch.cuda.synchronize()
+            lib.ddpm_prof_enable(0)
+            buf = ctypes.create_string_buffer(1 << 20)
+            lib.ddpm_prof_report(buf, len(buf))
+            import json
+
+            prof = json.loads(buf.value.decode())
+            tot = sum(v["ms"] for v in prof.values())
+            print(f"{'kernel':64s} {'launch':>6s} {'ms':>9s} {'%':>6s} {'TFLOP/s':>8s} {'GB/s':>8s}")
+            for kname, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+                print(f"{kname:64s} {v['launches']:6d} {v['ms']:9.3f} {100 * v['ms'] / tot:6.1f} "
+                      f"{v['flops'] / v['ms'] / 1e9 if v['ms'] else 0:8.1f} {v['bytes'] / v['ms'] / 1e6 if v['ms'] else 0:8.1f}")
+            print(f"{'sum':64s} {'':6s} {tot:9.3f}")
     print(f"native: batch {B}: {dt * 1e3:.2f} ms per step = {B / dt:.0f} images/s")
 if which in ("aten", "both", "all"):
     m = model()
