@@ -658,13 +658,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_kernel(const WgradP p
 // dW[co][ci][tap] = sum over the S partial slabs, slab order fixed
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int S, int Cout, int Cin, int taps,
                                     int out_taps, int out_off) {
-  const size_t n = (size_t)Cout * Cin * taps;
+  const size_t cc_n = (size_t)Cout * Cin, n = cc_n * taps;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int tap = (int)(i % taps);
-  const size_t cc = i / taps;  // co * Cin + ci
+  // consecutive threads walk (cout, cin) inside one tap: the S reads are contiguous, the one write is strided
+  const int tap = (int)(i / cc_n);
+  const size_t cc = i - (size_t)tap * cc_n;  // co * Cin + ci
   float s = 0.f;
-  for (int k = 0; k < S; ++k) s += part[((size_t)k * taps + tap) * Cout * Cin + cc];
+  for (int k = 0; k < S; ++k) s += part[((size_t)k * taps + tap) * cc_n + cc];
   dw[cc * out_taps + out_off + tap] = s;  // (out_taps = 27, out_off = 9 kd: one depth tap of a [Cout, Cin, 3, 3, 3] weight)
 }
 
@@ -855,7 +856,7 @@ bool wgrad_plan(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ks
   // one workgroup per CU is what the kernel's registers allow: the most slices that still run as ONE round (12 blocks x 22 slices
   // = 264 workgroups took two rounds on 256 CUs, the second for 8 of them: 137 against 220-250 TFLOP/s for the other shapes)
   int S = cus / blocks;
-  if (S > p.T) S = p.T;
+  if (S > p.T / 4) S = p.T / 4;  // at least four pixel tiles per slice: a small batch would spend more on adding slices than on making them
   if (S < 1) S = 1;
   p.S = S;
   return true;
@@ -905,9 +906,11 @@ void wgrad_launch(const WgradP &p, bool aligned, hipStream_t s) {
 
 // image slices of the generic form: enough workgroups for the chip when there are few (cout, cin) pairs and many pixels
 int wgrad_generic_slices(int B, int Cin, int Cout, int Ho, int Wo) {
-  const long pairs = (long)Cout * Cin;
-  if (pairs >= 2L * device_cus() || (long)B * Ho * Wo < 16384) return 1;
-  long S = (2L * device_cus() + pairs - 1) / pairs;
+  // (32 workgroups per CU: each walks its pixels in a latency-bound loop of 4-byte loads -- 2 per CU took 0.5 ms for the first
+  // convolution's 128 pairs x 262 144 pixels at batch 256)
+  const long pairs = (long)Cout * Cin, want = 32L * device_cus();
+  if (pairs >= want || (long)B * Ho * Wo < 16384) return 1;
+  long S = (want + pairs - 1) / pairs;
   if (S > B) S = B;
   return S < 2 ? 1 : (int)S;
 }

@@ -256,10 +256,20 @@ __global__ void axpby_kernel(const float *__restrict__ a, const float *__restric
   if (i < n) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
 }
 // dst[b, cd0 + c, :] (+)= src[b, cs0 + c, :]  (torch.cat in the forward, its split in the backward)
+// (per image the source and the destination block are contiguous runs of C HW floats: VEC moves them in 16-byte pieces)
+template <bool VEC>
 __global__ void chan_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int Cs, int cs0, int Cd, int cd0, int HW,
                                  int64_t n, int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (VEC) {  // n and i count quads
+    const int64_t run = (int64_t)C * HW / 4;
+    const int64_t b = i / run, r = i - b * run;
+    const f4 v = reinterpret_cast<const f4 *>(src + ((size_t)b * Cs + cs0) * HW)[r];
+    f4 *o = reinterpret_cast<f4 *>(dst + ((size_t)b * Cd + cd0) * HW) + r;
+    *o = accumulate ? *o + v : v;
+    return;
+  }
   const int px = (int)(i % HW);
   const int64_t r = i / HW;
   const int c = (int)(r % C), b = (int)(r / C);
@@ -532,7 +542,10 @@ extern "C" int ddpm_chan_copy_f32(const float *src, float *dst, int B, int C, in
   hipStream_t s = as_stream(stream);
   const int64_t n = (int64_t)B * C * HW;
   ProfScope prof(s, "train_chan_copy", 0.0, 8.0 * n);
-  hipLaunchKernelGGL(chan_copy_kernel, dim3(blocks_for(n)), dim3(256), 0, s, src, dst, C, Csrc, csrc0, Cdst, cdst0, HW, n, accumulate);
+  if (vec4_ok(HW, {src, dst}))
+    hipLaunchKernelGGL(chan_copy_kernel<true>, dim3(blocks_for(n / 4)), dim3(256), 0, s, src, dst, C, Csrc, csrc0, Cdst, cdst0, HW, n / 4, accumulate);
+  else
+    hipLaunchKernelGGL(chan_copy_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, s, src, dst, C, Csrc, csrc0, Cdst, cdst0, HW, n, accumulate);
   DDPM_CHECK_LAUNCH();
   return 0;
 }
