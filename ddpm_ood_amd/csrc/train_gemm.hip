@@ -21,6 +21,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace ddpm {
 
@@ -253,6 +254,9 @@ struct WgradP {
   // split-f16 form (stride 1, W a power of two in 8 .. 64, 64-pixel tiles): f16 LDS tiles, v_mfma_f32_32x32x16_f16
   int h16;                // the form applies
   int ACSh;               // input tile channel stride in halves ((R + 2) W + 8: a multiple of 8 with an odd 16-byte count)
+  int DCSh;               // dY tile channel stride in halves (R rows of W + 8, an odd 16-byte count)
+  int DHh, LDSh;          // halves of the dY tiles (8 in front + two planes) and of the whole LDS image
+  int lw;                 // log2 W
   const unsigned *amax;   // float bits of the partial maxima of |dY| (amax_nd of them) then |a| (amax_na) (wgrad_absmax_kernel)
   int amax_nd, amax_na;
 };
@@ -445,15 +449,17 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_staged_kernel(const WgradP 
 // fp32 accumulate), 16 pixels per instruction instead of 2: per 64-pixel tile a wave issues 4 x 27 MFMAs of 8 passes where the fp32
 // form issues 32 x 9 of 16 -- 3 456 against 18 432 matrix-pipe cycles.
 // K runs over INPUT pixels q = (y, x + kx - 1), so that the eight consecutive k of a lane are eight consecutive, 16-byte-aligned
-// halves of one input row for every tap: dW[co][ci][ky][kx] = sum_{y, q} dY[co][y][q - kx + 1] a[ci][y + ky - 1][q].  The kx shift
-// sits on the dY side, staged as three shifted copies (dY is the smaller tile: 64 couts x 64 pixels), the ky shift is a row offset
-// into the single copy of the input tile (rows y - 1 .. y + R, no column halo: q is a real pixel).  Positions a shifted copy never
-// receives (dY[.][-1], dY[.][W]) are zeroed once.
+// halves of one input row for every tap: dW[co][ci][ky][kx] = sum_{y, q} dY[co][y][q - kx + 1] a[ci][y + ky - 1][q].  The ky shift is
+// a row offset into the input tile (rows y - 1 .. y + R, no column halo: q is a real pixel).  The kx shift sits on the dY side and is
+// made IN REGISTERS: a lane reads its aligned eight halves dY[q .. q + 7] plus the words holding dY[q - 1] and dY[q + 8], and
+// v_alignbit_b32 slides them by one half for kx = 2 / kx = 0.  dY rows are stored W + 8 halves apart, the 8 spare halves zero, so
+// that the neighbour words of a row's first / last lane are the zeros the convolution's padding asks for.
+// (First form, round 6: three pre-shifted copies of the dY tile in LDS -- 14 LDS stores per staged quad instead of 2, 90-106 KB
+// per workgroup, one workgroup per CU: 193-265 TFLOP/s on the step's shapes, profiles/r06_wgrad_f16x3_ablations.log; staging was a
+// third of the kernel, and nothing overlapped it.  This form fits two workgroups per CU.)
 // Both operands are scaled by a power of two chosen from their largest magnitude (wgrad_absmax_kernel, read from device memory: no
 // host round trip) so that the high halves sit at 2^13 .. 2^14 and the scaled low halves stay normal for every element within 2^-21
 // of the maximum; the accumulators are scaled back as they are written.
-constexpr int kDH = 72;  // dY tile channel stride in halves (64 pixels + 8: 9 16-byte slots, odd)
-
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
@@ -504,41 +510,43 @@ __device__ __forceinline__ void wgrad_split4(const float (&v)[4], h4v &hi, h4v &
   }
 }
 
+// Pipeline: the next tile's quads are fetched into registers while this tile multiplies, converted and stored between the tiles.
+// (Measured, same shapes, batch 256, weighted by the step's counts -- profiles/r06_wgrad_f16x3_variants.log: three pre-shifted dY
+// copies in LDS 6.78 ms; register-shifted dY 6.63 ms, with branch-free fetch / staging (this form) 5.95 ms; without the register
+// prefetch at two workgroups per CU 7.05 ms; TWO LDS images
+// with the conversion of tile i + 1 and the loads of tile i + 2 issued between the MFMAs of tile i, one barrier per tile 7.49 ms --
+// with one wave per SIMD an MFMA hides about five other issues (MI355X_MICROARCH.md) and the 650 of a tile do not fit behind 108.
+// Ablations of the first form: no MFMAs 4.76, no conversion + LDS stores 4.56, no global loads 6.00.)
+// NA: staging slots of the input tile per thread (5, 6, 8, 12 for W = 8, 16, 32, 64: 64 (R + 2) (channel, row) pairs of W / 4
+// quads over 256 threads, exactly -- with W a power of two and R W = 64 every slot of every lane is a real quad, so the staging code
+// carries no branch and the scheduler is free to move it between the MFMAs)
+template <int NA>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_kernel(const WgradP p) {
   extern __shared__ float smem[];
-  _Float16 *Dh = reinterpret_cast<_Float16 *>(smem);  // [3 kx][hi, lo][64 co][kDH]
-  _Float16 *Ah = Dh + 3 * 2 * kWT * kDH;              // [hi, lo][64 ci][ACSh]: rows y0 - 1 .. y0 + R of W pixels
+  _Float16 *Dh = reinterpret_cast<_Float16 *>(smem) + 8;  // [hi, lo][64 co][DCSh]: R rows of W + 8 halves; 8 zero halves in front
+  _Float16 *Ah = Dh - 8 + p.DHh;                           // [hi, lo][64 ci][ACSh]: rows y0 - 1 .. y0 + R of W pixels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
+  // (An XCD-aware decode of the workgroup id -- the (cout, cin) blocks of one slice, which read the same tiles at the same time,
+  // on one XCD's L2 -- measured +-0: 5.95 against 5.98 ms over the step's shapes.)
   const int cob = blockIdx.x * kWT, cib = blockIdx.y * kWT, sp = blockIdx.z;
   const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
   const int hw_i = p.Hi * p.Wi, hw_o = p.Ho * p.Wo;
-  const int W = p.Wo, ACS = p.ACSh;
-  const int aplane = kWT * ACS, dplane = kWT * kDH;
-  // ---- this thread's staging slots (as in the staged fp32 form; LDS offsets in halves, no column halo)
-  int a_lds[kNA], a_g[kNA], a_r[kNA];
-#pragma unroll
-  for (int it = 0; it < kNA; ++it) {
-    const int q = (it * 4 + wave) * p.RPI + lane / p.LPR, lc = lane % p.LPR;
-    const bool ok = it < p.NA && q < kWT * p.AR && lane < p.RPI * p.LPR;
-    const int c = q / p.AR, r = q - c * p.AR;
-    a_lds[it] = c * ACS + r * W + 4 * lc;
-    a_g[it] = c * (int)p.a_cs + r * p.Wi + 4 * lc;
-    a_r[it] = ok ? r : -(1 << 20);
-  }
-  int d_lds[kND], d_g[kND], d_px[kND];
-#pragma unroll
-  for (int it = 0; it < kND; ++it) {
-    const int c = (it * 4 + wave) * p.CPI + lane / p.LPD, px0 = 4 * (lane % p.LPD);
-    const bool ok = it < p.ND && c < kWT && lane < p.CPI * p.LPD;
-    d_lds[it] = c * kDH + px0;
-    d_g[it] = c * (int)p.dy_cs + px0;
-    d_px[it] = ok ? px0 : (1 << 20);
-  }
-  const int dx = (4 * (lane % p.LPD)) & (W - 1);  // column of this thread's dY quads (the same for every slot)
-  const bool d_left = dx > 0, d_right = dx + 4 < W;
+  const int W = p.Wo, ACS = p.ACSh, DCS = p.DCSh, lw = p.lw;
+  const int aplane = kWT * ACS, dplane = kWT * DCS;
+  // ---- this thread's staging slots.  (channel, input row) pair q = it 4 RPI + (wave RPI + lane / LPR) -> row q / 64, channel
+  // q % 64; 4 RPI is 16 .. 128, so the `it` part of both is uniform (scalar registers) and only the lane part below lives in
+  // vector registers -- the staged fp32 form's per-slot arrays were 48 of them, and this kernel has 256 to fit two workgroups per CU
+  const int ql = wave * p.RPI + lane / p.LPR, lc = lane % p.LPR;
+  const int a_c0 = ql & 63, a_r0 = ql >> 6;  // (a_r0 = 1 only for W = 8: 128 pairs per step)
+  const int a_lds0 = a_c0 * ACS + a_r0 * W + 4 * lc, a_g0 = a_c0 * (int)p.a_cs + a_r0 * p.Wi + 4 * lc;
+  const int qstep = 4 * p.RPI;
+  // dY: channel it 4 CPI + (wave CPI + lane / LPD), pixels 4 (lane % LPD) ..
+  const int d_c0 = wave * p.CPI + lane / p.LPD, d_px0 = 4 * (lane % p.LPD);
+  const int d_lds0 = d_c0 * DCS + (d_px0 >> lw) * (W + 8) + (d_px0 & (W - 1)), d_g0 = d_c0 * (int)p.dy_cs + d_px0;
+  const int cstep = 4 * p.CPI;
   {
-    const int n16 = (3 * 2 * dplane + 2 * aplane) / 8;  // (both extents are multiples of 8 halves)
+    const int n16 = p.LDSh / 8;  // (a multiple of 8 halves)
     uint4 *z = reinterpret_cast<uint4 *>(smem);
     for (int e = tid; e < n16; e += 256) z[e] = uint4{0u, 0u, 0u, 0u};
   }
@@ -565,84 +573,120 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_kernel(const WgradP p
   }
   const float inv = 1.f / (sD * sA);
   typedef float v4 __attribute__((ext_vector_type(4)));
-  v4 ra[kNA], rd[kND];
-  auto fetch = [&](int tile) __attribute__((always_inline)) {
+  v4 ra[NA], rd[kND];
+  // the tile whose quads the fetch_* below load: base pointers and row limits (uniform)
+  const float *f_ab = p.a, *f_dyb = p.dy;
+  int f_yi0 = 0, f_rows_px = 0;
+  bool f_zok = false;
+  auto aim = [&](int tile) __attribute__((always_inline)) {
     const int sl = tile / p.tiles_per_img, rb = tile - sl * p.tiles_per_img;
     const int b = sl / p.Do, zo = sl - b * p.Do, zi = zo + p.kd - 1;
-    const bool zok = zi >= 0 && zi < p.Di;
-    const int yo0 = rb * p.R, yi0 = yo0 - 1;
-    const int rows_px = zok ? min(p.R, p.Ho - yo0) * p.Wo : 0;
-    const float *ab = p.a + ((size_t)b * p.Cin + cib) * p.a_cs + (ptrdiff_t)(zok ? zi : 0) * hw_i + (ptrdiff_t)yi0 * p.Wi;
-    const float *dyb = p.dy + ((size_t)b * p.Cout + cob) * p.dy_cs + (size_t)zo * hw_o + (size_t)yo0 * p.Wo;
-#pragma unroll
-    for (int it = 0; it < kNA; ++it) {
-      const int yi = yi0 + a_r[it];
-      ra[it] = zok && yi >= 0 && yi < p.Hi ? *reinterpret_cast<const v4 *>(ab + a_g[it]) : v4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int it = 0; it < kND; ++it)
-      rd[it] = d_px[it] < rows_px ? *reinterpret_cast<const v4 *>(dyb + d_g[it]) : v4{0.f, 0.f, 0.f, 0.f};
+    f_zok = zi >= 0 && zi < p.Di;
+    const int yo0 = rb * p.R;
+    f_yi0 = yo0 - 1;
+    f_rows_px = f_zok ? min(p.R, p.Ho - yo0) * p.Wo : 0;
+    f_ab = p.a + ((size_t)b * p.Cin + cib) * p.a_cs + (ptrdiff_t)(f_zok ? zi : 0) * hw_i + (ptrdiff_t)f_yi0 * p.Wi;
+    f_dyb = p.dy + ((size_t)b * p.Cout + cob) * p.dy_cs + (size_t)zo * hw_o + (size_t)yo0 * p.Wo;
+  };
+  // (rows outside the image / the volume: the load goes to the tensor's first quad and a select zeroes it -- no branch)
+  auto fetch_a = [&](int it) __attribute__((always_inline)) {
+    if (it >= NA) return;  // (compile time)
+    const int qu = it * qstep, ru = qu >> 6, cu = qu & 63;  // (uniform)
+    const int yi = f_yi0 + ru + a_r0;
+    const bool ok = f_zok && yi >= 0 && yi < p.Hi;
+    const v4 v = *reinterpret_cast<const v4 *>(ok ? f_ab + a_g0 + cu * (int)p.a_cs + ru * p.Wi : p.a);
+    ra[it] = ok ? v : v4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto fetch_d = [&](int it) __attribute__((always_inline)) {
+    const bool ok = d_px0 < f_rows_px;
+    const v4 v = *reinterpret_cast<const v4 *>(ok ? f_dyb + d_g0 + it * cstep * (int)p.dy_cs : p.dy);
+    rd[it] = ok ? v : v4{0.f, 0.f, 0.f, 0.f};
   };
   f32x16 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-  const _Float16 *dsw = Dh + (wco + l31) * kDH + 8 * lhi;
+  const _Float16 *dsw = Dh + (wco + l31) * DCS;
   const _Float16 *asw = Ah + (wci + l31) * ACS + 8 * lhi;
   const f16x8 down = {(_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale),
                       (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale)};
-  if (sp < p.T) fetch(sp);
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  // the aligned eight halves m = dY[q .. q + 7] with the word left of them (dY[q - 2], dY[q - 1]) / right of them (dY[q + 8], dY[q + 9])
+  // -> dY[q + 1 .. q + 8] (kx = 0) and dY[q - 1 .. q + 6] (kx = 2)
+  auto slide_up = [](const f16x8 m, unsigned right) __attribute__((always_inline)) {
+    const u4v w = __builtin_bit_cast(u4v, m);
+    const u4v r = {__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
+                   __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(right, w[3], 16)};
+    return __builtin_bit_cast(f16x8, r);
+  };
+  auto slide_down = [](const f16x8 m, unsigned left) __attribute__((always_inline)) {
+    const u4v w = __builtin_bit_cast(u4v, m);
+    const u4v r = {__builtin_amdgcn_alignbit(w[0], left, 16), __builtin_amdgcn_alignbit(w[1], w[0], 16),
+                   __builtin_amdgcn_alignbit(w[2], w[1], 16), __builtin_amdgcn_alignbit(w[3], w[2], 16)};
+    return __builtin_bit_cast(f16x8, r);
+  };
+  // staging slot `it` of the tile in ra / rd -> LDS
+  auto stage_a = [&](int it) __attribute__((always_inline)) {
+    if (it >= NA) return;  // (compile time)
+    const int qu = it * qstep, ru = qu >> 6, cu = qu & 63;
+    const float v[4] = {ra[it][0] * sA, ra[it][1] * sA, ra[it][2] * sA, ra[it][3] * sA};
+    h4v hi, lo;
+    wgrad_split4(v, hi, lo);
+    _Float16 *o = Ah + a_lds0 + cu * ACS + ru * W;
+    *reinterpret_cast<h4v *>(o) = hi;
+    *reinterpret_cast<h4v *>(o + aplane) = lo;
+  };
+  auto stage_d = [&](int it) __attribute__((always_inline)) {
+    const float v[4] = {rd[it][0] * sD, rd[it][1] * sD, rd[it][2] * sD, rd[it][3] * sD};
+    h4v hi, lo;
+    wgrad_split4(v, hi, lo);
+    _Float16 *o = Dh + d_lds0 + it * cstep * DCS;
+    *reinterpret_cast<h4v *>(o) = hi;
+    *reinterpret_cast<h4v *>(o + dplane) = lo;
+  };
+  if (sp < p.T) {
+    aim(sp);
+#pragma unroll
+    for (int it = 0; it < NA; ++it) fetch_a(it);
+#pragma unroll
+    for (int it = 0; it < kND; ++it) fetch_d(it);
+  }
   for (int tile = sp; tile < p.T; tile += p.S) {
     __syncthreads();  // the previous tile's MFMAs have read their operands (first pass: the zeroing above is done)
 #pragma unroll
-    for (int it = 0; it < kNA; ++it)
-      if (a_r[it] >= 0) {
-        const float v[4] = {ra[it][0] * sA, ra[it][1] * sA, ra[it][2] * sA, ra[it][3] * sA};
-        h4v hi, lo;
-        wgrad_split4(v, hi, lo);
-        *reinterpret_cast<h4v *>(Ah + a_lds[it]) = hi;
-        *reinterpret_cast<h4v *>(Ah + aplane + a_lds[it]) = lo;
-      }
+    for (int it = 0; it < NA; ++it) stage_a(it);
 #pragma unroll
-    for (int it = 0; it < kND; ++it)
-      if (d_px[it] < (1 << 20)) {
-        const float v[4] = {rd[it][0] * sD, rd[it][1] * sD, rd[it][2] * sD, rd[it][3] * sD};
-        h4v q[2];
-        wgrad_split4(v, q[0], q[1]);
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-          _Float16 *o0 = Dh + (0 * 2 + pl) * dplane + d_lds[it];  // kx = 0: dY[x'] -> q = x' - 1
-          _Float16 *o1 = Dh + (1 * 2 + pl) * dplane + d_lds[it];  // kx = 1: q = x'
-          _Float16 *o2 = Dh + (2 * 2 + pl) * dplane + d_lds[it];  // kx = 2: q = x' + 1
-          const h4v h = q[pl];
-          *reinterpret_cast<h4v *>(o1) = h;
-          if (d_left) o0[-1] = h[0];
-          *reinterpret_cast<h2v *>(o0) = h2v{h[1], h[2]};
-          o0[2] = h[3];
-          o2[1] = h[0];
-          *reinterpret_cast<h2v *>(o2 + 2) = h2v{h[1], h[2]};
-          if (d_right) o2[4] = h[3];
-        }
-      }
+    for (int it = 0; it < kND; ++it) stage_d(it);
     __syncthreads();
-    if (tile + p.S < p.T) fetch(tile + p.S);  // in flight while this tile multiplies
+    aim(tile + p.S < p.T ? tile + p.S : tile);  // in flight while this tile multiplies (no next tile: a tile nobody stages)
+#pragma unroll
+    for (int it = 0; it < NA; ++it) fetch_a(it);
+#pragma unroll
+    for (int it = 0; it < kND; ++it) fetch_d(it);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {  // 16 pixels per step: this lane's k are pixels 16 s + 8 lhi .. + 7 of the tile
-      f16x8 ah[3], al[3], as[3], bh[3], bl[3], bs[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        ah[k] = *reinterpret_cast<const f16x8 *>(dsw + (k * 2 + 0) * dplane + 16 * s);
-        al[k] = *reinterpret_cast<const f16x8 *>(dsw + (k * 2 + 1) * dplane + 16 * s);
-        bh[k] = *reinterpret_cast<const f16x8 *>(asw + k * W + 16 * s);           // input row y + ky - 1 = tile row y + ky
-        bl[k] = *reinterpret_cast<const f16x8 *>(asw + aplane + k * W + 16 * s);
-        as[k] = ah[k] * down;
-        bs[k] = bh[k] * down;
+      const int px = 16 * s + 8 * lhi;
+      const _Float16 *dp = dsw + (px >> lw) * (W + 8) + (px & (W - 1));
+      f16x8 ah[3], al[3], as[3];
+      {
+        const f16x8 mh = *reinterpret_cast<const f16x8 *>(dp), ml = *reinterpret_cast<const f16x8 *>(dp + dplane);
+        const unsigned hl = *reinterpret_cast<const unsigned *>(dp - 2), hr = *reinterpret_cast<const unsigned *>(dp + 8);
+        const unsigned ll = *reinterpret_cast<const unsigned *>(dp + dplane - 2), lr = *reinterpret_cast<const unsigned *>(dp + dplane + 8);
+        ah[0] = slide_up(mh, hr);   al[0] = slide_up(ml, lr);
+        ah[1] = mh;                 al[1] = ml;
+        ah[2] = slide_down(mh, hl); al[2] = slide_down(ml, ll);
       }
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+      for (int k = 0; k < 3; ++k) as[k] = ah[k] * down;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) DDPM_MFMA_F16X3(acc[3 * ky + kx], ah[kx], al[kx], as[kx], bh[ky], bl[ky], bs[ky]);
+      for (int ky = 0; ky < 3; ++ky) {
+        const f16x8 bh = *reinterpret_cast<const f16x8 *>(asw + ky * W + 16 * s);  // input row y + ky - 1 = tile row y + ky
+        const f16x8 bl = *reinterpret_cast<const f16x8 *>(asw + aplane + ky * W + 16 * s);
+        const f16x8 bs = bh * down;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) DDPM_MFMA_F16X3(acc[3 * ky + kx], ah[kx], al[kx], as[kx], bh, bl, bs);
+      }
     }
   }
   float *out = p.part + (size_t)sp * 9 * p.Cout * p.Cin;
@@ -846,10 +890,15 @@ bool wgrad_plan(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ks
     p.ND = p.CPI > 0 ? (kWT + 4 * p.CPI - 1) / (4 * p.CPI) : kND + 1;
     p.fast = p.RPI > 0 && p.NA <= kNA && p.ND <= kND;
   }
-  p.h16 = 0; p.ACSh = 0; p.amax = nullptr; p.amax_nd = p.amax_na = 0;
+  p.h16 = 0; p.ACSh = p.DCSh = p.DHh = p.LDSh = p.lw = 0; p.amax = nullptr; p.amax_nd = p.amax_na = 0;
   if (p.fast && stride == 1 && (Wo == 8 || Wo == 16 || Wo == 32 || Wo == 64) && p.R * Wo == 64) {
-    p.h16 = 1;
+    p.h16 = p.NA == (Wo == 8 ? 5 : Wo == 16 ? 6 : Wo == 32 ? 8 : 12) && p.ND == 4 && p.RPI * p.LPR == 64 && p.CPI * p.LPD == 64;
     p.ACSh = (p.R + 2) * Wo + 8;
+    p.DCSh = p.R * (Wo + 8);
+    if (!((p.DCSh / 8) & 1)) p.DCSh += 8;
+    p.DHh = 8 + 2 * kWT * p.DCSh;
+    p.LDSh = p.DHh + 2 * kWT * p.ACSh;
+    p.lw = Wo == 8 ? 3 : Wo == 16 ? 4 : Wo == 32 ? 5 : 6;
   }
   const int blocks = (Cout / kWT) * (Cin / kWT);
   const int cus = device_cus();
@@ -873,7 +922,10 @@ void wgrad_attrs() {
   for (const void *f : {reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<1>), reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<2>),
                         reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<1>),
                         reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<2>),
-                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel)})
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<5>),
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<6>),
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<8>),
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<12>)})
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   done = true;
 }
@@ -896,8 +948,13 @@ void wgrad_launch(const WgradP &p, bool aligned, hipStream_t s) {
   const size_t lds = (size_t)kWT * (p.ACS + p.DCS) * sizeof(float);
   const bool staged = p.fast && aligned && !wgrad_plain_form();
   if (p.amax) {
-    const size_t ldsh = ((size_t)3 * 2 * kWT * kDH + (size_t)2 * kWT * p.ACSh) * sizeof(_Float16);
-    hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel, grid, dim3(256), ldsh, s, p);
+    const size_t ldsh = (size_t)p.LDSh * sizeof(_Float16);
+    switch (p.NA) {
+      case 5: hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel<5>, grid, dim3(256), ldsh, s, p); break;
+      case 6: hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel<6>, grid, dim3(256), ldsh, s, p); break;
+      case 8: hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel<8>, grid, dim3(256), ldsh, s, p); break;
+      default: hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel<12>, grid, dim3(256), ldsh, s, p); break;
+    }
   } else if (staged && p.stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<1>, grid, dim3(256), lds, s, p);
   else if (staged) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<2>, grid, dim3(256), lds, s, p);
   else if (p.stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), lds, s, p);
