@@ -175,7 +175,7 @@ static bool wino_geom(const ddpm_conv_desc &d, WinoGeom &g) {
   // one workgroup per CU (150 KB of LDS): a grid a little over the chip -- 6 cout tiles x 48 slices = 288 workgroups on 256 CUs, the
   // 384-channel input gradient of the training step -- runs a second round for 32 of them.  More items per workgroup until the
   // grid is one round (the item -> workgroup map moves, no sum changes)
-  while (items > cus && (long)g.KT * ((g.NS + 7) / 8) * 8 > cus && g.IPW < g.NIT) {
+  while (items > cus && (long)g.KT * 8 <= cus && (long)g.KT * ((g.NS + 7) / 8) * 8 > cus && g.IPW < g.NIT) {
     ++g.IPW;
     g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW);
   }
