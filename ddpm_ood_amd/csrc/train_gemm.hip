@@ -1,23 +1,27 @@
-// train_gemm.hip -- the two fp32-MFMA contractions of the native training step (reference:
+// train_gemm.hip -- the contractions of the native training step (reference:
 // /root/reference/src/trainers/ddpm_trainer.py:78-109 -- loss.backward() through generative's DiffusionModelUNet -- and
 // /root/reference/src/trainers/base.py:156).  Round 6.
 //
-//   gemm_f32_kernel        C[z] = alpha op(A[z]) op(B[z]) + beta C[z], every operand addressed by element strides, the K index and
-//                          the batch index each split in two levels (k = k0 K1 + k1, z = z0 Z1 + z1).  One kernel therefore
+//   gemm_f32_kernel,       C[z] = alpha op(A[z]) op(B[z]) + beta C[z], every operand addressed by element strides, the K index and
+//   gemm_f32_v4_kernel     the batch index each split in two levels (k = k0 K1 + k1, z = z0 Z1 + z1).  One entry point therefore
 //                          covers everything in the backward pass that is not a 3x3 convolution: Linear weight / input gradients
 //                          (time_embed, time_emb_proj, to_q / to_k / to_v), 1x1-convolution weight gradients (K = (image, pixel)),
 //                          1x1 input gradients, and the five batched products of the attention block's forward and backward
 //                          (Q^T K, V P^T, dO^T V, dS K, dS^T Q) on channel-major [B, C, N] tensors without a transpose pass.
-//   conv3x3_wgrad_kernel   dW[co, ci, ky, kx] = sum over (image, output pixel) of dY[co, p] A[ci, s p + (ky, kx) - 1]: 64 couts x
+//                          fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//   conv3x3_wgrad_*        dW[co, ci, ky, kx] = sum over (image, output pixel) of dY[co, p] A[ci, s p + (ky, kx) - 1]: 64 couts x
 //                          64 cins x 9 taps per workgroup (a wave holds nine 32x32 accumulator tiles, one per tap), the pixel
 //                          stream split over workgroups, partial sums reduced in a fixed order by a second pass (no atomics:
-//                          bit-reproducible).  stride 1 (ResnetBlock / Upsample convolutions) and stride 2 (Downsample).
+//                          bit-reproducible).  _f16x3_kernel: stride 1, W in 8 .. 64, on v_mfma_f32_32x32x16_f16 at split
+//                          precision (three f16 products per fp32 product, operands rescaled from their measured maxima: the
+//                          same <= 3e-6 bound against float64 as the fp32 form is tested to); _staged_kernel / _kernel: fp32
+//                          MFMA, stride 1 (other widths) and stride 2 (Downsample).
 //
-// Both multiply on v_mfma_f32_32x32x2_f32 (157 TFLOP/s dense): training needs gradients to ~1e-6 of their scale (the Adam step
-// of the test is compared with CPU autograd), so the products are plain fp32 -- the split-f16 forms of the inference path buy
-// nothing here until the loop is MFMA-bound, which a once-per-dataset training run is not.
-// Operand lanes: A: lane -> (m = lane % 32, k = lane / 32); B: lane -> (k = lane / 32, n = lane % 32);
-// accumulator register i of lane l: row m = 8 (i / 4) + 4 (l / 32) + i % 4, column n = l % 32.
+// Training needs gradients to ~1e-6 of their scale (the Adam step of the test is compared with CPU autograd): a single f16
+// product (11 bits) does not give that, the split form does.
+// Operand lanes of the fp32 MFMA: A: lane -> (m = lane % 32, k = lane / 32); B: lane -> (k = lane / 32, n = lane % 32);
+// of the f16 MFMA: A: lane -> (m = lane % 32, k = 8 (lane / 32) .. + 7), B alike;
+// accumulator register i of lane l (both): row m = 8 (i / 4) + 4 (l / 32) + i % 4, column n = l % 32.
 #include "common.h"
 
 #include <algorithm>
