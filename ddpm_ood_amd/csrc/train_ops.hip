@@ -186,6 +186,86 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float *__restrict__ x
   }
 }
 
+// The same backward for planes of up to 1 024 values and groups of up to 16 channels (every GroupNorm of a 32 x 32 UNet): x-hat and dz
+// of the wave's CPW channels stay in registers between the two passes (QPL quads per lane and channel) -- no second read of x and
+// dy, no second sigmoid.
+template <int CPW, int QPL>
+__global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                         const float *__restrict__ mr, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, float *__restrict__ ws, float *__restrict__ dx,
+                                                         int C, int HW, int G, int act, int accumulate) {
+  __shared__ float sums[2 * 16];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int Cg = C / G, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nq = HW / 4;
+  const float mean = mr[2 * blockIdx.x], rstd = mr[2 * blockIdx.x + 1];
+  f4 xh[CPW][QPL], dz[CPW][QPL];
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const int k = wave + 4 * j;
+    const bool kok = k < Cg;
+    const int c = g * Cg + (kok ? k : 0);
+    const float ga = gamma[c], be = beta[c];
+    const f4 *p = reinterpret_cast<const f4 *>(x + ((size_t)b * C + c) * HW), *d = reinterpret_cast<const f4 *>(dy + ((size_t)b * C + c) * HW);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < QPL; ++q) {
+      const int i = lane + 64 * q;
+      const bool ok = kok && i < nq;
+      const f4 xv = p[ok ? i : 0], dv = d[ok ? i : 0];  // (an unused slot re-reads the plane's first quad and contributes zero)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float h = (xv[e] - mean) * rstd;
+        float t = ok ? dv[e] : 0.f;
+        if (act == DDPM_ACT_SILU) {
+          const float z = __builtin_fmaf(h, ga, be), sg = sigmoid_f(z);
+          t *= sg * (1.0f + z * (1.0f - sg));
+        }
+        xh[j][q][e] = h;
+        dz[j][q][e] = t;
+        s1 += t;
+        s2 = __builtin_fmaf(t, h, s2);
+      }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0 && kok) {
+      sums[2 * k] = s1;
+      sums[2 * k + 1] = s2;
+      ws[2 * ((size_t)b * C + c)] = s1;
+      ws[2 * ((size_t)b * C + c) + 1] = s2;
+    }
+  }
+  __syncthreads();
+  float A = 0.f, Bq = 0.f;
+  for (int k = 0; k < Cg; ++k) {
+    const float gk = gamma[g * Cg + k];
+    A = __builtin_fmaf(gk, sums[2 * k], A);
+    Bq = __builtin_fmaf(gk, sums[2 * k + 1], Bq);
+  }
+  const float inv = 1.0f / ((float)Cg * (float)HW);
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const int k = wave + 4 * j;
+    if (k >= Cg) break;  // (uniform per wave)
+    const int c = g * Cg + k;
+    const float ga = gamma[c];
+    f4 *o = reinterpret_cast<f4 *>(dx + ((size_t)b * C + c) * HW);
+#pragma unroll
+    for (int q = 0; q < QPL; ++q) {
+      const int i = lane + 64 * q;
+      if (i < nq) {
+        f4 r = accumulate ? o[i] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = rstd * (dz[j][q][e] * ga - (A + xh[j][q][e] * Bq) * inv);
+          r[e] = accumulate ? r[e] + v : v;
+        }
+        o[i] = r;
+      }
+    }
+  }
+}
+
 // ---- reductions ---------------------------------------------------------------------------------------------------------------
 // out[r] = sum of the r-th row of `cols` contiguous floats (bias / temb gradients: rows = (image, channel) planes): one wave per row
 template <bool VEC>
@@ -473,7 +553,20 @@ extern "C" int ddpm_gn_backward_f32(const float *x, const float *dy, const float
   hipStream_t s = as_stream(stream);
   // algorithmic traffic: x and dy read, dx written (and read when it accumulates)
   ProfScope prof(s, "train_gn_backward", 0.0, 4.0 * (3 + (accumulate_dx ? 1 : 0)) * B * C * (double)HW);
-  if (vec4_ok(HW, {x, dy, dx}))
+  const int Cg = C / groups;
+  static const bool two_pass = getenv("DDPM_GN_BWD_REG") && atoi(getenv("DDPM_GN_BWD_REG")) == 0;  // (A/B switch)
+  if (vec4_ok(HW, {x, dy, dx}) && HW <= 1024 && Cg <= 16 && !two_pass) {
+    const int cpw = (Cg + 3) / 4;
+    const dim3 grid(B * groups);
+#define DDPM_GN_BWD_REG(CPW, QPL) \
+  hipLaunchKernelGGL((gn_bwd_reg_kernel<CPW, QPL>), grid, dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, dx, C, HW, groups, act, accumulate_dx)
+    if (HW <= 256) {
+      if (cpw == 1) DDPM_GN_BWD_REG(1, 1); else if (cpw == 2) DDPM_GN_BWD_REG(2, 1); else if (cpw == 3) DDPM_GN_BWD_REG(3, 1); else DDPM_GN_BWD_REG(4, 1);
+    } else {
+      if (cpw == 1) DDPM_GN_BWD_REG(1, 4); else if (cpw == 2) DDPM_GN_BWD_REG(2, 4); else if (cpw == 3) DDPM_GN_BWD_REG(3, 4); else DDPM_GN_BWD_REG(4, 4);
+    }
+#undef DDPM_GN_BWD_REG
+  } else if (vec4_ok(HW, {x, dy, dx}))
     hipLaunchKernelGGL(gn_bwd_kernel<true>, dim3(B * groups), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, dx, C, HW, groups, act,
                        accumulate_dx);
   else

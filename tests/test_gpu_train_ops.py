@@ -203,7 +203,7 @@ def test_conv_input_gradient_forms_vs_autograd(device, case):
 
 # ---- GroupNorm (+ SiLU) training form -----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,C,H,act", [(4, 128, 32, 1), (3, 256, 8, 1), (2, 384, 16, 0), (2, 64, 4, 1), (2, 64, 5, 1), (5, 512, 8, 1),
-                                       (2, 96, 7, 0)])
+                                       (2, 96, 7, 0), (2, 256, 32, 1), (1, 512, 32, 1), (2, 384, 32, 0), (1, 128, 64, 1)])
 def test_group_norm_forward_and_backward_vs_autograd(device, B, C, H, act):
     from ddpm_ood_amd import train_ops as T
 
