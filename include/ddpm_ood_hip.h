@@ -501,10 +501,14 @@ int ddpm_gemm_f32(const ddpm_gemm_desc *g, ddpm_stream_t stream);
 /* Weight gradient of F.conv2d(a, w, stride, padding = ksize / 2): dw[Cout, Cin, k, k] (torch layout, overwritten) =
  * sum over images and output pixels of dy[b, co, p] a[b, ci, stride p + tap - pad].  a: [B, Cin, Hi, Wi] (the convolution's
  * input as it was multiplied: after GroupNorm / SiLU / concat / upsampling), dy: [B, Cout, Ho, Wo].  ksize 3 with
- * Cin % 64 == 0, Cout % 64 == 0 and an even Wo <= 64 runs on the fp32 MFMA (64 couts x 64 cins x 9 taps per workgroup, the
+ * Cin % 64 == 0, Cout % 64 == 0 and an even Wo <= 64 runs on the matrix pipe (64 couts x 64 cins x 9 taps per workgroup, the
  * pixel stream split over workgroups into `scratch` -- ddpm_conv_wgrad_scratch_floats floats, 0 = no such tiling -- and
- * reduced in a fixed order); anything else (ksize 1; the 1- / 3-channel first and last convolutions) one workgroup per
- * (cout, cin) pair.  force_generic != 0: always the latter (tests).  */
+ * reduced in a fixed order: bit-reproducible): stride 1 with Wo in {8, 16, 32, 64} and 16-byte aligned tensors on the f16 MFMA
+ * at split precision (three f16 products per fp32 product, both operands rescaled by a power of two from their maxima, which
+ * are measured on the device into the head of `scratch`; within 3e-6 of float64 relative to the gradient's largest element, a
+ * non-finite operand gives a non-finite result; DDPM_WGRAD_F16X3=0 or ddpm_set_split_f16(0) select the fp32 MFMA), every other
+ * tiled shape on the fp32 MFMA; anything else (ksize 1; the 1- / 3-channel first and last convolutions) one workgroup per
+ * (cout, cin) pair and image slice.  force_generic != 0: always the latter, unsliced (tests).  */
 size_t ddpm_conv_wgrad_scratch_floats(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ksize, int stride);
 int ddpm_conv_wgrad_f32(const float *a, const float *dy, float *dw, int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo,
                         int ksize, int stride, float *scratch, size_t scratch_floats, int force_generic, ddpm_stream_t stream);
@@ -522,7 +526,7 @@ int ddpm_conv_weight_rot180t_f32(const float *w, float *wt, int Cout, int Cin, i
 /* F.group_norm in its training form.  mean_rstd: [B, groups, 2] = {mean, 1 / sqrt(var + eps)} (biased variance), kept for the
  * backward; ddpm_gn_apply_f32: y = act((x - mean) rstd gamma + beta), act = DDPM_ACT_NONE or DDPM_ACT_SILU;
  * ddpm_gn_backward_f32: dx (+= if accumulate_dx) the gradient of that through act and the normalisation, dgamma / dbeta [C]
- * overwritten; ws: B * C * 2 floats of scratch.  x, y, dy, dx: [B, C, HW].  */
+ * overwritten; ws: B * C * 2 floats of scratch; at most 64 channels per group.  x, y, dy, dx: [B, C, HW].  */
 int ddpm_gn_stats_f32(const float *x, float *mean_rstd, int B, int C, int HW, int groups, float eps, ddpm_stream_t stream);
 int ddpm_gn_apply_f32(const float *x, const float *mean_rstd, const float *gamma, const float *beta, float *y, int B, int C, int HW,
                       int groups, int act, ddpm_stream_t stream);
@@ -531,7 +535,7 @@ int ddpm_gn_backward_f32(const float *x, const float *dy, const float *mean_rstd
                          ddpm_stream_t stream);
 
 /* out[r] = sum of row r of a [rows, cols] matrix (bias gradients: rows = (image, channel) planes);
- * out[c] (+= if accumulate) alpha * sum over rows of in[r * row_stride + c], rows in order.  */
+ * out[c] (+= if accumulate) alpha * sum over rows of in[r * row_stride + c], in a fixed order (interleaved row groups).  */
 int ddpm_row_sum_f32(const float *in, float *out, int64_t rows, int cols, ddpm_stream_t stream);
 int ddpm_col_sum_f32(const float *in, float *out, int rows, int cols, int64_t row_stride, float alpha, int accumulate,
                      ddpm_stream_t stream);
