@@ -172,7 +172,9 @@ def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NON
         Ho, Wo = 2 * Hi, 2 * Wi
     else:
         Ho, Wo = Hi, Wi
-    if packed is None and not force_direct:
+    if packed is False:  # the caller supplies the Winograd weights of a launch that takes them: no direct-MFMA form (the
+        packed = None    # dispatcher's last resort is then the plain direct kernel on the raw weights)
+    elif packed is None and not force_direct:
         packed = pack_conv_weight(w)
     out = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device)
     keep = [x, w, out, packed]

@@ -114,9 +114,12 @@ class NativeUNetStep:
         if stride2:
             return ops.conv(x, w, b, mode=ops.CONV_STRIDE2, wino44h=ops.pack_conv_s2h_weight(w))
         if w.ndim == 4 and w.shape[2] == 3:
+            # (every step re-packs: the weights changed.  The F(2x2) form is there for launches the F(4x4) kernel does not take;
+            # with either present the direct-MFMA packing would be a third, unused one)
             return ops.conv(x, w, b, chan_add=chan_add, residual=residual,
                             wino44h=ops.pack_wino44h_weight(w) if form == "wino44h" else None,
-                            wino=ops.pack_wino_weight(w) if form in ("wino44h", "wino") else None)
+                            wino=ops.pack_wino_weight(w) if form in ("wino44h", "wino") else None,
+                            packed=False if form in ("wino44h", "wino") else None)
         return ops.conv(x, w, b, chan_add=chan_add, residual=residual)
 
     def _wgrad3(self, a, dy, w, stride=1):
