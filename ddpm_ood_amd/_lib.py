@@ -166,6 +166,7 @@ SIGNATURES = {
     "ddpm_conv_weight_rot180t_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_gn_stats_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "ddpm_gn_apply_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
+    "ddpm_gn_forward_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
     "ddpm_gn_backward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
     "ddpm_row_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "ddpm_col_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),

@@ -100,6 +100,76 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
   }
 }
 
+// statistics + apply in one kernel for planes of up to 1 024 values and groups of up to 16 channels: the group's values are read ONCE
+// into registers (the wave's CPW channels, QPL quads per lane and channel), mean and centred variance are block sums over them, y is
+// written from them -- x crosses the memory system once instead of three times (gn_stats twice, gn_apply once).
+template <int CPW, int QPL>
+__global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ mr,
+                                                         int C, int HW, int G, float eps, int act) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int Cg = C / G, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nq = HW / 4;
+  f4 xv[CPW][QPL];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const int k = wave + 4 * j;
+    const bool kok = k < Cg;
+    const f4 *p = reinterpret_cast<const f4 *>(x + ((size_t)b * C + g * Cg + (kok ? k : 0)) * HW);
+#pragma unroll
+    for (int q = 0; q < QPL; ++q) {
+      const int i = lane + 64 * q;
+      const bool ok = kok && i < nq;
+      const f4 v = p[ok ? i : 0];
+      xv[j][q] = ok ? v : f4{0.f, 0.f, 0.f, 0.f};
+      s += (xv[j][q][0] + xv[j][q][1]) + (xv[j][q][2] + xv[j][q][3]);
+    }
+  }
+  const float n = (float)Cg * (float)HW;
+  const float mean = block_sum_256(s, red) / n;
+  float qq = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const bool kok = wave + 4 * j < Cg;
+#pragma unroll
+    for (int q = 0; q < QPL; ++q) {
+      const bool ok = kok && lane + 64 * q < nq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = ok ? xv[j][q][e] - mean : 0.f;
+        qq = __builtin_fmaf(d, d, qq);
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(block_sum_256(qq, red) / n + eps);
+  if (threadIdx.x == 0) {
+    mr[2 * blockIdx.x] = mean;
+    mr[2 * blockIdx.x + 1] = rstd;
+  }
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const int k = wave + 4 * j;
+    if (k >= Cg) break;  // (uniform per wave)
+    const int c = g * Cg + k;
+    const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
+    f4 *o = reinterpret_cast<f4 *>(y + ((size_t)b * C + c) * HW);
+#pragma unroll
+    for (int q = 0; q < QPL; ++q) {
+      const int i = lane + 64 * q;
+      if (i < nq) {
+        f4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = __builtin_fmaf(xv[j][q][e], sc, sh);
+          r[e] = act == DDPM_ACT_SILU ? z * sigmoid_f(z) : z;
+        }
+        o[i] = r;
+      }
+    }
+  }
+}
+
 // backward: per channel plane  s1 = sum dz, s2 = sum dz xhat  with dz = dy act'(z), z = xhat gamma + beta  (ws[b][c] = {s1, s2} for
 // the parameter gradients), then  dx = rstd (dz gamma - (A + xhat Bq) / (Cg HW)),  A = sum_{c in group} gamma_c s1_c,
 // Bq = sum gamma_c s2_c.  The second pass reads x and dy again -- out of the L2, the group's planes were just streamed through it.
@@ -540,6 +610,33 @@ extern "C" int ddpm_gn_apply_f32(const float *x, const float *mean_rstd, const f
   if (vec4_ok(HW, {x, y}))
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(B * groups), dim3(256), 0, s, x, mean_rstd, gamma, beta, y, C, HW, groups, act);
   else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(B * groups), dim3(256), 0, s, x, mean_rstd, gamma, beta, y, C, HW, groups, act);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_gn_forward_f32(const float *x, const float *gamma, const float *beta, float *y, float *mean_rstd, int B, int C,
+                                   int HW, int groups, float eps, int act, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(x && gamma && beta && y && mean_rstd && B > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0 &&
+                     (act == DDPM_ACT_NONE || act == DDPM_ACT_SILU),
+                 "gn_forward: bad arguments");
+  const int Cg = C / groups;
+  static const bool split = getenv("DDPM_GN_FWD_REG") && atoi(getenv("DDPM_GN_FWD_REG")) == 0;  // (A/B switch)
+  if (!(vec4_ok(HW, {x, y}) && HW <= 1024 && Cg <= 16) || split) {
+    const int rc = ddpm_gn_stats_f32(x, mean_rstd, B, C, HW, groups, eps, stream);
+    return rc ? rc : ddpm_gn_apply_f32(x, mean_rstd, gamma, beta, y, B, C, HW, groups, act, stream);
+  }
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(s, "train_gn_forward", 0.0, 8.0 * B * C * (double)HW);
+  const int cpw = (Cg + 3) / 4;
+  const dim3 grid(B * groups);
+#define DDPM_GN_FWD_REG(CPW, QPL) \
+  hipLaunchKernelGGL((gn_fwd_reg_kernel<CPW, QPL>), grid, dim3(256), 0, s, x, gamma, beta, y, mean_rstd, C, HW, groups, eps, act)
+  if (HW <= 256) {
+    if (cpw == 1) DDPM_GN_FWD_REG(1, 1); else if (cpw == 2) DDPM_GN_FWD_REG(2, 1); else if (cpw == 3) DDPM_GN_FWD_REG(3, 1); else DDPM_GN_FWD_REG(4, 1);
+  } else {
+    if (cpw == 1) DDPM_GN_FWD_REG(1, 4); else if (cpw == 2) DDPM_GN_FWD_REG(2, 4); else if (cpw == 3) DDPM_GN_FWD_REG(3, 4); else DDPM_GN_FWD_REG(4, 4);
+  }
+#undef DDPM_GN_FWD_REG
   DDPM_CHECK_LAUNCH();
   return 0;
 }

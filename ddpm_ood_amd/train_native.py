@@ -154,8 +154,8 @@ class NativeUNetStep:
         return dx
 
     def _gn_fwd(self, x, norm, act):
-        mr = T.gn_stats(x, self.G, self.gn_eps)
-        return T.gn_apply(x, mr, norm.weight, norm.bias, self.G, act), (x, mr, norm, act)
+        y, mr = T.gn_forward(x, norm.weight, norm.bias, self.G, self.gn_eps, act)
+        return y, (x, mr, norm, act)
 
     def _gn_bwd(self, ctx, da, dx=None, accumulate=False):
         x, mr, norm, act = ctx

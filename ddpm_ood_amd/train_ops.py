@@ -106,6 +106,16 @@ def gn_apply(x, mean_rstd, gamma, beta, groups: int, act: int = ACT_NONE):
     return y
 
 
+def gn_forward(x, gamma, beta, groups: int, eps: float, act: int = ACT_NONE):
+    """(y, mean_rstd) = gn_apply(x, gn_stats(x)) in one call -- one kernel for the UNet's plane sizes."""
+    x = require_device_f32(x, "x")
+    B, Cc = x.shape[:2]
+    y, mr = torch.empty_like(x), _empty((B, groups, 2), x)
+    check(_lib.load().ddpm_gn_forward_f32(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mr), B, Cc, x[0, 0].numel(), groups, eps, act,
+                                          stream_ptr()), "gn_forward")
+    return y, mr
+
+
 def gn_backward(x, dy, mean_rstd, gamma, beta, groups: int, act: int, dgamma, dbeta, dx=None, accumulate: bool = False):
     B, Cc = x.shape[:2]
     if dx is None:

@@ -530,6 +530,10 @@ int ddpm_conv_weight_rot180t_f32(const float *w, float *wt, int Cout, int Cin, i
 int ddpm_gn_stats_f32(const float *x, float *mean_rstd, int B, int C, int HW, int groups, float eps, ddpm_stream_t stream);
 int ddpm_gn_apply_f32(const float *x, const float *mean_rstd, const float *gamma, const float *beta, float *y, int B, int C, int HW,
                       int groups, int act, ddpm_stream_t stream);
+/* ddpm_gn_stats_f32 + ddpm_gn_apply_f32 in one call (one kernel, x read once, for planes of up to 1 024 values in groups of up to
+ * 16 channels; the two launches otherwise): y and mean_rstd both written.  */
+int ddpm_gn_forward_f32(const float *x, const float *gamma, const float *beta, float *y, float *mean_rstd, int B, int C, int HW,
+                        int groups, float eps, int act, ddpm_stream_t stream);
 int ddpm_gn_backward_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta, float *dx,
                          int accumulate_dx, float *dgamma, float *dbeta, float *ws, int B, int C, int HW, int groups, int act,
                          ddpm_stream_t stream);

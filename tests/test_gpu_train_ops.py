@@ -221,6 +221,9 @@ def test_group_norm_forward_and_backward_vs_autograd(device, B, C, H, act):
     mr = T.gn_stats(dev(x), 32, 1e-6)
     yh = T.gn_apply(dev(x), mr, dev(gamma), dev(beta), 32, act)
     assert _rel(yh, y.detach()) < 3e-6
+    yf, mrf = T.gn_forward(dev(x), dev(gamma), dev(beta), 32, 1e-6, act)  # statistics + apply in one call (one kernel where it fits)
+    assert _rel(yf, y.detach()) < 3e-6 and _rel(mrf, mr.cpu()) < 3e-6
+    assert torch.equal(yf, T.gn_forward(dev(x), dev(gamma), dev(beta), 32, 1e-6, act)[0])
     dgam, dbet = torch.empty(C, device=device), torch.empty(C, device=device)
     dx = T.gn_backward(dev(x), dev(dy), mr, dev(gamma), dev(beta), 32, act, dgam, dbet)
     assert _rel(dx, rx) < 1e-5 and _rel(dgam, rg) < 1e-5 and _rel(dbet, rb) < 1e-5, (_rel(dx, rx), _rel(dgam, rg), _rel(dbet, rb))
