@@ -159,15 +159,16 @@ SIGNATURES = {
     "ddpm_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "ddpm_gemm_scratch_floats": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "ddpm_conv_wgrad_scratch_floats": (C.c_size_t, [C.c_int] * 9),
-    "ddpm_conv_wgrad_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 9 + [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "ddpm_conv_wgrad_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 9 + [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_int, C.c_void_p]),
     "ddpm_conv3d_wgrad_scratch_floats": (C.c_size_t, [C.c_int] * 10),
     "ddpm_conv3d_wgrad_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 10 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddpm_resample3_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_conv_weight_rot180t_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_gn_stats_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "ddpm_gn_apply_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
-    "ddpm_gn_forward_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
-    "ddpm_gn_backward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
+    "ddpm_gn_forward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
+    "ddpm_gn_backward_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
     "ddpm_row_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "ddpm_col_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "ddpm_silu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -261,7 +261,9 @@ struct WgradP {
   int DCSh;               // dY tile channel stride in halves (R rows of W + 8, an odd 16-byte count)
   int DHh, LDSh;          // halves of the dY tiles (8 in front + two planes) and of the whole LDS image
   int lw;                 // log2 W
-  const unsigned *amax;   // float bits of the partial maxima of |dY| (amax_nd of them) then |a| (amax_na) (wgrad_absmax_kernel)
+  // float bits of partial maxima of |dY| (amax_nd of them) and of |a| (amax_na): wgrad_absmax_kernel's, or the caller's (the
+  // kernels that wrote the two tensors -- ddpm_gn_backward_f32 / ddpm_gn_forward_f32 -- emit them for free)
+  const unsigned *amax_d, *amax_a;
   int amax_nd, amax_na;
 };
 
@@ -559,8 +561,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_kernel(const WgradP p
   float sD, sA;
   {  // the operand maxima from their per-workgroup parts
     unsigned md = 0, ma = 0;
-    for (int e = tid; e < p.amax_nd; e += 256) md = max(md, p.amax[e]);
-    for (int e = tid; e < p.amax_na; e += 256) ma = max(ma, p.amax[p.amax_nd + e]);
+    for (int e = tid; e < p.amax_nd; e += 256) md = max(md, p.amax_d[e]);
+    for (int e = tid; e < p.amax_na; e += 256) ma = max(ma, p.amax_a[e]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       md = max(md, (unsigned)__shfl_xor((int)md, o, 64));
@@ -896,7 +898,7 @@ bool wgrad_plan(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ks
     p.ND = p.CPI > 0 ? (kWT + 4 * p.CPI - 1) / (4 * p.CPI) : kND + 1;
     p.fast = p.RPI > 0 && p.NA <= kNA && p.ND <= kND;
   }
-  p.h16 = 0; p.ACSh = p.DCSh = p.DHh = p.LDSh = p.lw = 0; p.amax = nullptr; p.amax_nd = p.amax_na = 0;
+  p.h16 = 0; p.ACSh = p.DCSh = p.DHh = p.LDSh = p.lw = 0; p.amax_d = p.amax_a = nullptr; p.amax_nd = p.amax_na = 0;
   if (p.fast && stride == 1 && (Wo == 8 || Wo == 16 || Wo == 32 || Wo == 64) && p.R * Wo == 64) {
     p.h16 = p.NA == (Wo == 8 ? 5 : Wo == 16 ? 6 : Wo == 32 ? 8 : 12) && p.ND == 4 && p.RPI * p.LPR == 64 && p.CPI * p.LPD == 64;
     p.ACSh = (p.R + 2) * Wo + 8;
@@ -938,22 +940,32 @@ void wgrad_attrs() {
 
 // the operand maxima of the split-f16 form into scratch[0 .. 1] (p.part already points behind the head)
 bool wgrad_use_h16(const WgradP &p, bool aligned) { return p.h16 && aligned && split_f16_on(sw().wgrad_f16x3) && !wgrad_plain_form(); }
-void wgrad_h16_maxima(WgradP &p, float *scratch, hipStream_t s) {
+void wgrad_h16_maxima(WgradP &p, float *scratch, hipStream_t s, const unsigned *a_amax = nullptr, int a_n = 0,
+                      const unsigned *dy_amax = nullptr, int dy_n = 0) {
   unsigned *mx = reinterpret_cast<unsigned *>(scratch);
   const size_t nd = (size_t)p.B * p.Cout * p.dy_cs / 4, na = (size_t)p.B * p.Cin * p.a_cs / 4;
   // 16 KB per workgroup and pass, up to two workgroups per CU
-  p.amax_nd = (int)std::min<size_t>((nd + 4095) / 4096, kAmaxBlocks);
-  p.amax_na = (int)std::min<size_t>((na + 4095) / 4096, kAmaxBlocks);
-  hipLaunchKernelGGL(wgrad_absmax_kernel, dim3(p.amax_nd), dim3(256), 0, s, p.dy, nd, mx);
-  hipLaunchKernelGGL(wgrad_absmax_kernel, dim3(p.amax_na), dim3(256), 0, s, p.a, na, mx + p.amax_nd);
-  p.amax = mx;
+  if (dy_amax && dy_n > 0) {
+    p.amax_d = dy_amax; p.amax_nd = dy_n;
+  } else {
+    p.amax_nd = (int)std::min<size_t>((nd + 4095) / 4096, kAmaxBlocks);
+    hipLaunchKernelGGL(wgrad_absmax_kernel, dim3(p.amax_nd), dim3(256), 0, s, p.dy, nd, mx);
+    p.amax_d = mx;
+  }
+  if (a_amax && a_n > 0) {
+    p.amax_a = a_amax; p.amax_na = a_n;
+  } else {
+    p.amax_na = (int)std::min<size_t>((na + 4095) / 4096, kAmaxBlocks);
+    hipLaunchKernelGGL(wgrad_absmax_kernel, dim3(p.amax_na), dim3(256), 0, s, p.a, na, mx + kAmaxBlocks);
+    p.amax_a = mx + kAmaxBlocks;
+  }
 }
 // one launch of the MFMA form the plan and the switches select
 void wgrad_launch(const WgradP &p, bool aligned, hipStream_t s) {
   dim3 grid(p.Cout / kWT, p.Cin / kWT, p.S);
   const size_t lds = (size_t)kWT * (p.ACS + p.DCS) * sizeof(float);
   const bool staged = p.fast && aligned && !wgrad_plain_form();
-  if (p.amax) {
+  if (p.amax_d) {
     const size_t ldsh = (size_t)p.LDSh * sizeof(_Float16);
     switch (p.NA) {
       case 5: hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel<5>, grid, dim3(256), ldsh, s, p); break;
@@ -988,6 +1000,7 @@ extern "C" size_t ddpm_conv_wgrad_scratch_floats(int B, int Cin, int Cout, int H
 
 extern "C" int ddpm_conv_wgrad_f32(const float *a, const float *dy, float *dw, int B, int Cin, int Cout, int Hi, int Wi, int Ho,
                                    int Wo, int ksize, int stride, float *scratch, size_t scratch_floats, int force_generic,
+                                   const unsigned *a_absmax, int a_absmax_n, const unsigned *dy_absmax, int dy_absmax_n,
                                    ddpm_stream_t stream) {
   DDPM_CHECK_ARG(a && dy && dw, "conv_wgrad: null operand");
   DDPM_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "conv_wgrad: ksize %d / stride %d", ksize, stride);
@@ -1010,7 +1023,7 @@ extern "C" int ddpm_conv_wgrad_f32(const float *a, const float *dy, float *dw, i
         kname = kshape;
       }
       ProfScope prof(s, kname, flops, bytes);
-      if (wgrad_use_h16(p, aligned)) wgrad_h16_maxima(p, scratch, s);
+      if (wgrad_use_h16(p, aligned)) wgrad_h16_maxima(p, scratch, s, a_absmax, a_absmax_n, dy_absmax, dy_absmax_n);
       wgrad_launch(p, aligned, s);
       DDPM_CHECK_LAUNCH();
     }

@@ -100,14 +100,37 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
   }
 }
 
+// max over the workgroup of a float's magnitude bits (NaN orders above every finite value); `red4` = 4 words of LDS
+__device__ __forceinline__ unsigned block_absmax_bits_256(unsigned b, unsigned *red4) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = b;
+  __syncthreads();
+  return max(max(red4[0], red4[1]), max(red4[2], red4[3]));
+}
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+// out[blockIdx] = magnitude bits of the largest of the block's `chunk` contiguous floats (the maxima the kernels above emit, for the
+// shapes their register forms do not take)
+__global__ __launch_bounds__(256) void absmax_chunks_kernel(const float *__restrict__ x, size_t chunk, unsigned *__restrict__ out) {
+  __shared__ unsigned red4[4];
+  const float *p = x + (size_t)blockIdx.x * chunk;
+  unsigned m = 0;
+  for (size_t i = threadIdx.x; i < chunk; i += 256) m = max(m, abs_bits(p[i]));
+  m = block_absmax_bits_256(m, red4);
+  if (threadIdx.x == 0) out[blockIdx.x] = m;
+}
+
 // statistics + apply in one kernel for planes of up to 1 024 values and groups of up to 16 channels: the group's values are read ONCE
 // into registers (the wave's CPW channels, QPL quads per lane and channel), mean and centred variance are block sums over them, y is
 // written from them -- x crosses the memory system once instead of three times (gn_stats twice, gn_apply once).
 template <int CPW, int QPL>
 __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ mr,
-                                                         int C, int HW, int G, float eps, int act) {
+                                                         unsigned *__restrict__ amax, int C, int HW, int G, float eps, int act) {
   __shared__ float red[4];
+  __shared__ unsigned red4[4];
+  unsigned ymax = 0;
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
   const int Cg = C / G, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nq = HW / 4;
   f4 xv[CPW][QPL];
@@ -163,10 +186,15 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const float *__restrict
         for (int e = 0; e < 4; ++e) {
           const float z = __builtin_fmaf(xv[j][q][e], sc, sh);
           r[e] = act == DDPM_ACT_SILU ? z * sigmoid_f(z) : z;
+          ymax = max(ymax, abs_bits(r[e]));
         }
         o[i] = r;
       }
     }
+  }
+  if (amax) {  // (uniform)
+    ymax = block_absmax_bits_256(ymax, red4);
+    if (threadIdx.x == 0) amax[blockIdx.x] = ymax;
   }
 }
 
@@ -178,8 +206,11 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void gn_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                      const float *__restrict__ mr, const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, float *__restrict__ ws, float *__restrict__ dx,
-                                                     int C, int HW, int G, int act, int accumulate) {
+                                                     unsigned *__restrict__ amax, float *__restrict__ rowsum, int C, int HW, int G,
+                                                     int act, int accumulate) {
   __shared__ float sums[2 * kGnMaxCg];
+  __shared__ unsigned red4[4];
+  unsigned dmax = 0;
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
   const int Cg = C / G, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float mean = mr[2 * blockIdx.x], rstd = mr[2 * blockIdx.x + 1];
@@ -234,6 +265,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float *__restrict__ x
     const float ga = gamma[c], be = beta[c];
     const float *p = x + ((size_t)b * C + c) * HW, *d = dy + ((size_t)b * C + c) * HW;
     float *o = dx + ((size_t)b * C + c) * HW;
+    float rs = 0.f;
     if (VEC) {
       for (int i = lane; i < HW / 4; i += 64) {
         const f4 xv = reinterpret_cast<const f4 *>(p)[i], dv = reinterpret_cast<const f4 *>(d)[i];
@@ -243,6 +275,8 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float *__restrict__ x
           const float xh = (xv[j] - mean) * rstd, dz = dz_of(dv[j], xh, ga, be);
           const float v = rstd * (dz * ga - (A + xh * Bq) * inv);
           r[j] = accumulate ? r[j] + v : v;
+          rs += r[j];
+          dmax = max(dmax, abs_bits(r[j]));
         }
         reinterpret_cast<f4 *>(o)[i] = r;
       }
@@ -250,9 +284,20 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float *__restrict__ x
       for (int i = lane; i < HW; i += 64) {
         const float xh = (p[i] - mean) * rstd, dz = dz_of(d[i], xh, ga, be);
         const float v = rstd * (dz * ga - (A + xh * Bq) * inv);
-        o[i] = accumulate ? o[i] + v : v;
+        const float r = accumulate ? o[i] + v : v;
+        o[i] = r;
+        rs += r;
+        dmax = max(dmax, abs_bits(r));
       }
     }
+    if (rowsum) {  // (uniform)
+      rs = wave_sum(rs);
+      if (lane == 0) rowsum[(size_t)b * C + c] = rs;
+    }
+  }
+  if (amax) {  // (uniform)
+    dmax = block_absmax_bits_256(dmax, red4);
+    if (threadIdx.x == 0) amax[blockIdx.x] = dmax;
   }
 }
 
@@ -263,8 +308,11 @@ template <int CPW, int QPL>
 __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                          const float *__restrict__ mr, const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, float *__restrict__ ws, float *__restrict__ dx,
-                                                         int C, int HW, int G, int act, int accumulate) {
+                                                         unsigned *__restrict__ amax, float *__restrict__ rowsum, int C, int HW, int G,
+                                                         int act, int accumulate) {
   __shared__ float sums[2 * 16];
+  __shared__ unsigned red4[4];
+  unsigned dmax = 0;
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
   const int Cg = C / G, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nq = HW / 4;
   const float mean = mr[2 * blockIdx.x], rstd = mr[2 * blockIdx.x + 1];
@@ -320,6 +368,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const float *__restrict
     const int c = g * Cg + k;
     const float ga = gamma[c];
     f4 *o = reinterpret_cast<f4 *>(dx + ((size_t)b * C + c) * HW);
+    float rs = 0.f;
 #pragma unroll
     for (int q = 0; q < QPL; ++q) {
       const int i = lane + 64 * q;
@@ -329,10 +378,20 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const float *__restrict
         for (int e = 0; e < 4; ++e) {
           const float v = rstd * (dz[j][q][e] * ga - (A + xh[j][q][e] * Bq) * inv);
           r[e] = accumulate ? r[e] + v : v;
+          rs += r[e];
+          dmax = max(dmax, abs_bits(r[e]));
         }
         o[i] = r;
       }
     }
+    if (rowsum) {  // (uniform)
+      rs = wave_sum(rs);
+      if (lane == 0) rowsum[(size_t)b * C + c] = rs;
+    }
+  }
+  if (amax) {  // (uniform)
+    dmax = block_absmax_bits_256(dmax, red4);
+    if (threadIdx.x == 0) amax[blockIdx.x] = dmax;
   }
 }
 
@@ -614,23 +673,28 @@ extern "C" int ddpm_gn_apply_f32(const float *x, const float *mean_rstd, const f
   return 0;
 }
 
-extern "C" int ddpm_gn_forward_f32(const float *x, const float *gamma, const float *beta, float *y, float *mean_rstd, int B, int C,
-                                   int HW, int groups, float eps, int act, ddpm_stream_t stream) {
+extern "C" int ddpm_gn_forward_f32(const float *x, const float *gamma, const float *beta, float *y, float *mean_rstd,
+                                   unsigned *y_absmax, int B, int C, int HW, int groups, float eps, int act, ddpm_stream_t stream) {
   DDPM_CHECK_ARG(x && gamma && beta && y && mean_rstd && B > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0 &&
                      (act == DDPM_ACT_NONE || act == DDPM_ACT_SILU),
                  "gn_forward: bad arguments");
   const int Cg = C / groups;
   static const bool split = getenv("DDPM_GN_FWD_REG") && atoi(getenv("DDPM_GN_FWD_REG")) == 0;  // (A/B switch)
   if (!(vec4_ok(HW, {x, y}) && HW <= 1024 && Cg <= 16) || split) {
-    const int rc = ddpm_gn_stats_f32(x, mean_rstd, B, C, HW, groups, eps, stream);
-    return rc ? rc : ddpm_gn_apply_f32(x, mean_rstd, gamma, beta, y, B, C, HW, groups, act, stream);
+    int rc = ddpm_gn_stats_f32(x, mean_rstd, B, C, HW, groups, eps, stream);
+    if (!rc) rc = ddpm_gn_apply_f32(x, mean_rstd, gamma, beta, y, B, C, HW, groups, act, stream);
+    if (!rc && y_absmax) {
+      hipLaunchKernelGGL(absmax_chunks_kernel, dim3(B * groups), dim3(256), 0, as_stream(stream), y, (size_t)Cg * HW, y_absmax);
+      DDPM_CHECK_LAUNCH();
+    }
+    return rc;
   }
   hipStream_t s = as_stream(stream);
   ProfScope prof(s, "train_gn_forward", 0.0, 8.0 * B * C * (double)HW);
   const int cpw = (Cg + 3) / 4;
   const dim3 grid(B * groups);
 #define DDPM_GN_FWD_REG(CPW, QPL) \
-  hipLaunchKernelGGL((gn_fwd_reg_kernel<CPW, QPL>), grid, dim3(256), 0, s, x, gamma, beta, y, mean_rstd, C, HW, groups, eps, act)
+  hipLaunchKernelGGL((gn_fwd_reg_kernel<CPW, QPL>), grid, dim3(256), 0, s, x, gamma, beta, y, mean_rstd, y_absmax, C, HW, groups, eps, act)
   if (HW <= 256) {
     if (cpw == 1) DDPM_GN_FWD_REG(1, 1); else if (cpw == 2) DDPM_GN_FWD_REG(2, 1); else if (cpw == 3) DDPM_GN_FWD_REG(3, 1); else DDPM_GN_FWD_REG(4, 1);
   } else {
@@ -642,8 +706,8 @@ extern "C" int ddpm_gn_forward_f32(const float *x, const float *gamma, const flo
 }
 
 extern "C" int ddpm_gn_backward_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta,
-                                    float *dx, int accumulate_dx, float *dgamma, float *dbeta, float *ws, int B, int C, int HW,
-                                    int groups, int act, ddpm_stream_t stream) {
+                                    float *dx, int accumulate_dx, float *dgamma, float *dbeta, float *ws, unsigned *dx_absmax,
+                                    float *dx_rowsum, int B, int C, int HW, int groups, int act, ddpm_stream_t stream) {
   DDPM_CHECK_ARG(x && dy && mean_rstd && gamma && beta && dx && dgamma && dbeta && ws && groups > 0 && C % groups == 0,
                  "gn_backward: bad arguments");
   DDPM_CHECK_ARG(C / groups <= kGnMaxCg, "gn_backward: %d channels per group (at most %d)", C / groups, kGnMaxCg);
@@ -656,7 +720,7 @@ extern "C" int ddpm_gn_backward_f32(const float *x, const float *dy, const float
     const int cpw = (Cg + 3) / 4;
     const dim3 grid(B * groups);
 #define DDPM_GN_BWD_REG(CPW, QPL) \
-  hipLaunchKernelGGL((gn_bwd_reg_kernel<CPW, QPL>), grid, dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, dx, C, HW, groups, act, accumulate_dx)
+  hipLaunchKernelGGL((gn_bwd_reg_kernel<CPW, QPL>), grid, dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, dx, dx_absmax, dx_rowsum, C, HW, groups, act, accumulate_dx)
     if (HW <= 256) {
       if (cpw == 1) DDPM_GN_BWD_REG(1, 1); else if (cpw == 2) DDPM_GN_BWD_REG(2, 1); else if (cpw == 3) DDPM_GN_BWD_REG(3, 1); else DDPM_GN_BWD_REG(4, 1);
     } else {
@@ -664,11 +728,11 @@ extern "C" int ddpm_gn_backward_f32(const float *x, const float *dy, const float
     }
 #undef DDPM_GN_BWD_REG
   } else if (vec4_ok(HW, {x, dy, dx}))
-    hipLaunchKernelGGL(gn_bwd_kernel<true>, dim3(B * groups), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, dx, C, HW, groups, act,
-                       accumulate_dx);
+    hipLaunchKernelGGL(gn_bwd_kernel<true>, dim3(B * groups), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, dx, dx_absmax, dx_rowsum,
+                       C, HW, groups, act, accumulate_dx);
   else
-    hipLaunchKernelGGL(gn_bwd_kernel<false>, dim3(B * groups), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, dx, C, HW, groups, act,
-                       accumulate_dx);
+    hipLaunchKernelGGL(gn_bwd_kernel<false>, dim3(B * groups), dim3(256), 0, s, x, dy, mean_rstd, gamma, beta, ws, dx, dx_absmax, dx_rowsum,
+                       C, HW, groups, act, accumulate_dx);
   // dbeta[c] = sum_b s1[b, c], dgamma[c] = sum_b s2[b, c]  (ws is [B][C][{s1, s2}]: 2 C columns, alternating outputs)
   const int cwl = col_sum_cwl(2 * C);
   hipLaunchKernelGGL(col_sum_kernel, dim3((2 * C + (1 << cwl) - 1) >> cwl), dim3(256), 0, s, ws, dbeta, dgamma, B, 2 * C, (long long)2 * C,

@@ -61,6 +61,8 @@ class NativeUNetStep:
         # of a parameter gradient's scale at the first layers (F(2x2): measured in tests/test_gpu_train.py, bar 1e-4).
         self.fwd_form = os.environ.get("DDPM_TRAIN_FWD", "wino44h")
         self.dgrad_form = os.environ.get("DDPM_TRAIN_DGRAD", "wino")
+        # operand maxima / plane sums taken from the GroupNorm kernels that wrote the tensors (0: every consumer reads them again; A/B)
+        self.fused_stats = os.environ.get("DDPM_TRAIN_FUSED_STATS", "1") != "0"
         self._flatten()
 
     # ---- flat parameter / gradient / moment buffers ----------------------------------------------------------------------
@@ -122,12 +124,13 @@ class NativeUNetStep:
                             packed=False if form in ("wino44h", "wino") else None)
         return ops.conv(x, w, b, chan_add=chan_add, residual=residual)
 
-    def _wgrad3(self, a, dy, w, stride=1):
-        """The 3x3(x3) weight gradient into the weight's gradient view."""
+    def _wgrad3(self, a, dy, w, stride=1, a_absmax=None, dy_absmax=None):
+        """The 3x3(x3) weight gradient into the weight's gradient view.  *_absmax: the operand maxima where the kernel that
+        wrote the operand emitted them (GroupNorm forward / backward) -- otherwise the split-f16 form reads the operand to find it."""
         if a.ndim == 5:
             T.conv3d_wgrad(a, dy, stride, out=self.g(w))
         else:
-            T.conv_wgrad(a, dy, 3, stride, out=self.g(w))
+            T.conv_wgrad(a, dy, 3, stride, out=self.g(w), a_absmax=a_absmax, dy_absmax=dy_absmax)
 
     def _bias_grad(self, dy, bias_param, keep_rows=False):
         B, Cc = dy.shape[:2]
@@ -154,17 +157,23 @@ class NativeUNetStep:
         return dx
 
     def _gn_fwd(self, x, norm, act):
-        y, mr = T.gn_forward(x, norm.weight, norm.bias, self.G, self.gn_eps, act)
-        return y, (x, mr, norm, act)
+        """y = act(GroupNorm(x)) and the backward's context; ctx[4] = the maxima of |y| per (image, group) (2-D: _wgrad3's a_absmax)."""
+        if x.ndim == 4:
+            y, mr, amax = T.gn_forward(x, norm.weight, norm.bias, self.G, self.gn_eps, act, want_absmax=True)
+        else:
+            (y, mr), amax = T.gn_forward(x, norm.weight, norm.bias, self.G, self.gn_eps, act), None
+        return y, (x, mr, norm, act, amax)
 
-    def _gn_bwd(self, ctx, da, dx=None, accumulate=False):
-        x, mr, norm, act = ctx
+    def _gn_bwd(self, ctx, da, dx=None, accumulate=False, want=False):
+        """want: returns (dx, maxima of |dx| per (image, group), [B, C] plane sums of dx) -- the weight gradient's dy_absmax and the
+        bias / time-embedding gradient of the convolution whose output gradient dx is."""
+        x, mr, norm, act = ctx[:4]
         return T.gn_backward(x, da, mr, norm.weight, norm.bias, self.G, act, self.g(norm.weight), self.g(norm.bias), dx=dx,
-                             accumulate=accumulate)
+                             accumulate=accumulate, want_absmax=want and x.ndim == 4, want_rowsum=want)
 
-    def _conv3_bwd(self, a, w, dy, need_dx=True):
+    def _conv3_bwd(self, a, w, dy, need_dx=True, a_absmax=None, dy_absmax=None):
         """dW into the weight's gradient view; returns da = conv(dy, rot180(w)^T)."""
-        self._wgrad3(a, dy, w)
+        self._wgrad3(a, dy, w, a_absmax=a_absmax, dy_absmax=dy_absmax)
         if not need_dx:
             return None
         return self._conv(dy, T.conv_weight_rot180t(w), form=self.dgrad_form)
@@ -198,11 +207,17 @@ class NativeUNetStep:
         blk, x, a1, c1, a2, c2, ident = ctx
         es = self._es
         rows = self._bias_grad(dout, blk.conv2.conv.bias, keep_rows=not ident)
-        da2 = self._conv3_bwd(a2, blk.conv2.conv.weight, dout)
-        dh1 = self._gn_bwd(c2, da2)
-        dte = self._bias_grad(dh1, blk.conv1.conv.bias, keep_rows=True).view(dh1.shape[0], dh1.shape[1])
+        da2 = self._conv3_bwd(a2, blk.conv2.conv.weight, dout, a_absmax=c2[4] if self.fused_stats else None)
+        # the GroupNorm backward also leaves the maxima and the plane sums of dh1: conv1's weight gradient does not measure dh1, its
+        # bias gradient and the time embedding's gradient do not read dh1 again
+        if self.fused_stats:
+            dh1, dh1_max, dte = self._gn_bwd(c2, da2, want=True)
+            T.col_sum(dte, dh1.shape[0], dh1.shape[1], out=self.g(blk.conv1.conv.bias))
+        else:  # (A/B: DDPM_TRAIN_FUSED_STATS=0 -- every consumer reads dh1 for itself)
+            dh1, dh1_max = self._gn_bwd(c2, da2), None
+            dte = self._bias_grad(dh1, blk.conv1.conv.bias, keep_rows=True).view(dh1.shape[0], dh1.shape[1])
         self._linear_bwd(es, blk.time_emb_proj, dte, dx=self._des, accumulate=True)
-        da1 = self._conv3_bwd(a1, blk.conv1.conv.weight, dh1)
+        da1 = self._conv3_bwd(a1, blk.conv1.conv.weight, dh1, a_absmax=c1[4] if self.fused_stats else None, dy_absmax=dh1_max)
         dx = self._gn_bwd(c1, da1)
         if ident:
             T.axpby(dx, dout, 1.0, 1.0, out=dx)

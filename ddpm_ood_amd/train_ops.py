@@ -44,8 +44,10 @@ def gemm(A, B, Cout, M, N, K, *, a_m, a_k, b_k, b_n, c_m, c_n, batch=1, a_batch=
     return Cout
 
 
-def conv_wgrad(a, dy, ksize: int, stride: int = 1, out=None, force_generic: bool = False):
-    """dw[Cout, Cin, k, k] of F.conv2d(a, w, stride=stride, padding=k // 2) given dy."""
+def conv_wgrad(a, dy, ksize: int, stride: int = 1, out=None, force_generic: bool = False, a_absmax=None, dy_absmax=None):
+    """dw[Cout, Cin, k, k] of F.conv2d(a, w, stride=stride, padding=k // 2) given dy.  a_absmax / dy_absmax: int32 tensors of float
+    bit patterns whose largest is the largest |a| / |dy| (gn_forward / gn_backward emit them): the split-f16 form then does not
+    read the tensor once more to measure it."""
     lib = _lib.load()
     a, dy = require_device_f32(a, "a"), require_device_f32(dy, "dy")
     B, Cin, Hi, Wi = a.shape
@@ -55,7 +57,8 @@ def conv_wgrad(a, dy, ksize: int, stride: int = 1, out=None, force_generic: bool
     need = 0 if force_generic else lib.ddpm_conv_wgrad_scratch_floats(B, Cin, Cout, Hi, Wi, Ho, Wo, ksize, stride)
     scratch = _empty((need,), a) if need else None
     check(lib.ddpm_conv_wgrad_f32(ptr(a), ptr(dy), ptr(out), B, Cin, Cout, Hi, Wi, Ho, Wo, ksize, stride, ptr(scratch), need,
-                                  int(force_generic), stream_ptr()), "conv_wgrad")
+                                  int(force_generic), ptr(a_absmax), 0 if a_absmax is None else a_absmax.numel(), ptr(dy_absmax),
+                                  0 if dy_absmax is None else dy_absmax.numel(), stream_ptr()), "conv_wgrad")
     return out
 
 
@@ -106,25 +109,32 @@ def gn_apply(x, mean_rstd, gamma, beta, groups: int, act: int = ACT_NONE):
     return y
 
 
-def gn_forward(x, gamma, beta, groups: int, eps: float, act: int = ACT_NONE):
-    """(y, mean_rstd) = gn_apply(x, gn_stats(x)) in one call -- one kernel for the UNet's plane sizes."""
+def gn_forward(x, gamma, beta, groups: int, eps: float, act: int = ACT_NONE, want_absmax: bool = False):
+    """(y, mean_rstd) = gn_apply(x, gn_stats(x)) in one call -- one kernel for the UNet's plane sizes.  want_absmax: also the
+    [B * groups] int32 tensor of the float bit patterns of max |y| per (image, group) (conv_wgrad's a_absmax)."""
     x = require_device_f32(x, "x")
     B, Cc = x.shape[:2]
     y, mr = torch.empty_like(x), _empty((B, groups, 2), x)
-    check(_lib.load().ddpm_gn_forward_f32(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mr), B, Cc, x[0, 0].numel(), groups, eps, act,
-                                          stream_ptr()), "gn_forward")
-    return y, mr
+    amax = torch.empty((B * groups,), dtype=torch.int32, device=x.device) if want_absmax else None
+    check(_lib.load().ddpm_gn_forward_f32(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mr), ptr(amax), B, Cc, x[0, 0].numel(), groups, eps,
+                                          act, stream_ptr()), "gn_forward")
+    return (y, mr, amax) if want_absmax else (y, mr)
 
 
-def gn_backward(x, dy, mean_rstd, gamma, beta, groups: int, act: int, dgamma, dbeta, dx=None, accumulate: bool = False):
+def gn_backward(x, dy, mean_rstd, gamma, beta, groups: int, act: int, dgamma, dbeta, dx=None, accumulate: bool = False,
+                want_absmax: bool = False, want_rowsum: bool = False):
+    """dx (+= if accumulate) and the parameter gradients.  want_absmax / want_rowsum: returns (dx, absmax, rowsum) -- the bit
+    patterns of max |dx| per (image, group) (conv_wgrad's dy_absmax) and the [B, C] plane sums of the final dx (None if not asked)."""
     B, Cc = x.shape[:2]
     if dx is None:
         dx, accumulate = torch.empty_like(x), False
     ws = _empty((B, Cc, 2), x)
+    amax = torch.empty((B * groups,), dtype=torch.int32, device=x.device) if want_absmax else None
+    rows = _empty((B, Cc), x) if want_rowsum else None
     check(_lib.load().ddpm_gn_backward_f32(ptr(x), ptr(dy), ptr(mean_rstd), ptr(gamma), ptr(beta), ptr(dx), int(accumulate),
-                                           ptr(dgamma), ptr(dbeta), ptr(ws), B, Cc, x[0, 0].numel(), groups, act, stream_ptr()),
-          "gn_backward")
-    return dx
+                                           ptr(dgamma), ptr(dbeta), ptr(ws), ptr(amax), ptr(rows), B, Cc, x[0, 0].numel(), groups, act,
+                                           stream_ptr()), "gn_backward")
+    return (dx, amax, rows) if (want_absmax or want_rowsum) else dx
 
 
 def row_sum(x, rows: int, cols: int, out=None):

@@ -508,10 +508,13 @@ int ddpm_gemm_f32(const ddpm_gemm_desc *g, ddpm_stream_t stream);
  * are measured on the device into the head of `scratch`; within 3e-6 of float64 relative to the gradient's largest element, a
  * non-finite operand gives a non-finite result; DDPM_WGRAD_F16X3=0 or ddpm_set_split_f16(0) select the fp32 MFMA), every other
  * tiled shape on the fp32 MFMA; anything else (ksize 1; the 1- / 3-channel first and last convolutions) one workgroup per
- * (cout, cin) pair and image slice.  force_generic != 0: always the latter, unsliced (tests).  */
+ * (cout, cin) pair and image slice.  force_generic != 0: always the latter, unsliced (tests).  a_absmax / dy_absmax (optional):
+ * *_n float bit patterns whose largest is the largest |a| / |dy| -- partial maxima from the kernel that wrote the tensor
+ * (ddpm_gn_forward_f32 / ddpm_gn_backward_f32); NULL: the split form measures the tensor itself (one more read of it).  */
 size_t ddpm_conv_wgrad_scratch_floats(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ksize, int stride);
 int ddpm_conv_wgrad_f32(const float *a, const float *dy, float *dw, int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo,
-                        int ksize, int stride, float *scratch, size_t scratch_floats, int force_generic, ddpm_stream_t stream);
+                        int ksize, int stride, float *scratch, size_t scratch_floats, int force_generic, const unsigned *a_absmax,
+                        int a_absmax_n, const unsigned *dy_absmax, int dy_absmax_n, ddpm_stream_t stream);
 /* The same for F.conv3d(a, w[Cout, Cin, 3, 3, 3], stride, padding = 1) on NCDHW tensors (the 3-D latent UNet of the LDM
  * configuration): one launch of the 3x3 kernel per depth tap, an "image" = (batch item, output slice).  Needs Cin % 64 == 0,
  * Cout % 64 == 0, an even Wo <= 64 and the scratch of ddpm_conv3d_wgrad_scratch_floats.  */
@@ -531,12 +534,18 @@ int ddpm_gn_stats_f32(const float *x, float *mean_rstd, int B, int C, int HW, in
 int ddpm_gn_apply_f32(const float *x, const float *mean_rstd, const float *gamma, const float *beta, float *y, int B, int C, int HW,
                       int groups, int act, ddpm_stream_t stream);
 /* ddpm_gn_stats_f32 + ddpm_gn_apply_f32 in one call (one kernel, x read once, for planes of up to 1 024 values in groups of up to
- * 16 channels; the two launches otherwise): y and mean_rstd both written.  */
-int ddpm_gn_forward_f32(const float *x, const float *gamma, const float *beta, float *y, float *mean_rstd, int B, int C, int HW,
-                        int groups, float eps, int act, ddpm_stream_t stream);
+ * 16 channels; the two launches otherwise): y and mean_rstd both written.  y_absmax (optional, B * groups words): the float bit
+ * pattern of the largest |y| of each (image, group) -- what ddpm_conv_wgrad_f32 takes as a_absmax when y is the convolution's
+ * input.
+ * ddpm_gn_backward_f32's optional outputs, of the FINAL dx (after the accumulation when accumulate_dx): dx_absmax (B * groups words,
+ * as above: ddpm_conv_wgrad_f32's dy_absmax when dx is the gradient of the preceding convolution's output) and dx_rowsum
+ * ([B, C]: the sum of each plane -- that convolution's bias gradient before the sum over images, and the gradient of the time
+ * embedding it adds).  */
+int ddpm_gn_forward_f32(const float *x, const float *gamma, const float *beta, float *y, float *mean_rstd, unsigned *y_absmax, int B,
+                        int C, int HW, int groups, float eps, int act, ddpm_stream_t stream);
 int ddpm_gn_backward_f32(const float *x, const float *dy, const float *mean_rstd, const float *gamma, const float *beta, float *dx,
-                         int accumulate_dx, float *dgamma, float *dbeta, float *ws, int B, int C, int HW, int groups, int act,
-                         ddpm_stream_t stream);
+                         int accumulate_dx, float *dgamma, float *dbeta, float *ws, unsigned *dx_absmax, float *dx_rowsum, int B,
+                         int C, int HW, int groups, int act, ddpm_stream_t stream);
 
 /* out[r] = sum of row r of a [rows, cols] matrix (bias gradients: rows = (image, channel) planes);
  * out[c] (+= if accumulate) alpha * sum over rows of in[r * row_stride + c], in a fixed order (interleaved row groups).  */

@@ -125,6 +125,11 @@ def test_conv_wgrad_split_f16_form(device, monkeypatch, case, dy_scale, a_scale)
         assert torch.equal(T.conv_wgrad(ad, dyd, 3, 1), f32)
     finally:
         _lib.load().ddpm_set_split_f16(1)
+    # operand maxima handed in (as the GroupNorm kernels emit them: partial maxima, any number): the same scale, the same bits
+    amax = ad.abs().view(B, -1).amax(dim=1).view(torch.int32)
+    dmax = dyd.abs().view(B * 4, -1).amax(dim=1).view(torch.int32)
+    assert torch.equal(T.conv_wgrad(ad, dyd, 3, 1, a_absmax=amax, dy_absmax=dmax), dw)
+    assert torch.equal(T.conv_wgrad(ad, dyd, 3, 1, dy_absmax=dmax), dw)
     # a non-finite gradient stays non-finite (the scale is taken from the maximum's bit pattern, NaN included)
     bad = dyd.clone()
     bad[0, 0, 0, 0] = float("nan")
@@ -230,6 +235,15 @@ def test_group_norm_forward_and_backward_vs_autograd(device, B, C, H, act):
     base = torch.randn(x.shape, generator=g)
     acc = T.gn_backward(dev(x), dev(dy), mr, dev(gamma), dev(beta), 32, act, dgam, dbet, dx=dev(base), accumulate=True)
     assert _rel(acc, rx + base.double()) < 1e-5
+    # the optional outputs: maxima per (image, group) as float bit patterns, plane sums -- of the FINAL dx / y
+    yf, _, ymax = T.gn_forward(dev(x), dev(gamma), dev(beta), 32, 1e-6, act, want_absmax=True)
+    want = yf.abs().view(B, 32, -1).amax(dim=2).reshape(-1)
+    assert torch.equal(ymax.view(torch.float32), want)
+    acc2, dmax, rows = T.gn_backward(dev(x), dev(dy), mr, dev(gamma), dev(beta), 32, act, dgam, dbet, dx=dev(base), accumulate=True,
+                                     want_absmax=True, want_rowsum=True)
+    assert torch.equal(acc2, acc)
+    assert torch.equal(dmax.view(torch.float32), acc.abs().view(B, 32, -1).amax(dim=2).reshape(-1))
+    assert rows.shape == (B, C) and _rel(rows, acc.double().cpu().sum(dim=(2, 3))) < 3e-6
 
 
 # ---- the small ones -------------------------------------------------------------------------------------------------------------
