@@ -130,6 +130,13 @@ bool w44h_geom(const ddpm_conv_desc &d, W44HGeom &g, bool sizing) {
   }
   g.IPW = (int)((items + cus - 1) / cus);
   g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW) * g.S;
+  // one workgroup per CU: a grid a little over the chip (6 cout tiles x 48 slots = 288 on 256 CUs: the 384-channel input gradients
+  // of the training step under DDPM_TRAIN_DGRAD=wino44h; no layer of the reconstruction path has 6 cout tiles) would run a second
+  // round for 32 workgroups -- more items per workgroup until it is one round (as conv_wino.hip)
+  while (g.S == 1 && items > cus && (long)g.KT * 8 <= cus && (long)g.KT * ((g.NS + 7) / 8) * 8 > cus && g.IPW < g.NIT) {
+    ++g.IPW;
+    g.NS = g.parts * ((g.NIT + g.IPW - 1) / g.IPW);
+  }
   g.grid = g.KT * ((g.NS + 7) / 8) * 8;
   g.xitem = sw().w44h_xitem;
   g.rev = 0;
