@@ -174,6 +174,7 @@ SIGNATURES = {
     "ddpm_silu_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ddpm_silu_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ddpm_axpby_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_void_p]),
+    "ddpm_scale_check_f32": (C.c_int, [C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
     "ddpm_chan_copy_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "ddpm_resample2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ddpm_softmax_rows_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
@@ -239,7 +240,8 @@ def stream_ptr() -> int:
 
 # ---- numeric guard (include/ddpm_ood_hip.h, "Numeric guard of the split-f16 kernel families") -------------------
 STATUS_BITS = {1: "non-finite UNet output (eps) at a PLMS step", 2: "non-finite reconstruction at clamp + MSE",
-               4: "non-finite latent at the VQ-VAE quantiser"}
+               4: "non-finite latent at the VQ-VAE quantiser", 8: "non-finite gradient after a scaled backward (training)"}
+STATUS_NONFINITE_GRAD = 8
 
 
 def status_read(clear: bool = True) -> int:

@@ -464,6 +464,26 @@ __global__ void axpby_kernel(const float *__restrict__ a, const float *__restric
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
 }
+// x *= alpha in place; a non-finite value ORs `bit` into the device status word (the unscale + overflow check of a scaled backward)
+__global__ void scale_check_kernel(float *__restrict__ x, float alpha, int64_t n, unsigned *__restrict__ status, unsigned bit) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool bad = false;
+  if (4 * i + 3 < n) {
+    f4 v = reinterpret_cast<f4 *>(x)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bad |= (__float_as_uint(v[j]) & 0x7f800000u) == 0x7f800000u;
+      v[j] *= alpha;
+    }
+    reinterpret_cast<f4 *>(x)[i] = v;
+  } else {
+    for (int64_t k = 4 * i; k < n; ++k) {
+      bad |= (__float_as_uint(x[k]) & 0x7f800000u) == 0x7f800000u;
+      x[k] *= alpha;
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0 && status) atomicOr(status, bit);
+}
 // dst[b, cd0 + c, :] (+)= src[b, cs0 + c, :]  (torch.cat in the forward, its split in the backward)
 // (per image the source and the destination block are contiguous runs of C HW floats: VEC moves them in 16-byte pieces)
 template <bool VEC>
@@ -785,6 +805,15 @@ extern "C" int ddpm_axpby_f32(const float *a, const float *b, float *out, float 
   hipStream_t s = as_stream(stream);
   ProfScope prof(s, "train_axpby", 0.0, 12.0 * n);
   hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(n)), dim3(256), 0, s, a, b, out, alpha, beta, n);
+  DDPM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ddpm_scale_check_f32(float *x, float alpha, int64_t n, ddpm_stream_t stream) {
+  DDPM_CHECK_ARG(x && n > 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "scale_check: bad arguments (x 16-byte aligned)");
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(s, "train_scale_check", 0.0, 8.0 * n);
+  hipLaunchKernelGGL(scale_check_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, s, x, alpha, n, status_word(), DDPM_STATUS_NONFINITE_GRAD);
   DDPM_CHECK_LAUNCH();
   return 0;
 }

@@ -56,11 +56,24 @@ class NativeUNetStep:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
         self.G, self.gn_eps = model.norm_num_groups, model.norm_eps
-        # Which 3x3 kernel multiplies (see _conv).  The forward keeps the inference path's F(4x4); the INPUT gradients default to
-        # F(2x2): a gradient passes through ~45 convolutions on its way back and F(4x4)'s transform rounding accumulated to 1.4e-4
-        # of a parameter gradient's scale at the first layers (F(2x2): measured in tests/test_gpu_train.py, bar 1e-4).
+        # Which 3x3 kernel multiplies (see _conv).  Forward and input gradients both run on the inference path's split-f16 F(4x4)
+        # kernel.  Its operands must sit in the f16 exponent range, and a gradient does not: |dY| is 1e-7 .. 1e-4 at batch 256, below
+        # f16's smallest normal (6e-5) -- unscaled, the input gradients lost the low half of the split and a parameter gradient was
+        # 1.5e-4 off at the first layers (which round 6 first read as F(4x4)'s transform rounding and answered with F(2x2) on the
+        # fp32 pipe).  Every backward kernel is linear in the gradient, so the backward runs on dpred * 2^k and the flat gradient
+        # buffer is multiplied by 2^-k afterwards (exact): 4e-7 .. 7e-6 (profiles/r06_train_loss_scale_grad_error.log).
+        #   DDPM_TRAIN_DGRAD=wino: F(2x2) on the fp32 MFMA (needs no scale; 6e-6; ~15 % slower steps)
+        #   DDPM_TRAIN_LOSS_SCALE=<power of two>: a fixed scale instead of the adaptive one (1: none)
         self.fwd_form = os.environ.get("DDPM_TRAIN_FWD", "wino44h")
-        self.dgrad_form = os.environ.get("DDPM_TRAIN_DGRAD", "wino")
+        self.dgrad_form = os.environ.get("DDPM_TRAIN_DGRAD", "wino44h")
+        ls = os.environ.get("DDPM_TRAIN_LOSS_SCALE", "")
+        self.loss_scale = float(ls) if ls else None  # None: adaptive (set from the first batch's element count, lowered on overflow)
+        self.scale_adaptive = self.loss_scale is None and self.dgrad_form == "wino44h"
+        if self.loss_scale is None and not self.scale_adaptive:
+            self.loss_scale = 1.0
+        self.overflow_retries = 0      # backward passes repeated at a lower scale
+        self.fp32_dgrad_steps = 0      # steps whose input gradients fell back to the fp32 pipe
+        self._clean_steps = 0
         # operand maxima / plane sums taken from the GroupNorm kernels that wrote the tensors (0: every consumer reads them again; A/B)
         self.fused_stats = os.environ.get("DDPM_TRAIN_FUSED_STATS", "1") != "0"
         self._flatten()
@@ -411,11 +424,45 @@ class NativeUNetStep:
         self._linear_bwd(e0, m.time_embed[0], de1, need_dx=False)
         self._tape = None
 
+    SCALE_GROWTH_INTERVAL = 2000  # clean steps after which the adaptive scale doubles (gradients shrink as training converges)
+
     def loss_and_grads(self, noisy, timesteps, target):
-        """F.mse_loss(model(noisy, timesteps), target) and every parameter gradient; returns the loss as a 1-element device tensor."""
+        """F.mse_loss(model(noisy, timesteps), target) and every parameter gradient; returns the loss as a 1-element device tensor.
+
+        The backward runs on dpred * loss_scale (a power of two) and the flat gradient buffer is unscaled afterwards; the unscale
+        pass flags non-finite values in the device status word, which is read here (one 4-byte read-back per step: the trainer
+        reads the loss every step anyway).  Overflow (the scale pushed an input-gradient operand past f16): the scale drops by
+        2^4 and the backward runs again on the same tape -- twice at most, then once with the input gradients on the fp32 pipe; a
+        gradient that is still non-finite is a genuine one and is left in place, as the reference would."""
+        from . import _lib
+
         pred = self.forward(noisy, timesteps)
-        loss, dpred = T.mse_loss_grad(pred, target)
-        self.backward(dpred)
+        loss, dpred0 = T.mse_loss_grad(pred, target)
+        if self.scale_adaptive and self.loss_scale is None:
+            # dpred = 2 (pred - target) / n: n / 2 brings it to the error's own magnitude; the gradients further down are smaller
+            # still (2^11 more was measured safe at batch 4 .. 256 -- and the overflow check below is what makes a guess harmless)
+            self.loss_scale = 2.0 ** (math.floor(math.log2(max(pred.numel() / 2, 1))) + 8)
+        tape, form = self._tape, self.dgrad_form
+        for attempt in range(4):  # (a bit left in the word by something else costs one spurious repeat)
+            scale = self.loss_scale if self.dgrad_form == "wino44h" or not self.scale_adaptive else 1.0
+            dpred = dpred0 if scale == 1.0 else T.axpby(dpred0, None, scale, 0.0)
+            self._tape = tape
+            self.backward(dpred)
+            T.scale_check_(self.gflat, 1.0 / scale)
+            if not (_lib.status_read(clear=True) & _lib.STATUS_NONFINITE_GRAD) or not self.scale_adaptive or attempt == 3:
+                break
+            self.overflow_retries += 1
+            self._clean_steps = 0
+            if attempt < 2:
+                self.loss_scale = max(self.loss_scale / 16.0, 1.0)
+            else:
+                self.dgrad_form = "wino"  # this step only
+                self.fp32_dgrad_steps += 1
+        self.dgrad_form = form
+        if self.scale_adaptive:
+            self._clean_steps += 1
+            if self._clean_steps >= self.SCALE_GROWTH_INTERVAL:
+                self.loss_scale, self._clean_steps = self.loss_scale * 2.0, 0
         return loss
 
     def adam_step(self, grad_scale: float = 1.0):

@@ -171,6 +171,12 @@ def axpby(a, b=None, alpha: float = 1.0, beta: float = 1.0, out=None):
     return out
 
 
+def scale_check_(x, alpha: float):
+    """x *= alpha in place; a non-finite value sets _lib.STATUS_NONFINITE_GRAD in the device status word."""
+    check(_lib.load().ddpm_scale_check_f32(ptr(x), alpha, x.numel(), stream_ptr()), "scale_check")
+    return x
+
+
 def chan_copy(src, dst, C_, csrc0: int = 0, cdst0: int = 0, accumulate: bool = False):
     B = src.shape[0]
     check(_lib.load().ddpm_chan_copy_f32(ptr(src), ptr(dst), B, C_, src.shape[1], csrc0, dst.shape[1], cdst0, src[0, 0].numel(),

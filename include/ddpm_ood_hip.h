@@ -441,6 +441,7 @@ int ddpm_attention_ws_f32(const float *qkv, const float *residual, float *out, i
 #define DDPM_STATUS_NONFINITE_EPS 1u    /* ddpm_plms_step_f32 read a non-finite model output           */
 #define DDPM_STATUS_NONFINITE_RECON 2u  /* ddpm_clamp_mse_f32 read a non-finite reconstruction          */
 #define DDPM_STATUS_NONFINITE_LATENT 4u /* ddpm_vq_nearest_f32 read a non-finite latent                 */
+#define DDPM_STATUS_NONFINITE_GRAD 8u   /* ddpm_scale_check_f32 read a non-finite gradient (training)   */
 /* Copies the current device's status word to *word (host memory), clears it if `clear`, and synchronises `stream`. */
 int ddpm_status_read(unsigned *word, int clear, ddpm_stream_t stream);
 /* ABI 9.  The quantiser is the one discontinuous op of the path (the reference re-quantises the denoised latent in
@@ -556,6 +557,11 @@ int ddpm_silu_f32(const float *x, float *y, int64_t n, ddpm_stream_t stream);
 int ddpm_silu_backward_f32(const float *x, const float *dy, float *dx, int64_t n, ddpm_stream_t stream);
 /* out = alpha a + beta b (b may be NULL; out may alias a or b)  */
 int ddpm_axpby_f32(const float *a, const float *b, float *out, float alpha, float beta, int64_t n, ddpm_stream_t stream);
+/* x *= alpha in place (x 16-byte aligned); a non-finite value of x sets DDPM_STATUS_NONFINITE_GRAD in the device status word.  The
+ * training step runs its backward on a gradient scaled by a power of two (the input gradients multiply on the f16 MFMA, where an
+ * unscaled gradient of 1e-6 is subnormal) and takes the factor out of the flat gradient buffer with this call; a set bit means
+ * the scale overflowed f16 somewhere: the caller lowers it and runs the backward again (train_native.py).  */
+int ddpm_scale_check_f32(float *x, float alpha, int64_t n, ddpm_stream_t stream);
 /* dst[b, cdst0 + c, :] (+= if accumulate) src[b, csrc0 + c, :], c < C: torch.cat in the forward, its split in the backward  */
 int ddpm_chan_copy_f32(const float *src, float *dst, int B, int C, int Csrc, int csrc0, int Cdst, int cdst0, int HW, int accumulate,
                        ddpm_stream_t stream);

@@ -183,6 +183,63 @@ def test_native_step_matches_aten_autograd_on_other_unets(device, model_type, ch
     print(f"{model_type}, {channels} x {size}^{dims}, B = {B}: loss {loss_r.item():.6f}, worst gradient error {worst[1]:.2e} ({worst[0]})")
 
 
+def test_loss_scale_of_the_f16_input_gradients_and_its_overflow_retry(device, monkeypatch):
+    """Input gradients on the split-f16 F(4x4) kernel need the gradient inside f16's exponent range: the backward runs on
+    dpred * 2^k and the flat gradient is unscaled afterwards.  (1) unscaled (DDPM_TRAIN_LOSS_SCALE=1) the first layers' gradients
+    are an order of magnitude further from the fp32-pipe form's than under the adaptive scale; (2) a scale far too large
+    overflows, is detected by the unscale pass (status word), lowered twice, and the step ends on the fp32 pipe -- with the same
+    gradients as the fp32-pipe form, from the same tape; (3) the repeat leaves the saved activations untouched (bit-equal
+    gradients from two backward passes over one tape)."""
+    from ddpm_ood_amd import DiffusionModelUNet
+    from ddpm_ood_amd.synthetic import random_state_dict
+    from ddpm_ood_amd.train_native import NativeUNetStep
+    from ddpm_ood_amd.trainer import MODEL_CONFIGS
+
+    sd = random_state_dict("small", 1, seed=1)
+    g = torch.Generator().manual_seed(21)
+    B = 64  # (the 32 x 32 launches fill the chip: the F(4x4) kernel takes them)
+    x = torch.rand(B, 1, 32, 32, generator=g).to(device)
+    t = torch.randint(0, 1000, (B,), generator=g).to(device)
+    noise = torch.randn(B, 1, 32, 32, generator=g).to(device)
+
+    def grads(setup=None, **env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = DiffusionModelUNet(2, 1, 1, **MODEL_CONFIGS["small"])
+        m.load_state_dict(sd)
+        m = m.to(device).train()
+        with torch.no_grad():
+            st = NativeUNetStep(m)
+            if setup:
+                setup(st)
+            st.loss_and_grads(x, t, noise)
+        for k in env:
+            monkeypatch.delenv(k)
+        return st, st.gflat.clone()
+
+    _, ref = grads(DDPM_TRAIN_DGRAD="wino")  # fp32 pipe, no scale
+    scale_of = lambda v: float(v.abs().max())  # noqa: E731
+    st, auto = grads()
+    assert st.dgrad_form == "wino44h" and st.scale_adaptive and st.loss_scale >= 2.0 ** 20 and st.overflow_retries == 0
+    err_auto = float((auto - ref).abs().max()) / scale_of(ref)
+    _, raw = grads(DDPM_TRAIN_LOSS_SCALE="1")
+    err_raw = float((raw - ref).abs().max()) / scale_of(ref)
+    assert err_auto < 2e-5 and err_raw > 5 * err_auto, (err_auto, err_raw)
+
+    def too_large(st):
+        st.loss_scale = 2.0 ** 60
+
+    st, over = grads(setup=too_large)
+    assert st.overflow_retries == 3 and st.fp32_dgrad_steps == 1 and st.loss_scale == 2.0 ** 52 and st.dgrad_form == "wino44h"
+    assert bool(torch.isfinite(over).all()) and torch.equal(over, ref)  # same kernels, same tape, same order: the same bits
+    # the next step of that stepper runs at the lowered scale; once it stops overflowing nothing falls back any more
+    st.loss_scale = 2.0 ** 24
+    with torch.no_grad():
+        st.loss_and_grads(x, t, noise)
+    assert st.fp32_dgrad_steps == 1 and bool(torch.isfinite(st.gflat).all())
+    assert float((st.gflat - ref).abs().max()) / scale_of(ref) < 2e-5
+
+
 def test_ldm_training_runs_natively_on_vqvae_latents(device, tmp_path):
     """BASELINE configs[4]'s training side (the reference trains the latent DDPM with --vqvae_checkpoint and
     --spatial_dimension=3, /root/reference/src/trainers/ddpm_trainer.py:78-101 over base.py:44-61): 32^3 volumes -> a small
