@@ -9,13 +9,15 @@ Adam launch, one all-reduce payload.  No ATen / MIOpen / rocBLAS kernel runs bet
 the updated parameters; ``torch.empty`` only asks the caching allocator for memory.
 
 Forward (activations kept for the backward):
-  GroupNorm statistics + a MATERIALISED GroupNorm/SiLU output (ddpm_gn_stats_f32 / ddpm_gn_apply_f32) -> the inference path's
+  GroupNorm statistics + a MATERIALISED GroupNorm/SiLU output (ddpm_gn_forward_f32: one kernel) -> the inference path's
   convolution kernels (ddpm_conv_f32: split-f16 F(4x4) Winograd where a launch fills the chip, its bias / temb / residual
   epilogue), attention as two batched GEMMs around a row softmax (the probabilities are kept).
-Backward:
+Backward (on the loss gradient times a power of two -- 1e-6-sized gradients are below f16's normal range --, the factor taken out
+of the flat gradient buffer by ddpm_scale_check_f32, which also flags an overflow; see loss_and_grads):
   3x3 / 1x1 input gradients = ddpm_conv_f32 with the weights rotated by 180 degrees and transposed; Downsample through a
-  zero-stuffed dY; Upsample followed by a 2x2 sum; 3x3 weight gradients on ddpm_conv_wgrad_f32 (fp32 MFMA, 64 x 64 x 9 taps per
-  workgroup); every other contraction (Linear / 1x1 weight and input gradients, the five attention products) on ddpm_gemm_f32;
+  zero-stuffed dY; Upsample followed by a 2x2 sum; 3x3 weight gradients on ddpm_conv_wgrad_f32 (f16 MFMA at split precision,
+  64 x 64 x 9 taps per workgroup; its operand maxima and the bias / temb plane sums come from the GroupNorm kernels that wrote the
+  operands); every other contraction (Linear / 1x1 weight and input gradients, the five attention products) on ddpm_gemm_f32;
   GroupNorm + SiLU backward, bias sums, SiLU backward, softmax backward, MSE, Adam in train_ops.hip.
 """
 
