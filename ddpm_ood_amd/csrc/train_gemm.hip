@@ -261,6 +261,7 @@ struct WgradP {
   int DCSh;               // dY tile channel stride in halves (R rows of W + 8, an odd 16-byte count)
   int DHh, LDSh;          // halves of the dY tiles (8 in front + two planes) and of the whole LDS image
   int lw;                 // log2 W
+  int nw;                 // waves per workgroup of the split-f16 form (4: 64 couts per workgroup, 8: 128)
   // float bits of partial maxima of |dY| (amax_nd of them) and of |a| (amax_na): wgrad_absmax_kernel's, or the caller's (the
   // kernels that wrote the two tensors -- ddpm_gn_backward_f32 / ddpm_gn_forward_f32 -- emit them for free)
   const unsigned *amax_d, *amax_a;
@@ -528,41 +529,45 @@ __device__ __forceinline__ void wgrad_split4(const float (&v)[4], h4v &hi, h4v &
 // NA: staging slots of the input tile per thread (5, 6, 8, 12 for W = 8, 16, 32, 64: 64 (R + 2) (channel, row) pairs of W / 4
 // quads over 256 threads, exactly -- with W a power of two and R W = 64 every slot of every lane is a real quad, so the staging code
 // carries no branch and the scheduler is free to move it between the MFMAs)
-template <int NA>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_kernel(const WgradP p) {
+// NW: waves per workgroup.  4: 64 couts x 64 cins, one wave per SIMD.  8: 128 couts x 64 cins (wave w: couts 32 (w / 2) .., cins
+// 32 (w % 2) ..), two waves per SIMD and at most 256 registers each -- the input tile, which every cout block of a layer re-reads
+// and re-converts, is staged once per 128 couts instead of once per 64, and a wave's load wait overlaps its SIMD partner's MFMAs.
+template <int NA, int NW>
+__global__ __launch_bounds__(64 * NW) void conv3x3_wgrad_f16x3_kernel(const WgradP p) {
+  constexpr int NT = 64 * NW, CO = 16 * NW;  // threads, couts per workgroup
   extern __shared__ float smem[];
-  _Float16 *Dh = reinterpret_cast<_Float16 *>(smem) + 8;  // [hi, lo][64 co][DCSh]: R rows of W + 8 halves; 8 zero halves in front
+  _Float16 *Dh = reinterpret_cast<_Float16 *>(smem) + 8;  // [hi, lo][CO co][DCSh]: R rows of W + 8 halves; 8 zero halves in front
   _Float16 *Ah = Dh - 8 + p.DHh;                           // [hi, lo][64 ci][ACSh]: rows y0 - 1 .. y0 + R of W pixels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   // (An XCD-aware decode of the workgroup id -- the (cout, cin) blocks of one slice, which read the same tiles at the same time,
   // on one XCD's L2 -- measured +-0: 5.95 against 5.98 ms over the step's shapes.)
-  const int cob = blockIdx.x * kWT, cib = blockIdx.y * kWT, sp = blockIdx.z;
+  const int cob = blockIdx.x * CO, cib = blockIdx.y * kWT, sp = blockIdx.z;
   const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
   const int hw_i = p.Hi * p.Wi, hw_o = p.Ho * p.Wo;
   const int W = p.Wo, ACS = p.ACSh, DCS = p.DCSh, lw = p.lw;
-  const int aplane = kWT * ACS, dplane = kWT * DCS;
+  const int aplane = kWT * ACS, dplane = CO * DCS;
   // ---- this thread's staging slots.  (channel, input row) pair q = it 4 RPI + (wave RPI + lane / LPR) -> row q / 64, channel
-  // q % 64; 4 RPI is 16 .. 128, so the `it` part of both is uniform (scalar registers) and only the lane part below lives in
+  // q % 64 (NW RPI pairs per step: 16 .. 256), so the `it` part of both is uniform (scalar registers) and only the lane part below lives in
   // vector registers -- the staged fp32 form's per-slot arrays were 48 of them, and this kernel has 256 to fit two workgroups per CU
   const int ql = wave * p.RPI + lane / p.LPR, lc = lane % p.LPR;
-  const int a_c0 = ql & 63, a_r0 = ql >> 6;  // (a_r0 = 1 only for W = 8: 128 pairs per step)
+  const int a_c0 = ql & 63, a_r0 = ql >> 6;  // (a_r0 > 0 when a step covers more than 64 pairs)
   const int a_lds0 = a_c0 * ACS + a_r0 * W + 4 * lc, a_g0 = a_c0 * (int)p.a_cs + a_r0 * p.Wi + 4 * lc;
-  const int qstep = 4 * p.RPI;
+  const int qstep = NW * p.RPI;
   // dY: channel it 4 CPI + (wave CPI + lane / LPD), pixels 4 (lane % LPD) ..
   const int d_c0 = wave * p.CPI + lane / p.LPD, d_px0 = 4 * (lane % p.LPD);
   const int d_lds0 = d_c0 * DCS + (d_px0 >> lw) * (W + 8) + (d_px0 & (W - 1)), d_g0 = d_c0 * (int)p.dy_cs + d_px0;
-  const int cstep = 4 * p.CPI;
+  const int cstep = NW * p.CPI;
   {
     const int n16 = p.LDSh / 8;  // (a multiple of 8 halves)
     uint4 *z = reinterpret_cast<uint4 *>(smem);
-    for (int e = tid; e < n16; e += 256) z[e] = uint4{0u, 0u, 0u, 0u};
+    for (int e = tid; e < n16; e += NT) z[e] = uint4{0u, 0u, 0u, 0u};
   }
   float sD, sA;
   {  // the operand maxima from their per-workgroup parts
     unsigned md = 0, ma = 0;
-    for (int e = tid; e < p.amax_nd; e += 256) md = max(md, p.amax_d[e]);
-    for (int e = tid; e < p.amax_na; e += 256) ma = max(ma, p.amax_a[e]);
+    for (int e = tid; e < p.amax_nd; e += NT) md = max(md, p.amax_d[e]);
+    for (int e = tid; e < p.amax_na; e += NT) ma = max(ma, p.amax_a[e]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       md = max(md, (unsigned)__shfl_xor((int)md, o, 64));
@@ -570,12 +575,16 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_kernel(const WgradP p
     }
     unsigned *red = reinterpret_cast<unsigned *>(smem);
     __syncthreads();  // (the zeroing above is complete before its first words are borrowed ...)
-    if (lane == 0) { red[wave] = md; red[4 + wave] = ma; }
+    if (lane == 0) { red[wave] = md; red[NW + wave] = ma; }
     __syncthreads();
-    md = max(max(red[0], red[1]), max(red[2], red[3]));
-    ma = max(max(red[4], red[5]), max(red[6], red[7]));
+    md = ma = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      md = max(md, red[w]);
+      ma = max(ma, red[NW + w]);
+    }
     __syncthreads();
-    if (tid < 8) red[tid] = 0u;  // (... and they are zero again before the first tile is staged: the loop opens with a barrier)
+    if (tid < 2 * NW) red[tid] = 0u;  // (... and they are zero again before the first tile is staged: the loop opens with a barrier)
     sD = wgrad_scale_of(md);
     sA = wgrad_scale_of(ma);
   }
@@ -898,17 +907,21 @@ bool wgrad_plan(int B, int Cin, int Cout, int Hi, int Wi, int Ho, int Wo, int ks
     p.ND = p.CPI > 0 ? (kWT + 4 * p.CPI - 1) / (4 * p.CPI) : kND + 1;
     p.fast = p.RPI > 0 && p.NA <= kNA && p.ND <= kND;
   }
-  p.h16 = 0; p.ACSh = p.DCSh = p.DHh = p.LDSh = p.lw = 0; p.amax_d = p.amax_a = nullptr; p.amax_nd = p.amax_na = 0;
+  p.h16 = 0; p.nw = 4; p.ACSh = p.DCSh = p.DHh = p.LDSh = p.lw = 0; p.amax_d = p.amax_a = nullptr; p.amax_nd = p.amax_na = 0;
   if (p.fast && stride == 1 && (Wo == 8 || Wo == 16 || Wo == 32 || Wo == 64) && p.R * Wo == 64) {
     p.h16 = p.NA == (Wo == 8 ? 5 : Wo == 16 ? 6 : Wo == 32 ? 8 : 12) && p.ND == 4 && p.RPI * p.LPR == 64 && p.CPI * p.LPD == 64;
+    // 128 couts per workgroup where the staging slots still divide evenly (W >= 16) and the layer has them; DDPM_WGRAD_WAVES=4: A/B
+    static const bool four = getenv("DDPM_WGRAD_WAVES") && atoi(getenv("DDPM_WGRAD_WAVES")) == 4;
+    p.nw = p.h16 && Wo >= 16 && Cout % 128 == 0 && !four && split_f16_on(sw().wgrad_f16x3) && !wgrad_plain_form() ? 8 : 4;
+    const int co = 16 * p.nw;
     p.ACSh = (p.R + 2) * Wo + 8;
     p.DCSh = p.R * (Wo + 8);
     if (!((p.DCSh / 8) & 1)) p.DCSh += 8;
-    p.DHh = 8 + 2 * kWT * p.DCSh;
+    p.DHh = 8 + 2 * co * p.DCSh;
     p.LDSh = p.DHh + 2 * kWT * p.ACSh;
     p.lw = Wo == 8 ? 3 : Wo == 16 ? 4 : Wo == 32 ? 5 : 6;
   }
-  const int blocks = (Cout / kWT) * (Cin / kWT);
+  const int blocks = (Cout / (16 * p.nw)) * (Cin / kWT);
   const int cus = device_cus();
   // one workgroup per CU is what the kernel's registers allow: the most slices that still run as ONE round (12 blocks x 22 slices
   // = 264 workgroups took two rounds on 256 CUs, the second for 8 of them: 137 against 220-250 TFLOP/s for the other shapes)
@@ -930,10 +943,13 @@ void wgrad_attrs() {
   for (const void *f : {reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<1>), reinterpret_cast<const void *>(&conv3x3_wgrad_kernel<2>),
                         reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<1>),
                         reinterpret_cast<const void *>(&conv3x3_wgrad_staged_kernel<2>),
-                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<5>),
-                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<6>),
-                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<8>),
-                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<12>)})
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<5, 4>),
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<6, 4>),
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<8, 4>),
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<12, 4>),
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<3, 8>),
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<4, 8>),
+                        reinterpret_cast<const void *>(&conv3x3_wgrad_f16x3_kernel<6, 8>)})
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   done = true;
 }
@@ -967,11 +983,20 @@ void wgrad_launch(const WgradP &p, bool aligned, hipStream_t s) {
   const bool staged = p.fast && aligned && !wgrad_plain_form();
   if (p.amax_d) {
     const size_t ldsh = (size_t)p.LDSh * sizeof(_Float16);
-    switch (p.NA) {
-      case 5: hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel<5>, grid, dim3(256), ldsh, s, p); break;
-      case 6: hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel<6>, grid, dim3(256), ldsh, s, p); break;
-      case 8: hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel<8>, grid, dim3(256), ldsh, s, p); break;
-      default: hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel<12>, grid, dim3(256), ldsh, s, p); break;
+    if (p.nw == 8) {
+      const dim3 g8(p.Cout / 128, p.Cin / kWT, p.S);
+      switch (p.NA) {
+        case 6: hipLaunchKernelGGL((conv3x3_wgrad_f16x3_kernel<3, 8>), g8, dim3(512), ldsh, s, p); break;
+        case 8: hipLaunchKernelGGL((conv3x3_wgrad_f16x3_kernel<4, 8>), g8, dim3(512), ldsh, s, p); break;
+        default: hipLaunchKernelGGL((conv3x3_wgrad_f16x3_kernel<6, 8>), g8, dim3(512), ldsh, s, p); break;
+      }
+    } else {
+      switch (p.NA) {
+        case 5: hipLaunchKernelGGL((conv3x3_wgrad_f16x3_kernel<5, 4>), grid, dim3(256), ldsh, s, p); break;
+        case 6: hipLaunchKernelGGL((conv3x3_wgrad_f16x3_kernel<6, 4>), grid, dim3(256), ldsh, s, p); break;
+        case 8: hipLaunchKernelGGL((conv3x3_wgrad_f16x3_kernel<8, 4>), grid, dim3(256), ldsh, s, p); break;
+        default: hipLaunchKernelGGL((conv3x3_wgrad_f16x3_kernel<12, 4>), grid, dim3(256), ldsh, s, p); break;
+      }
     }
   } else if (staged && p.stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<1>, grid, dim3(256), lds, s, p);
   else if (staged) hipLaunchKernelGGL(conv3x3_wgrad_staged_kernel<2>, grid, dim3(256), lds, s, p);
