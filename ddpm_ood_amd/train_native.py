@@ -78,6 +78,7 @@ class NativeUNetStep:
         self._clean_steps = 0
         # operand maxima / plane sums taken from the GroupNorm kernels that wrote the tensors (0: every consumer reads them again; A/B)
         self.fused_stats = os.environ.get("DDPM_TRAIN_FUSED_STATS", "1") != "0"
+        self.conv1_dgrad_conv = os.environ.get("DDPM_TRAIN_1X1_DGRAD", "conv") != "gemm"
         self._flatten()
 
     # ---- flat parameter / gradient / moment buffers ----------------------------------------------------------------------
@@ -201,11 +202,19 @@ class NativeUNetStep:
                b_k_outer=cin * hw, c_m=cin, c_n=1)
 
     def _conv1_dgrad(self, w, dy, dx, accumulate):
-        """dx[b, i, p] (+)= sum_o W[o, i] dy[b, o, p]."""
+        """dx[b, i, p] (+)= sum_o W[o, i] dy[b, o, p]; returns the result (a new tensor on the convolution route).  A 1x1 input
+        gradient IS a 1x1 convolution with the transposed weight: it runs on the inference path's DMA-fed 1x1 kernel (split-f16;
+        the gradient scale of loss_and_grads keeps dy in range), the accumulation as its residual epilogue.
+        DDPM_TRAIN_1X1_DGRAD=gemm: the strided fp32 GEMM, in place (A/B)."""
+        if self.conv1_dgrad_conv:
+            return self._conv(dy, T.conv_weight_rot180t(w), residual=dx if accumulate else None)
         B, cout = dy.shape[:2]
-        cin, hw = dx.shape[1], dy[0, 0].numel()
+        cin, hw = w.shape[1], dy[0, 0].numel()
+        if dx is None:
+            dx = torch.empty((B, cin) + tuple(dy.shape[2:]), dtype=torch.float32, device=dy.device)
         T.gemm(w, dy, dx, cin, hw, cout, a_m=1, a_k=cin, b_k=hw, b_n=1, c_m=hw, c_n=1, batch=B, a_batch=0, b_batch=cout * hw,
                c_batch=cin * hw, beta=1.0 if accumulate else 0.0)
+        return dx
 
     # ---- ResnetBlock --------------------------------------------------------------------------------------------------------
     def _resnet_fwd(self, blk, x, es):
@@ -240,7 +249,7 @@ class NativeUNetStep:
             sk = blk.skip_connection.conv
             self._conv1_wgrad(x, sk.weight, dout)
             T.col_sum(rows, dout.shape[0], dout.shape[1], out=self.g(sk.bias))
-            self._conv1_dgrad(sk.weight, dout, dx, accumulate=True)
+            dx = self._conv1_dgrad(sk.weight, dout, dx, accumulate=True)
         return dx
 
     # ---- AttentionBlock -------------------------------------------------------------------------------------------------------
@@ -280,8 +289,7 @@ class NativeUNetStep:
         if o_in is not None:
             self._conv1_wgrad(o_in, blk.proj_attn.weight, dout)
             self._bias_grad(dout, blk.proj_attn.bias)
-            do = torch.empty_like(dout)
-            self._conv1_dgrad(blk.proj_attn.weight, dout, do, accumulate=False)
+            do = self._conv1_dgrad(blk.proj_attn.weight, dout, None, accumulate=False)
         zq = dict(batch=B * heads, batch_inner=heads)
         cn = dict(c_m=n, c_n=1)
         dv, dq, dk = torch.empty_like(v), torch.empty_like(q), torch.empty_like(k)
@@ -303,7 +311,7 @@ class NativeUNetStep:
         for i, (lin, dt) in enumerate(((blk.to_q, dq), (blk.to_k, dk), (blk.to_v, dv))):
             self._conv1_wgrad(xn, lin.weight, dt)
             self._bias_grad(dt, lin.bias)
-            self._conv1_dgrad(lin.weight, dt, dxn, accumulate=i > 0)
+            dxn = self._conv1_dgrad(lin.weight, dt, dxn, accumulate=i > 0)
         dx = self._gn_bwd(c, dxn)
         T.axpby(dx, dout, 1.0, 1.0, out=dx)
         return dx
