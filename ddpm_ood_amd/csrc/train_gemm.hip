@@ -523,9 +523,10 @@ __device__ __forceinline__ void wgrad_split4(const float (&v)[4], h4v &hi, h4v &
 // prefetch at two workgroups per CU 7.05 ms; TWO LDS images
 // with the conversion of tile i + 1 and the loads of tile i + 2 issued between the MFMAs of tile i, one barrier per tile 7.49 ms --
 // with one wave per SIMD an MFMA hides about five other issues (MI355X_MICROARCH.md) and the 650 of a tile do not fit behind 108.
-// A second register set (two tiles of loads in flight) 6.95 ms.  Ablations of THIS form (base 6.13 on that box): no MFMAs 6.08, no
-// conversion + LDS stores 5.52, no global loads 4.63 -- the matrix pipe is hidden, the waves wait for their loads (49 % of wave
-// cycles waiting, L2 hit rate 0.37, profiles/r06_pmc_wgrad_f16x3.log), and more loads in flight do not help.)
+// A second register set (two tiles of loads in flight) 6.95 ms.  Ablations of this form on 4 waves (base 6.13 on that box): no MFMAs
+// 6.08, no conversion + LDS stores 5.52, no global loads 4.63 -- the matrix pipe is hidden, the waves wait for their loads (49 % of
+// wave cycles waiting, L2 hit rate 0.37, profiles/r06_pmc_wgrad_f16x3.log), and more loads in flight do not help; what helps is a
+// second wave per SIMD with half the input traffic per MFMA: the 8-wave form below, 5.24 ms (its ablations: 3.24 / 3.90 / 4.08).)
 // NA: staging slots of the input tile per thread (5, 6, 8, 12 for W = 8, 16, 32, 64: 64 (R + 2) (channel, row) pairs of W / 4
 // quads over 256 threads, exactly -- with W a power of two and R W = 64 every slot of every lane is a real quad, so the staging code
 // carries no branch and the scheduler is free to move it between the MFMAs)
