@@ -258,7 +258,11 @@ class DDPMTrainer(BaseTrainer):
             epoch_step += images.shape[0]
             if self.quick_test:
                 break
-        print(f"Epoch {epoch}: loss {epoch_loss / max(epoch_step, 1):.6f} ({time.time() - t0:.1f} s)")
+        extra = ""
+        if self.native and getattr(self.stepper, "scale_adaptive", False) and self.stepper.loss_scale:
+            extra = (f"; gradient scale 2^{int(math.log2(self.stepper.loss_scale))}, {self.stepper.overflow_retries} repeated backward "
+                     f"passes, {self.stepper.fp32_dgrad_steps} steps on the fp32 pipe so far")
+        print(f"Epoch {epoch}: loss {epoch_loss / max(epoch_step, 1):.6f} ({time.time() - t0:.1f} s{extra})")
         return epoch_loss / max(epoch_step, 1)
 
     @torch.no_grad()
