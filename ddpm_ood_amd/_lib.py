@@ -63,6 +63,7 @@ class GemmDesc(C.Structure):
         ("c_batch", C.c_int64), ("c_batch_outer", C.c_int64),
         ("alpha", C.c_float), ("beta", C.c_float),
         ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t),
+        ("split_f16", C.c_int), ("reserved0", C.c_int),
     ]
 
 

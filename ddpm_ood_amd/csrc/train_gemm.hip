@@ -219,6 +219,109 @@ __global__ __launch_bounds__(256) void gemm_f32_v4_kernel(const GemmP p) {
   }
 }
 
+// Both operands K-major and inside the f16 exponent range (ddpm_gemm_desc.split_f16: the 1x1 weight gradients of a backward that
+// runs under the training step's gradient scale -- dy pre-scaled, x an activation): the same 64 x 64 tile on
+// v_mfma_f32_32x32x16_f16 at split precision, 2 x 3 MFMAs of 8 passes per 32-K stage instead of 16 of 16.  Staged quads are
+// converted to (hi, lo 2^5) halves on their way into LDS; rows are 40 halves (80 bytes: five 16-byte slots, odd) apart.
+constexpr int kGH = 40;
+__global__ __launch_bounds__(256) void gemm_f16x3_kk_kernel(const GemmP p) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  __shared__ _Float16 Ah[2][kGT * kGH], Bh[2][kGT * kGH];  // [hi, lo][row][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int z = blockIdx.z / p.S, sp = blockIdx.z - z * p.S;
+  const int z0 = z / p.Z1, z1 = z - z0 * p.Z1;
+  const int kbeg = sp * p.kchunk, kend = p.S > 1 ? min(p.K, kbeg + p.kchunk) : p.K;
+  const float *A = p.A + z0 * p.sAz0 + z1 * p.sAz1;
+  const float *B = p.B + z0 * p.sBz0 + z1 * p.sBz1;
+  float *C = p.C + z0 * p.sCz0 + z1 * p.sCz1;
+  const int m0 = blockIdx.y * kGT, n0 = blockIdx.x * kGT;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  int s_k[2], s_r[2];  // staging slots: quad = (row e / 8, k = 4 (e % 8) .. + 3)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + 256 * i;
+    s_k[i] = 4 * (e & 7);
+    s_r[i] = e >> 3;
+  }
+  v4 ra[2], rb[2];
+  auto fetch = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kg = kt + s_k[i];
+      const int k0 = kg / p.K1, k1 = kg - k0 * p.K1;
+      const bool ka = kg < kend;
+      const bool oa = ka && m0 + s_r[i] < p.M, ob = ka && n0 + s_r[i] < p.N;
+      const v4 va = *reinterpret_cast<const v4 *>(oa ? A + (m0 + s_r[i]) * p.sAm + k0 * p.sAk0 + k1 : p.A);
+      const v4 vb = *reinterpret_cast<const v4 *>(ob ? B + (n0 + s_r[i]) * p.sBn + k0 * p.sBk0 + k1 : p.B);
+      ra[i] = oa ? va : v4{0.f, 0.f, 0.f, 0.f};
+      rb[i] = ob ? vb : v4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto split4 = [](const v4 v, h4 &hi, h4 &lo) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const _Float16 h = (_Float16)v[t];
+      hi[t] = h;
+      lo[t] = (_Float16)((v[t] - (float)h) * kF16LoScale);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const f16x8 down = {(_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale),
+                      (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale), (_Float16)(1.f / kF16LoScale)};
+  const int ro = (lane & 31) * kGH + 8 * (lane >> 5);  // this lane's operand row and k group
+  if (kbeg < kend) fetch(kbeg);
+  for (int kt = kbeg; kt < kend; kt += kGKF) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      h4 hi, lo;
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<h4 *>(&Ah[0][s_r[i] * kGH + s_k[i]]) = hi;
+      *reinterpret_cast<h4 *>(&Ah[1][s_r[i] * kGH + s_k[i]]) = lo;
+      split4(rb[i], hi, lo);
+      *reinterpret_cast<h4 *>(&Bh[0][s_r[i] * kGH + s_k[i]]) = hi;
+      *reinterpret_cast<h4 *>(&Bh[1][s_r[i] * kGH + s_k[i]]) = lo;
+    }
+    __syncthreads();
+    if (kt + kGKF < kend) fetch(kt + kGKF);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const f16x8 ah = *reinterpret_cast<const f16x8 *>(&Ah[0][wm * kGH + ro + 16 * ks]);
+      const f16x8 al = *reinterpret_cast<const f16x8 *>(&Ah[1][wm * kGH + ro + 16 * ks]);
+      const f16x8 bh = *reinterpret_cast<const f16x8 *>(&Bh[0][wn * kGH + ro + 16 * ks]);
+      const f16x8 bl = *reinterpret_cast<const f16x8 *>(&Bh[1][wn * kGH + ro + 16 * ks]);
+      const f16x8 as = ah * down, bs = bh * down;
+      DDPM_MFMA_F16X3(acc, ah, al, as, bh, bl, bs);
+    }
+  }
+  const int n = n0 + wn + (lane & 31);
+  if (p.S > 1) {
+    float *out = p.part + (size_t)blockIdx.z * p.M * p.N;
+    if (n < p.N) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = m0 + wm + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+        if (m < p.M) out[(size_t)m * p.N + n] = acc[i];
+      }
+    }
+    return;
+  }
+  if (n < p.N) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = m0 + wm + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+      if (m < p.M) {
+        float *c = C + m * p.sCm + n * p.sCn;
+        const float v = p.alpha * acc[i];
+        *c = p.beta != 0.f ? v + p.beta * *c : v;
+      }
+    }
+  }
+}
+
 __global__ void gemm_splitk_reduce_kernel(const GemmP p) {
   const size_t mn = (size_t)p.M * p.N;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -850,7 +953,10 @@ extern "C" int ddpm_gemm_f32(const ddpm_gemm_desc *g, ddpm_stream_t stream) {
                  : p.sBn == 1 && quad(p.sBk1) && quad(p.N)                                                  ? 2
                                                                                                             : 0;
   static const bool plain = getenv("DDPM_GEMM_V4") && atoi(getenv("DDPM_GEMM_V4")) == 0;  // (A/B switch)
-  if (fa && fb && !plain) {
+  static const bool no_h = getenv("DDPM_GEMM_F16X3") && atoi(getenv("DDPM_GEMM_F16X3")) == 0;  // (A/B switch)
+  if (fa == 1 && fb == 1 && g->split_f16 && !plain && !no_h && split_f16_on(true)) {
+    hipLaunchKernelGGL(gemm_f16x3_kk_kernel, grid, dim3(256), 0, s, p);
+  } else if (fa && fb && !plain) {
     if (fa == 1 && fb == 1) hipLaunchKernelGGL((gemm_f32_v4_kernel<true, true>), grid, dim3(256), 0, s, p);
     else if (fa == 1) hipLaunchKernelGGL((gemm_f32_v4_kernel<true, false>), grid, dim3(256), 0, s, p);
     else if (fb == 1) hipLaunchKernelGGL((gemm_f32_v4_kernel<false, true>), grid, dim3(256), 0, s, p);

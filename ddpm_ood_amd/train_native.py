@@ -73,6 +73,7 @@ class NativeUNetStep:
         self.scale_adaptive = self.loss_scale is None and self.dgrad_form == "wino44h"
         if self.loss_scale is None and not self.scale_adaptive:
             self.loss_scale = 1.0
+        self._scaled = False           # the running backward's gradients are scaled into f16's range
         self.overflow_retries = 0      # backward passes repeated at a lower scale
         self.fp32_dgrad_steps = 0      # steps whose input gradients fell back to the fp32 pipe
         self._clean_steps = 0
@@ -198,8 +199,10 @@ class NativeUNetStep:
         """1x1 convolution / per-pixel Linear: dW[o, i] = sum over (image, pixel) dy[b, o, p] x[b, i, p]."""
         B, cin = x.shape[:2]
         cout, hw = dy.shape[1], dy[0, 0].numel()
+        # (under the gradient scale dy sits in the f16 exponent range like the activation x: the product multiplies on the f16 MFMA
+        # at split precision; an unscaled backward keeps the fp32 MFMA)
         T.gemm(dy, x, self.g(w), cout, cin, B * hw, k_inner=hw, a_m=hw, a_k=1, a_k_outer=cout * hw, b_n=hw, b_k=1,
-               b_k_outer=cin * hw, c_m=cin, c_n=1)
+               b_k_outer=cin * hw, c_m=cin, c_n=1, split_f16=self._scaled)
 
     def _conv1_dgrad(self, w, dy, dx, accumulate):
         """dx[b, i, p] (+)= sum_o W[o, i] dy[b, o, p]; returns the result (a new tensor on the convolution route).  A 1x1 input
@@ -456,7 +459,7 @@ class NativeUNetStep:
         for attempt in range(4):  # (a bit left in the word by something else costs one spurious repeat)
             scale = self.loss_scale if self.dgrad_form == "wino44h" or not self.scale_adaptive else 1.0
             dpred = dpred0 if scale == 1.0 else T.axpby(dpred0, None, scale, 0.0)
-            self._tape = tape
+            self._tape, self._scaled = tape, scale >= 1024.0
             self.backward(dpred)
             T.scale_check_(self.gflat, 1.0 / scale)
             if not (_lib.status_read(clear=True) & _lib.STATUS_NONFINITE_GRAD) or not self.scale_adaptive or attempt == 3:

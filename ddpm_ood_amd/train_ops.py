@@ -23,7 +23,7 @@ def _empty(shape, like):
 
 def gemm(A, B, Cout, M, N, K, *, a_m, a_k, b_k, b_n, c_m, c_n, batch=1, a_batch=0, b_batch=0, c_batch=0, k_inner=0,
          a_k_outer=0, b_k_outer=0, batch_inner=0, a_batch_outer=0, b_batch_outer=0, c_batch_outer=0, alpha=1.0, beta=0.0,
-         a_off=0, b_off=0, c_off=0):
+         a_off=0, b_off=0, c_off=0, split_f16=False):
     """C = alpha A B + beta C with element strides (ddpm_gemm_desc).  *_off: element offsets into the three tensors."""
     g = GemmDesc()
     g.A, g.B, g.C = A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, Cout.data_ptr() + 4 * c_off
@@ -35,6 +35,7 @@ def gemm(A, B, Cout, M, N, K, *, a_m, a_k, b_k, b_n, c_m, c_n, batch=1, a_batch=
     g.a_batch, g.a_batch_outer, g.b_batch, g.b_batch_outer = a_batch, a_batch_outer, b_batch, b_batch_outer
     g.c_batch, g.c_batch_outer = c_batch, c_batch_outer
     g.alpha, g.beta = alpha, beta
+    g.split_f16 = int(split_f16)  # both operands inside the f16 exponent range (the caller's promise): K-major products on the f16 MFMA
     lib = _lib.load()
     need = lib.ddpm_gemm_scratch_floats(C.byref(g))  # K slices for products with a small (M, N, batch) grid and a long K
     if need:

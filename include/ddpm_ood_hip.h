@@ -495,6 +495,13 @@ typedef struct ddpm_gemm_desc {
    * added in slice order by a second pass (deterministic).  NULL / too small: one workgroup walks the whole K range.  */
   float *scratch;
   size_t scratch_floats;
+  /* != 0: the caller vouches that both operands sit in the f16 exponent range (|v| < 65 504; full precision for |v| >= 4e-3,
+   * graceful below) -- the product of two K-major, 16-byte aligned operands then multiplies on the f16 MFMA at split precision
+   * (three f16 products per fp32 product, fp32 accumulate: ~2^-22 relative per product).  The training step sets it for the
+   * 1x1 weight gradients of a backward that runs under its gradient scale.  Ignored for other layouts and under
+   * ddpm_set_split_f16(0).  */
+  int split_f16;
+  int reserved0;
 } ddpm_gemm_desc;
 size_t ddpm_gemm_scratch_floats(const ddpm_gemm_desc *g);
 int ddpm_gemm_f32(const ddpm_gemm_desc *g, ddpm_stream_t stream);

@@ -45,7 +45,7 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(UNetConfig) == 4 * 4 + 4 * 8 * 4 + 4 + 4 + 4
     from ddpm_ood_amd._lib import GemmDesc
 
-    assert C.sizeof(GemmDesc) == 3 * 8 + 4 * 4 + 8 * 8 + 2 * 4 + 6 * 8 + 2 * 4 + 8 + 8  # ddpm_gemm_desc (ABI 10)
+    assert C.sizeof(GemmDesc) == 3 * 8 + 4 * 4 + 8 * 8 + 2 * 4 + 6 * 8 + 2 * 4 + 8 + 8 + 2 * 4  # ddpm_gemm_desc (ABI 10)
     assert GemmDesc.a_m.offset == 40 and GemmDesc.batch.offset == 104 and GemmDesc.alpha.offset == 160
 
 

@@ -45,6 +45,18 @@ def test_gemm_two_level_k_and_batch_like_a_1x1_weight_gradient_and_attention(dev
     T.gemm(dy.to(device), x.to(device), dw, cout, cin, B * hw, k_inner=hw, a_m=hw, a_k=1, a_k_outer=cout * hw, b_n=hw, b_k=1,
            b_k_outer=cin * hw, c_m=cin, c_n=1)
     assert _rel(dw, ref) < 2e-6
+    # ... and on the f16 MFMA at split precision when the caller vouches for the operands' range (both K-major, aligned extents)
+    Bq, co2, ci2, hw2 = 5, 192, 128, 64
+    dy2, x2 = 0.3 * torch.randn(Bq, co2, hw2, generator=g), 2.0 * torch.randn(Bq, ci2, hw2, generator=g)
+    ref2 = torch.einsum("bop,bip->oi", dy2.double(), x2.double())
+    outs = []
+    for flag in (True, False):
+        dw2 = torch.empty(co2, ci2, device=device)
+        T.gemm(dy2.to(device), x2.to(device), dw2, co2, ci2, Bq * hw2, k_inner=hw2, a_m=hw2, a_k=1, a_k_outer=co2 * hw2, b_n=hw2,
+               b_k=1, b_k_outer=ci2 * hw2, c_m=ci2, c_n=1, split_f16=flag)
+        assert _rel(dw2, ref2) < 2e-6, (flag, _rel(dw2, ref2))
+        outs.append(dw2)
+    assert not torch.equal(outs[0], outs[1])  # (two different kernels ran)
     # one batch level (a 1x1 convolution's input gradient: dx[b] += W^T dy[b], the weight shared by every image)
     w = torch.randn(cout, cin, generator=g)
     dx0 = torch.randn(B, cin, hw, generator=g)
