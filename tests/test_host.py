@@ -587,5 +587,5 @@ def test_native_training_host_logic():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         NativeUNetStep(small2d)
     names = [f[0] for f in GemmDesc._fields_]
-    assert names[:7] == ["A", "B", "C", "M", "N", "K", "k_inner"] and names[-2:] == ["scratch", "scratch_floats"]
+    assert names[:7] == ["A", "B", "C", "M", "N", "K", "k_inner"] and names[-4:] == ["scratch", "scratch_floats", "split_f16", "reserved0"]
     assert C.sizeof(GemmDesc) % 8 == 0
