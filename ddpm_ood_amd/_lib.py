@@ -73,6 +73,7 @@ SIGNATURES = {
     "ddpm_last_error": (C.c_char_p, []),
     "ddpm_conv_f32": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "ddpm_conv_scratch_floats": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "ddpm_conv_takes_wino44h": (C.c_int, [C.POINTER(ConvDesc)]),
     "ddpm_conv_stats_parts": (C.c_int, [C.POINTER(ConvDesc)]),
     "ddpm_conv_s2h_weight_halves": (C.c_size_t, [C.c_int, C.c_int]),
     "ddpm_pack_conv_s2h_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

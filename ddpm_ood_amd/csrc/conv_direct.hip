@@ -537,3 +537,19 @@ int conv_dispatch(const ddpm_conv_desc &d, hipStream_t s) {
 }
 
 }  // namespace ddpm
+
+// Would ddpm_conv_f32 run this stride-1 3x3 descriptor on the split-f16 F(4x4) kernel if it were given w_wino44h?  (A caller that
+// re-packs weights every step -- the training step -- packs the F(2x2) fallback form only when the answer is no.)
+extern "C" int ddpm_conv_takes_wino44h(const ddpm_conv_desc *dp) {
+  if (!dp) return 0;
+  ddpm_conv_desc d = *dp;
+  if (d.dims == 3 || d.ksize != 3) return 0;
+  if (!d.w_wino44h) d.w_wino44h = reinterpret_cast<const uint16_t *>(uintptr_t(64));  // (only tested for non-NULL)
+  if (!d.scratch) {  // (a launch split over channel slices needs scratch: the caller will size it with ddpm_conv_scratch_floats)
+    d.scratch = reinterpret_cast<float *>(uintptr_t(64));
+    d.scratch_floats = ~size_t(0);
+  }
+  if (ddpm::linear_skinny_supported(d) || (d.w_d3h && ddpm::conv_d3s_supported(d))) return 0;
+  return ddpm::conv_wino44h_supported(d) ? 1 : 0;
+}
+

@@ -227,6 +227,16 @@ def conv(x, weight, bias=None, *, x2=None, gscale=None, gshift=None, act=ACT_NON
     return out[:, :, 0, 0] if was_linear else out
 
 
+def conv_takes_wino44h(x_shape, cout: int) -> bool:
+    """Would conv() run a plain stride-1 3x3 convolution of an input of this shape ([B, Cin, H, W]) to `cout` channels on the
+    split-f16 F(4x4) kernel, given its packed weights?  (ddpm_conv_takes_wino44h: the dispatcher's own rule.)"""
+    B, cin, H, W = x_shape
+    d = ConvDesc()
+    d.C1, d.B, d.Cout, d.Hi, d.Wi, d.Ho, d.Wo = cin, B, cout, H, W, H, W
+    d.ksize, d.mode, d.act, d.out_act = 3, CONV_NORMAL, ACT_NONE, ACT_NONE
+    return bool(_lib.load().ddpm_conv_takes_wino44h(C.byref(d)))
+
+
 CONV_TRANSPOSE2 = 3
 WINO_MAX_TENSOR_BYTES = 2 ** 31 - 1  # 32-bit buffer offsets of the Winograd kernels
 

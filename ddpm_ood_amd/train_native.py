@@ -73,6 +73,7 @@ class NativeUNetStep:
         self.scale_adaptive = self.loss_scale is None and self.dgrad_form == "wino44h"
         if self.loss_scale is None and not self.scale_adaptive:
             self.loss_scale = 1.0
+        self._w44_cache = {}           # (input shape, couts) -> does the dispatcher take the F(4x4) kernel
         self._scaled = False           # the running backward's gradients are scaled into f16's range
         self.overflow_retries = 0      # backward passes repeated at a lower scale
         self.fp32_dgrad_steps = 0      # steps whose input gradients fell back to the fp32 pipe
@@ -133,13 +134,20 @@ class NativeUNetStep:
         if stride2:
             return ops.conv(x, w, b, mode=ops.CONV_STRIDE2, wino44h=ops.pack_conv_s2h_weight(w))
         if w.ndim == 4 and w.shape[2] == 3:
-            # (every step re-packs: the weights changed.  The F(2x2) form is there for launches the F(4x4) kernel does not take;
-            # with either present the direct-MFMA packing would be a third, unused one)
+            # (every step re-packs: the weights changed.  ONE form is packed: F(4x4) where the dispatcher would take it for this
+            # shape -- asked once per shape --, else F(2x2); the direct-MFMA packing would be an unused third)
+            w44 = form == "wino44h" and self._takes_wino44h(tuple(x.shape), w.shape[0])
             return ops.conv(x, w, b, chan_add=chan_add, residual=residual,
-                            wino44h=ops.pack_wino44h_weight(w) if form == "wino44h" else None,
-                            wino=ops.pack_wino_weight(w) if form in ("wino44h", "wino") else None,
+                            wino44h=ops.pack_wino44h_weight(w) if w44 else None,
+                            wino=ops.pack_wino_weight(w) if form in ("wino44h", "wino") and not w44 else None,
                             packed=False if form in ("wino44h", "wino") else None)
         return ops.conv(x, w, b, chan_add=chan_add, residual=residual)
+
+    def _takes_wino44h(self, x_shape, cout):
+        key = (x_shape, cout)
+        if key not in self._w44_cache:
+            self._w44_cache[key] = ops.conv_takes_wino44h(x_shape, cout)
+        return self._w44_cache[key]
 
     def _wgrad3(self, a, dy, w, stride=1, a_absmax=None, dy_absmax=None):
         """The 3x3(x3) weight gradient into the weight's gradient view.  *_absmax: the operand maxima where the kernel that

@@ -150,6 +150,9 @@ typedef struct ddpm_conv_desc {
 
 int ddpm_conv_f32(const ddpm_conv_desc *d, ddpm_stream_t stream);
 /* Floats of scratch this descriptor can use (0: none); device- and shape-dependent, constant for a given process.  */
+/* 1 if ddpm_conv_f32 would run this 2-D stride-1 3x3 descriptor on the split-f16 F(4x4) kernel given w_wino44h (which may be NULL
+ * here): lets a caller that re-packs its weights every step (the training step) skip packing the F(2x2) fallback form.  */
+int ddpm_conv_takes_wino44h(const ddpm_conv_desc *desc);
 size_t ddpm_conv_scratch_floats(const ddpm_conv_desc *d);
 /* Optional, 1x1 convolutions (ResnetBlock.skip_connection, the fused q / k / v projection; ABI 8): the weights pre-split into
  * the two f16 planes the DMA-fed split-f16 kernel multiplies (hi = f16(2^6 w), lo = f16((2^6 w - hi) 2^5), laid out
